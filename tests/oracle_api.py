@@ -1,0 +1,162 @@
+"""ctypes binding of oracle/liboracle.so — the CPU restatement of the reference host operators.
+
+TEST INFRASTRUCTURE: importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+
+MATPC = {"ee": 0, "oo": 1, "eeasym": 2, "ooasym": 3}
+TWIST_DIRECT, TWIST_INVERSE = 0, 1
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+
+
+def _p(a):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_dp if a.dtype == np.float64 else _fp)
+
+
+def _g(gauge):
+    """gauge: (4, V*18) array -> C array of 4 row pointers"""
+    t = _dp if gauge.dtype == np.float64 else _fp
+    arr = (t * 4)()
+    for d in range(4):
+        arr[d] = gauge[d].ctypes.data_as(t)
+    return arr
+
+
+def _x(X):
+    return (C.c_int * 4)(*[int(v) for v in X])
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        lib.qo_norm2_d.restype = C.c_double
+        lib.qo_neighbor_index.restype = C.c_int
+        lib.qo_full_lattice_index.restype = C.c_int
+
+    def set_threads(self, n):
+        self.lib.qo_set_threads(C.c_int(n))
+
+    # -- geometry
+    def neighbor_index(self, X, i, odd, dx4, dx3, dx2, dx1):
+        return self.lib.qo_neighbor_index(_x(X), i, odd, dx4, dx3, dx2, dx1)
+
+    def full_index(self, X, i, odd):
+        return self.lib.qo_full_lattice_index(_x(X), i, odd)
+
+    # -- operators (fp64 unless the arrays are float32)
+    def _sfx(self, a):
+        return "_d" if a.dtype == np.float64 else "_f"
+
+    def wil_dslash(self, gauge, inp, X, parity, dagger):
+        out = np.empty_like(inp)
+        getattr(self.lib, "qo_wil_dslash" + self._sfx(inp))(_p(out), _g(gauge), _p(inp), parity, dagger, _x(X))
+        return out
+
+    def twist_gamma5(self, inp, kappa, mu, flavor, dagger, twist):
+        out = np.empty_like(inp)
+        T = C.c_double if inp.dtype == np.float64 else C.c_float
+        getattr(self.lib, "qo_twist_gamma5" + self._sfx(inp))(_p(out), _p(inp), dagger, T(kappa), T(mu), flavor,
+                                                               inp.size // 24, twist)
+        return out
+
+    def tm_dslash(self, gauge, inp, X, kappa, mu, flavor, parity, matpc, dagger):
+        inp = inp.copy()  # the reference mutates-and-restores its input
+        out = np.empty_like(inp)
+        getattr(self.lib, "qo_tm_dslash" + self._sfx(inp))(_p(out), _g(gauge), _p(inp), C.c_double(kappa), C.c_double(mu),
+                                                            flavor, parity, MATPC[matpc], dagger, _x(X))
+        return out
+
+    def tm_matpc(self, gauge, inp, X, kappa, mu, flavor, matpc, dagger):
+        inp = inp.copy()
+        out = np.empty_like(inp)
+        getattr(self.lib, "qo_tm_matpc" + self._sfx(inp))(_p(out), _g(gauge), _p(inp), C.c_double(kappa), C.c_double(mu),
+                                                           flavor, MATPC[matpc], dagger, _x(X))
+        return out
+
+    def tm_mat(self, gauge, inp, X, kappa, mu, flavor, dagger):
+        out = np.empty_like(inp)
+        getattr(self.lib, "qo_tm_mat" + self._sfx(inp))(_p(out), _g(gauge), _p(inp), C.c_double(kappa), C.c_double(mu),
+                                                         flavor, dagger, _x(X))
+        return out
+
+    def wil_mat(self, gauge, inp, X, kappa, dagger):
+        out = np.empty_like(inp)
+        self.lib.qo_wil_mat_d(_p(out), _g(gauge), _p(inp), C.c_double(kappa), dagger, _x(X))
+        return out
+
+    def wil_matpc(self, gauge, inp, X, kappa, matpc, dagger):
+        out = np.empty_like(inp)
+        self.lib.qo_wil_matpc_d(_p(out), _g(gauge), _p(inp), C.c_double(kappa), MATPC[matpc], dagger, _x(X))
+        return out
+
+    def apply_clover(self, clover, inp, X, parity):
+        out = np.empty_like(inp)
+        getattr(self.lib, "qo_apply_clover" + self._sfx(inp))(_p(out), _p(clover), _p(inp), parity, _x(X))
+        return out
+
+    def twist_clover_gamma5(self, inp, clover, cinv, X, kappa, mu, flavor, parity, dagger, twist):
+        out = np.empty_like(inp)
+        self.lib.qo_twist_clover_gamma5_d(_p(out), _p(inp), _p(clover), _p(cinv) if cinv is not None else None, dagger,
+                                          C.c_double(kappa), C.c_double(mu), flavor, parity, twist, _x(X))
+        return out
+
+    def tmc_dslash(self, gauge, inp, clover, cinv, X, kappa, mu, flavor, parity, matpc, dagger):
+        out = np.empty_like(inp)
+        self.lib.qo_tmc_dslash_d(_p(out), _g(gauge), _p(inp), _p(clover), _p(cinv), C.c_double(kappa), C.c_double(mu),
+                                 flavor, parity, MATPC[matpc], dagger, _x(X))
+        return out
+
+    def tmc_matpc(self, gauge, inp, clover, cinv, X, kappa, mu, flavor, matpc, dagger):
+        out = np.empty_like(inp)
+        self.lib.qo_tmc_matpc_d(_p(out), _g(gauge), _p(inp), _p(clover), _p(cinv), C.c_double(kappa), C.c_double(mu),
+                                flavor, MATPC[matpc], dagger, _x(X))
+        return out
+
+    def tmc_mat(self, gauge, clover, inp, X, kappa, mu, flavor, dagger):
+        out = np.empty_like(inp)
+        self.lib.qo_tmc_mat_d(_p(out), _g(gauge), _p(clover), _p(inp), C.c_double(kappa), C.c_double(mu), flavor, dagger,
+                              _x(X))
+        return out
+
+    # -- synthetic inputs (glibc rand(), as the reference harness)
+    def make_fields(self, X, seed=137, antiperiodic_t=True, clover=True):
+        V = int(np.prod(X))
+        self.lib.qo_srand(C.c_uint(seed))
+        gauge = np.empty((4, V * 18))
+        self.lib.qo_construct_gauge_field_d(_g(gauge), _x(X), C.c_double(1.0), int(antiperiodic_t))
+        spinor = np.empty(V * 24)
+        self.lib.qo_construct_spinor_field_d(_p(spinor), spinor.size)
+        clv = None
+        if clover:
+            clv = np.empty(V * 72)
+            self.lib.qo_construct_clover_field_d(_p(clv), V, C.c_double(0.1), C.c_double(1.0))
+        return gauge, spinor, clv
+
+    def clover_twisted_inverse(self, clover, mu2):
+        out = np.empty_like(clover)
+        self.lib.qo_clover_twisted_inverse_d(_p(out), _p(clover), clover.size // 72, C.c_double(mu2))
+        return out
+
+    def norm2(self, a):
+        return self.lib.qo_norm2_d(_p(a), C.c_long(a.size))
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ODIR, "liboracle.so"])
+
+
+def load():
+    path = os.path.join(ODIR, "liboracle.so")
+    if not os.path.exists(path):
+        build()
+    return Oracle(C.CDLL(path))
