@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline benchmark on MI355X: even-odd twisted-mass Dslash throughput on a 32^4 lattice.
+
+A "step" is ONE application of DiracTwistedMassPC::Dslash (stencil + fused inverse twist) on device-resident
+fields, exactly what tests/dslash_test.cpp times with transfer=0 (:455-616).  `value` is GFLOP/s with the
+reference's kernel-level flop count (1368 / checkerboard site, lib/dslash_twisted_mass.cu:144-160).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--prec 8|4|2] [--recon 18|12] [--dslash tm|tmc|wilson]
+
+N > 1 (launched by torch.distributed.run): the global lattice is 4-D block-decomposed over the ranks and the
+halo exchange rides RCCL (strong scaling: the global volume is fixed).
+
+One JSON line on stdout; `roofline` is computed from the ALGORITHMIC bytes of the stencil kernel
+divided by its average duration measured with HIP events on the stream the kernel runs on; `cpu_baseline` is
+the oracle (CPU restatement of the reference host path, kind "port") timed on this box's host cores.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def random_su3(rng, n):
+    g = rng.standard_normal((n, 3, 3)) + 1j * rng.standard_normal((n, 3, 3))
+    q, r = np.linalg.qr(g)
+    d = np.diagonal(r, axis1=-2, axis2=-1)
+    q = q * (d / np.abs(d))[..., None, :]
+    q = q / np.linalg.det(q)[..., None, None] ** (1.0 / 3.0)
+    return q
+
+
+def make_gauge(X, seed=137, antiperiodic=True):
+    """random SU(3) links in the host QDP order (4, V*18): even sites then odd, anti-periodic T folded into the last slice"""
+    rng = np.random.default_rng(seed)
+    V = int(np.prod(X))
+    out = np.empty((4, V * 18))
+    for mu in range(4):
+        q = random_su3(rng, V)
+        out[mu] = np.stack([q.real, q.imag], axis=-1).reshape(-1)
+    if antiperiodic:
+        Vh = V // 2
+        lo = (X[0] // 2) * X[1] * X[2] * (X[3] - 1)
+        g3 = out[3].reshape(2, Vh, 18)
+        g3[:, lo:, :] *= -1.0
+    return out
+
+
+def make_clover(X, seed=11):
+    rng = np.random.default_rng(seed)
+    V = int(np.prod(X))
+    c = rng.uniform(-0.1, 0.1, size=(V, 72))
+    c[:, 0:6] += 1.0
+    c[:, 36:42] += 1.0
+    return c.reshape(-1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--prec", type=int, default=8, choices=[8, 4, 2])
+    ap.add_argument("--recon", type=int, default=18, choices=[18, 12])
+    ap.add_argument("--dslash", default="tm", choices=["tm", "tmc", "wilson"])
+    ap.add_argument("--lattice", default="32,32,32,32")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other-precision sweep")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+
+    qa = importlib.import_module("quda-qkxtm-multigrid_amd")
+    X = [int(v) for v in args.lattice.split(",")]
+    kappa, mu = 0.1, 0.01  # tests/dslash_test.cpp:124-129
+
+    dist = None
+    if world > 1:
+        import multi_gpu  # repo-root helper: process grid, RCCL bootstrap through torch.distributed
+        dist = multi_gpu.setup(qa, rank, world, local_rank, X)
+        Xl = dist.local_dims
+    else:
+        qa.init(0)
+        Xl = X
+    Vh_local = int(np.prod(Xl)) // 2
+    Vh_global = int(np.prod(X)) // 2
+
+    dtype_name = {8: "f64", 4: "f32", 2: "i16+f32scale"}
+    kinds = {"tm": qa.QUDA_TWISTED_MASS_DSLASH, "tmc": qa.QUDA_TWISTED_CLOVER_DSLASH, "wilson": qa.QUDA_WILSON_DSLASH}
+
+    gauge = make_gauge(X) if dist is None else dist.scatter_gauge(make_gauge(X) if rank == 0 else None)
+    clover = None
+    rng = np.random.default_rng(1234 + rank)
+    src_h = rng.random(Vh_local * 24)
+
+    def run(prec, recon, kind, steps, warmup):
+        gp = qa.gauge_param(Xl, cuda_prec=prec, recon=recon)
+        qa.load_gauge(gauge, gp)
+        ip = qa.invert_param(kinds[kind], kappa, mu, +1, "ee", 0, cuda_prec=prec)
+        if kind == "tmc":
+            nonlocal clover
+            if clover is None:
+                clover = make_clover(Xl, seed=11 + rank)
+            qa.load_clover(clover, None, ip)
+        src, dst = qa.Spinor(prec), qa.Spinor(prec)
+        src.load(src_h, ip)
+        d = qa.Dirac(ip, pc=True)
+        d.time_dslash(dst, src, 0, max(1, warmup))
+        if dist is not None:
+            dist.barrier()
+        qa.lib().qudaAmdDeviceSynchronize()
+        t0 = time.perf_counter()
+        sec_kernel = d.time_dslash(dst, src, 0, steps)  # HIP events on the compute stream, per application
+        qa.lib().qudaAmdDeviceSynchronize()
+        if dist is not None:
+            dist.barrier()
+        wall = time.perf_counter() - t0
+        if dist is not None:
+            wall = dist.max_over_ranks(wall)
+            sec_kernel = dist.max_over_ranks(sec_kernel)
+        flops_site = qa.lib().qudaAmdDslashFlopsPerSite(ip, 0)
+        bytes_site = qa.lib().qudaAmdDslashBytesPerSite(ip, 0, 0)
+        n2 = dst.norm2()
+        for f in (src, dst):
+            f.free()
+        d.free()
+        return dict(wall=wall, sec=sec_kernel, flops_site=flops_site, bytes_site=bytes_site, norm2=n2)
+
+    r = run(args.prec, args.recon, args.dslash, args.steps, args.warmup)
+    ms_per_step = 1e3 * r["wall"] / args.steps
+    gflops = r["flops_site"] * Vh_global / (r["wall"] / args.steps) * 1e-9
+    achieved = r["bytes_site"] * Vh_local / r["sec"] * 1e-9  # GB/s of ONE GPU's kernel (per launch)
+
+    extra = {}
+    if not args.no_extra and rank == 0 and world == 1:
+        for prec, recon, kind in ((4, 18, "tm"), (4, 12, "tm"), (2, 18, "tm"), (8, 18, "tmc"), (4, 18, "tmc"), (2, 18, "tmc")):
+            e = run(prec, recon, kind, max(20, args.steps // 2), 5)
+            extra["%s_%s_r%d" % (kind, dtype_name[prec].split("+")[0], recon)] = dict(
+                gflops=round(e["flops_site"] * Vh_global / e["sec"] * 1e-9, 1), hbm_gbs=round(e["bytes_site"] * Vh_local / e["sec"] * 1e-9, 1),
+                frac=round(e["bytes_site"] * Vh_local / e["sec"] * 1e-9 / HBM_PEAK_GBS, 4), bytes_per_site=e["bytes_site"], us=round(1e6 * e["sec"], 2))
+
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        import oracle_api  # TEST INFRASTRUCTURE used as the reported CPU baseline ("port" of the reference host path)
+        oracle = oracle_api.load()
+        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        Xc = Xl
+        g_cpu = gauge if dist is None else gauge
+        inp = src_h.copy()
+        oracle.set_threads(1)
+        t0 = time.perf_counter()
+        oracle.tm_dslash(g_cpu, inp, Xc, kappa, mu, +1, 0, "ee", 0)
+        t1 = time.perf_counter() - t0
+        oracle.set_threads(cores)
+        n_all = max(3, min(40, int(12.0 / max(t1 / cores, 1e-3))))
+        oracle.tm_dslash(g_cpu, inp, Xc, kappa, mu, +1, 0, "ee", 0)
+        t0 = time.perf_counter()
+        for _ in range(n_all):
+            oracle.tm_dslash(g_cpu, inp, Xc, kappa, mu, +1, 0, "ee", 0)
+        tall = (time.perf_counter() - t0) / n_all
+        oracle.set_threads(1)
+        cpu = dict(value=round(1368.0 * Vh_local / tall * 1e-9, 3), unit="GFLOP/s", cores=cores, kind="port",
+                   sample="%d x tm_dslash fp64 on %s (oracle/liboracle.so, outer parallel-for over sites); 1 thread = %.3f GFLOP/s"
+                   % (n_all, "x".join(str(v) for v in Xc), 1368.0 * Vh_local / t1 * 1e-9))
+
+    if rank == 0:
+        out = {
+            "metric": "twisted-mass Dslash GFLOP/s (even-odd, 32^4)" if X == [32, 32, 32, 32] else "twisted-mass Dslash GFLOP/s",
+            "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None, "dtype": dtype_name[args.prec], "data": "synthetic",
+            "config": {"workload": "%s even-odd Dslash (DiracTwistedMassPC::Dslash, kappa=%g mu=%g), %s lattice, recon-%d, fields resident in HBM"
+                       % ({"tm": "twisted-mass", "tmc": "twisted-clover", "wilson": "Wilson"}[args.dslash], kappa, mu, "x".join(map(str, X)), args.recon),
+                       "local_lattice": Xl, "process_grid": dist.grid if dist else [1, 1, 1, 1], "flops_per_site": r["flops_site"]},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "bytes_per_site": r["bytes_site"], "kernel_us": round(1e6 * r["sec"], 3)},
+            "cpu_baseline": cpu,
+            "extra": extra,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.finalize()
+    else:
+        qa.end()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,69 @@
+/*
+ * quda_amd_ext.h — C-ABI handles onto the C++ surface of the library (resident fields and operator
+ * objects), for callers that cannot bind C++ classes (ctypes / cgo / JNI style FFI) and for the
+ * benchmark, which — like the reference's tests/dslash_test.cpp with transfer=0 (:455-616) — times
+ * Dirac::Dslash on fields that stay in HBM.
+ *
+ * Each function is a thin wrapper over the C++ method it cites:
+ *   qudaAmdSpinor*      -> cudaColorSpinorField ctor / operator= (reference include/color_spinor_field.h:458-640,
+ *                          lib/cuda_color_spinor_field.cu:513-590)
+ *   qudaAmdDirac*       -> Dirac::create, Dslash, DslashXpay, M, Mdag, MdagM, prepare/reconstruct
+ *                          (reference include/dirac_quda.h:88-164, :449-617; lib/interface_quda.cpp:1265, :1386)
+ *   qudaAmdBlas*        -> blas::norm2 / cDotProduct / axpy (reference include/blas_quda.h:33-144)
+ * Plain pointers and PODs only; errors follow quda.h (message + exit(1)).
+ */
+#ifndef QUDA_AMD_EXT_H
+#define QUDA_AMD_EXT_H
+
+#include "quda.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* device-resident spinor field on the local lattice loaded by loadGaugeQuda.
+ * site_subset: QUDA_PARITY_SITE_SUBSET (1) or QUDA_FULL_SITE_SUBSET (2). */
+void *qudaAmdSpinorCreate(QudaPrecision prec, QudaSiteSubset site_subset, QudaTwistFlavorType flavor);
+void qudaAmdSpinorDestroy(void *field);
+/* host <-> device with reorder, precision and gamma-basis change; host layout described by inv_param
+ * (cpu_prec, dirac_order, gamma_basis) exactly as for dslashQuda */
+void qudaAmdSpinorLoad(void *field, const void *h_src, const QudaInvertParam *inv_param);
+void qudaAmdSpinorSave(const void *field, void *h_dst, const QudaInvertParam *inv_param);
+void qudaAmdSpinorCopy(void *dst, const void *src);   /* device-device, any precision pair */
+void qudaAmdSpinorSetTwist(void *field, QudaTwistFlavorType flavor);
+
+/* operator object built from the resident gauge/clover fields.
+ * pc != 0: even-odd preconditioned type (Dirac::create of *PC_DIRAC); which: 0 precise, 1 sloppy, 2 precondition */
+void *qudaAmdDiracCreate(QudaInvertParam *inv_param, int pc, int which);
+void qudaAmdDiracDestroy(void *dirac);
+void qudaAmdDiracDslash(void *dirac, void *out, const void *in, QudaParity parity);
+void qudaAmdDiracDslashXpay(void *dirac, void *out, const void *in, QudaParity parity, const void *x, double k);
+void qudaAmdDiracM(void *dirac, void *out, const void *in);
+void qudaAmdDiracMdag(void *dirac, void *out, const void *in);
+void qudaAmdDiracMdagM(void *dirac, void *out, const void *in);
+unsigned long long qudaAmdDiracFlops(void *dirac);
+
+/* niter back-to-back Dslash applications bracketed by device events on the compute stream;
+ * returns seconds per application (reference tests/dslash_test.cpp:455-616). */
+double qudaAmdTimeDslash(void *dirac, void *out, const void *in, QudaParity parity, int niter);
+double qudaAmdTimeM(void *dirac, void *out, const void *in, int niter);
+
+double qudaAmdBlasNorm2(const void *field);
+void qudaAmdBlasCDot(const void *x, const void *y, double result[2]);
+void qudaAmdBlasAxpy(double a, const void *x, void *y);
+
+/* algorithmic work model of the stencil kernel behind Dirac::Dslash */
+long long qudaAmdDslashBytesPerSite(QudaInvertParam *inv_param, int which, int xpay);
+long long qudaAmdDslashFlopsPerSite(QudaInvertParam *inv_param, int xpay);
+
+/* single-process emulation of a partitioned dimension (reference tests --partition, commDimPartitionedSet) */
+void qudaAmdSetPartitionMask(int mask);
+
+/* stream the kernels are launched on (hipStream_t), for callers that bracket work with their own events */
+void *qudaAmdComputeStream(void);
+void qudaAmdDeviceSynchronize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,344 @@
+"""quda-qkxtm-multigrid_amd — MI355X-native twisted-mass Dslash / multigrid library behind the QUDA C ABI.
+
+This package is only the Python-side binding used by tests and bench.py: ctypes mirrors of the PODs in
+include/quda.h (field-for-field, the ABI of reference include/quda.h:25-409) and thin wrappers over the
+extern "C" entry points of lib/libquda.so (built from csrc/ by `make`, see __graft_entry__.build()).
+There is NO CPU fallback: importing works without a GPU (so the symbol table can be checked), but any
+compute call needs a gfx950 device, and a missing library raises immediately.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libquda.so")
+INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
+
+# ---- enum values (include/quda.h) ----
+QUDA_INVALID_ENUM = -(2**31)
+QUDA_CPU_FIELD_LOCATION, QUDA_CUDA_FIELD_LOCATION = 1, 2
+QUDA_HALF_PRECISION, QUDA_SINGLE_PRECISION, QUDA_DOUBLE_PRECISION = 2, 4, 8
+QUDA_RECONSTRUCT_NO, QUDA_RECONSTRUCT_12 = 18, 12
+QUDA_WILSON_LINKS = 0
+QUDA_QDP_GAUGE_ORDER = 5
+QUDA_ANTI_PERIODIC_T, QUDA_PERIODIC_T = -1, 1
+QUDA_GAUGE_FIXED_NO = 0
+QUDA_WILSON_DSLASH, QUDA_TWISTED_MASS_DSLASH, QUDA_TWISTED_CLOVER_DSLASH = 0, 7, 8
+QUDA_CG_INVERTER, QUDA_BICGSTAB_INVERTER, QUDA_GCR_INVERTER, QUDA_MR_INVERTER, QUDA_MG_INVERTER = 0, 1, 2, 3, 15
+QUDA_MAT_SOLUTION, QUDA_MATDAG_MAT_SOLUTION, QUDA_MATPC_SOLUTION, QUDA_MATPC_DAG_SOLUTION, QUDA_MATPCDAG_MATPC_SOLUTION = 0, 1, 2, 3, 4
+QUDA_DIRECT_SOLVE, QUDA_NORMOP_SOLVE, QUDA_DIRECT_PC_SOLVE, QUDA_NORMOP_PC_SOLVE = 0, 1, 2, 3
+QUDA_MG_CYCLE_VCYCLE, QUDA_MG_CYCLE_FCYCLE, QUDA_MG_CYCLE_WCYCLE, QUDA_MG_CYCLE_RECURSIVE = 0, 1, 2, 3
+QUDA_ADDITIVE_SCHWARZ = 0
+QUDA_L2_RELATIVE_RESIDUAL = 1
+QUDA_MATPC_EVEN_EVEN, QUDA_MATPC_ODD_ODD, QUDA_MATPC_EVEN_EVEN_ASYMMETRIC, QUDA_MATPC_ODD_ODD_ASYMMETRIC = 0, 1, 2, 3
+MATPC = {"ee": 0, "oo": 1, "eeasym": 2, "ooasym": 3}
+QUDA_DAG_NO, QUDA_DAG_YES = 0, 1
+QUDA_KAPPA_NORMALIZATION, QUDA_MASS_NORMALIZATION, QUDA_ASYMMETRIC_MASS_NORMALIZATION = 0, 1, 2
+QUDA_DEFAULT_NORMALIZATION = 0
+QUDA_PRESERVE_SOURCE_NO, QUDA_PRESERVE_SOURCE_YES = 0, 1
+QUDA_DIRAC_ORDER, QUDA_QDP_DIRAC_ORDER = 1, 2
+QUDA_PACKED_CLOVER_ORDER = 5
+QUDA_SILENT, QUDA_SUMMARIZE, QUDA_VERBOSE, QUDA_DEBUG_VERBOSE = 0, 1, 2, 3
+QUDA_TUNE_NO = 0
+QUDA_EVEN_PARITY, QUDA_ODD_PARITY = 0, 1
+QUDA_PARITY_SITE_SUBSET, QUDA_FULL_SITE_SUBSET = 1, 2
+QUDA_DEGRAND_ROSSI_GAMMA_BASIS, QUDA_UKQCD_GAMMA_BASIS = 0, 1
+QUDA_TWIST_MINUS, QUDA_TWIST_PLUS, QUDA_TWIST_NO = -1, 1, 0
+QUDA_USE_INIT_GUESS_NO, QUDA_USE_INIT_GUESS_YES = 0, 1
+QUDA_COMPUTE_NULL_VECTOR_NO, QUDA_COMPUTE_NULL_VECTOR_YES = 0, 1
+QUDA_BOOLEAN_NO, QUDA_BOOLEAN_YES = 0, 1
+
+QUDA_MAX_DIM, QUDA_MAX_MULTI_SHIFT, QUDA_MAX_DWF_LS, QUDA_MAX_MG_LEVEL = 6, 32, 128, 4
+
+_i, _d, _p = C.c_int, C.c_double, C.c_void_p
+
+
+class QudaGaugeParam(C.Structure):
+    _fields_ = [("location", _i), ("X", _i * 4), ("anisotropy", _d), ("tadpole_coeff", _d), ("scale", _d), ("type", _i),
+                ("gauge_order", _i), ("t_boundary", _i), ("cpu_prec", _i), ("cuda_prec", _i), ("reconstruct", _i),
+                ("cuda_prec_sloppy", _i), ("reconstruct_sloppy", _i), ("cuda_prec_precondition", _i),
+                ("reconstruct_precondition", _i), ("gauge_fix", _i), ("ga_pad", _i), ("site_ga_pad", _i), ("staple_pad", _i),
+                ("llfat_ga_pad", _i), ("mom_ga_pad", _i), ("gaugeGiB", _d), ("preserve_gauge", _i),
+                ("staggered_phase_type", _i), ("staggered_phase_applied", _i), ("i_mu", _d), ("overlap", _i),
+                ("overwrite_mom", _i), ("use_resident_gauge", _i), ("use_resident_mom", _i), ("make_resident_gauge", _i),
+                ("make_resident_mom", _i), ("return_result_gauge", _i), ("return_result_mom", _i)]
+
+
+class QudaInvertParam(C.Structure):
+    _fields_ = [("input_location", _i), ("output_location", _i), ("dslash_type", _i), ("inv_type", _i), ("mass", _d),
+                ("kappa", _d), ("m5", _d), ("Ls", _i), ("b_5", _d * QUDA_MAX_DWF_LS), ("c_5", _d * QUDA_MAX_DWF_LS), ("mu", _d),
+                ("epsilon", _d), ("twist_flavor", _i), ("tol", _d), ("tol_restart", _d), ("tol_hq", _d), ("true_res", _d),
+                ("true_res_hq", _d), ("maxiter", _i), ("reliable_delta", _d), ("use_sloppy_partial_accumulator", _i),
+                ("max_res_increase", _i), ("max_res_increase_total", _i), ("heavy_quark_check", _i), ("pipeline", _i),
+                ("num_offset", _i), ("num_src", _i), ("overlap", _i), ("offset", _d * QUDA_MAX_MULTI_SHIFT),
+                ("tol_offset", _d * QUDA_MAX_MULTI_SHIFT), ("tol_hq_offset", _d * QUDA_MAX_MULTI_SHIFT),
+                ("true_res_offset", _d * QUDA_MAX_MULTI_SHIFT), ("iter_res_offset", _d * QUDA_MAX_MULTI_SHIFT),
+                ("true_res_hq_offset", _d * QUDA_MAX_MULTI_SHIFT), ("solution_type", _i), ("solve_type", _i), ("matpc_type", _i),
+                ("dagger", _i), ("mass_normalization", _i), ("solver_normalization", _i), ("preserve_source", _i),
+                ("cpu_prec", _i), ("cuda_prec", _i), ("cuda_prec_sloppy", _i), ("cuda_prec_precondition", _i),
+                ("dirac_order", _i), ("gamma_basis", _i), ("clover_location", _i), ("clover_cpu_prec", _i),
+                ("clover_cuda_prec", _i), ("clover_cuda_prec_sloppy", _i), ("clover_cuda_prec_precondition", _i),
+                ("clover_order", _i), ("use_init_guess", _i), ("clover_coeff", _d), ("compute_clover_trlog", _i),
+                ("trlogA", _d * 2), ("compute_clover", _i), ("compute_clover_inverse", _i), ("return_clover", _i),
+                ("return_clover_inverse", _i), ("verbosity", _i), ("sp_pad", _i), ("cl_pad", _i), ("iter", _i),
+                ("spinorGiB", _d), ("cloverGiB", _d), ("gflops", _d), ("secs", _d), ("tune", _i), ("Nsteps", _i),
+                ("gcrNkrylov", _i), ("inv_type_precondition", _i), ("preconditioner", _p), ("preconditionerUP", _p),
+                ("preconditionerDN", _p), ("dslash_type_precondition", _i), ("verbosity_precondition", _i),
+                ("tol_precondition", _d), ("maxiter_precondition", _i), ("omega", _d), ("precondition_cycle", _i),
+                ("schwarz_type", _i), ("residual_type", _i), ("cuda_prec_ritz", _i), ("nev", _i), ("max_search_dim", _i),
+                ("rhs_idx", _i), ("deflation_grid", _i), ("use_reduced_vector_set", _i), ("eigenval_tol", _d),
+                ("use_cg_updates", _i), ("cg_iterref_tol", _d), ("eigcg_max_restarts", _i), ("max_restart_num", _i),
+                ("inc_tol", _d), ("make_resident_solution", _i), ("use_resident_solution", _i)]
+
+
+class QudaMultigridParam(C.Structure):
+    _L = QUDA_MAX_MG_LEVEL
+    _fields_ = [("invert_param", C.POINTER(QudaInvertParam)), ("n_level", _i), ("geo_block_size", (_i * QUDA_MAX_DIM) * _L),
+                ("spin_block_size", _i * _L), ("n_vec", _i * _L), ("smoother", _i * _L), ("coarse_grid_solution_type", _i * _L),
+                ("smoother_solve_type", _i * _L), ("cycle_type", _i * _L), ("nu_pre", _i * _L), ("nu_post", _i * _L),
+                ("smoother_tol", _d * _L), ("setup_maxiter", _i), ("setup_tol", _d), ("omega", _d * _L),
+                ("global_reduction", _i * _L), ("location", _i * _L), ("compute_null_vector", _i), ("generate_all_levels", _i),
+                ("run_verify", _i), ("vec_infile", C.c_char * 256), ("vec_outfile", C.c_char * 256), ("gflops", _d), ("secs", _d),
+                ("delta_muPR", _d), ("delta_kappaPR", _d), ("delta_cswPR", _d), ("delta_muCG", _d), ("delta_kappaCG", _d),
+                ("delta_cswCG", _d)]
+
+
+# every extern "C" symbol include/quda.h and include/quda_amd_ext.h declare
+QUDA_H_SYMBOLS = ["setVerbosityQuda", "initCommsGridQuda", "initQudaDevice", "initQudaMemory", "initQuda", "endQuda",
+                  "newQudaGaugeParam", "newQudaInvertParam", "newQudaMultigridParam", "printQudaGaugeParam", "printQudaInvertParam",
+                  "printQudaMultigridParam", "loadGaugeQuda", "freeGaugeQuda", "loadCloverQuda", "freeCloverQuda", "invertQuda",
+                  "newMultigridQuda", "destroyMultigridQuda", "dslashQuda", "cloverQuda", "MatQuda", "MatDagMatQuda", "openMagma",
+                  "closeMagma"]
+EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLoad", "qudaAmdSpinorSave", "qudaAmdSpinorCopy",
+                 "qudaAmdSpinorSetTwist", "qudaAmdDiracCreate", "qudaAmdDiracDestroy", "qudaAmdDiracDslash", "qudaAmdDiracDslashXpay",
+                 "qudaAmdDiracM", "qudaAmdDiracMdag", "qudaAmdDiracMdagM", "qudaAmdDiracFlops", "qudaAmdTimeDslash", "qudaAmdTimeM",
+                 "qudaAmdBlasNorm2", "qudaAmdBlasCDot", "qudaAmdBlasAxpy", "qudaAmdDslashBytesPerSite", "qudaAmdDslashFlopsPerSite",
+                 "qudaAmdSetPartitionMask", "qudaAmdComputeStream", "qudaAmdDeviceSynchronize"]
+
+_lib = None
+
+
+def lib():
+    """The loaded libquda.so; raises if the HIP extension has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: build it with `make -C %s` (or __graft_entry__.build()); "
+                               "there is no CPU fallback" % (LIB_PATH, _HERE))
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        L.newQudaGaugeParam.restype = QudaGaugeParam
+        L.newQudaInvertParam.restype = QudaInvertParam
+        L.newQudaMultigridParam.restype = QudaMultigridParam
+        L.newMultigridQuda.restype = _p
+        L.newMultigridQuda.argtypes = [C.POINTER(QudaMultigridParam)]
+        L.destroyMultigridQuda.argtypes = [_p]
+        for name in ("qudaAmdSpinorCreate", "qudaAmdDiracCreate", "qudaAmdComputeStream"):
+            getattr(L, name).restype = _p
+        L.qudaAmdSpinorCreate.argtypes = [_i, _i, _i]
+        L.qudaAmdSpinorDestroy.argtypes = [_p]
+        L.qudaAmdSpinorLoad.argtypes = [_p, _p, C.POINTER(QudaInvertParam)]
+        L.qudaAmdSpinorSave.argtypes = [_p, _p, C.POINTER(QudaInvertParam)]
+        L.qudaAmdSpinorCopy.argtypes = [_p, _p]
+        L.qudaAmdSpinorSetTwist.argtypes = [_p, _i]
+        L.qudaAmdDiracCreate.argtypes = [C.POINTER(QudaInvertParam), _i, _i]
+        L.qudaAmdDiracDestroy.argtypes = [_p]
+        L.qudaAmdDiracDslash.argtypes = [_p, _p, _p, _i]
+        L.qudaAmdDiracDslashXpay.argtypes = [_p, _p, _p, _i, _p, _d]
+        for name in ("qudaAmdDiracM", "qudaAmdDiracMdag", "qudaAmdDiracMdagM"):
+            getattr(L, name).argtypes = [_p, _p, _p]
+        L.qudaAmdDiracFlops.argtypes = [_p]
+        L.qudaAmdDiracFlops.restype = C.c_ulonglong
+        L.qudaAmdTimeDslash.argtypes = [_p, _p, _p, _i, _i]
+        L.qudaAmdTimeDslash.restype = _d
+        L.qudaAmdTimeM.argtypes = [_p, _p, _p, _i]
+        L.qudaAmdTimeM.restype = _d
+        L.qudaAmdBlasNorm2.argtypes = [_p]
+        L.qudaAmdBlasNorm2.restype = _d
+        L.qudaAmdBlasCDot.argtypes = [_p, _p, C.POINTER(_d)]
+        L.qudaAmdBlasAxpy.argtypes = [_d, _p, _p]
+        L.qudaAmdDslashBytesPerSite.argtypes = [C.POINTER(QudaInvertParam), _i, _i]
+        L.qudaAmdDslashBytesPerSite.restype = C.c_longlong
+        L.qudaAmdDslashFlopsPerSite.argtypes = [C.POINTER(QudaInvertParam), _i]
+        L.qudaAmdDslashFlopsPerSite.restype = C.c_longlong
+        L.dslashQuda.argtypes = [_p, _p, C.POINTER(QudaInvertParam), _i]
+        L.MatQuda.argtypes = [_p, _p, C.POINTER(QudaInvertParam)]
+        L.MatDagMatQuda.argtypes = [_p, _p, C.POINTER(QudaInvertParam)]
+        L.invertQuda.argtypes = [_p, _p, C.POINTER(QudaInvertParam)]
+        L.cloverQuda.argtypes = [_p, _p, C.POINTER(QudaInvertParam), C.POINTER(_i), _i]
+        L.loadGaugeQuda.argtypes = [_p, C.POINTER(QudaGaugeParam)]
+        L.loadCloverQuda.argtypes = [_p, _p, C.POINTER(QudaInvertParam)]
+        _lib = L
+    return _lib
+
+
+def _vp(a):
+    return a.ctypes.data_as(_p) if a is not None else None
+
+
+# ---- helpers written the way the reference's tests set things up (tests/dslash_test.cpp:84-200) ----
+def gauge_param(X, cpu_prec=QUDA_DOUBLE_PRECISION, cuda_prec=QUDA_DOUBLE_PRECISION, recon=QUDA_RECONSTRUCT_NO,
+                prec_sloppy=None, recon_sloppy=None, prec_precondition=None, t_boundary=QUDA_ANTI_PERIODIC_T):
+    gp = lib().newQudaGaugeParam()
+    for d in range(4):
+        gp.X[d] = int(X[d])
+    gp.anisotropy = 1.0
+    gp.type = QUDA_WILSON_LINKS
+    gp.gauge_order = QUDA_QDP_GAUGE_ORDER
+    gp.t_boundary = t_boundary
+    gp.cpu_prec = cpu_prec
+    gp.cuda_prec = cuda_prec
+    gp.reconstruct = recon
+    gp.cuda_prec_sloppy = prec_sloppy or cuda_prec
+    gp.reconstruct_sloppy = recon_sloppy or recon
+    gp.cuda_prec_precondition = prec_precondition or gp.cuda_prec_sloppy
+    gp.reconstruct_precondition = gp.reconstruct_sloppy
+    gp.gauge_fix = QUDA_GAUGE_FIXED_NO
+    gp.ga_pad = 0
+    return gp
+
+
+def invert_param(dslash_type=QUDA_TWISTED_MASS_DSLASH, kappa=0.1, mu=0.01, flavor=QUDA_TWIST_PLUS, matpc="ee", dagger=0,
+                 cpu_prec=QUDA_DOUBLE_PRECISION, cuda_prec=QUDA_DOUBLE_PRECISION, prec_sloppy=None, prec_precondition=None,
+                 solution_type=QUDA_MATPC_SOLUTION, gamma_basis=QUDA_DEGRAND_ROSSI_GAMMA_BASIS, dirac_order=QUDA_DIRAC_ORDER):
+    ip = lib().newQudaInvertParam()
+    ip.dslash_type = dslash_type
+    ip.kappa = kappa
+    ip.mu = mu
+    ip.epsilon = 0.0
+    ip.mass = 0.5 / kappa - 4.0
+    ip.twist_flavor = flavor if dslash_type != QUDA_WILSON_DSLASH else QUDA_TWIST_NO
+    ip.matpc_type = MATPC[matpc] if isinstance(matpc, str) else matpc
+    ip.dagger = dagger
+    ip.solution_type = solution_type
+    ip.solve_type = QUDA_DIRECT_PC_SOLVE
+    ip.mass_normalization = QUDA_KAPPA_NORMALIZATION
+    ip.cpu_prec = cpu_prec
+    ip.cuda_prec = cuda_prec
+    ip.cuda_prec_sloppy = prec_sloppy or cuda_prec
+    ip.cuda_prec_precondition = prec_precondition or ip.cuda_prec_sloppy
+    ip.gamma_basis = gamma_basis
+    ip.dirac_order = dirac_order
+    ip.clover_cpu_prec = cpu_prec
+    ip.clover_cuda_prec = cuda_prec
+    ip.clover_cuda_prec_sloppy = ip.cuda_prec_sloppy
+    ip.clover_cuda_prec_precondition = ip.cuda_prec_precondition
+    ip.clover_order = QUDA_PACKED_CLOVER_ORDER
+    ip.clover_coeff = 0.0
+    ip.input_location = ip.output_location = QUDA_CPU_FIELD_LOCATION
+    ip.tune = QUDA_TUNE_NO
+    ip.sp_pad = ip.cl_pad = 0
+    ip.verbosity = QUDA_SILENT
+    ip.inv_type = QUDA_GCR_INVERTER
+    ip.inv_type_precondition = QUDA_INVALID_ENUM
+    ip.tol = 1e-10
+    ip.maxiter = 1000
+    ip.reliable_delta = 1e-4
+    ip.gcrNkrylov = 20
+    ip.use_init_guess = QUDA_USE_INIT_GUESS_NO
+    ip.preserve_source = QUDA_PRESERVE_SOURCE_YES
+    ip.residual_type = QUDA_L2_RELATIVE_RESIDUAL
+    return ip
+
+
+def init(device=0, verbosity=QUDA_SILENT):
+    lib().setVerbosityQuda(verbosity, b"", None)
+    lib().initQuda(int(device))
+
+
+def end():
+    lib().endQuda()
+
+
+def load_gauge(gauge, gp):
+    """gauge: (4, V*18) float64/float32 array in QDP order (even sites then odd)."""
+    gauge = np.ascontiguousarray(gauge)
+    ptrs = (_p * 4)(*[gauge[d].ctypes.data_as(_p) for d in range(4)])
+    lib().loadGaugeQuda(C.cast(ptrs, _p), C.byref(gp))
+    return gp
+
+
+def load_clover(clover, clover_inv, ip):
+    lib().loadCloverQuda(_vp(clover), _vp(clover_inv), C.byref(ip))
+
+
+def dslash(h_in, ip, parity):
+    out = np.empty_like(h_in)
+    lib().dslashQuda(_vp(out), _vp(h_in), C.byref(ip), int(parity))
+    return out
+
+
+def mat(h_in, ip):
+    out = np.empty_like(h_in)
+    lib().MatQuda(_vp(out), _vp(h_in), C.byref(ip))
+    return out
+
+
+def matdagmat(h_in, ip):
+    out = np.empty_like(h_in)
+    lib().MatDagMatQuda(_vp(out), _vp(h_in), C.byref(ip))
+    return out
+
+
+def invert(h_b, ip):
+    x = np.zeros_like(h_b)
+    lib().invertQuda(_vp(x), _vp(h_b), C.byref(ip))
+    return x
+
+
+class Spinor:
+    """Device-resident ColorSpinorField handle (quda_amd_ext.h)."""
+
+    def __init__(self, prec, subset=QUDA_PARITY_SITE_SUBSET, flavor=QUDA_TWIST_PLUS):
+        self.h = lib().qudaAmdSpinorCreate(int(prec), int(subset), int(flavor))
+        self.prec, self.subset = prec, subset
+
+    def load(self, host, ip):
+        lib().qudaAmdSpinorLoad(self.h, _vp(np.ascontiguousarray(host)), C.byref(ip))
+        return self
+
+    def save(self, ip, like):
+        out = np.empty_like(like)
+        lib().qudaAmdSpinorSave(self.h, _vp(out), C.byref(ip))
+        return out
+
+    def norm2(self):
+        return lib().qudaAmdBlasNorm2(self.h)
+
+    def free(self):
+        if self.h:
+            lib().qudaAmdSpinorDestroy(self.h)
+            self.h = None
+
+
+class Dirac:
+    """Operator handle: Dirac::create over the resident gauge/clover (quda_amd_ext.h)."""
+
+    def __init__(self, ip, pc=True, which=0):
+        self.h = lib().qudaAmdDiracCreate(C.byref(ip), int(pc), int(which))
+
+    def dslash(self, out, inp, parity):
+        lib().qudaAmdDiracDslash(self.h, out.h, inp.h, int(parity))
+
+    def dslash_xpay(self, out, inp, parity, x, k):
+        lib().qudaAmdDiracDslashXpay(self.h, out.h, inp.h, int(parity), x.h, float(k))
+
+    def M(self, out, inp):
+        lib().qudaAmdDiracM(self.h, out.h, inp.h)
+
+    def Mdag(self, out, inp):
+        lib().qudaAmdDiracMdag(self.h, out.h, inp.h)
+
+    def MdagM(self, out, inp):
+        lib().qudaAmdDiracMdagM(self.h, out.h, inp.h)
+
+    def time_dslash(self, out, inp, parity, niter):
+        return lib().qudaAmdTimeDslash(self.h, out.h, inp.h, int(parity), int(niter))
+
+    def time_M(self, out, inp, niter):
+        return lib().qudaAmdTimeM(self.h, out.h, inp.h, int(niter))
+
+    def free(self):
+        if self.h:
+            lib().qudaAmdDiracDestroy(self.h)
+            self.h = None

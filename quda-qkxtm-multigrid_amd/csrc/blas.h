@@ -1,0 +1,67 @@
+// blas.h — the fused BLAS-1 / reduction set the GCR / MR / BiCGstab / MG path uses
+// (reference include/blas_quda.h:33-144; CPU twins lib/blas_cpu.cpp:10-358 define the semantics).
+#pragma once
+
+#include <complex>
+#include <vector>
+
+#include "fields.h"
+
+namespace quda {
+
+typedef std::complex<double> Complex;
+struct double3_t { double x, y, z; };
+
+namespace blas {
+
+extern unsigned long long flops;
+extern unsigned long long bytes;
+
+void init();
+void end();
+// when false, reductions stay rank-local (reference global_reduction switch, lib/face_buffer.cpp:409)
+void setGlobalReduction(bool on);
+
+void zero(ColorSpinorField &a);
+void copy(ColorSpinorField &dst, const ColorSpinorField &src);
+
+double norm2(const ColorSpinorField &a);
+double reDotProduct(const ColorSpinorField &x, const ColorSpinorField &y);
+Complex cDotProduct(const ColorSpinorField &x, const ColorSpinorField &y);           // sum conj(x) y
+double3_t cDotProductNormA(const ColorSpinorField &x, const ColorSpinorField &y);    // (re, im, |x|^2)
+double3_t cDotProductNormB(const ColorSpinorField &x, const ColorSpinorField &y);    // (re, im, |y|^2)
+
+void ax(const double &a, ColorSpinorField &x);                                        // x = a x
+void axpy(const double &a, const ColorSpinorField &x, ColorSpinorField &y);           // y = a x + y
+void xpy(const ColorSpinorField &x, ColorSpinorField &y);                             // y = x + y
+void xpay(const ColorSpinorField &x, const double &a, ColorSpinorField &y);           // y = x + a y
+void mxpy(const ColorSpinorField &x, ColorSpinorField &y);                            // y = y - x
+void axpby(const double &a, const ColorSpinorField &x, const double &b, ColorSpinorField &y);  // y = a x + b y
+double xmyNorm(const ColorSpinorField &x, ColorSpinorField &y);                       // y = x - y ; |y|^2
+double axpyNorm(const double &a, const ColorSpinorField &x, ColorSpinorField &y);     // y = a x + y ; |y|^2
+
+void caxpy(const Complex &a, const ColorSpinorField &x, ColorSpinorField &y);         // y = a x + y
+void caxpby(const Complex &a, const ColorSpinorField &x, const Complex &b, ColorSpinorField &y);
+void cxpaypbz(const ColorSpinorField &x, const Complex &a, const ColorSpinorField &y, const Complex &b, ColorSpinorField &z);  // z = x + a y + b z
+double caxpyNorm(const Complex &a, const ColorSpinorField &x, ColorSpinorField &y);
+void caxpyXmaz(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z);   // y += a x ; x -= a z
+void caxpyXmazMR(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z);
+double caxpyXmazNormX(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z);
+void cabxpyAx(const double &a, const Complex &b, ColorSpinorField &x, ColorSpinorField &y);             // x = a x ; y += b x
+double cabxpyAxNorm(const double &a, const Complex &b, ColorSpinorField &x, ColorSpinorField &y);
+Complex caxpyDotzy(const Complex &a, const ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z);  // y += a x ; (z,y)
+void caxpbypzYmbw(const Complex &a, const ColorSpinorField &x, const Complex &b, ColorSpinorField &y, ColorSpinorField &z,
+                  const ColorSpinorField &w);                                         // z += a x + b y ; y -= b w
+double3_t HeavyQuarkResidualNorm(const ColorSpinorField &x, const ColorSpinorField &r);
+
+// vectorised forms used by GCR's orthogonalisation / solution update
+void caxpy(const Complex *a, std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorField *> &y);
+void cDotProduct(Complex *result, std::vector<ColorSpinorField *> &a, std::vector<ColorSpinorField *> &b);
+
+}  // namespace blas
+
+// rank reductions (comm layer)
+void comm_allreduce(double *data, int n);
+void comm_allreduce_max(double *data, int n);
+
+}  // namespace quda

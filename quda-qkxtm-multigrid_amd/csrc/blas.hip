@@ -1,0 +1,396 @@
+// blas.hip — fused BLAS-1 updates and reductions on spinor fields (gfx950).
+//
+// One templated grid-stride kernel; the functor says which of x,y,z,w it reads / writes and how many
+// double-precision partial sums it produces.  Every operand is streamed once with 16-byte per-lane
+// accesses (HBM-bound: (n_in + n_out) x field bytes); sums are accumulated in fp64 regardless of the
+// storage precision (reference QudaSumFloat, lib/reduce_quda.cu:61-63), reduced by wave shuffles
+// (64 lanes) -> LDS -> one fp64 atomic per block, and read back through pinned host memory.
+// fp64/fp32 fields of any spin/colour are treated as flat arrays (complex pairs stay adjacent in the
+// FLOAT2/FLOAT4 planar orders); 16-bit fields go site by site because of their per-site scale.
+#include "blas.h"
+
+#include "device_io.h"
+
+namespace quda {
+namespace blas {
+
+unsigned long long flops = 0;
+unsigned long long bytes = 0;
+
+static double *d_red = nullptr;   // device accumulators
+static double *h_red = nullptr;   // pinned host copy
+static bool g_global_reduction = true;
+constexpr int kMaxRed = 64;
+
+void init() {
+  if (!d_red) HIP_CHECK(hipMalloc((void **)&d_red, kMaxRed * sizeof(double)));
+  if (!h_red) HIP_CHECK(hipHostMalloc((void **)&h_red, kMaxRed * sizeof(double), hipHostMallocDefault));
+}
+void end() {
+  if (d_red) (void)hipFree(d_red);
+  if (h_red) (void)hipHostFree(h_red);
+  d_red = h_red = nullptr;
+}
+void setGlobalReduction(bool on) { g_global_reduction = on; }
+
+struct Seg {           // one contiguous parity block of a field
+  void *v[2];
+  float *norm[2];
+};
+
+template <typename F> struct BlasArg {
+  Seg x, y, z, w;
+  int nseg;
+  long n;        // chunks per segment
+  int stride;    // site path: plane stride
+  F f;
+  double *red;
+};
+
+template <typename real, int M> struct alignas(16) Chunk { real v[M]; };
+
+// ---- functors: operate on one chunk (M reals, complex pairs adjacent) ----
+#define QA_FLAGS(RX, RY, RZ, RW, WX, WY, WZ, WW, NRED)                                        \
+  static constexpr bool rx = RX, ry = RY, rz = RZ, rw = RW, wx = WX, wy = WY, wz = WZ, ww = WW; \
+  static constexpr int nred = NRED;
+
+struct Norm2F { QA_FLAGS(1, 0, 0, 0, 0, 0, 0, 0, 1)
+  template <typename real, int M> __device__ void operator()(real *x, real *, real *, real *, double *r) const {
+#pragma unroll
+    for (int i = 0; i < M; i++) r[0] += (double)x[i] * (double)x[i];
+  } };
+struct ReDotF { QA_FLAGS(1, 1, 0, 0, 0, 0, 0, 0, 1)
+  template <typename real, int M> __device__ void operator()(real *x, real *y, real *, real *, double *r) const {
+#pragma unroll
+    for (int i = 0; i < M; i++) r[0] += (double)x[i] * (double)y[i];
+  } };
+// r0 + i r1 = conj(x) y ; r2 = |x|^2 (NORM=1) or |y|^2 (NORM=2)
+template <int NORM> struct CDotF { QA_FLAGS(1, 1, 0, 0, 0, 0, 0, 0, (NORM ? 3 : 2))
+  template <typename real, int M> __device__ void operator()(real *x, real *y, real *, real *, double *r) const {
+#pragma unroll
+    for (int i = 0; i < M; i += 2) {
+      const double xr = x[i], xi = x[i + 1], yr = y[i], yi = y[i + 1];
+      r[0] += xr * yr + xi * yi;
+      r[1] += xr * yi - xi * yr;
+      if (NORM == 1) r[2] += xr * xr + xi * xi;
+      if (NORM == 2) r[2] += yr * yr + yi * yi;
+    }
+  } };
+struct AxF { double a; QA_FLAGS(1, 0, 0, 0, 1, 0, 0, 0, 0)
+  template <typename real, int M> __device__ void operator()(real *x, real *, real *, real *, double *) const {
+#pragma unroll
+    for (int i = 0; i < M; i++) x[i] *= (real)a;
+  } };
+// y = a x + b y (+ |y|^2 if NRM)
+template <int NRM> struct AxpbyF { double a, b; QA_FLAGS(1, 1, 0, 0, 0, 1, 0, 0, NRM)
+  template <typename real, int M> __device__ void operator()(real *x, real *y, real *, real *, double *r) const {
+#pragma unroll
+    for (int i = 0; i < M; i++) { y[i] = (real)a * x[i] + (real)b * y[i]; if (NRM) r[0] += (double)y[i] * (double)y[i]; }
+  } };
+// y = a x + b y complex (+ |y|^2)
+template <int NRM> struct CaxpbyF { double ar, ai, br, bi; QA_FLAGS(1, 1, 0, 0, 0, 1, 0, 0, NRM)
+  template <typename real, int M> __device__ void operator()(real *x, real *y, real *, real *, double *r) const {
+#pragma unroll
+    for (int i = 0; i < M; i += 2) {
+      const real xr = x[i], xi = x[i + 1], yr = y[i], yi = y[i + 1];
+      y[i] = (real)ar * xr - (real)ai * xi + (real)br * yr - (real)bi * yi;
+      y[i + 1] = (real)ar * xi + (real)ai * xr + (real)br * yi + (real)bi * yr;
+      if (NRM) r[0] += (double)y[i] * (double)y[i] + (double)y[i + 1] * (double)y[i + 1];
+    }
+  } };
+// z = x + a y + b z
+struct CxpaypbzF { double ar, ai, br, bi; QA_FLAGS(1, 1, 1, 0, 0, 0, 1, 0, 0)
+  template <typename real, int M> __device__ void operator()(real *x, real *y, real *z, real *, double *) const {
+#pragma unroll
+    for (int i = 0; i < M; i += 2) {
+      const real yr = y[i], yi = y[i + 1], zr = z[i], zi = z[i + 1];
+      z[i] = x[i] + (real)ar * yr - (real)ai * yi + (real)br * zr - (real)bi * zi;
+      z[i + 1] = x[i + 1] + (real)ar * yi + (real)ai * yr + (real)br * zi + (real)bi * zr;
+    }
+  } };
+// y += a x ; x -= a z  (+ |x|^2)
+template <int NRM> struct CaxpyXmazF { double ar, ai; QA_FLAGS(1, 1, 1, 0, 1, 1, 0, 0, NRM)
+  template <typename real, int M> __device__ void operator()(real *x, real *y, real *z, real *, double *r) const {
+#pragma unroll
+    for (int i = 0; i < M; i += 2) {
+      const real xr = x[i], xi = x[i + 1], zr = z[i], zi = z[i + 1];
+      y[i] += (real)ar * xr - (real)ai * xi;
+      y[i + 1] += (real)ar * xi + (real)ai * xr;
+      x[i] = xr - ((real)ar * zr - (real)ai * zi);
+      x[i + 1] = xi - ((real)ar * zi + (real)ai * zr);
+      if (NRM) r[0] += (double)x[i] * (double)x[i] + (double)x[i + 1] * (double)x[i + 1];
+    }
+  } };
+// x = a x ; y += b x (+ |y|^2)
+template <int NRM> struct CabxpyAxF { double a, br, bi; QA_FLAGS(1, 1, 0, 0, 1, 1, 0, 0, NRM)
+  template <typename real, int M> __device__ void operator()(real *x, real *y, real *, real *, double *r) const {
+#pragma unroll
+    for (int i = 0; i < M; i += 2) {
+      const real xr = (real)a * x[i], xi = (real)a * x[i + 1];
+      x[i] = xr; x[i + 1] = xi;
+      y[i] += (real)br * xr - (real)bi * xi;
+      y[i + 1] += (real)br * xi + (real)bi * xr;
+      if (NRM) r[0] += (double)y[i] * (double)y[i] + (double)y[i + 1] * (double)y[i + 1];
+    }
+  } };
+// y += a x ; (z, y)
+struct CaxpyDotzyF { double ar, ai; QA_FLAGS(1, 1, 1, 0, 0, 1, 0, 0, 2)
+  template <typename real, int M> __device__ void operator()(real *x, real *y, real *z, real *, double *r) const {
+#pragma unroll
+    for (int i = 0; i < M; i += 2) {
+      y[i] += (real)ar * x[i] - (real)ai * x[i + 1];
+      y[i + 1] += (real)ar * x[i + 1] + (real)ai * x[i];
+      const double zr = z[i], zi = z[i + 1], yr = y[i], yi = y[i + 1];
+      r[0] += zr * yr + zi * yi;
+      r[1] += zr * yi - zi * yr;
+    }
+  } };
+// z += a x + b y ; y -= b w
+struct CaxpbypzYmbwF { double ar, ai, br, bi; QA_FLAGS(1, 1, 1, 1, 0, 1, 1, 0, 0)
+  template <typename real, int M> __device__ void operator()(real *x, real *y, real *z, real *w, double *) const {
+#pragma unroll
+    for (int i = 0; i < M; i += 2) {
+      const real yr = y[i], yi = y[i + 1];
+      z[i] += (real)ar * x[i] - (real)ai * x[i + 1] + (real)br * yr - (real)bi * yi;
+      z[i + 1] += (real)ar * x[i + 1] + (real)ai * x[i] + (real)br * yi + (real)bi * yr;
+      y[i] = yr - ((real)br * w[i] - (real)bi * w[i + 1]);
+      y[i + 1] = yi - ((real)br * w[i + 1] + (real)bi * w[i]);
+    }
+  } };
+
+// ---- kernel ----
+template <typename T, int M, bool SITE, typename F>
+__global__ void __launch_bounds__(256) blas_kernel(BlasArg<F> arg) {
+  using real = typename Store<T>::real;
+  double red[F::nred > 0 ? F::nred : 1];
+#pragma unroll
+  for (int k = 0; k < (F::nred > 0 ? F::nred : 1); k++) red[k] = 0.0;
+  const long total = arg.n * arg.nseg;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int seg = i >= arg.n ? 1 : 0;
+    const long j = i - seg * arg.n;
+    alignas(16) real x[M];
+    alignas(16) real y[M];
+    alignas(16) real z[M];
+    alignas(16) real w[M];
+    if (SITE) {
+      if (F::rx) Planar<T, M>::load(x, arg.x.v[seg], arg.stride, (int)j, arg.x.norm[seg], (int)j);
+      if (F::ry) Planar<T, M>::load(y, arg.y.v[seg], arg.stride, (int)j, arg.y.norm[seg], (int)j);
+      if (F::rz) Planar<T, M>::load(z, arg.z.v[seg], arg.stride, (int)j, arg.z.norm[seg], (int)j);
+      if (F::rw) Planar<T, M>::load(w, arg.w.v[seg], arg.stride, (int)j, arg.w.norm[seg], (int)j);
+    } else {
+      using V = Chunk<real, M>;
+      if (F::rx) *reinterpret_cast<V *>(x) = reinterpret_cast<const V *>(arg.x.v[seg])[j];
+      if (F::ry) *reinterpret_cast<V *>(y) = reinterpret_cast<const V *>(arg.y.v[seg])[j];
+      if (F::rz) *reinterpret_cast<V *>(z) = reinterpret_cast<const V *>(arg.z.v[seg])[j];
+      if (F::rw) *reinterpret_cast<V *>(w) = reinterpret_cast<const V *>(arg.w.v[seg])[j];
+    }
+    arg.f.template operator()<real, M>(x, y, z, w, red);
+    if (SITE) {
+      if (F::wx) Planar<T, M>::store(x, arg.x.v[seg], arg.stride, (int)j, arg.x.norm[seg], (int)j);
+      if (F::wy) Planar<T, M>::store(y, arg.y.v[seg], arg.stride, (int)j, arg.y.norm[seg], (int)j);
+      if (F::wz) Planar<T, M>::store(z, arg.z.v[seg], arg.stride, (int)j, arg.z.norm[seg], (int)j);
+      if (F::ww) Planar<T, M>::store(w, arg.w.v[seg], arg.stride, (int)j, arg.w.norm[seg], (int)j);
+    } else {
+      using V = Chunk<real, M>;
+      if (F::wx) reinterpret_cast<V *>(arg.x.v[seg])[j] = *reinterpret_cast<V *>(x);
+      if (F::wy) reinterpret_cast<V *>(arg.y.v[seg])[j] = *reinterpret_cast<V *>(y);
+      if (F::wz) reinterpret_cast<V *>(arg.z.v[seg])[j] = *reinterpret_cast<V *>(z);
+      if (F::ww) reinterpret_cast<V *>(arg.w.v[seg])[j] = *reinterpret_cast<V *>(w);
+    }
+  }
+  if (F::nred > 0) {
+    __shared__ double lds[4][F::nred > 0 ? F::nred : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < F::nred; k++) {
+      double v = red[k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) lds[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < F::nred) {
+      double v = 0;
+      for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) v += lds[wv][threadIdx.x];
+      atomicAdd(&arg.red[threadIdx.x], v);
+    }
+  }
+}
+
+static Seg segOf(const ColorSpinorField &f) {
+  Seg s;
+  ColorSpinorField &g = const_cast<ColorSpinorField &>(f);
+  if (f.SiteSubset() == QUDA_FULL_SITE_SUBSET) {
+    s.v[0] = g.Even().V(); s.v[1] = g.Odd().V();
+    s.norm[0] = (float *)g.Even().Norm(); s.norm[1] = (float *)g.Odd().Norm();
+  } else {
+    s.v[0] = g.V(); s.v[1] = nullptr; s.norm[0] = (float *)g.Norm(); s.norm[1] = nullptr;
+  }
+  return s;
+}
+
+static void checkSame(const ColorSpinorField &a, const ColorSpinorField &b) {
+  if (a.Location() != QUDA_CUDA_FIELD_LOCATION || b.Location() != QUDA_CUDA_FIELD_LOCATION) errorQuda("blas needs device fields");
+  if (a.Precision() != b.Precision()) errorQuda("blas precision mismatch %d vs %d (copy to a common precision first)", a.Precision(), b.Precision());
+  if (a.VolumeCB() != b.VolumeCB() || a.SiteSubset() != b.SiteSubset() || a.Nspin() != b.Nspin() || a.Ncolor() != b.Ncolor() || a.Stride() != b.Stride())
+    errorQuda("blas geometry mismatch");
+}
+
+template <typename F>
+static void launch(const F &f, const ColorSpinorField &x, const ColorSpinorField *y, const ColorSpinorField *z, const ColorSpinorField *w, double *out) {
+  if (!d_red) init();
+  if (y) checkSame(x, *y);
+  if (z) checkSame(x, *z);
+  if (w) checkSame(x, *w);
+  BlasArg<F> arg;
+  arg.x = segOf(x);
+  arg.y = y ? segOf(*y) : arg.x;
+  arg.z = z ? segOf(*z) : arg.x;
+  arg.w = w ? segOf(*w) : arg.x;
+  arg.nseg = x.SiteSubset() == QUDA_FULL_SITE_SUBSET ? 2 : 1;
+  arg.stride = x.Stride();
+  arg.f = f;
+  arg.red = d_red;
+  hipStream_t s = computeStream();
+  if (F::nred > 0) HIP_CHECK(hipMemsetAsync(d_red, 0, F::nred * sizeof(double), s));
+  const long nreal = (long)x.Stride() * x.Nspin() * x.Ncolor() * 2;
+  const int bs = 256;
+  auto grid = [&](long n) { long b = (n * arg.nseg + bs - 1) / bs; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); };
+  switch (x.Precision()) {
+    case QUDA_DOUBLE_PRECISION:
+      arg.n = nreal / 2;
+      hipLaunchKernelGGL((blas_kernel<double, 2, false, F>), dim3(grid(arg.n)), dim3(bs), 0, s, arg);
+      break;
+    case QUDA_SINGLE_PRECISION:
+      arg.n = nreal / 4;
+      if (nreal % 4) errorQuda("field length %ld not a multiple of 4", nreal);
+      hipLaunchKernelGGL((blas_kernel<float, 4, false, F>), dim3(grid(arg.n)), dim3(bs), 0, s, arg);
+      break;
+    case QUDA_HALF_PRECISION:
+      if (x.Nspin() != 4 || x.Ncolor() != 3) errorQuda("16-bit blas only for fine-grid spinors");
+      arg.n = x.VolumeCB();
+      hipLaunchKernelGGL((blas_kernel<short, 24, true, F>), dim3(grid(arg.n)), dim3(bs), 0, s, arg);
+      break;
+    default: errorQuda("bad precision %d", x.Precision());
+  }
+  HIP_CHECK(hipGetLastError());
+  if (F::nred > 0) {
+    HIP_CHECK(hipMemcpyAsync(h_red, d_red, F::nred * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (int k = 0; k < F::nred; k++) out[k] = h_red[k];
+    if (g_global_reduction) comm_allreduce(out, F::nred);
+  }
+  const int nrd = F::rx + F::ry + F::rz + F::rw, nwr = F::wx + F::wy + F::wz + F::ww;
+  bytes += (unsigned long long)(nrd + nwr) * x.RealLength() * x.Precision();
+  flops += (unsigned long long)2 * x.RealLength() * (nrd + nwr);
+}
+
+void zero(ColorSpinorField &a) { a.zero(); }
+void copy(ColorSpinorField &dst, const ColorSpinorField &src) { copyColorSpinor(dst, src); }
+
+double norm2(const ColorSpinorField &a) { double r[1]; launch(Norm2F(), a, nullptr, nullptr, nullptr, r); return r[0]; }
+double reDotProduct(const ColorSpinorField &x, const ColorSpinorField &y) { double r[1]; launch(ReDotF(), x, &y, nullptr, nullptr, r); return r[0]; }
+Complex cDotProduct(const ColorSpinorField &x, const ColorSpinorField &y) { double r[2]; launch(CDotF<0>(), x, &y, nullptr, nullptr, r); return Complex(r[0], r[1]); }
+double3_t cDotProductNormA(const ColorSpinorField &x, const ColorSpinorField &y) { double r[3]; launch(CDotF<1>(), x, &y, nullptr, nullptr, r); return {r[0], r[1], r[2]}; }
+double3_t cDotProductNormB(const ColorSpinorField &x, const ColorSpinorField &y) { double r[3]; launch(CDotF<2>(), x, &y, nullptr, nullptr, r); return {r[0], r[1], r[2]}; }
+
+void ax(const double &a, ColorSpinorField &x) { AxF f; f.a = a; launch(f, x, nullptr, nullptr, nullptr, nullptr); }
+void axpby(const double &a, const ColorSpinorField &x, const double &b, ColorSpinorField &y) { AxpbyF<0> f; f.a = a; f.b = b; launch(f, x, &y, nullptr, nullptr, nullptr); }
+void axpy(const double &a, const ColorSpinorField &x, ColorSpinorField &y) { axpby(a, x, 1.0, y); }
+void xpy(const ColorSpinorField &x, ColorSpinorField &y) { axpby(1.0, x, 1.0, y); }
+void xpay(const ColorSpinorField &x, const double &a, ColorSpinorField &y) { axpby(1.0, x, a, y); }
+void mxpy(const ColorSpinorField &x, ColorSpinorField &y) { axpby(-1.0, x, 1.0, y); }
+double xmyNorm(const ColorSpinorField &x, ColorSpinorField &y) { AxpbyF<1> f; f.a = 1.0; f.b = -1.0; double r[1]; launch(f, x, &y, nullptr, nullptr, r); return r[0]; }
+double axpyNorm(const double &a, const ColorSpinorField &x, ColorSpinorField &y) { AxpbyF<1> f; f.a = a; f.b = 1.0; double r[1]; launch(f, x, &y, nullptr, nullptr, r); return r[0]; }
+
+void caxpby(const Complex &a, const ColorSpinorField &x, const Complex &b, ColorSpinorField &y) {
+  CaxpbyF<0> f; f.ar = a.real(); f.ai = a.imag(); f.br = b.real(); f.bi = b.imag();
+  launch(f, x, &y, nullptr, nullptr, nullptr);
+}
+void caxpy(const Complex &a, const ColorSpinorField &x, ColorSpinorField &y) { caxpby(a, x, Complex(1.0, 0.0), y); }
+double caxpyNorm(const Complex &a, const ColorSpinorField &x, ColorSpinorField &y) {
+  CaxpbyF<1> f; f.ar = a.real(); f.ai = a.imag(); f.br = 1.0; f.bi = 0.0; double r[1];
+  launch(f, x, &y, nullptr, nullptr, r); return r[0];
+}
+void cxpaypbz(const ColorSpinorField &x, const Complex &a, const ColorSpinorField &y, const Complex &b, ColorSpinorField &z) {
+  CxpaypbzF f; f.ar = a.real(); f.ai = a.imag(); f.br = b.real(); f.bi = b.imag();
+  launch(f, x, &y, &z, nullptr, nullptr);
+}
+void caxpyXmaz(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z) {
+  CaxpyXmazF<0> f; f.ar = a.real(); f.ai = a.imag(); launch(f, x, &y, &z, nullptr, nullptr);
+}
+void caxpyXmazMR(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z) { caxpyXmaz(a, x, y, z); }
+double caxpyXmazNormX(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z) {
+  CaxpyXmazF<1> f; f.ar = a.real(); f.ai = a.imag(); double r[1]; launch(f, x, &y, &z, nullptr, r); return r[0];
+}
+void cabxpyAx(const double &a, const Complex &b, ColorSpinorField &x, ColorSpinorField &y) {
+  CabxpyAxF<0> f; f.a = a; f.br = b.real(); f.bi = b.imag(); launch(f, x, &y, nullptr, nullptr, nullptr);
+}
+double cabxpyAxNorm(const double &a, const Complex &b, ColorSpinorField &x, ColorSpinorField &y) {
+  CabxpyAxF<1> f; f.a = a; f.br = b.real(); f.bi = b.imag(); double r[1]; launch(f, x, &y, nullptr, nullptr, r); return r[0];
+}
+Complex caxpyDotzy(const Complex &a, const ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z) {
+  CaxpyDotzyF f; f.ar = a.real(); f.ai = a.imag(); double r[2]; launch(f, x, &y, &z, nullptr, r); return Complex(r[0], r[1]);
+}
+void caxpbypzYmbw(const Complex &a, const ColorSpinorField &x, const Complex &b, ColorSpinorField &y, ColorSpinorField &z, const ColorSpinorField &w) {
+  CaxpbypzYmbwF f; f.ar = a.real(); f.ai = a.imag(); f.br = b.real(); f.bi = b.imag();
+  launch(f, x, &y, &z, &w, nullptr);
+}
+
+// heavy-quark residual: sum_sites |r(x)|^2 / |x(x)|^2 — needs the site structure (reference lib/blas_cpu.cpp:311-352)
+template <typename T> __global__ void hq_kernel(const void *x, const float *xn, const void *r, const float *rn, int stride, int Vh, double *red) {
+  using real = typename Store<T>::real;
+  double acc[3] = {0, 0, 0};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Vh; i += gridDim.x * blockDim.x) {
+    real a[24], b[24];
+    Planar<T, 24>::load(a, x, stride, i, xn, i);
+    Planar<T, 24>::load(b, r, stride, i, rn, i);
+    double x2 = 0, r2 = 0;
+#pragma unroll
+    for (int k = 0; k < 24; k++) { x2 += (double)a[k] * a[k]; r2 += (double)b[k] * b[k]; }
+    acc[0] += x2; acc[1] += r2; acc[2] += x2 > 0.0 ? r2 / x2 : 1.0;
+  }
+  for (int k = 0; k < 3; k++) {
+    double v = acc[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&red[k], v);
+  }
+}
+
+double3_t HeavyQuarkResidualNorm(const ColorSpinorField &x, const ColorSpinorField &r) {
+  if (!d_red) init();
+  checkSame(x, r);
+  if (x.Nspin() != 4 || x.Ncolor() != 3) errorQuda("heavy-quark residual only for fine-grid spinors");
+  hipStream_t s = computeStream();
+  HIP_CHECK(hipMemsetAsync(d_red, 0, 3 * sizeof(double), s));
+  const Seg sx = segOf(x), sr = segOf(r);
+  const int nseg = x.SiteSubset() == QUDA_FULL_SITE_SUBSET ? 2 : 1, bs = 256;
+  for (int sg = 0; sg < nseg; sg++) {
+    int nb = (x.VolumeCB() + bs - 1) / bs; if (nb > 2048) nb = 2048;
+    switch (x.Precision()) {
+      case QUDA_DOUBLE_PRECISION: hipLaunchKernelGGL((hq_kernel<double>), dim3(nb), dim3(bs), 0, s, sx.v[sg], sx.norm[sg], sr.v[sg], sr.norm[sg], x.Stride(), x.VolumeCB(), d_red); break;
+      case QUDA_SINGLE_PRECISION: hipLaunchKernelGGL((hq_kernel<float>), dim3(nb), dim3(bs), 0, s, sx.v[sg], sx.norm[sg], sr.v[sg], sr.norm[sg], x.Stride(), x.VolumeCB(), d_red); break;
+      default: hipLaunchKernelGGL((hq_kernel<short>), dim3(nb), dim3(bs), 0, s, sx.v[sg], sx.norm[sg], sr.v[sg], sr.norm[sg], x.Stride(), x.VolumeCB(), d_red); break;
+    }
+  }
+  HIP_CHECK(hipMemcpyAsync(h_red, d_red, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  double out[3] = {h_red[0], h_red[1], h_red[2]};
+  double vol = (double)x.Volume();
+  if (g_global_reduction) { comm_allreduce(out, 3); double v[1] = {vol}; comm_allreduce(v, 1); vol = v[0]; }
+  return {out[0], out[1], out[2] / vol};
+}
+
+// vectorised forms: y_j += sum_i a[i*ny + j] x_i ; result[i*nb + j] = (a_i, b_j)
+void caxpy(const Complex *a, std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorField *> &y) {
+  for (size_t j = 0; j < y.size(); j++)
+    for (size_t i = 0; i < x.size(); i++) caxpy(a[i * y.size() + j], *x[i], *y[j]);
+}
+void cDotProduct(Complex *result, std::vector<ColorSpinorField *> &a, std::vector<ColorSpinorField *> &b) {
+  for (size_t i = 0; i < a.size(); i++)
+    for (size_t j = 0; j < b.size(); j++) result[i * b.size() + j] = cDotProduct(*a[i], *b[j]);
+}
+
+}  // namespace blas
+}  // namespace quda

@@ -1,0 +1,199 @@
+// device_io.h — register <-> HBM accessors for the planar field layouts (gfx950).
+//
+// All loads/stores are 16 bytes per lane where the layout allows it (double2 / float4; short4 = 8 B for
+// the 16-bit formats), unit stride across the wave, so one wave instruction moves 1 KiB (or 512 B) of
+// consecutive addresses.  16-bit storage is int16 fixed point with an fp32 per-site (spinor) / per-chiral-
+// block (clover) scale, as in the reference (lib/io_spinor.h:49-62, :282-319; MAX_SHORT quda_internal.h:30);
+// links use a fixed scale (|U_ij| <= 1).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace quda {
+
+constexpr float kShortMax = 32767.0f;
+constexpr float kShortInv = 1.0f / 32767.0f;
+
+template <typename T> struct Store;
+template <> struct Store<double> {
+  using real = double;
+  static constexpr int N = 2;       // reals per 16-byte vector
+  static constexpr bool fixed = false;
+};
+template <> struct Store<float> {
+  using real = float;
+  static constexpr int N = 4;
+  static constexpr bool fixed = false;
+};
+template <> struct Store<short> {
+  using real = float;
+  static constexpr int N = 4;
+  static constexpr bool fixed = true;
+};
+
+// ---- generic planar vector field of NR reals per site ----
+template <typename T, int NR> struct Planar;
+
+// Addressing: every planar block is accessed through a raw buffer descriptor (4 SGPRs: base, bytes) with
+// ONE 32-bit per-lane byte offset (VGPR) and the plane offset k*stride*16 as the instruction's scalar
+// soffset -> `buffer_load_dwordx4 v[..], v_off, s[rsrc], s_plane offen`.  Compared with flat global loads
+// this removes a 64-bit address pair per plane (21 planes per hop in fp64), which is what lets the stencil
+// double-buffer two directions in registers without spilling; out-of-range lanes read 0 instead of faulting.
+// One block (NR reals x stride sites) must stay below 4 GiB, true for every local volume of interest.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+template <typename T, int NR> __device__ __forceinline__ __amdgpu_buffer_rsrc_t planar_rsrc(const void *base, int stride) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)((unsigned)stride * (unsigned)(NR * sizeof(T))), 0x00020000);
+}
+
+template <int NR> struct Planar<double, NR> {
+  static __device__ __forceinline__ void load(double *r, const void *base, int stride, int x, const float *, int) {
+    const __amdgpu_buffer_rsrc_t rs = planar_rsrc<double, NR>(base, stride);
+    const int off = x * 16;
+#pragma unroll
+    for (int k = 0; k < NR / 2; k++) {
+      const double2 t = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, off, k * stride * 16, 0));
+      r[2 * k] = t.x;
+      r[2 * k + 1] = t.y;
+    }
+  }
+  static __device__ __forceinline__ void store(const double *r, void *base, int stride, int x, float *, int) {
+    const __amdgpu_buffer_rsrc_t rs = planar_rsrc<double, NR>(base, stride);
+    const int off = x * 16;
+#pragma unroll
+    for (int k = 0; k < NR / 2; k++)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, make_double2(r[2 * k], r[2 * k + 1])), rs, off, k * stride * 16, 0);
+  }
+};
+
+template <int NR> struct Planar<float, NR> {
+  static __device__ __forceinline__ void load(float *r, const void *base, int stride, int x, const float *, int) {
+    const __amdgpu_buffer_rsrc_t rs = planar_rsrc<float, NR>(base, stride);
+    const int off = x * 16;
+#pragma unroll
+    for (int k = 0; k < NR / 4; k++) {
+      const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, k * stride * 16, 0));
+      r[4 * k] = t.x; r[4 * k + 1] = t.y; r[4 * k + 2] = t.z; r[4 * k + 3] = t.w;
+    }
+    if (NR % 4) {  // trailing float2 plane (18-real links)
+      const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, x * 8, (NR / 4) * stride * 16, 0));
+      r[NR - 2] = t.x; r[NR - 1] = t.y;
+    }
+  }
+  static __device__ __forceinline__ void store(const float *r, void *base, int stride, int x, float *, int) {
+    const __amdgpu_buffer_rsrc_t rs = planar_rsrc<float, NR>(base, stride);
+    const int off = x * 16;
+#pragma unroll
+    for (int k = 0; k < NR / 4; k++)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, make_float4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3])), rs, off,
+                                             k * stride * 16, 0);
+    if (NR % 4) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, make_float2(r[NR - 2], r[NR - 1])), rs, x * 8, (NR / 4) * stride * 16, 0);
+  }
+};
+
+// 16-bit fixed point.  norm == nullptr: fixed unit scale (links); else per-site scale at norm[nidx].
+template <int NR> struct Planar<short, NR> {
+  static __device__ __forceinline__ void load(float *r, const void *base, int stride, int x, const float *norm, int nidx) {
+    const float s = norm ? norm[nidx] * kShortInv : kShortInv;
+    const __amdgpu_buffer_rsrc_t rs = planar_rsrc<short, NR>(base, stride);
+    const int off = x * 8;
+#pragma unroll
+    for (int k = 0; k < NR / 4; k++) {
+      const short4 t = __builtin_bit_cast(short4, __builtin_amdgcn_raw_buffer_load_b64(rs, off, k * stride * 8, 0));
+      r[4 * k] = t.x * s; r[4 * k + 1] = t.y * s; r[4 * k + 2] = t.z * s; r[4 * k + 3] = t.w * s;
+    }
+    if (NR % 4) {
+      const short2 t = __builtin_bit_cast(short2, __builtin_amdgcn_raw_buffer_load_b32(rs, x * 4, (NR / 4) * stride * 8, 0));
+      r[NR - 2] = t.x * s; r[NR - 1] = t.y * s;
+    }
+  }
+  static __device__ __forceinline__ short q16(float v) { return (short)__float2int_rn(fminf(fmaxf(v, -kShortMax), kShortMax)); }
+  static __device__ __forceinline__ void store(const float *r, void *base, int stride, int x, float *norm, int nidx) {
+    float s = kShortMax;
+    if (norm) {
+      float m = 0.f;
+#pragma unroll
+      for (int k = 0; k < NR; k++) m = fmaxf(m, fabsf(r[k]));
+      norm[nidx] = m;
+      s = m > 0.f ? kShortMax / m : 0.f;
+    }
+    const __amdgpu_buffer_rsrc_t rs = planar_rsrc<short, NR>(base, stride);
+    const int off = x * 8;
+#pragma unroll
+    for (int k = 0; k < NR / 4; k++)
+      __builtin_amdgcn_raw_buffer_store_b64(
+          __builtin_bit_cast(u32x2_t, make_short4(q16(r[4 * k] * s), q16(r[4 * k + 1] * s), q16(r[4 * k + 2] * s), q16(r[4 * k + 3] * s))), rs, off,
+          k * stride * 8, 0);
+    if (NR % 4)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, make_short2(q16(r[NR - 2] * s), q16(r[NR - 1] * s))), rs, x * 4,
+                                            (NR / 4) * stride * 8, 0);
+  }
+};
+
+// bytes of one planar block of NR reals x stride sites
+template <typename T> __host__ __device__ constexpr size_t storeSize() { return sizeof(T); }
+
+// ---- SU(3) link: 18 reals row-major (row*6 + col*2 + re/im); R = 18 stored fully, R = 12 rows 0,1 stored,
+// row 2 = conj(row0 x row1) * sign (sign carries a folded anti-periodic boundary, reference
+// tests/test_util.cpp:283-296 / lib/read_gauge.h) ----
+template <typename T, int R> struct Link {
+  using real = typename Store<T>::real;
+  static __device__ __forceinline__ void load(real *U, const void *blk, int stride, int x, real sign) {
+    Planar<T, R>::load(U, blk, stride, x, nullptr, 0);
+    if (R == 12) {
+      // c = conj(a x b)
+#define QA_CROSS(i, j, k)                                                                               \
+  U[12 + 2 * i] = sign * ((U[2 * j] * U[6 + 2 * k] - U[2 * j + 1] * U[6 + 2 * k + 1]) -                \
+                          (U[2 * k] * U[6 + 2 * j] - U[2 * k + 1] * U[6 + 2 * j + 1]));                \
+  U[12 + 2 * i + 1] = -sign * ((U[2 * j] * U[6 + 2 * k + 1] + U[2 * j + 1] * U[6 + 2 * k]) -           \
+                               (U[2 * k] * U[6 + 2 * j + 1] + U[2 * k + 1] * U[6 + 2 * j]));
+      QA_CROSS(0, 1, 2)
+      QA_CROSS(1, 2, 0)
+      QA_CROSS(2, 0, 1)
+#undef QA_CROSS
+    }
+  }
+};
+
+// out(3 complex) = U(3x3) * in(3 complex)
+template <typename real> __device__ __forceinline__ void su3_mv(real *o, const real *U, const real *v) {
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    real re = U[r * 6 + 0] * v[0] - U[r * 6 + 1] * v[1];
+    real im = U[r * 6 + 0] * v[1] + U[r * 6 + 1] * v[0];
+    re += U[r * 6 + 2] * v[2] - U[r * 6 + 3] * v[3];
+    im += U[r * 6 + 2] * v[3] + U[r * 6 + 3] * v[2];
+    re += U[r * 6 + 4] * v[4] - U[r * 6 + 5] * v[5];
+    im += U[r * 6 + 4] * v[5] + U[r * 6 + 5] * v[4];
+    o[2 * r] = re;
+    o[2 * r + 1] = im;
+  }
+}
+
+// Hermitian 6x6 chiral block in packed order (6 real diagonal + 15 complex strictly-lower entries stored
+// column by column; reference tests/clover_reference.cpp:45-53) times 6 complex.
+template <typename real> __device__ __forceinline__ void clover_block_mv(real *o, const real *C, const real *v) {
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    real re = C[i] * v[2 * i], im = C[i] * v[2 * i + 1];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      if (j < i) {  // lower triangle: L(i,j)
+        const int k = 15 - (6 - j) * (5 - j) / 2 + i - j - 1;
+        const real lr = C[6 + 2 * k], li = C[6 + 2 * k + 1];
+        re += lr * v[2 * j] - li * v[2 * j + 1];
+        im += lr * v[2 * j + 1] + li * v[2 * j];
+      } else if (j > i) {  // upper triangle: conj(L(j,i))
+        const int k = 15 - (6 - i) * (5 - i) / 2 + j - i - 1;
+        const real lr = C[6 + 2 * k], li = -C[6 + 2 * k + 1];
+        re += lr * v[2 * j] - li * v[2 * j + 1];
+        im += lr * v[2 * j + 1] + li * v[2 * j];
+      }
+    }
+    o[2 * i] = re;
+    o[2 * i + 1] = im;
+  }
+}
+
+}  // namespace quda

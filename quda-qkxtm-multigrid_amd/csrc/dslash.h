@@ -1,0 +1,50 @@
+// dslash.h — host interface of the fine-grid stencil kernels (Wilson / twisted-mass / twisted-clover).
+//
+// Replaces the reference's per-action free functions wilsonDslashCuda (include/dslash_quda.h:45),
+// twistedMassDslashCuda (lib/dslash_twisted_mass.cu:167), twistedCloverDslashCuda
+// (lib/dslash_twisted_clover.cu:257), twistGamma5Cuda (lib/dslash_quda.cu:430) and
+// twistCloverGamma5Cuda (:562) with one parameterised launch.
+#pragma once
+
+#include "fields.h"
+
+namespace quda {
+
+// what the kernel does with the accumulated hopping term  acc = sum_{8 dirs} U P psi
+enum DslashMode {
+  DSLASH_PLAIN = 0,            // out = acc                       [xpay: out = x + k acc]             (Wilson)
+  DSLASH_TWIST_INV = 1,        // out = b (1 + i a g5) acc        [xpay: out = x + b(..)acc, b incl. k] (QUDA_DEG_DSLASH_TWIST_INV)
+  DSLASH_TWIST_INV_DSLASH = 2, // acc built from (1 + i a g5) psi; out = b acc [xpay: x + b acc]       (QUDA_DEG_TWIST_INV_DSLASH)
+  DSLASH_TWIST_XPAY = 3,       // out = k acc + (1 + i a g5) x                                         (QUDA_DEG_DSLASH_TWIST_XPAY)
+  DSLASH_CLOVER_TWIST_INV = 4, // out = Ainv (A + i a g5) acc     [xpay: out = x + k Ainv(..)acc]      (QUDA_DEG_DSLASH_CLOVER_TWIST_INV)
+  DSLASH_CLOVER_TWIST_XPAY = 5 // out = k acc + (A + i a g5) x                                         (QUDA_DEG_DSLASH_CLOVER_TWIST_XPAY)
+};
+
+struct DslashParam {
+  DslashMode mode = DSLASH_PLAIN;
+  int parity = 0;      // parity of the OUTPUT sites
+  int dagger = 0;
+  double a = 0, b = 1, k = 0;   // already dagger-adjusted by the caller
+  const ColorSpinorField *x = nullptr;  // xpay field or nullptr
+  const CloverField *clover = nullptr;
+  int kernel_type = 0;  // 0 interior(+all if unpartitioned), 1 exterior
+};
+
+// out(parity) = stencil(in(other parity)); fields must be device parity fields of equal precision.
+void applyDslash(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, const DslashParam &p);
+
+// site-local kernels
+enum SiteOp {
+  SITE_TWIST = 0,              // out = b (1 + i a g5) in
+  SITE_CLOVER = 1,             // out = A in           (or Ainv in if inverse)
+  SITE_CLOVER_TWIST = 2,       // out = (A + i a g5) in
+  SITE_CLOVER_TWIST_INV = 3    // out = Ainv (A + i a g5) in
+};
+void applySite(ColorSpinorField &out, const ColorSpinorField &in, SiteOp op, double a, double b, const CloverField *clover,
+               int parity, bool inverse);
+
+// analytic work model per checkerboard site
+long long dslashFlopsPerSite(DslashMode mode, bool xpay);
+long long dslashBytesPerSite(QudaPrecision prec, int recon, DslashMode mode, bool xpay);
+
+}  // namespace quda

@@ -1,0 +1,457 @@
+// dslash.hip — fine-grid even-odd Wilson / twisted-mass / twisted-clover stencil for gfx950 (MI355X).
+//
+// What it computes (reference semantics): tests/wilson_dslash_reference.cpp:106-133 (hop), :233-263 (twist),
+// tests/clover_reference.cpp:19-64, :203-232 (clover, twisted clover); device-side behaviour of
+// lib/dslash_core/tm_dslash_gt200_core.h / tmc_dslash_*_core.h (epilogues) — re-designed, not translated:
+//
+//  * one lane = one checkerboard site; every global access is a 16-byte (fp64/fp32) or 8-byte (16-bit)
+//    per-lane, unit-stride stream, i.e. 1 KiB / 512 B per wave instruction;
+//  * links come from the bidirectional pre-daggered layout (fields.h): no neighbour index and no dagger
+//    branch on the link side, 8 perfectly aligned streams per site;
+//  * spin basis is chiral (DeGrand-Rossi): each of the 8 projections keeps two independent colour vectors
+//    (h0,h1), the other two rows are +-1/+-i multiples; the twist is a per-chirality complex scale and
+//    the clover term two Hermitian 6x6 blocks — all fused into the epilogue, nothing is re-read;
+//  * spinor neighbour re-use is left to L2/MALL: the block index is re-mapped so that each XCD (private
+//    4 MiB L2) sweeps a contiguous slab of time slices instead of the default round-robin interleave;
+//  * index arithmetic uses multiply-high fast division (no software integer divide on gfx950).
+//
+// Roofline: HBM-bound; algorithmic bytes per site = 8 R P + 24 P (in) + 24 P (out) [+ 24 P xpay]
+// [+ 144 P clover & inverse] (+ norms for 16-bit), SURVEY.md section 8d.
+#include "dslash.h"
+
+#include "device_io.h"
+
+namespace quda {
+
+template <typename real> struct DslashArg {
+  void *out;
+  float *outNorm;
+  const void *in;
+  const float *inNorm;
+  const void *x;
+  const float *xNorm;
+  const char *gauge;  // base of this parity's 8 direction blocks
+  size_t link_bytes;
+  const void *clA, *clAinv;
+  const float *clAn, *clAinvN;
+  int sp_stride, g_stride, cl_stride;
+  int Vh, Xh, Y, Z, T;
+  FastDiv dXh, dY, dZ;
+  int parity, mode, xpay;
+  real sfwd;              // +1 no dagger, -1 dagger (selects P-/+ per reference :122)
+  real a, b, k;
+  real tsign_fwd, tsign_bwd;  // recon-12: sign of the reconstructed row of t-links on the boundary slices
+  int nblocks, xcd_q, xcd_r;
+};
+
+// ---- spin projection / reconstruction in the chiral basis; s = +1 selects projector[2 mu], -1 projector[2 mu + 1]
+// of the reference table (tests/wilson_dslash_reference.cpp:21-70) ----
+template <int MU, typename real> __device__ __forceinline__ void spin_project(real *h, const real *p, real s) {
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const real p0r = p[0 + 2 * c], p0i = p[1 + 2 * c], p1r = p[6 + 2 * c], p1i = p[7 + 2 * c];
+    const real p2r = p[12 + 2 * c], p2i = p[13 + 2 * c], p3r = p[18 + 2 * c], p3i = p[19 + 2 * c];
+    if (MU == 0) {  // h0 = p0 - s i p3, h1 = p1 - s i p2
+      h[2 * c] = p0r + s * p3i; h[2 * c + 1] = p0i - s * p3r;
+      h[6 + 2 * c] = p1r + s * p2i; h[7 + 2 * c] = p1i - s * p2r;
+    } else if (MU == 1) {  // h0 = p0 + s p3, h1 = p1 - s p2
+      h[2 * c] = p0r + s * p3r; h[2 * c + 1] = p0i + s * p3i;
+      h[6 + 2 * c] = p1r - s * p2r; h[7 + 2 * c] = p1i - s * p2i;
+    } else if (MU == 2) {  // h0 = p0 - s i p2, h1 = p1 + s i p3
+      h[2 * c] = p0r + s * p2i; h[2 * c + 1] = p0i - s * p2r;
+      h[6 + 2 * c] = p1r - s * p3i; h[7 + 2 * c] = p1i + s * p3r;
+    } else {  // h0 = p0 - s p2, h1 = p1 - s p3
+      h[2 * c] = p0r - s * p2r; h[2 * c + 1] = p0i - s * p2i;
+      h[6 + 2 * c] = p1r - s * p3r; h[7 + 2 * c] = p1i - s * p3i;
+    }
+  }
+}
+
+template <int MU, typename real> __device__ __forceinline__ void spin_reconstruct(real *acc, const real *g, real s) {
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const real g0r = g[2 * c], g0i = g[2 * c + 1], g1r = g[6 + 2 * c], g1i = g[7 + 2 * c];
+    acc[0 + 2 * c] += g0r; acc[1 + 2 * c] += g0i;
+    acc[6 + 2 * c] += g1r; acc[7 + 2 * c] += g1i;
+    if (MU == 0) {  // r2 = s i g1, r3 = s i g0
+      acc[12 + 2 * c] -= s * g1i; acc[13 + 2 * c] += s * g1r;
+      acc[18 + 2 * c] -= s * g0i; acc[19 + 2 * c] += s * g0r;
+    } else if (MU == 1) {  // r2 = -s g1, r3 = s g0
+      acc[12 + 2 * c] -= s * g1r; acc[13 + 2 * c] -= s * g1i;
+      acc[18 + 2 * c] += s * g0r; acc[19 + 2 * c] += s * g0i;
+    } else if (MU == 2) {  // r2 = s i g0, r3 = -s i g1
+      acc[12 + 2 * c] -= s * g0i; acc[13 + 2 * c] += s * g0r;
+      acc[18 + 2 * c] += s * g1i; acc[19 + 2 * c] -= s * g1r;
+    } else {  // r2 = -s g0, r3 = -s g1
+      acc[12 + 2 * c] -= s * g0r; acc[13 + 2 * c] -= s * g0i;
+      acc[18 + 2 * c] -= s * g1r; acc[19 + 2 * c] -= s * g1i;
+    }
+  }
+}
+
+// (1 + i a g5) in place; g5 = diag(+,+,-,-)
+template <typename real> __device__ __forceinline__ void twist_inplace(real *p, real a) {
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const real r = p[2 * k], i = p[2 * k + 1];
+    p[2 * k] = r - a * i;
+    p[2 * k + 1] = i + a * r;
+  }
+#pragma unroll
+  for (int k = 6; k < 12; k++) {
+    const real r = p[2 * k], i = p[2 * k + 1];
+    p[2 * k] = r + a * i;
+    p[2 * k + 1] = i - a * r;
+  }
+}
+
+// One hop = load (neighbour spinor + this site's pre-daggered link) then project / multiply / reconstruct.
+// The two phases are separate so the kernel can software-pipeline them: loads of direction d+1 are issued
+// before the arithmetic of direction d (register double-buffering), fenced with sched_barrier so hipcc neither
+// hoists all 8 directions' loads to the top (fp64: 512 registers + scratch spills, 1 wave/SIMD) nor serialises them.
+template <typename T, int R, int DIR, typename real>
+__device__ __forceinline__ void hop_load(real *psi, real *U, const DslashArg<real> &arg, int idx, int nbr, real sign) {
+  Planar<T, 24>::load(psi, arg.in, arg.sp_stride, nbr, arg.inNorm, nbr);
+  Link<T, R>::load(U, arg.gauge + (size_t)DIR * arg.link_bytes, arg.g_stride, idx, sign);
+}
+template <int DIR, bool PRETWIST, typename real>
+__device__ __forceinline__ void hop_compute(real *acc, real *psi, const real *U, const DslashArg<real> &arg) {
+  constexpr int MU = DIR / 2;
+  real h[12], g[12];
+  if (PRETWIST) twist_inplace(psi, arg.a);  // QUDA_DEG_TWIST_INV_DSLASH: A^-1 applied to the neighbour before the hop
+  const real s = (DIR & 1) ? -arg.sfwd : arg.sfwd;
+  spin_project<MU>(h, psi, s);
+  su3_mv(g, U, h);
+  su3_mv(g + 6, U, h + 6);
+  spin_reconstruct<MU>(acc, g, s);
+}
+
+// VARIANT: 0 = Wilson / twist epilogues, 1 = twist applied to the neighbours first (TWIST_INV_DSLASH), 2 = clover epilogues.
+// Compile-time so the 8-hop pipeline below is one straight-line basic block (a wave-uniform runtime branch per hop
+// made hipcc split it into ~80 blocks and shuttle the double buffers through AGPRs).
+template <typename T, int R, int VARIANT>
+__global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename Store<T>::real> arg) {
+  using real = typename Store<T>::real;
+  // XCD-aware block remap: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch); give each XCD a
+  // contiguous range of logical blocks (a slab of time slices) so t/z neighbours hit its own L2.
+  const int b = blockIdx.x;
+  const int xcd = b & 7, within = b >> 3;
+  const int lb = (xcd < arg.xcd_r ? xcd * (arg.xcd_q + 1) : arg.xcd_r * (arg.xcd_q + 1) + (xcd - arg.xcd_r) * arg.xcd_q) + within;
+  const int idx = lb * blockDim.x + threadIdx.x;
+  if (idx >= arg.Vh) return;
+
+  // checkerboard index -> coordinates (tests/test_util.cpp:419-443)
+  const uint32_t za = arg.dXh.div((uint32_t)idx);
+  const int xh = idx - (int)za * arg.Xh;
+  const uint32_t zb = arg.dY.div(za);
+  const int y = (int)za - (int)zb * arg.Y;
+  const int t = (int)arg.dZ.div(zb);
+  const int z = (int)zb - t * arg.Z;
+  const int xodd = (y + z + t + arg.parity) & 1;
+
+  const int Xh = arg.Xh, sy = Xh, sz = Xh * arg.Y, st = Xh * arg.Y * arg.Z;
+  const int n_xp = xodd ? (xh == Xh - 1 ? idx - (Xh - 1) : idx + 1) : idx;
+  const int n_xm = xodd ? idx : (xh == 0 ? idx + (Xh - 1) : idx - 1);
+  const int n_yp = y == arg.Y - 1 ? idx - (arg.Y - 1) * sy : idx + sy;
+  const int n_ym = y == 0 ? idx + (arg.Y - 1) * sy : idx - sy;
+  const int n_zp = z == arg.Z - 1 ? idx - (arg.Z - 1) * sz : idx + sz;
+  const int n_zm = z == 0 ? idx + (arg.Z - 1) * sz : idx - sz;
+  const int n_tp = t == arg.T - 1 ? idx - (arg.T - 1) * st : idx + st;
+  const int n_tm = t == 0 ? idx + (arg.T - 1) * st : idx - st;
+
+  real acc[24];
+#pragma unroll
+  for (int k = 0; k < 24; k++) acc[k] = 0;
+
+  constexpr bool PT = VARIANT == 1;
+  constexpr bool CLOVER = VARIANT == 2;
+  const real one = 1;
+  const real sg_tp = t == arg.T - 1 ? arg.tsign_fwd : one, sg_tm = t == 0 ? arg.tsign_bwd : one;
+  // direction order: dir = 2 mu + (0 forward, 1 backward), as the reference (tests/dslash_util.h:131-140)
+  real pA[24], uA[18], pB[24], uB[18];
+  // QA_FENCE: nothing may be scheduled across (machine scheduler).  QA_PIN: an empty volatile asm that "modifies" the
+  // accumulators, so LLVM's IR-level sinking cannot push a hop's arithmetic past the following loads either (without it
+  // all 8 hops' FMAs sink below the last fence and every loaded register stays live: 390-512 registers, scratch spills).
+#define QA_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define QA_PIN()                                                   \
+  _Pragma("unroll") for (int k_ = 0; k_ < 24; k_++) asm volatile("" : "+v"(acc[k_]))
+  hop_load<T, R, 0>(pA, uA, arg, idx, n_xp, one);
+  hop_load<T, R, 1>(pB, uB, arg, idx, n_xm, one);
+  QA_FENCE(); hop_compute<0, PT>(acc, pA, uA, arg); QA_PIN(); QA_FENCE();
+  hop_load<T, R, 2>(pA, uA, arg, idx, n_yp, one);
+  QA_FENCE(); hop_compute<1, PT>(acc, pB, uB, arg); QA_PIN(); QA_FENCE();
+  hop_load<T, R, 3>(pB, uB, arg, idx, n_ym, one);
+  QA_FENCE(); hop_compute<2, PT>(acc, pA, uA, arg); QA_PIN(); QA_FENCE();
+  hop_load<T, R, 4>(pA, uA, arg, idx, n_zp, one);
+  QA_FENCE(); hop_compute<3, PT>(acc, pB, uB, arg); QA_PIN(); QA_FENCE();
+  hop_load<T, R, 5>(pB, uB, arg, idx, n_zm, one);
+  QA_FENCE(); hop_compute<4, PT>(acc, pA, uA, arg); QA_PIN(); QA_FENCE();
+  hop_load<T, R, 6>(pA, uA, arg, idx, n_tp, sg_tp);
+  QA_FENCE(); hop_compute<5, PT>(acc, pB, uB, arg); QA_PIN(); QA_FENCE();
+  hop_load<T, R, 7>(pB, uB, arg, idx, n_tm, sg_tm);
+  QA_FENCE(); hop_compute<6, PT>(acc, pA, uA, arg); QA_PIN(); QA_FENCE();
+  hop_compute<7, PT>(acc, pB, uB, arg);
+#undef QA_FENCE
+#undef QA_PIN
+
+  // ---- epilogue ----
+  real xs[24];
+  if (arg.xpay) Planar<T, 24>::load(xs, arg.x, arg.sp_stride, idx, arg.xNorm, idx);
+
+  if (arg.mode == DSLASH_PLAIN) {
+    if (arg.xpay) {
+#pragma unroll
+      for (int k = 0; k < 24; k++) acc[k] = xs[k] + arg.k * acc[k];
+    }
+  } else if (arg.mode == DSLASH_TWIST_INV || arg.mode == DSLASH_TWIST_INV_DSLASH) {
+    if (arg.mode == DSLASH_TWIST_INV) twist_inplace(acc, arg.a);
+    if (arg.xpay) {
+#pragma unroll
+      for (int k = 0; k < 24; k++) acc[k] = xs[k] + arg.b * acc[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 24; k++) acc[k] *= arg.b;
+    }
+  } else if (arg.mode == DSLASH_TWIST_XPAY) {
+    twist_inplace(xs, arg.a);
+#pragma unroll
+    for (int k = 0; k < 24; k++) acc[k] = arg.k * acc[k] + xs[k];
+  } else if (CLOVER) {
+    real C[36], tmp[24];
+    if (arg.mode == DSLASH_CLOVER_TWIST_INV) {
+      // tmp = (A + i a g5) acc ; res = Ainv tmp
+#pragma unroll
+      for (int chi = 0; chi < 2; chi++) {
+        Planar<T, 36>::load(C, (const char *)arg.clA + (size_t)chi * 36 * sizeof(T) * arg.cl_stride, arg.cl_stride, idx, arg.clAn,
+                            chi * arg.cl_stride + idx);
+        clover_block_mv(tmp + 12 * chi, C, acc + 12 * chi);
+      }
+      {
+        real t2[24];
+#pragma unroll
+        for (int k = 0; k < 24; k++) t2[k] = acc[k];
+        // i a g5 acc
+#pragma unroll
+        for (int k = 0; k < 6; k++) { tmp[2 * k] -= arg.a * t2[2 * k + 1]; tmp[2 * k + 1] += arg.a * t2[2 * k]; }
+#pragma unroll
+        for (int k = 6; k < 12; k++) { tmp[2 * k] += arg.a * t2[2 * k + 1]; tmp[2 * k + 1] -= arg.a * t2[2 * k]; }
+      }
+#pragma unroll
+      for (int chi = 0; chi < 2; chi++) {
+        Planar<T, 36>::load(C, (const char *)arg.clAinv + (size_t)chi * 36 * sizeof(T) * arg.cl_stride, arg.cl_stride, idx,
+                            arg.clAinvN, chi * arg.cl_stride + idx);
+        clover_block_mv(acc + 12 * chi, C, tmp + 12 * chi);
+      }
+      if (arg.xpay) {
+#pragma unroll
+        for (int k = 0; k < 24; k++) acc[k] = xs[k] + arg.k * acc[k];
+      }
+    } else {  // DSLASH_CLOVER_TWIST_XPAY: out = k acc + (A + i a g5) x
+#pragma unroll
+      for (int chi = 0; chi < 2; chi++) {
+        Planar<T, 36>::load(C, (const char *)arg.clA + (size_t)chi * 36 * sizeof(T) * arg.cl_stride, arg.cl_stride, idx, arg.clAn,
+                            chi * arg.cl_stride + idx);
+        clover_block_mv(tmp + 12 * chi, C, xs + 12 * chi);
+      }
+#pragma unroll
+      for (int k = 0; k < 6; k++) { tmp[2 * k] -= arg.a * xs[2 * k + 1]; tmp[2 * k + 1] += arg.a * xs[2 * k]; }
+#pragma unroll
+      for (int k = 6; k < 12; k++) { tmp[2 * k] += arg.a * xs[2 * k + 1]; tmp[2 * k + 1] -= arg.a * xs[2 * k]; }
+#pragma unroll
+      for (int k = 0; k < 24; k++) acc[k] = arg.k * acc[k] + tmp[k];
+    }
+  }
+  Planar<T, 24>::store(acc, arg.out, arg.sp_stride, idx, arg.outNorm, idx);
+}
+
+// ---- site-local kernel: twist / clover / twisted clover and inverse (reference lib/dslash_quda.cu:348-600) ----
+template <typename real> struct SiteArg {
+  void *out; float *outNorm;
+  const void *in; const float *inNorm;
+  const void *clA, *clAinv;
+  const float *clAn, *clAinvN;
+  int sp_stride, cl_stride, Vh, op;
+  real a, b;
+};
+
+template <typename T, bool CLOVER>
+__global__ void __launch_bounds__(256) site_kernel(const SiteArg<typename Store<T>::real> arg) {
+  using real = typename Store<T>::real;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= arg.Vh) return;
+  real v[24];
+  Planar<T, 24>::load(v, arg.in, arg.sp_stride, idx, arg.inNorm, idx);
+  if (arg.op == SITE_TWIST) {
+    twist_inplace(v, arg.a);
+#pragma unroll
+    for (int k = 0; k < 24; k++) v[k] *= arg.b;
+  } else if (CLOVER) {
+    real C[36], tmp[24];
+#pragma unroll
+    for (int chi = 0; chi < 2; chi++) {
+      Planar<T, 36>::load(C, (const char *)arg.clA + (size_t)chi * 36 * sizeof(T) * arg.cl_stride, arg.cl_stride, idx, arg.clAn,
+                          chi * arg.cl_stride + idx);
+      clover_block_mv(tmp + 12 * chi, C, v + 12 * chi);
+    }
+    if (arg.op != SITE_CLOVER) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) { tmp[2 * k] -= arg.a * v[2 * k + 1]; tmp[2 * k + 1] += arg.a * v[2 * k]; }
+#pragma unroll
+      for (int k = 6; k < 12; k++) { tmp[2 * k] += arg.a * v[2 * k + 1]; tmp[2 * k + 1] -= arg.a * v[2 * k]; }
+    }
+    if (arg.op == SITE_CLOVER_TWIST_INV) {
+#pragma unroll
+      for (int chi = 0; chi < 2; chi++) {
+        Planar<T, 36>::load(C, (const char *)arg.clAinv + (size_t)chi * 36 * sizeof(T) * arg.cl_stride, arg.cl_stride, idx,
+                            arg.clAinvN, chi * arg.cl_stride + idx);
+        clover_block_mv(v + 12 * chi, C, tmp + 12 * chi);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 24; k++) v[k] = tmp[k];
+    }
+  }
+  Planar<T, 24>::store(v, arg.out, arg.sp_stride, idx, arg.outNorm, idx);
+}
+
+// ------------------------------------------------------------------------------------------------
+static int dslashBlockSize() {
+  static int bs = 0;
+  if (!bs) {
+    const char *e = getenv("QUDA_AMD_DSLASH_BLOCK");
+    bs = e ? atoi(e) : 256;
+    if (bs < 64 || bs > 256 || bs % 64) bs = 256;
+  }
+  return bs;
+}
+
+template <typename T, int R, int VARIANT>
+static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, const DslashParam &p) {
+  using real = typename Store<T>::real;
+  DslashArg<real> arg;
+  const LatticeGeom &g = U.geom;
+  arg.out = out.V(); arg.outNorm = (float *)out.Norm();
+  arg.in = in.V(); arg.inNorm = (const float *)in.Norm();
+  arg.x = p.x ? p.x->V() : nullptr; arg.xNorm = p.x ? (const float *)p.x->Norm() : nullptr;
+  arg.gauge = (const char *)U.parityBase(p.parity);
+  arg.link_bytes = U.link_bytes;
+  arg.clA = arg.clAinv = nullptr; arg.clAn = arg.clAinvN = nullptr;
+  arg.cl_stride = 0;
+  if (VARIANT == 2) {
+    arg.clA = p.clover->A(p.parity); arg.clAinv = p.clover->Ainv(p.parity);
+    arg.clAn = p.clover->Anorm(p.parity); arg.clAinvN = p.clover->AinvNorm(p.parity);
+    arg.cl_stride = p.clover->stride;
+  }
+  arg.sp_stride = in.Stride(); arg.g_stride = U.stride;
+  arg.Vh = g.Vh; arg.Xh = g.Xh; arg.Y = g.X[1]; arg.Z = g.X[2]; arg.T = g.X[3];
+  arg.dXh = g.dXh; arg.dY = g.dY; arg.dZ = g.dZ;
+  arg.parity = p.parity; arg.mode = p.mode; arg.xpay = p.x ? 1 : 0;
+  arg.sfwd = p.dagger ? -1 : 1;
+  arg.a = (real)p.a; arg.b = (real)p.b; arg.k = (real)p.k;
+  // recon-12: the reconstructed row of boundary t-links carries the (folded) boundary sign
+  const bool first_t = commGrid().coords[3] == 0, last_t = commGrid().coords[3] == commGrid().dims[3] - 1;
+  arg.tsign_fwd = (R == 12 && U.t_boundary == QUDA_ANTI_PERIODIC_T && last_t) ? -1 : 1;
+  arg.tsign_bwd = (R == 12 && U.t_boundary == QUDA_ANTI_PERIODIC_T && first_t) ? -1 : 1;
+  const int bs = dslashBlockSize();
+  const int nb = (g.Vh + bs - 1) / bs;
+  arg.nblocks = nb; arg.xcd_q = nb / 8; arg.xcd_r = nb % 8;
+  hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT>), dim3(nb), dim3(bs), 0, computeStream(), arg);
+  HIP_CHECK(hipGetLastError());
+}
+
+template <typename T> static void dispatchRecon(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, const DslashParam &p) {
+  const bool clover = p.mode == DSLASH_CLOVER_TWIST_INV || p.mode == DSLASH_CLOVER_TWIST_XPAY;
+  if (clover && !p.clover) errorQuda("clover field required for dslash mode %d", p.mode);
+  const int variant = clover ? 2 : (p.mode == DSLASH_TWIST_INV_DSLASH ? 1 : 0);
+  if (U.reconstruct == QUDA_RECONSTRUCT_NO) {
+    if (variant == 2) launchDslash<T, 18, 2>(out, in, U, p);
+    else if (variant == 1) launchDslash<T, 18, 1>(out, in, U, p);
+    else launchDslash<T, 18, 0>(out, in, U, p);
+  } else if (U.reconstruct == QUDA_RECONSTRUCT_12) {
+    if (variant == 2) launchDslash<T, 12, 2>(out, in, U, p);
+    else if (variant == 1) launchDslash<T, 12, 1>(out, in, U, p);
+    else launchDslash<T, 12, 0>(out, in, U, p);
+  } else {
+    errorQuda("reconstruct %d not supported (18 and 12 only)", U.reconstruct);
+  }
+}
+
+void applyDslash(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, const DslashParam &p) {
+  if (out.Location() != QUDA_CUDA_FIELD_LOCATION || in.Location() != QUDA_CUDA_FIELD_LOCATION) errorQuda("device fields required");
+  if (in.SiteSubset() != QUDA_PARITY_SITE_SUBSET || out.SiteSubset() != QUDA_PARITY_SITE_SUBSET) errorQuda("parity fields required");
+  if (in.Precision() != out.Precision() || in.Precision() != U.precision) errorQuda("precision mismatch: spinor %d/%d gauge %d", in.Precision(), out.Precision(), U.precision);
+  if (p.x && p.x->Precision() != in.Precision()) errorQuda("xpay precision mismatch");
+  if (in.VolumeCB() != U.geom.Vh || out.VolumeCB() != U.geom.Vh) errorQuda("volume mismatch: spinor %d gauge %d", in.VolumeCB(), U.geom.Vh);
+  if (in.V() == out.V()) errorQuda("in and out must not alias");
+  if (in.Nspin() != 4 || in.Ncolor() != 3) errorQuda("fine-grid dslash needs nSpin=4 nColor=3");
+  if (p.clover && p.clover->precision != in.Precision()) errorQuda("clover precision mismatch");
+  switch (in.Precision()) {
+    case QUDA_DOUBLE_PRECISION: dispatchRecon<double>(out, in, U, p); break;
+    case QUDA_SINGLE_PRECISION: dispatchRecon<float>(out, in, U, p); break;
+    case QUDA_HALF_PRECISION: dispatchRecon<short>(out, in, U, p); break;
+    default: errorQuda("bad precision %d", in.Precision());
+  }
+}
+
+template <typename T> static void launchSite(ColorSpinorField &out, const ColorSpinorField &in, SiteOp op, double a, double b,
+                                             const CloverField *cl, int parity, bool inverse) {
+  using real = typename Store<T>::real;
+  SiteArg<real> arg;
+  arg.out = out.V(); arg.outNorm = (float *)out.Norm();
+  arg.in = in.V(); arg.inNorm = (const float *)in.Norm();
+  arg.sp_stride = in.Stride(); arg.Vh = in.VolumeCB(); arg.op = op;
+  arg.a = (real)a; arg.b = (real)b;
+  arg.clA = arg.clAinv = nullptr; arg.clAn = arg.clAinvN = nullptr; arg.cl_stride = 0;
+  const int bs = 256, nb = (arg.Vh + bs - 1) / bs;
+  if (op == SITE_TWIST) {
+    hipLaunchKernelGGL((site_kernel<T, false>), dim3(nb), dim3(bs), 0, computeStream(), arg);
+  } else {
+    if (!cl) errorQuda("clover field required");
+    if (op == SITE_CLOVER && inverse) { arg.clA = cl->Ainv(parity); arg.clAn = cl->AinvNorm(parity); }
+    else { arg.clA = cl->A(parity); arg.clAn = cl->Anorm(parity); }
+    arg.clAinv = cl->Ainv(parity); arg.clAinvN = cl->AinvNorm(parity);
+    arg.cl_stride = cl->stride;
+    hipLaunchKernelGGL((site_kernel<T, true>), dim3(nb), dim3(bs), 0, computeStream(), arg);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+void applySite(ColorSpinorField &out, const ColorSpinorField &in, SiteOp op, double a, double b, const CloverField *clover,
+               int parity, bool inverse) {
+  if (in.Precision() != out.Precision()) errorQuda("precision mismatch");
+  if (in.SiteSubset() != QUDA_PARITY_SITE_SUBSET) errorQuda("parity fields required");
+  if (clover && clover->precision != in.Precision()) errorQuda("clover precision mismatch");
+  switch (in.Precision()) {
+    case QUDA_DOUBLE_PRECISION: launchSite<double>(out, in, op, a, b, clover, parity, inverse); break;
+    case QUDA_SINGLE_PRECISION: launchSite<float>(out, in, op, a, b, clover, parity, inverse); break;
+    case QUDA_HALF_PRECISION: launchSite<short>(out, in, op, a, b, clover, parity, inverse); break;
+    default: errorQuda("bad precision %d", in.Precision());
+  }
+}
+
+long long dslashFlopsPerSite(DslashMode mode, bool xpay) {
+  long long f = 1320;  // lib/dslash_quda.cuh:480-495
+  switch (mode) {
+    case DSLASH_PLAIN: f += xpay ? 48 : 0; break;
+    case DSLASH_TWIST_INV: case DSLASH_TWIST_INV_DSLASH: case DSLASH_TWIST_XPAY: f += 48 + (xpay ? 48 : 0); break;  // lib/dslash_twisted_mass.cu:144-160
+    case DSLASH_CLOVER_TWIST_INV: case DSLASH_CLOVER_TWIST_XPAY: f += 552 + (xpay ? 48 : 0); break;  // lib/dslash_twisted_clover.cu:213-230
+  }
+  return f;
+}
+
+long long dslashBytesPerSite(QudaPrecision prec, int recon, DslashMode mode, bool xpay) {
+  const long long P = prec;
+  long long b = 8LL * recon * P + 24 * P + 24 * P;
+  const bool x = xpay || mode == DSLASH_TWIST_XPAY || mode == DSLASH_CLOVER_TWIST_XPAY;
+  if (x) b += 24 * P;
+  if (mode == DSLASH_CLOVER_TWIST_INV) b += 144 * P;
+  if (mode == DSLASH_CLOVER_TWIST_XPAY) b += 72 * P;
+  if (prec == QUDA_HALF_PRECISION) {
+    b += 4 * (2 + (x ? 1 : 0));
+    if (mode == DSLASH_CLOVER_TWIST_INV) b += 16;
+    if (mode == DSLASH_CLOVER_TWIST_XPAY) b += 8;
+  }
+  return b;
+}
+
+}  // namespace quda

@@ -1,0 +1,633 @@
+// fields.hip — field allocation, host<->device reorder (+ precision / gamma-basis change), gauge and clover
+// upload into the CDNA4 device layouts.  Reference behaviour restated: lib/color_spinor_field.cpp:129-216
+// (geometry), lib/copy_color_spinor.cuh:49-91 (basis rotation), lib/cuda_color_spinor_field.cu:513-590
+// (load/save), lib/clover_invert.cu:56-85 (twisted inverse).
+#include "fields.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "device_io.h"
+
+namespace quda {
+
+// ================================================================================================
+// ColorSpinorField
+// ================================================================================================
+ColorSpinorParam::ColorSpinorParam(void *V, const QudaInvertParam &inv, const int *X, bool pc_solution) {
+  location = QUDA_CPU_FIELD_LOCATION;
+  nColor = 3; nSpin = 4; nDim = 4;
+  for (int d = 0; d < 4; d++) x[d] = X[d];
+  siteSubset = pc_solution ? QUDA_PARITY_SITE_SUBSET : QUDA_FULL_SITE_SUBSET;
+  if (pc_solution) x[0] /= 2;
+  precision = inv.cpu_prec;
+  pad = 0;
+  twistFlavor = inv.twist_flavor;
+  siteOrder = QUDA_EVEN_ODD_SITE_ORDER;
+  if (inv.dirac_order == QUDA_DIRAC_ORDER) fieldOrder = QUDA_SPACE_SPIN_COLOR_FIELD_ORDER;
+  else if (inv.dirac_order == QUDA_QDP_DIRAC_ORDER) fieldOrder = QUDA_SPACE_COLOR_SPIN_FIELD_ORDER;
+  else errorQuda("Dirac order %d not supported (QUDA_DIRAC_ORDER, QUDA_QDP_DIRAC_ORDER)", inv.dirac_order);
+  gammaBasis = inv.gamma_basis;
+  create = QUDA_REFERENCE_FIELD_CREATE;
+  v = V;
+}
+
+static size_t alignUp(size_t n, size_t a) { return (n + a - 1) / a * a; }
+
+ColorSpinorField::ColorSpinorField(const ColorSpinorParam &p)
+    : location(p.location), nColor(p.nColor), nSpin(p.nSpin), nDim(p.nDim), pad(p.pad), precision(p.precision),
+      siteSubset(p.siteSubset), siteOrder(p.siteOrder), fieldOrder(p.fieldOrder), gammaBasis(p.gammaBasis),
+      twistFlavor(p.twistFlavor), v_(nullptr), norm_(nullptr), owns(false), even_(nullptr), odd_(nullptr) {
+  volume = 1;
+  for (int d = 0; d < 4; d++) { x[d] = p.x[d]; volume *= p.x[d]; }
+  if (volume <= 0) errorQuda("empty field: x = %d %d %d %d", x[0], x[1], x[2], x[3]);
+  const int nsub = siteSubset == QUDA_FULL_SITE_SUBSET ? 2 : 1;
+  volumeCB = volume / nsub;
+  if (location == QUDA_CPU_FIELD_LOCATION) pad = 0;
+  stride = volumeCB + pad;
+  if (location == QUDA_CUDA_FIELD_LOCATION) {
+    fieldOrder = (precision == QUDA_DOUBLE_PRECISION || nSpin != 4) ? QUDA_FLOAT2_FIELD_ORDER : QUDA_FLOAT4_FIELD_ORDER;
+    if (nSpin == 4) gammaBasis = QUDA_DEGRAND_ROSSI_GAMMA_BASIS;  // device-internal basis (see fields.h)
+    if (nSpin != 4 && precision == QUDA_HALF_PRECISION) errorQuda("16-bit coarse fields are not supported");
+  } else {
+    if (precision == QUDA_HALF_PRECISION) errorQuda("16-bit host fields are not supported");
+    if (fieldOrder == QUDA_INVALID_FIELD_ORDER) fieldOrder = QUDA_SPACE_SPIN_COLOR_FIELD_ORDER;
+  }
+  const size_t per_parity = (size_t)stride * nColor * nSpin * 2 * precision;
+  // keep each parity half 1 KiB aligned like the reference (TEX_ALIGN_REQ, include/quda_internal.h:32-33)
+  const size_t half = location == QUDA_CUDA_FIELD_LOCATION ? alignUp(per_parity, 1024) : per_parity;
+  bytes = nsub * half;
+  norm_bytes = precision == QUDA_HALF_PRECISION ? nsub * alignUp((size_t)stride * sizeof(float), 1024) : 0;
+
+  if (p.create == QUDA_REFERENCE_FIELD_CREATE) {
+    v_ = p.v; norm_ = p.norm;
+    if (!v_) errorQuda("reference field without data pointer");
+  } else {
+    owns = true;
+    if (location == QUDA_CUDA_FIELD_LOCATION) {
+      HIP_CHECK(hipMalloc(&v_, bytes));
+      if (norm_bytes) HIP_CHECK(hipMalloc(&norm_, norm_bytes));
+    } else {
+      v_ = malloc(bytes);
+      if (!v_) errorQuda("host allocation of %zu bytes failed", bytes);
+    }
+    if (p.create == QUDA_ZERO_FIELD_CREATE) zero();
+  }
+}
+
+ColorSpinorParam ColorSpinorField::param() const {
+  ColorSpinorParam p;
+  p.location = location; p.nColor = nColor; p.nSpin = nSpin; p.nDim = nDim;
+  for (int d = 0; d < 4; d++) p.x[d] = x[d];
+  p.precision = precision; p.pad = pad; p.twistFlavor = twistFlavor; p.siteSubset = siteSubset; p.siteOrder = siteOrder;
+  p.fieldOrder = fieldOrder; p.gammaBasis = gammaBasis; p.create = QUDA_NULL_FIELD_CREATE;
+  return p;
+}
+
+ColorSpinorField::ColorSpinorField(const ColorSpinorField &src) : ColorSpinorField([&] { ColorSpinorParam p = src.param(); return p; }()) {
+  copyColorSpinor(*this, src);
+}
+
+ColorSpinorField::~ColorSpinorField() {
+  delete even_;
+  delete odd_;
+  if (owns) {
+    if (location == QUDA_CUDA_FIELD_LOCATION) {
+      if (v_) (void)hipFree(v_);
+      if (norm_) (void)hipFree(norm_);
+    } else {
+      free(v_);
+    }
+  }
+}
+
+void ColorSpinorField::zero() {
+  if (location == QUDA_CUDA_FIELD_LOCATION) {
+    HIP_CHECK(hipMemsetAsync(v_, 0, bytes, computeStream()));
+    if (norm_bytes) HIP_CHECK(hipMemsetAsync(norm_, 0, norm_bytes, computeStream()));
+  } else {
+    memset(v_, 0, bytes);
+  }
+}
+
+void ColorSpinorField::createViews() {
+  if (siteSubset != QUDA_FULL_SITE_SUBSET) errorQuda("Even()/Odd() need a full field");
+  ColorSpinorParam p = param();
+  p.siteSubset = QUDA_PARITY_SITE_SUBSET;
+  p.x[0] = x[0] / 2;
+  p.create = QUDA_REFERENCE_FIELD_CREATE;
+  p.v = v_; p.norm = norm_;
+  even_ = new ColorSpinorField(p);
+  p.v = (char *)v_ + bytes / 2;  // reference lib/cpu_color_spinor_field.cpp:165
+  p.norm = norm_ ? (char *)norm_ + norm_bytes / 2 : nullptr;
+  odd_ = new ColorSpinorField(p);
+}
+ColorSpinorField &ColorSpinorField::Even() { if (!even_) createViews(); return *even_; }
+ColorSpinorField &ColorSpinorField::Odd() { if (!odd_) createViews(); return *odd_; }
+
+ColorSpinorField &ColorSpinorField::operator=(const ColorSpinorField &src) {
+  if (&src != this) copyColorSpinor(*this, src);
+  return *this;
+}
+
+static ColorSpinorParam deviceParamFrom(const ColorSpinorParam &p) { ColorSpinorParam q = p; q.location = QUDA_CUDA_FIELD_LOCATION; return q; }
+static ColorSpinorParam hostParamFrom(const ColorSpinorParam &p) { ColorSpinorParam q = p; q.location = QUDA_CPU_FIELD_LOCATION; return q; }
+cudaColorSpinorField::cudaColorSpinorField(const ColorSpinorParam &p) : ColorSpinorField(deviceParamFrom(p)) {}
+cudaColorSpinorField::cudaColorSpinorField(const ColorSpinorField &src, const ColorSpinorParam &p) : ColorSpinorField(deviceParamFrom(p)) {
+  twistFlavor = src.twistFlavor;
+  copyColorSpinor(*this, src);
+}
+cpuColorSpinorField::cpuColorSpinorField(const ColorSpinorParam &p) : ColorSpinorField(hostParamFrom(p)) {}
+
+// ---- reorder kernels -----------------------------------------------------------------------------
+// host site-major record of NR reals: index (site*NR + (s*Nc + c)*2 + z)   [SPACE_SPIN_COLOR]
+//                                       or   (site*NR + (c*Ns + s)*2 + z)   [SPACE_COLOR_SPIN]
+enum BasisChange { BASIS_NONE = 0, BASIS_UKQCD_TO_DR = 1, BASIS_DR_TO_UKQCD = 2 };
+
+template <typename real> __device__ __forceinline__ void rotate_basis(real *o, const real *in, int change) {
+  // DR -> UKQCD is the reference's NonRelBasis, UKQCD -> DR its RelBasis (lib/copy_color_spinor.cuh:49-91)
+  const real k = (real)0.70710678118654752440;
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    const real i0 = in[c], i1 = in[6 + c], i2 = in[12 + c], i3 = in[18 + c];
+    if (change == BASIS_UKQCD_TO_DR) {
+      o[c] = -k * (i1 + i3); o[6 + c] = k * (i0 + i2); o[12 + c] = k * (i3 - i1); o[18 + c] = k * (i0 - i2);
+    } else {
+      o[c] = k * (i1 + i3); o[6 + c] = -k * (i0 + i2); o[12 + c] = k * (i1 - i3); o[18 + c] = k * (i2 - i0);
+    }
+  }
+}
+
+template <typename TDev, typename THost>
+__global__ void spinor_h2d_kernel(void *dev, float *norm, int stride, const THost *host, int Vh, int color_spin, int change) {
+  using real = typename Store<TDev>::real;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= Vh) return;
+  real r[24], q[24];
+  const THost *h = host + (size_t)x * 24;
+#pragma unroll
+  for (int s = 0; s < 4; s++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const int hi = color_spin ? (c * 4 + s) * 2 : (s * 3 + c) * 2;
+      r[(s * 3 + c) * 2] = (real)h[hi];
+      r[(s * 3 + c) * 2 + 1] = (real)h[hi + 1];
+    }
+  if (change) { rotate_basis(q, r, change); Planar<TDev, 24>::store(q, dev, stride, x, norm, x); }
+  else Planar<TDev, 24>::store(r, dev, stride, x, norm, x);
+}
+
+template <typename TDev, typename THost>
+__global__ void spinor_d2h_kernel(THost *host, const void *dev, const float *norm, int stride, int Vh, int color_spin, int change) {
+  using real = typename Store<TDev>::real;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= Vh) return;
+  real r[24], q[24];
+  Planar<TDev, 24>::load(r, dev, stride, x, norm, x);
+  if (change) rotate_basis(q, r, change);
+  THost *h = host + (size_t)x * 24;
+#pragma unroll
+  for (int s = 0; s < 4; s++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const int hi = color_spin ? (c * 4 + s) * 2 : (s * 3 + c) * 2;
+      h[hi] = (THost)(change ? q[(s * 3 + c) * 2] : r[(s * 3 + c) * 2]);
+      h[hi + 1] = (THost)(change ? q[(s * 3 + c) * 2 + 1] : r[(s * 3 + c) * 2 + 1]);
+    }
+}
+
+template <typename TOut, typename TIn>
+__global__ void spinor_d2d_kernel(void *out, float *onorm, int ostride, const void *in, const float *inorm, int istride, int Vh) {
+  using rin = typename Store<TIn>::real;
+  using rout = typename Store<TOut>::real;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= Vh) return;
+  rin r[24];
+  rout q[24];
+  Planar<TIn, 24>::load(r, in, istride, x, inorm, x);
+#pragma unroll
+  for (int k = 0; k < 24; k++) q[k] = (rout)r[k];
+  Planar<TOut, 24>::store(q, out, ostride, x, onorm, x);
+}
+
+// generic complex-plane fields (coarse grids: nSpin*nColor complex FLOAT2 planes), host site-major
+template <typename TDev, typename THost>
+__global__ void generic_h2d_kernel(TDev *dev, int stride, const THost *host, int Vh, int ncomplex) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= Vh) return;
+  for (int k = 0; k < ncomplex; k++) {
+    dev[((size_t)k * stride + x) * 2] = (TDev)host[((size_t)x * ncomplex + k) * 2];
+    dev[((size_t)k * stride + x) * 2 + 1] = (TDev)host[((size_t)x * ncomplex + k) * 2 + 1];
+  }
+}
+template <typename TDev, typename THost>
+__global__ void generic_d2h_kernel(THost *host, const TDev *dev, int stride, int Vh, int ncomplex) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= Vh) return;
+  for (int k = 0; k < ncomplex; k++) {
+    host[((size_t)x * ncomplex + k) * 2] = (THost)dev[((size_t)k * stride + x) * 2];
+    host[((size_t)x * ncomplex + k) * 2 + 1] = (THost)dev[((size_t)k * stride + x) * 2 + 1];
+  }
+}
+template <typename TOut, typename TIn>
+__global__ void generic_d2d_kernel(TOut *out, int ostride, const TIn *in, int istride, int Vh, int ncomplex) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= Vh) return;
+  for (int k = 0; k < ncomplex; k++) {
+    out[((size_t)k * ostride + x) * 2] = (TOut)in[((size_t)k * istride + x) * 2];
+    out[((size_t)k * ostride + x) * 2 + 1] = (TOut)in[((size_t)k * istride + x) * 2 + 1];
+  }
+}
+
+// staging buffer for host<->device transfers (grows on demand, lives until endQuda)
+static void *g_stage = nullptr;
+static size_t g_stage_bytes = 0;
+void *stagingBuffer(size_t bytes) {
+  if (bytes > g_stage_bytes) {
+    if (g_stage) HIP_CHECK(hipFree(g_stage));
+    HIP_CHECK(hipMalloc(&g_stage, bytes));
+    g_stage_bytes = bytes;
+  }
+  return g_stage;
+}
+void freeStagingBuffer() {
+  if (g_stage) (void)hipFree(g_stage);
+  g_stage = nullptr;
+  g_stage_bytes = 0;
+}
+
+static int basisChange(QudaGammaBasis from, QudaGammaBasis to) {
+  auto norm = [](QudaGammaBasis b) { return b == QUDA_CHIRAL_GAMMA_BASIS ? QUDA_DEGRAND_ROSSI_GAMMA_BASIS : b; };
+  from = norm(from); to = norm(to);
+  if (from == to) return BASIS_NONE;
+  if (from == QUDA_UKQCD_GAMMA_BASIS && to == QUDA_DEGRAND_ROSSI_GAMMA_BASIS) return BASIS_UKQCD_TO_DR;
+  if (from == QUDA_DEGRAND_ROSSI_GAMMA_BASIS && to == QUDA_UKQCD_GAMMA_BASIS) return BASIS_DR_TO_UKQCD;
+  errorQuda("unsupported basis change %d -> %d", from, to);
+  return 0;
+}
+
+template <typename TDev, typename THost> static void h2dParity(ColorSpinorField &dst, const ColorSpinorField &src) {
+  const int Vh = dst.VolumeCB(), bs = 256, nb = (Vh + bs - 1) / bs;
+  const size_t hbytes = (size_t)Vh * src.nSpin * src.nColor * 2 * sizeof(THost);
+  void *stage = stagingBuffer(hbytes);
+  HIP_CHECK(hipMemcpyAsync(stage, src.V(), hbytes, hipMemcpyHostToDevice, computeStream()));
+  if (dst.nSpin == 4 && dst.nColor == 3) {
+    const int cs = src.fieldOrder == QUDA_SPACE_COLOR_SPIN_FIELD_ORDER;
+    hipLaunchKernelGGL((spinor_h2d_kernel<TDev, THost>), dim3(nb), dim3(bs), 0, computeStream(), dst.V(), (float *)dst.Norm(), dst.Stride(),
+                       (const THost *)stage, Vh, cs, basisChange(src.gammaBasis, dst.gammaBasis));
+  } else {
+    if (sizeof(TDev) == 2) errorQuda("16-bit coarse fields unsupported");
+    using D = typename Store<TDev>::real;
+    hipLaunchKernelGGL((generic_h2d_kernel<D, THost>), dim3(nb), dim3(bs), 0, computeStream(), (D *)dst.V(), dst.Stride(), (const THost *)stage, Vh,
+                       dst.nSpin * dst.nColor);
+  }
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(computeStream()));  // staging buffer is reused by the next transfer
+}
+
+template <typename TDev, typename THost> static void d2hParity(ColorSpinorField &dst, const ColorSpinorField &src) {
+  const int Vh = src.VolumeCB(), bs = 256, nb = (Vh + bs - 1) / bs;
+  const size_t hbytes = (size_t)Vh * src.nSpin * src.nColor * 2 * sizeof(THost);
+  void *stage = stagingBuffer(hbytes);
+  if (src.nSpin == 4 && src.nColor == 3) {
+    const int cs = dst.fieldOrder == QUDA_SPACE_COLOR_SPIN_FIELD_ORDER;
+    hipLaunchKernelGGL((spinor_d2h_kernel<TDev, THost>), dim3(nb), dim3(bs), 0, computeStream(), (THost *)stage, src.V(), (const float *)src.Norm(),
+                       src.Stride(), Vh, cs, basisChange(src.gammaBasis, dst.gammaBasis));
+  } else {
+    using D = typename Store<TDev>::real;
+    hipLaunchKernelGGL((generic_d2h_kernel<D, THost>), dim3(nb), dim3(bs), 0, computeStream(), (THost *)stage, (const D *)src.V(), src.Stride(), Vh,
+                       src.nSpin * src.nColor);
+  }
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(dst.V(), stage, hbytes, hipMemcpyDeviceToHost, computeStream()));
+  HIP_CHECK(hipStreamSynchronize(computeStream()));
+}
+
+template <typename TOut, typename TIn> static void d2dParity(ColorSpinorField &dst, const ColorSpinorField &src) {
+  const int Vh = src.VolumeCB(), bs = 256, nb = (Vh + bs - 1) / bs;
+  if (src.nSpin == 4 && src.nColor == 3) {
+    hipLaunchKernelGGL((spinor_d2d_kernel<TOut, TIn>), dim3(nb), dim3(bs), 0, computeStream(), dst.V(), (float *)dst.Norm(), dst.Stride(), src.V(),
+                       (const float *)src.Norm(), src.Stride(), Vh);
+  } else {
+    using O = typename Store<TOut>::real;
+    using I = typename Store<TIn>::real;
+    hipLaunchKernelGGL((generic_d2d_kernel<O, I>), dim3(nb), dim3(bs), 0, computeStream(), (O *)dst.V(), dst.Stride(), (const I *)src.V(), src.Stride(),
+                       Vh, src.nSpin * src.nColor);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+#define QA_DISPATCH_DEV(prec, CALL)                      \
+  switch (prec) {                                        \
+    case QUDA_DOUBLE_PRECISION: { using TD = double; CALL; } break; \
+    case QUDA_SINGLE_PRECISION: { using TD = float; CALL; } break;  \
+    case QUDA_HALF_PRECISION: { using TD = short; CALL; } break;    \
+    default: errorQuda("bad precision %d", prec);        \
+  }
+
+static void copyParity(ColorSpinorField &dst, const ColorSpinorField &src) {
+  const bool dd = dst.Location() == QUDA_CUDA_FIELD_LOCATION, sd = src.Location() == QUDA_CUDA_FIELD_LOCATION;
+  if (dd && !sd) {
+    if (src.Precision() == QUDA_DOUBLE_PRECISION) { QA_DISPATCH_DEV(dst.Precision(), (h2dParity<TD, double>(dst, src))); }
+    else { QA_DISPATCH_DEV(dst.Precision(), (h2dParity<TD, float>(dst, src))); }
+  } else if (!dd && sd) {
+    if (dst.Precision() == QUDA_DOUBLE_PRECISION) { QA_DISPATCH_DEV(src.Precision(), (d2hParity<TD, double>(dst, src))); }
+    else { QA_DISPATCH_DEV(src.Precision(), (d2hParity<TD, float>(dst, src))); }
+  } else if (dd && sd) {
+    if (dst.Precision() == src.Precision() && dst.Stride() == src.Stride()) {
+      const size_t n = (size_t)src.Stride() * src.nSpin * src.nColor * 2 * src.Precision();
+      HIP_CHECK(hipMemcpyAsync(dst.V(), src.V(), n, hipMemcpyDeviceToDevice, computeStream()));
+      if (src.Precision() == QUDA_HALF_PRECISION)
+        HIP_CHECK(hipMemcpyAsync(dst.Norm(), src.Norm(), (size_t)src.Stride() * sizeof(float), hipMemcpyDeviceToDevice, computeStream()));
+    } else {
+      switch (src.Precision()) {
+        case QUDA_DOUBLE_PRECISION: QA_DISPATCH_DEV(dst.Precision(), (d2dParity<TD, double>(dst, src))); break;
+        case QUDA_SINGLE_PRECISION: QA_DISPATCH_DEV(dst.Precision(), (d2dParity<TD, float>(dst, src))); break;
+        case QUDA_HALF_PRECISION: QA_DISPATCH_DEV(dst.Precision(), (d2dParity<TD, short>(dst, src))); break;
+        default: errorQuda("bad precision");
+      }
+    }
+  } else {
+    if (dst.Precision() != src.Precision() || dst.fieldOrder != src.fieldOrder || dst.gammaBasis != src.gammaBasis)
+      errorQuda("host-to-host copies with layout change are not supported");
+    memcpy(dst.V(), src.V(), (size_t)src.VolumeCB() * src.nSpin * src.nColor * 2 * src.Precision());
+  }
+}
+
+void copyColorSpinor(ColorSpinorField &dst, const ColorSpinorField &src) {
+  if (dst.nSpin != src.nSpin || dst.nColor != src.nColor) errorQuda("spin/colour mismatch %d,%d vs %d,%d", dst.nSpin, dst.nColor, src.nSpin, src.nColor);
+  if (dst.SiteSubset() != src.SiteSubset()) errorQuda("site subset mismatch");
+  if (dst.VolumeCB() != src.VolumeCB()) errorQuda("volume mismatch %d vs %d", dst.VolumeCB(), src.VolumeCB());
+  if (src.SiteSubset() == QUDA_FULL_SITE_SUBSET) {
+    copyParity(dst.Even(), src.Even());
+    copyParity(dst.Odd(), src.Odd());
+  } else {
+    copyParity(dst, src);
+  }
+  dst.twistFlavor = dst.twistFlavor == QUDA_TWIST_NO || dst.twistFlavor == QUDA_TWIST_INVALID ? src.twistFlavor : dst.twistFlavor;
+}
+
+// ================================================================================================
+// GaugeField
+// ================================================================================================
+GaugeField::GaugeField(const LatticeGeom &g, QudaPrecision prec, QudaReconstructType recon, QudaTboundary tb, double aniso)
+    : geom(g), precision(prec), reconstruct(recon), t_boundary(tb), anisotropy(aniso), stride(g.Vh), data(nullptr), tbc_folded(true) {
+  if (recon != QUDA_RECONSTRUCT_NO && recon != QUDA_RECONSTRUCT_12) errorQuda("reconstruct %d not supported (18, 12)", recon);
+  if (prec == QUDA_HALF_PRECISION && aniso != 1.0) errorQuda("16-bit links need anisotropy 1 (fixed-point range)");
+  link_bytes = alignUp((size_t)stride * (int)recon * (int)prec, 1024);
+  bytes = 16 * link_bytes;
+  HIP_CHECK(hipMalloc(&data, bytes));
+}
+GaugeField::~GaugeField() { if (data) (void)hipFree(data); }
+
+// one thread per (parity, site): builds the 8 matrices the stencil needs at that site
+template <typename TDev, int R, typename THost>
+__global__ void gauge_load_kernel(char *data, size_t link_bytes, int stride, const THost *h0, const THost *h1, const THost *h2, const THost *h3,
+                                  LatticeGeom g) {
+  using real = typename Store<TDev>::real;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= 2 * g.Vh) return;
+  const int parity = gid >= g.Vh, idx = gid - parity * g.Vh;
+  const uint32_t za = g.dXh.div((uint32_t)idx);
+  const int xh = idx - (int)za * g.Xh;
+  const uint32_t zb = g.dY.div(za);
+  const int y = (int)za - (int)zb * g.X[1];
+  const int t = (int)g.dZ.div(zb);
+  const int z = (int)zb - t * g.X[2];
+  const int xodd = (y + z + t + parity) & 1;
+  const int Xh = g.Xh, sy = Xh, sz = Xh * g.X[1], st = Xh * g.X[1] * g.X[2];
+  int nb[4];
+  nb[0] = xodd ? idx : (xh == 0 ? idx + (Xh - 1) : idx - 1);
+  nb[1] = y == 0 ? idx + (g.X[1] - 1) * sy : idx - sy;
+  nb[2] = z == 0 ? idx + (g.X[2] - 1) * sz : idx - sz;
+  nb[3] = t == 0 ? idx + (g.X[3] - 1) * st : idx - st;
+  const THost *h[4] = {h0, h1, h2, h3};
+  char *base = data + (size_t)parity * 8 * link_bytes;
+#pragma unroll
+  for (int mu = 0; mu < 4; mu++) {
+    real U[18];
+    const THost *f = h[mu] + ((size_t)parity * g.Vh + idx) * 18;
+#pragma unroll
+    for (int k = 0; k < 18; k++) U[k] = (real)f[k];
+    Planar<TDev, R>::store(U, base + (size_t)(2 * mu) * link_bytes, stride, idx, nullptr, 0);
+    const THost *bk = h[mu] + ((size_t)(1 - parity) * g.Vh + nb[mu]) * 18;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {  // dagger
+        U[r * 6 + c * 2] = (real)bk[c * 6 + r * 2];
+        U[r * 6 + c * 2 + 1] = -(real)bk[c * 6 + r * 2 + 1];
+      }
+    Planar<TDev, R>::store(U, base + (size_t)(2 * mu + 1) * link_bytes, stride, idx, nullptr, 0);
+  }
+}
+
+template <typename TDev, int R, typename THost> static void gaugeLoad(GaugeField &U, void *const h_gauge[4]) {
+  const size_t n = (size_t)U.geom.V * 18 * sizeof(THost);
+  char *stage = (char *)stagingBuffer(4 * n);
+  for (int d = 0; d < 4; d++) HIP_CHECK(hipMemcpyAsync(stage + d * n, h_gauge[d], n, hipMemcpyHostToDevice, computeStream()));
+  const int bs = 256, nb = (2 * U.geom.Vh + bs - 1) / bs;
+  hipLaunchKernelGGL((gauge_load_kernel<TDev, R, THost>), dim3(nb), dim3(bs), 0, computeStream(), (char *)U.data, U.link_bytes, U.stride,
+                     (const THost *)stage, (const THost *)(stage + n), (const THost *)(stage + 2 * n), (const THost *)(stage + 3 * n), U.geom);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(computeStream()));
+}
+
+void GaugeField::loadQDP(void *const h_gauge[4], QudaPrecision cpu_prec) {
+  if (commGrid().size > 1) errorQuda("multi-rank gauge load goes through loadGaugeQuda's halo path");
+#define QA_GL(TD, RR)                                                     \
+  if (cpu_prec == QUDA_DOUBLE_PRECISION) gaugeLoad<TD, RR, double>(*this, h_gauge); \
+  else gaugeLoad<TD, RR, float>(*this, h_gauge);
+  if (reconstruct == QUDA_RECONSTRUCT_NO) { QA_DISPATCH_DEV(precision, QA_GL(TD, 18)); }
+  else { QA_DISPATCH_DEV(precision, QA_GL(TD, 12)); }
+#undef QA_GL
+}
+
+// ================================================================================================
+// CloverField
+// ================================================================================================
+CloverField::CloverField(const LatticeGeom &g, QudaPrecision prec)
+    : geom(g), precision(prec), stride(g.Vh), clover(nullptr), cloverInv(nullptr), norm(nullptr), invNorm(nullptr), twisted(false), mu2(0) {
+  parity_bytes = alignUp((size_t)stride * 72 * (int)prec, 1024);
+  bytes = 2 * parity_bytes;
+  HIP_CHECK(hipMalloc(&clover, bytes));
+  HIP_CHECK(hipMalloc(&cloverInv, bytes));
+  parity_norm_bytes = 0;
+  if (prec == QUDA_HALF_PRECISION) {
+    parity_norm_bytes = (size_t)2 * stride * sizeof(float);
+    HIP_CHECK(hipMalloc((void **)&norm, 2 * parity_norm_bytes));
+    HIP_CHECK(hipMalloc((void **)&invNorm, 2 * parity_norm_bytes));
+  }
+  trlog[0] = trlog[1] = 0;
+}
+CloverField::~CloverField() {
+  if (clover) (void)hipFree(clover);
+  if (cloverInv) (void)hipFree(cloverInv);
+  if (norm) (void)hipFree(norm);
+  if (invNorm) (void)hipFree(invNorm);
+}
+
+template <typename TDev, typename THost>
+__global__ void clover_load_kernel(char *dev, float *norm, size_t parity_bytes, int stride, const THost *host, int Vh) {
+  using real = typename Store<TDev>::real;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= 2 * Vh) return;
+  const int parity = gid >= Vh, idx = gid - parity * Vh;
+#pragma unroll
+  for (int chi = 0; chi < 2; chi++) {
+    real C[36];
+    const THost *h = host + (((size_t)parity * Vh + idx) * 2 + chi) * 36;
+#pragma unroll
+    for (int k = 0; k < 36; k++) C[k] = (real)h[k];
+    Planar<TDev, 36>::store(C, dev + (size_t)parity * parity_bytes + (size_t)chi * 36 * sizeof(TDev) * stride, stride, idx,
+                            norm ? norm + (size_t)parity * 2 * stride : nullptr, chi * stride + idx);
+  }
+}
+
+template <typename TDev, typename THost>
+__global__ void clover_save_kernel(THost *host, const char *dev, const float *norm, size_t parity_bytes, int stride, int Vh) {
+  using real = typename Store<TDev>::real;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= 2 * Vh) return;
+  const int parity = gid >= Vh, idx = gid - parity * Vh;
+#pragma unroll
+  for (int chi = 0; chi < 2; chi++) {
+    real C[36];
+    Planar<TDev, 36>::load(C, dev + (size_t)parity * parity_bytes + (size_t)chi * 36 * sizeof(TDev) * stride, stride, idx,
+                           norm ? norm + (size_t)parity * 2 * stride : nullptr, chi * stride + idx);
+    THost *h = host + (((size_t)parity * Vh + idx) * 2 + chi) * 36;
+#pragma unroll
+    for (int k = 0; k < 36; k++) h[k] = (THost)C[k];
+  }
+}
+
+// (A^2 + mu2)^-1 (mu2 == 0: A^-1) per chiral block, computed in fp64 registers by Gauss-Jordan on the
+// Hermitian 6x6 (small, setup-time only; reference lib/clover_invert.cu:56-85 uses Cholesky).
+template <typename TDev>
+__global__ void clover_invert_kernel(char *inv, float *invNorm, const char *A, const float *Anorm, size_t parity_bytes, int stride, int Vh,
+                                     double mu2, double *trlog) {
+  using real = typename Store<TDev>::real;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= 2 * Vh) return;
+  const int parity = gid >= Vh, idx = gid - parity * Vh;
+  double tl = 0.0;
+  for (int chi = 0; chi < 2; chi++) {
+    real C[36];
+    Planar<TDev, 36>::load(C, A + (size_t)parity * parity_bytes + (size_t)chi * 36 * sizeof(TDev) * stride, stride, idx,
+                           Anorm ? Anorm + (size_t)parity * 2 * stride : nullptr, chi * stride + idx);
+    double M[6][6][2], S[6][12][2];
+    for (int r = 0; r < 6; r++)
+      for (int c = 0; c < 6; c++) {
+        if (r == c) { M[r][c][0] = C[r]; M[r][c][1] = 0; }
+        else if (r > c) { const int k = 15 - (6 - c) * (5 - c) / 2 + r - c - 1; M[r][c][0] = C[6 + 2 * k]; M[r][c][1] = C[6 + 2 * k + 1]; }
+        else { const int k = 15 - (6 - r) * (5 - r) / 2 + c - r - 1; M[r][c][0] = C[6 + 2 * k]; M[r][c][1] = -C[6 + 2 * k + 1]; }
+      }
+    for (int r = 0; r < 6; r++)
+      for (int c = 0; c < 6; c++) {
+        double re, im;
+        if (mu2 != 0.0) {
+          re = 0; im = 0;
+          for (int k = 0; k < 6; k++) {
+            re += M[r][k][0] * M[k][c][0] - M[r][k][1] * M[k][c][1];
+            im += M[r][k][0] * M[k][c][1] + M[r][k][1] * M[k][c][0];
+          }
+          if (r == c) re += mu2;
+        } else { re = M[r][c][0]; im = M[r][c][1]; }
+        S[r][c][0] = re; S[r][c][1] = im;
+        S[r][c + 6][0] = r == c; S[r][c + 6][1] = 0;
+      }
+    for (int p = 0; p < 6; p++) {
+      int best = p; double bm = 0;
+      for (int r = p; r < 6; r++) { const double m = S[r][p][0] * S[r][p][0] + S[r][p][1] * S[r][p][1]; if (m > bm) { bm = m; best = r; } }
+      if (best != p)
+        for (int c = 0; c < 12; c++)
+          for (int zz = 0; zz < 2; zz++) { const double tt = S[p][c][zz]; S[p][c][zz] = S[best][c][zz]; S[best][c][zz] = tt; }
+      const double pr = S[p][p][0], pi = S[p][p][1], den = pr * pr + pi * pi;
+      tl += 0.5 * log(den);
+      const double ir = pr / den, ii = -pi / den;
+      for (int c = 0; c < 12; c++) {
+        const double re = S[p][c][0] * ir - S[p][c][1] * ii, im = S[p][c][0] * ii + S[p][c][1] * ir;
+        S[p][c][0] = re; S[p][c][1] = im;
+      }
+      for (int r = 0; r < 6; r++) {
+        if (r == p) continue;
+        const double fr = S[r][p][0], fi = S[r][p][1];
+        for (int c = 0; c < 12; c++) {
+          S[r][c][0] -= fr * S[p][c][0] - fi * S[p][c][1];
+          S[r][c][1] -= fr * S[p][c][1] + fi * S[p][c][0];
+        }
+      }
+    }
+    real O[36];
+    for (int r = 0; r < 6; r++) O[r] = (real)S[r][r + 6][0];
+    for (int c = 0; c < 6; c++)
+      for (int r = c + 1; r < 6; r++) {
+        const int k = 15 - (6 - c) * (5 - c) / 2 + r - c - 1;
+        O[6 + 2 * k] = (real)(0.5 * (S[r][c + 6][0] + S[c][r + 6][0]));
+        O[6 + 2 * k + 1] = (real)(0.5 * (S[r][c + 6][1] - S[c][r + 6][1]));
+      }
+    Planar<TDev, 36>::store(O, inv + (size_t)parity * parity_bytes + (size_t)chi * 36 * sizeof(TDev) * stride, stride, idx,
+                            invNorm ? invNorm + (size_t)parity * 2 * stride : nullptr, chi * stride + idx);
+  }
+  if (trlog) atomicAdd(&trlog[parity], tl);
+}
+
+template <typename TDev, typename THost> static void cloverLoad(CloverField &c, void *dev, float *nrm, const void *host) {
+  const size_t n = (size_t)c.geom.V * 72 * sizeof(THost);
+  void *stage = stagingBuffer(n);
+  HIP_CHECK(hipMemcpyAsync(stage, host, n, hipMemcpyHostToDevice, computeStream()));
+  const int bs = 256, nb = (2 * c.geom.Vh + bs - 1) / bs;
+  hipLaunchKernelGGL((clover_load_kernel<TDev, THost>), dim3(nb), dim3(bs), 0, computeStream(), (char *)dev, nrm, c.parity_bytes, c.stride,
+                     (const THost *)stage, c.geom.Vh);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(computeStream()));
+}
+
+void CloverField::loadPacked(const void *h_clover, const void *h_inv, QudaPrecision cpu_prec) {
+#define QA_CL(TD, DEV, NRM, HOST)                                                   \
+  if (cpu_prec == QUDA_DOUBLE_PRECISION) cloverLoad<TD, double>(*this, DEV, NRM, HOST); \
+  else cloverLoad<TD, float>(*this, DEV, NRM, HOST);
+  if (h_clover) { QA_DISPATCH_DEV(precision, QA_CL(TD, clover, norm, h_clover)); }
+  if (h_inv) { QA_DISPATCH_DEV(precision, QA_CL(TD, cloverInv, invNorm, h_inv)); }
+#undef QA_CL
+}
+
+template <typename TDev> static void launchCloverInvert(CloverField &c, int nb, int bs, double mu2, double *d_trlog) {
+  hipLaunchKernelGGL((clover_invert_kernel<TDev>), dim3(nb), dim3(bs), 0, computeStream(), (char *)c.cloverInv, c.invNorm, (const char *)c.clover,
+                     c.norm, c.parity_bytes, c.stride, c.geom.Vh, mu2, d_trlog);
+}
+
+void CloverField::computeInverse(double mu2_) {
+  mu2 = mu2_;
+  twisted = mu2_ != 0.0;
+  double *d_trlog = nullptr;
+  HIP_CHECK(hipMalloc((void **)&d_trlog, 2 * sizeof(double)));
+  HIP_CHECK(hipMemsetAsync(d_trlog, 0, 2 * sizeof(double), computeStream()));
+  const int bs = 128, nb = (2 * geom.Vh + bs - 1) / bs;
+  QA_DISPATCH_DEV(precision, (launchCloverInvert<TD>(*this, nb, bs, mu2_, d_trlog)));
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(trlog, d_trlog, 2 * sizeof(double), hipMemcpyDeviceToHost, computeStream()));
+  HIP_CHECK(hipStreamSynchronize(computeStream()));
+  HIP_CHECK(hipFree(d_trlog));
+}
+
+void CloverField::savePackedInverse(void *h_inv, QudaPrecision cpu_prec) const {
+  const size_t n = (size_t)geom.V * 72 * (int)cpu_prec;
+  void *stage = stagingBuffer(n);
+  const int bs = 256, nb = (2 * geom.Vh + bs - 1) / bs;
+#define QA_CS(TD)                                                                                                              \
+  if (cpu_prec == QUDA_DOUBLE_PRECISION)                                                                                       \
+    hipLaunchKernelGGL((clover_save_kernel<TD, double>), dim3(nb), dim3(bs), 0, computeStream(), (double *)stage, (const char *)cloverInv, invNorm, \
+                       parity_bytes, stride, geom.Vh);                                                                         \
+  else                                                                                                                         \
+    hipLaunchKernelGGL((clover_save_kernel<TD, float>), dim3(nb), dim3(bs), 0, computeStream(), (float *)stage, (const char *)cloverInv, invNorm,  \
+                       parity_bytes, stride, geom.Vh);
+  QA_DISPATCH_DEV(precision, QA_CS(TD));
+#undef QA_CS
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(h_inv, stage, n, hipMemcpyDeviceToHost, computeStream()));
+  HIP_CHECK(hipStreamSynchronize(computeStream()));
+}
+
+}  // namespace quda

@@ -1,0 +1,520 @@
+// interface.cpp — the quda.h C ABI.  Thin re-statement of the reference's interface layer
+// (lib/interface_quda.cpp:119-145 resident-field globals, :285-520 init, :521-730 loadGaugeQuda,
+// :730-930 loadCloverQuda, :1265-1412 setDiracParam/createDirac/massRescale, :1496 dslashQuda,
+// :1716 MatQuda, :1796 MatDagMatQuda) on top of the CDNA4 field/operator classes.
+#include <cmath>
+#include <cstring>
+#include <sys/time.h>
+
+#include "blas.h"
+#include "dirac.h"
+#include "interface_internal.h"
+#include "quda_amd_ext.h"
+
+namespace quda {
+
+void setVerbosityInternal(QudaVerbosity v, const char *prefix, FILE *f);
+void createStreams();
+void destroyStreams();
+void freeStagingBuffer();
+
+// resident fields (reference lib/interface_quda.cpp:119-145)
+GaugeField *gaugePrecise = nullptr, *gaugeSloppy = nullptr, *gaugePrecondition = nullptr;
+CloverField *cloverPrecise = nullptr, *cloverSloppy = nullptr, *cloverPrecondition = nullptr;
+static bool g_initialized = false, g_comms_initialized = false;
+static int g_device = -1;
+static LatticeGeom g_geom;
+static QudaGaugeParam g_gauge_param;
+
+// host copies kept so sloppy/precondition clover fields and MG setup can be (re)built
+const LatticeGeom &residentGeom() { return g_geom; }
+
+static double wallTime() {
+  timeval t;
+  gettimeofday(&t, nullptr);
+  return t.tv_sec + 1e-6 * t.tv_usec;
+}
+
+GaugeField *residentGauge(int which) {
+  GaugeField *g = which == 0 ? gaugePrecise : (which == 1 ? gaugeSloppy : gaugePrecondition);
+  if (!g) errorQuda("Gauge field not allocated");
+  return g;
+}
+CloverField *residentClover(int which) { return which == 0 ? cloverPrecise : (which == 1 ? cloverSloppy : cloverPrecondition); }
+
+// reference lib/interface_quda.cpp:1265-1340
+void setDiracParam(DiracParam &dp, QudaInvertParam *inv, const bool pc) {
+  switch (inv->dslash_type) {
+    case QUDA_WILSON_DSLASH: dp.type = pc ? QUDA_WILSONPC_DIRAC : QUDA_WILSON_DIRAC; break;
+    case QUDA_TWISTED_MASS_DSLASH:
+      dp.type = pc ? QUDA_TWISTED_MASSPC_DIRAC : QUDA_TWISTED_MASS_DIRAC;
+      if (inv->twist_flavor != QUDA_TWIST_MINUS && inv->twist_flavor != QUDA_TWIST_PLUS)
+        errorQuda("twist_flavor %d: only the degenerate +-1 flavours are on this library's path", inv->twist_flavor);
+      break;
+    case QUDA_TWISTED_CLOVER_DSLASH:
+      dp.type = pc ? QUDA_TWISTED_CLOVERPC_DIRAC : QUDA_TWISTED_CLOVER_DIRAC;
+      if (inv->twist_flavor != QUDA_TWIST_MINUS && inv->twist_flavor != QUDA_TWIST_PLUS) errorQuda("twist_flavor %d not supported", inv->twist_flavor);
+      break;
+    default: errorQuda("Unsupported dslash_type %d (Wilson, twisted-mass and twisted-clover are implemented)", inv->dslash_type);
+  }
+  dp.matpcType = inv->matpc_type;
+  dp.dagger = inv->dagger;
+  dp.gauge = gaugePrecise;
+  dp.clover = cloverPrecise;
+  dp.kappa = inv->kappa;
+  dp.mass = inv->mass;
+  dp.m5 = inv->m5;
+  dp.mu = inv->mu;
+  dp.epsilon = 0.0;
+  for (int i = 0; i < 4; i++) dp.commDim[i] = 1;
+}
+void setDiracSloppyParam(DiracParam &dp, QudaInvertParam *inv, const bool pc) {
+  setDiracParam(dp, inv, pc);
+  dp.gauge = gaugeSloppy ? gaugeSloppy : gaugePrecise;
+  dp.clover = cloverSloppy ? cloverSloppy : cloverPrecise;
+}
+void setDiracPreParam(DiracParam &dp, QudaInvertParam *inv, const bool pc) {
+  setDiracParam(dp, inv, pc);
+  dp.gauge = gaugePrecondition ? gaugePrecondition : (gaugeSloppy ? gaugeSloppy : gaugePrecise);
+  dp.clover = cloverPrecondition ? cloverPrecondition : (cloverSloppy ? cloverSloppy : cloverPrecise);
+}
+
+static void checkResident(const QudaInvertParam *inv) {
+  if (!g_initialized) errorQuda("QUDA not initialized");
+  if (!gaugePrecise) errorQuda("Gauge field not allocated");
+  if (!cloverPrecise && inv->dslash_type == QUDA_TWISTED_CLOVER_DSLASH) errorQuda("Clover field not allocated");
+}
+
+ColorSpinorParam deviceSpinorParam(QudaPrecision prec, QudaSiteSubset subset, QudaTwistFlavorType flavor) {
+  ColorSpinorParam p;
+  p.location = QUDA_CUDA_FIELD_LOCATION;
+  for (int d = 0; d < 4; d++) p.x[d] = g_geom.X[d];
+  if (subset == QUDA_PARITY_SITE_SUBSET) p.x[0] /= 2;
+  p.siteSubset = subset;
+  p.precision = prec;
+  p.twistFlavor = flavor;
+  p.create = QUDA_NULL_FIELD_CREATE;
+  return p;
+}
+
+}  // namespace quda
+
+using namespace quda;
+
+// ================================================================================================
+extern "C" {
+
+void setVerbosityQuda(QudaVerbosity verbosity, const char prefix[], FILE *outfile) { setVerbosityInternal(verbosity, prefix, outfile); }
+
+void initQudaDevice(int dev) {
+  if (g_device >= 0) return;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0) errorQuda("No HIP devices found — this library has no CPU fallback");
+  if (dev < 0) dev = commGrid().rank % n;  // rank-local index (reference :403-408)
+  if (dev >= n) errorQuda("Device %d does not exist (%d visible)", dev, n);
+  HIP_CHECK(hipSetDevice(dev));
+  g_device = dev;
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+  if (getVerbosity() >= QUDA_SUMMARIZE) printfQuda("QUDA-AMD %d.%d.%d: device %d = %s (%s), %d CUs\n", QUDA_VERSION_MAJOR, QUDA_VERSION_MINOR, QUDA_VERSION_SUBMINOR, dev, prop.name, prop.gcnArchName, prop.multiProcessorCount);
+}
+
+void initQudaMemory(void) {
+  if (g_initialized) return;
+  if (!g_comms_initialized) {
+    const int one[4] = {1, 1, 1, 1};
+    initCommsGridQuda(4, one, nullptr, nullptr);
+  }
+  createStreams();
+  blas::init();
+  g_initialized = true;
+}
+
+void initQuda(int device) {
+  if (!g_comms_initialized) {
+    const int one[4] = {1, 1, 1, 1};
+    initCommsGridQuda(4, one, nullptr, nullptr);
+  }
+  initQudaDevice(device);
+  initQudaMemory();
+}
+
+void endQuda(void) {
+  if (!g_initialized) return;
+  freeGaugeQuda();
+  freeCloverQuda();
+  freeStagingBuffer();
+  blas::end();
+  commFinalize();
+  destroyStreams();
+  g_initialized = false;
+  g_comms_initialized = false;
+  g_device = -1;
+}
+
+// reference :285 -> comm_init (lib/comm_mpi.cpp:50); transport here is RCCL, bootstrapped by the launcher (comm.cpp)
+void initCommsGridQuda(int nDim, const int *dims, QudaCommsMap func, void *fdata) {
+  if (nDim != 4) errorQuda("Number of communication grid dimensions must be 4");
+  commInit(dims, func, fdata);
+  g_comms_initialized = true;
+}
+
+// ---- param constructors / printers (reference lib/check_params.h X-macros) ----
+QudaGaugeParam newQudaGaugeParam(void) {
+  QudaGaugeParam p;
+  memset(&p, 0, sizeof(p));
+  p.location = QUDA_CPU_FIELD_LOCATION;
+  for (int d = 0; d < 4; d++) p.X[d] = INT_MIN;
+  p.anisotropy = NAN; p.tadpole_coeff = NAN; p.scale = 1.0;
+  p.type = QUDA_INVALID_LINKS; p.gauge_order = QUDA_INVALID_GAUGE_ORDER; p.t_boundary = QUDA_INVALID_T_BOUNDARY;
+  p.cpu_prec = p.cuda_prec = p.cuda_prec_sloppy = p.cuda_prec_precondition = QUDA_INVALID_PRECISION;
+  p.reconstruct = p.reconstruct_sloppy = p.reconstruct_precondition = QUDA_RECONSTRUCT_INVALID;
+  p.gauge_fix = QUDA_GAUGE_FIXED_INVALID;
+  p.ga_pad = INT_MIN;
+  p.staggered_phase_type = QUDA_INVALID_STAGGERED_PHASE;
+  p.make_resident_gauge = 1; p.return_result_gauge = 1;
+  return p;
+}
+
+QudaInvertParam newQudaInvertParam(void) {
+  QudaInvertParam p;
+  memset(&p, 0, sizeof(p));
+  p.input_location = p.output_location = QUDA_CPU_FIELD_LOCATION;
+  p.dslash_type = QUDA_INVALID_DSLASH; p.inv_type = QUDA_INVALID_INVERTER;
+  p.mass = NAN; p.kappa = NAN; p.m5 = NAN; p.Ls = INT_MIN; p.mu = NAN; p.epsilon = NAN;
+  p.twist_flavor = QUDA_TWIST_INVALID;
+  p.tol = NAN; p.tol_restart = 5e-3; p.tol_hq = 0.0; p.maxiter = INT_MIN; p.reliable_delta = NAN;
+  p.use_sloppy_partial_accumulator = 0; p.max_res_increase = 1; p.max_res_increase_total = 10; p.heavy_quark_check = 10;
+  p.pipeline = 0; p.num_offset = 0; p.num_src = 1; p.overlap = 0;
+  p.solution_type = QUDA_INVALID_SOLUTION; p.solve_type = QUDA_INVALID_SOLVE; p.matpc_type = QUDA_MATPC_INVALID;
+  p.dagger = QUDA_DAG_INVALID; p.mass_normalization = QUDA_INVALID_NORMALIZATION;
+  p.solver_normalization = QUDA_DEFAULT_NORMALIZATION; p.preserve_source = QUDA_PRESERVE_SOURCE_INVALID;
+  p.cpu_prec = p.cuda_prec = p.cuda_prec_sloppy = p.cuda_prec_precondition = QUDA_INVALID_PRECISION;
+  p.dirac_order = QUDA_INVALID_DIRAC_ORDER; p.gamma_basis = QUDA_INVALID_GAMMA_BASIS;
+  p.clover_location = QUDA_CPU_FIELD_LOCATION;
+  p.clover_cpu_prec = p.clover_cuda_prec = p.clover_cuda_prec_sloppy = p.clover_cuda_prec_precondition = QUDA_INVALID_PRECISION;
+  p.clover_order = QUDA_INVALID_CLOVER_ORDER; p.use_init_guess = QUDA_USE_INIT_GUESS_INVALID;
+  p.clover_coeff = NAN;
+  p.verbosity = QUDA_INVALID_VERBOSITY; p.sp_pad = INT_MIN; p.cl_pad = INT_MIN;
+  p.tune = QUDA_TUNE_INVALID; p.Nsteps = INT_MIN; p.gcrNkrylov = INT_MIN;
+  p.inv_type_precondition = QUDA_INVALID_INVERTER; p.preconditioner = p.preconditionerUP = p.preconditionerDN = nullptr;
+  p.dslash_type_precondition = QUDA_INVALID_DSLASH; p.verbosity_precondition = QUDA_INVALID_VERBOSITY;
+  p.tol_precondition = NAN; p.maxiter_precondition = INT_MIN; p.omega = NAN; p.precondition_cycle = 1;
+  p.schwarz_type = QUDA_INVALID_SCHWARZ; p.residual_type = QUDA_L2_RELATIVE_RESIDUAL;
+  p.cuda_prec_ritz = QUDA_SINGLE_PRECISION;
+  return p;
+}
+
+QudaMultigridParam newQudaMultigridParam(void) {
+  QudaMultigridParam p;
+  memset(&p, 0, sizeof(p));
+  p.invert_param = nullptr;
+  p.n_level = INT_MIN;
+  for (int i = 0; i < QUDA_MAX_MG_LEVEL; i++) {
+    for (int d = 0; d < QUDA_MAX_DIM; d++) p.geo_block_size[i][d] = INT_MIN;
+    p.spin_block_size[i] = INT_MIN; p.n_vec[i] = INT_MIN;
+    p.smoother[i] = QUDA_INVALID_INVERTER; p.coarse_grid_solution_type[i] = QUDA_INVALID_SOLUTION;
+    p.smoother_solve_type[i] = QUDA_INVALID_SOLVE; p.cycle_type[i] = QUDA_MG_CYCLE_INVALID;
+    p.nu_pre[i] = INT_MIN; p.nu_post[i] = INT_MIN; p.smoother_tol[i] = NAN; p.omega[i] = NAN;
+    p.global_reduction[i] = QUDA_BOOLEAN_INVALID; p.location[i] = QUDA_INVALID_FIELD_LOCATION;
+  }
+  // the reference leaves these two uninitialised; defaults documented in DESIGN.md
+  p.setup_maxiter = 500; p.setup_tol = 5e-6;
+  p.compute_null_vector = QUDA_COMPUTE_NULL_VECTOR_INVALID;
+  p.generate_all_levels = QUDA_BOOLEAN_INVALID; p.run_verify = QUDA_BOOLEAN_INVALID;
+  p.delta_muPR = p.delta_kappaPR = p.delta_cswPR = 1.0;
+  p.delta_muCG = p.delta_kappaCG = p.delta_cswCG = 1.0;
+  return p;
+}
+
+void printQudaGaugeParam(QudaGaugeParam *p) {
+  printfQuda("QUDA Gauge Parameters:\n");
+  printfQuda("X = %d %d %d %d\nanisotropy = %g\ntype = %d\ngauge_order = %d\nt_boundary = %d\ncpu_prec = %d\ncuda_prec = %d\nreconstruct = %d\n"
+             "cuda_prec_sloppy = %d\nreconstruct_sloppy = %d\ncuda_prec_precondition = %d\nreconstruct_precondition = %d\ngauge_fix = %d\nga_pad = %d\ngaugeGiB = %g\n",
+             p->X[0], p->X[1], p->X[2], p->X[3], p->anisotropy, p->type, p->gauge_order, p->t_boundary, p->cpu_prec, p->cuda_prec, p->reconstruct,
+             p->cuda_prec_sloppy, p->reconstruct_sloppy, p->cuda_prec_precondition, p->reconstruct_precondition, p->gauge_fix, p->ga_pad, p->gaugeGiB);
+}
+void printQudaInvertParam(QudaInvertParam *p) {
+  printfQuda("QUDA Inverter Parameters:\n");
+  printfQuda("dslash_type = %d\ninv_type = %d\nkappa = %g\nmu = %g\ntwist_flavor = %d\ntol = %g\nmaxiter = %d\nreliable_delta = %g\nsolution_type = %d\n"
+             "solve_type = %d\nmatpc_type = %d\ndagger = %d\nmass_normalization = %d\ncpu_prec = %d\ncuda_prec = %d\ncuda_prec_sloppy = %d\n"
+             "cuda_prec_precondition = %d\ndirac_order = %d\ngamma_basis = %d\nclover_cpu_prec = %d\nclover_cuda_prec = %d\nclover_order = %d\n"
+             "gcrNkrylov = %d\ninv_type_precondition = %d\nverbosity = %d\niter = %d\nsecs = %g\ngflops = %g\ntrue_res = %g\n",
+             p->dslash_type, p->inv_type, p->kappa, p->mu, p->twist_flavor, p->tol, p->maxiter, p->reliable_delta, p->solution_type, p->solve_type,
+             p->matpc_type, p->dagger, p->mass_normalization, p->cpu_prec, p->cuda_prec, p->cuda_prec_sloppy, p->cuda_prec_precondition, p->dirac_order,
+             p->gamma_basis, p->clover_cpu_prec, p->clover_cuda_prec, p->clover_order, p->gcrNkrylov, p->inv_type_precondition, p->verbosity, p->iter,
+             p->secs, p->gflops, p->true_res);
+}
+void printQudaMultigridParam(QudaMultigridParam *p) {
+  printfQuda("QUDA Multigrid Parameters:\nn_level = %d\nsetup_maxiter = %d\nsetup_tol = %g\n", p->n_level, p->setup_maxiter, p->setup_tol);
+  for (int i = 0; i < p->n_level && i < QUDA_MAX_MG_LEVEL; i++)
+    printfQuda("level %d: geo_block = %d %d %d %d spin_block = %d n_vec = %d smoother = %d solve_type = %d cycle = %d nu_pre = %d nu_post = %d omega = %g tol = %g\n", i,
+               p->geo_block_size[i][0], p->geo_block_size[i][1], p->geo_block_size[i][2], p->geo_block_size[i][3], p->spin_block_size[i], p->n_vec[i],
+               p->smoother[i], p->smoother_solve_type[i], p->cycle_type[i], p->nu_pre[i], p->nu_post[i], p->omega[i], p->smoother_tol[i]);
+}
+
+// reference lib/check_params.h via checkGaugeParam (:531)
+static void checkGaugeParam(const QudaGaugeParam *p) {
+  for (int d = 0; d < 4; d++) if (p->X[d] <= 0 || p->X[d] % 2) errorQuda("Parameter X[%d] = %d undefined or odd", d, p->X[d]);
+  if (!(p->anisotropy == p->anisotropy)) errorQuda("Parameter anisotropy undefined");
+  if (p->t_boundary != QUDA_ANTI_PERIODIC_T && p->t_boundary != QUDA_PERIODIC_T) errorQuda("Parameter t_boundary undefined");
+  if (p->cpu_prec != QUDA_DOUBLE_PRECISION && p->cpu_prec != QUDA_SINGLE_PRECISION) errorQuda("Parameter cpu_prec = %d undefined", p->cpu_prec);
+  if (p->cuda_prec != QUDA_DOUBLE_PRECISION && p->cuda_prec != QUDA_SINGLE_PRECISION && p->cuda_prec != QUDA_HALF_PRECISION) errorQuda("Parameter cuda_prec = %d undefined", p->cuda_prec);
+  if (p->reconstruct != QUDA_RECONSTRUCT_NO && p->reconstruct != QUDA_RECONSTRUCT_12) errorQuda("Parameter reconstruct = %d: this library implements 18 and 12", p->reconstruct);
+  if (p->gauge_order != QUDA_QDP_GAUGE_ORDER) errorQuda("Parameter gauge_order = %d: only QUDA_QDP_GAUGE_ORDER host fields are supported", p->gauge_order);
+  if (p->type != QUDA_WILSON_LINKS) errorQuda("Parameter type = %d: only Wilson (SU(3)) links are on this path", p->type);
+}
+
+void loadGaugeQuda(void *h_gauge, QudaGaugeParam *param) {
+  if (!g_initialized) errorQuda("QUDA not initialized");
+  checkGaugeParam(param);
+  freeGaugeQuda();
+  g_geom = LatticeGeom(param->X);
+  g_gauge_param = *param;
+  void **links = (void **)h_gauge;
+  gaugePrecise = new GaugeField(g_geom, param->cuda_prec, param->reconstruct, param->t_boundary, param->anisotropy);
+  loadGaugeWithHalo(*gaugePrecise, links, param->cpu_prec);
+  double gib = gaugePrecise->GiB();
+  auto valid = [](QudaPrecision p) { return p == QUDA_DOUBLE_PRECISION || p == QUDA_SINGLE_PRECISION || p == QUDA_HALF_PRECISION; };
+  if (valid(param->cuda_prec_sloppy) && (param->cuda_prec_sloppy != param->cuda_prec || param->reconstruct_sloppy != param->reconstruct)) {
+    QudaReconstructType r = (param->reconstruct_sloppy == QUDA_RECONSTRUCT_12) ? QUDA_RECONSTRUCT_12 : QUDA_RECONSTRUCT_NO;
+    gaugeSloppy = new GaugeField(g_geom, param->cuda_prec_sloppy, r, param->t_boundary, param->anisotropy);
+    loadGaugeWithHalo(*gaugeSloppy, links, param->cpu_prec);
+    gib += gaugeSloppy->GiB();
+  }
+  const QudaPrecision sp = gaugeSloppy ? gaugeSloppy->precision : gaugePrecise->precision;
+  const QudaReconstructType sr = gaugeSloppy ? gaugeSloppy->reconstruct : gaugePrecise->reconstruct;
+  if (valid(param->cuda_prec_precondition) && (param->cuda_prec_precondition != sp || (param->reconstruct_precondition != sr && param->reconstruct_precondition != QUDA_RECONSTRUCT_INVALID))) {
+    QudaReconstructType r = (param->reconstruct_precondition == QUDA_RECONSTRUCT_12) ? QUDA_RECONSTRUCT_12 : QUDA_RECONSTRUCT_NO;
+    gaugePrecondition = new GaugeField(g_geom, param->cuda_prec_precondition, r, param->t_boundary, param->anisotropy);
+    loadGaugeWithHalo(*gaugePrecondition, links, param->cpu_prec);
+    gib += gaugePrecondition->GiB();
+  }
+  param->gaugeGiB = gib;
+}
+
+void freeGaugeQuda(void) {
+  delete gaugePrecise; delete gaugeSloppy; delete gaugePrecondition;
+  gaugePrecise = gaugeSloppy = gaugePrecondition = nullptr;
+}
+
+// reference :730-930.  Host order: QUDA_PACKED_CLOVER_ORDER.  If the inverse is not supplied (or
+// compute_clover_inverse is set) it is computed on the device; for twisted clover it is (A^2 + 4 kappa^2 mu^2)^-1
+// (reference :780-790, lib/clover_invert.cu:56-85).
+void loadCloverQuda(void *h_clover, void *h_clovinv, QudaInvertParam *inv) {
+  if (!g_initialized) errorQuda("QUDA not initialized");
+  if (!gaugePrecise) errorQuda("Cannot call loadCloverQuda with no resident gauge field");
+  if (inv->clover_order != QUDA_PACKED_CLOVER_ORDER) errorQuda("clover_order %d: only QUDA_PACKED_CLOVER_ORDER host fields are supported", inv->clover_order);
+  if (inv->clover_cpu_prec != QUDA_DOUBLE_PRECISION && inv->clover_cpu_prec != QUDA_SINGLE_PRECISION) errorQuda("Parameter clover_cpu_prec undefined");
+  if (!h_clover) errorQuda("loadCloverQuda(NULL, ...): device construction of the clover term from the gauge field is a 'next' row (SURVEY 8f-2) and not built yet");
+  freeCloverQuda();
+  const bool twisted = inv->dslash_type == QUDA_TWISTED_CLOVER_DSLASH;
+  const double mu2 = twisted ? 4.0 * inv->kappa * inv->kappa * inv->mu * inv->mu : 0.0;
+  const bool compute_inv = !h_clovinv || inv->compute_clover_inverse || inv->return_clover_inverse;
+  auto make = [&](QudaPrecision prec) {
+    CloverField *c = new CloverField(g_geom, prec);
+    c->loadPacked(h_clover, compute_inv ? nullptr : h_clovinv, inv->clover_cpu_prec);
+    if (compute_inv) c->computeInverse(mu2);
+    else { c->twisted = twisted; c->mu2 = mu2; }
+    return c;
+  };
+  cloverPrecise = make(inv->clover_cuda_prec);
+  double gib = cloverPrecise->GiB();
+  auto valid = [](QudaPrecision p) { return p == QUDA_DOUBLE_PRECISION || p == QUDA_SINGLE_PRECISION || p == QUDA_HALF_PRECISION; };
+  if (valid(inv->clover_cuda_prec_sloppy) && inv->clover_cuda_prec_sloppy != inv->clover_cuda_prec) { cloverSloppy = make(inv->clover_cuda_prec_sloppy); gib += cloverSloppy->GiB(); }
+  const QudaPrecision sp = cloverSloppy ? cloverSloppy->precision : cloverPrecise->precision;
+  if (valid(inv->clover_cuda_prec_precondition) && inv->clover_cuda_prec_precondition != sp) { cloverPrecondition = make(inv->clover_cuda_prec_precondition); gib += cloverPrecondition->GiB(); }
+  inv->cloverGiB = gib;
+  inv->trlogA[0] = cloverPrecise->trlog[0];
+  inv->trlogA[1] = cloverPrecise->trlog[1];
+  if (h_clovinv && compute_inv && inv->return_clover_inverse) {
+    // hand the inverse back in double if the device field is 16-bit? no: from the most precise resident copy
+    cloverPrecise->savePackedInverse(h_clovinv, inv->clover_cpu_prec);
+  }
+}
+
+void freeCloverQuda(void) {
+  delete cloverPrecise; delete cloverSloppy; delete cloverPrecondition;
+  cloverPrecise = cloverSloppy = cloverPrecondition = nullptr;
+}
+
+// reference :1496-1570
+void dslashQuda(void *h_out, void *h_in, QudaInvertParam *inv, QudaParity parity) {
+  checkResident(inv);
+  ColorSpinorParam cpuParam(h_in, *inv, g_geom.X, true);
+  ColorSpinorField in_h(cpuParam);
+  ColorSpinorParam dp = deviceSpinorParam(inv->cuda_prec, QUDA_PARITY_SITE_SUBSET, inv->twist_flavor);
+  ColorSpinorField in(dp), out(dp);
+  in = in_h;
+  DiracParam diracParam;
+  setDiracParam(diracParam, inv, true);
+  Dirac *dirac = Dirac::create(diracParam);
+  if (inv->dslash_type == QUDA_TWISTED_CLOVER_DSLASH && inv->dagger) {
+    ColorSpinorField tmp1(dp);
+    ((DiracTwistedCloverPC *)dirac)->TwistCloverInv(tmp1, in, (parity + 1) % 2);
+    dirac->Dslash(out, tmp1, parity);
+  } else {
+    dirac->Dslash(out, in, parity);
+  }
+  delete dirac;
+  cpuParam.v = h_out;
+  ColorSpinorField out_h(cpuParam);
+  out_h = out;
+}
+
+static void normalizeMat(ColorSpinorField &out, const QudaInvertParam *inv, bool pc, bool squared) {
+  const double kappa = inv->kappa;
+  double f = 1.0;
+  if (pc) {
+    if (inv->mass_normalization == QUDA_MASS_NORMALIZATION) f = 0.25 / (kappa * kappa);
+    else if (inv->mass_normalization == QUDA_ASYMMETRIC_MASS_NORMALIZATION) f = 0.5 / kappa;
+  } else if (inv->mass_normalization == QUDA_MASS_NORMALIZATION || inv->mass_normalization == QUDA_ASYMMETRIC_MASS_NORMALIZATION) {
+    f = 0.5 / kappa;
+  }
+  if (squared) f *= f;
+  if (f != 1.0) blas::ax(f, out);
+}
+
+static void applyMat(void *h_out, void *h_in, QudaInvertParam *inv, bool dagmat) {
+  checkResident(inv);
+  const bool pc = inv->solution_type == QUDA_MATPC_SOLUTION || inv->solution_type == QUDA_MATPCDAG_MATPC_SOLUTION;
+  ColorSpinorParam cpuParam(h_in, *inv, g_geom.X, pc);
+  ColorSpinorField in_h(cpuParam);
+  ColorSpinorParam dp = deviceSpinorParam(inv->cuda_prec, pc ? QUDA_PARITY_SITE_SUBSET : QUDA_FULL_SITE_SUBSET, inv->twist_flavor);
+  ColorSpinorField in(dp), out(dp);
+  in = in_h;
+  DiracParam diracParam;
+  setDiracParam(diracParam, inv, pc);
+  Dirac *dirac = Dirac::create(diracParam);
+  if (dagmat) dirac->MdagM(out, in);
+  else dirac->M(out, in);
+  delete dirac;
+  normalizeMat(out, inv, pc, dagmat);
+  cpuParam.v = h_out;
+  ColorSpinorField out_h(cpuParam);
+  out_h = out;
+}
+
+void MatQuda(void *h_out, void *h_in, QudaInvertParam *inv) { applyMat(h_out, h_in, inv, false); }
+void MatDagMatQuda(void *h_out, void *h_in, QudaInvertParam *inv) { applyMat(h_out, h_in, inv, true); }
+
+// reference :1650-1714: out = A in (or A^-1 in) on one parity
+void cloverQuda(void *h_out, void *h_in, QudaInvertParam *inv, QudaParity *parity, int inverse) {
+  if (!g_initialized) errorQuda("QUDA not initialized");
+  if (!cloverPrecise) errorQuda("Clover field not allocated");
+  ColorSpinorParam cpuParam(h_in, *inv, g_geom.X, true);
+  ColorSpinorField in_h(cpuParam);
+  ColorSpinorParam dp = deviceSpinorParam(inv->cuda_prec, QUDA_PARITY_SITE_SUBSET, inv->twist_flavor);
+  ColorSpinorField in(dp), out(dp);
+  in = in_h;
+  applySite(out, in, SITE_CLOVER, 0.0, 1.0, cloverPrecise, (int)*parity, inverse != 0);
+  cpuParam.v = h_out;
+  ColorSpinorField out_h(cpuParam);
+  out_h = out;
+}
+
+void openMagma(void) {}
+void closeMagma(void) {}
+
+// ================================================================================================
+// quda_amd_ext.h
+// ================================================================================================
+void *qudaAmdSpinorCreate(QudaPrecision prec, QudaSiteSubset subset, QudaTwistFlavorType flavor) {
+  if (!gaugePrecise) errorQuda("load a gauge field first (it defines the local lattice)");
+  ColorSpinorParam p = deviceSpinorParam(prec, subset, flavor);
+  p.create = QUDA_ZERO_FIELD_CREATE;
+  return new ColorSpinorField(p);
+}
+void qudaAmdSpinorDestroy(void *f) { delete (ColorSpinorField *)f; }
+void qudaAmdSpinorLoad(void *f, const void *h_src, const QudaInvertParam *inv) {
+  ColorSpinorField *d = (ColorSpinorField *)f;
+  ColorSpinorParam cp((void *)h_src, *inv, g_geom.X, d->SiteSubset() == QUDA_PARITY_SITE_SUBSET);
+  ColorSpinorField h(cp);
+  *d = h;
+}
+void qudaAmdSpinorSave(const void *f, void *h_dst, const QudaInvertParam *inv) {
+  const ColorSpinorField *d = (const ColorSpinorField *)f;
+  ColorSpinorParam cp(h_dst, *inv, g_geom.X, d->SiteSubset() == QUDA_PARITY_SITE_SUBSET);
+  ColorSpinorField h(cp);
+  h = *d;
+}
+void qudaAmdSpinorCopy(void *dst, const void *src) { copyColorSpinor(*(ColorSpinorField *)dst, *(const ColorSpinorField *)src); }
+void qudaAmdSpinorSetTwist(void *f, QudaTwistFlavorType flavor) { ((ColorSpinorField *)f)->changeTwist(flavor); }
+
+void *qudaAmdDiracCreate(QudaInvertParam *inv, int pc, int which) {
+  checkResident(inv);
+  DiracParam dp;
+  if (which == 0) setDiracParam(dp, inv, pc != 0);
+  else if (which == 1) setDiracSloppyParam(dp, inv, pc != 0);
+  else setDiracPreParam(dp, inv, pc != 0);
+  return Dirac::create(dp);
+}
+void qudaAmdDiracDestroy(void *d) { delete (Dirac *)d; }
+void qudaAmdDiracDslash(void *d, void *out, const void *in, QudaParity parity) { ((Dirac *)d)->Dslash(*(ColorSpinorField *)out, *(const ColorSpinorField *)in, parity); }
+void qudaAmdDiracDslashXpay(void *d, void *out, const void *in, QudaParity parity, const void *x, double k) {
+  ((Dirac *)d)->DslashXpay(*(ColorSpinorField *)out, *(const ColorSpinorField *)in, parity, *(const ColorSpinorField *)x, k);
+}
+void qudaAmdDiracM(void *d, void *out, const void *in) { ((Dirac *)d)->M(*(ColorSpinorField *)out, *(const ColorSpinorField *)in); }
+void qudaAmdDiracMdag(void *d, void *out, const void *in) { ((Dirac *)d)->Mdag(*(ColorSpinorField *)out, *(const ColorSpinorField *)in); }
+void qudaAmdDiracMdagM(void *d, void *out, const void *in) { ((Dirac *)d)->MdagM(*(ColorSpinorField *)out, *(const ColorSpinorField *)in); }
+unsigned long long qudaAmdDiracFlops(void *d) { return ((Dirac *)d)->Flops(); }
+
+double qudaAmdTimeDslash(void *d, void *out, const void *in, QudaParity parity, int niter) {
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0));
+  HIP_CHECK(hipEventCreate(&e1));
+  HIP_CHECK(hipEventRecord(e0, computeStream()));
+  for (int i = 0; i < niter; i++) ((Dirac *)d)->Dslash(*(ColorSpinorField *)out, *(const ColorSpinorField *)in, parity);
+  HIP_CHECK(hipEventRecord(e1, computeStream()));
+  HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  HIP_CHECK(hipEventDestroy(e0));
+  HIP_CHECK(hipEventDestroy(e1));
+  return 1e-3 * ms / niter;
+}
+double qudaAmdTimeM(void *d, void *out, const void *in, int niter) {
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0));
+  HIP_CHECK(hipEventCreate(&e1));
+  HIP_CHECK(hipEventRecord(e0, computeStream()));
+  for (int i = 0; i < niter; i++) ((Dirac *)d)->M(*(ColorSpinorField *)out, *(const ColorSpinorField *)in);
+  HIP_CHECK(hipEventRecord(e1, computeStream()));
+  HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  HIP_CHECK(hipEventDestroy(e0));
+  HIP_CHECK(hipEventDestroy(e1));
+  return 1e-3 * ms / niter;
+}
+
+double qudaAmdBlasNorm2(const void *f) { return blas::norm2(*(const ColorSpinorField *)f); }
+void qudaAmdBlasCDot(const void *x, const void *y, double r[2]) {
+  Complex c = blas::cDotProduct(*(const ColorSpinorField *)x, *(const ColorSpinorField *)y);
+  r[0] = c.real(); r[1] = c.imag();
+}
+void qudaAmdBlasAxpy(double a, const void *x, void *y) { blas::axpy(a, *(const ColorSpinorField *)x, *(ColorSpinorField *)y); }
+
+static DslashMode pcDslashMode(QudaInvertParam *inv) {
+  const bool asym = inv->matpc_type == QUDA_MATPC_EVEN_EVEN_ASYMMETRIC || inv->matpc_type == QUDA_MATPC_ODD_ODD_ASYMMETRIC;
+  switch (inv->dslash_type) {
+    case QUDA_WILSON_DSLASH: return DSLASH_PLAIN;
+    case QUDA_TWISTED_MASS_DSLASH: return (!inv->dagger || asym) ? DSLASH_TWIST_INV : DSLASH_TWIST_INV_DSLASH;
+    case QUDA_TWISTED_CLOVER_DSLASH: return (!inv->dagger || asym) ? DSLASH_CLOVER_TWIST_INV : DSLASH_PLAIN;
+    default: errorQuda("Unsupported dslash_type %d", inv->dslash_type);
+  }
+  return DSLASH_PLAIN;
+}
+long long qudaAmdDslashBytesPerSite(QudaInvertParam *inv, int which, int xpay) {
+  GaugeField *g = residentGauge(which);
+  return dslashBytesPerSite(g->precision, (int)g->reconstruct, pcDslashMode(inv), xpay != 0);
+}
+long long qudaAmdDslashFlopsPerSite(QudaInvertParam *inv, int xpay) { return dslashFlopsPerSite(pcDslashMode(inv), xpay != 0); }
+
+void qudaAmdSetPartitionMask(int mask) {
+  for (int d = 0; d < 4; d++) commGrid().forced[d] = (mask >> d) & 1;
+}
+void *qudaAmdComputeStream(void) { return (void *)computeStream(); }
+void qudaAmdDeviceSynchronize(void) { HIP_CHECK(hipDeviceSynchronize()); }
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+// qa_core.cpp — logging / error convention, streams, process-grid state.
+// Reference behaviour: include/util_quda.h:40-105 (printfQuda/warningQuda/errorQuda, verbosity),
+// lib/comm_common.cpp (topology), include/quda_internal.h:314-319 (streams).
+#include "qa_core.h"
+
+#include <cstring>
+
+namespace quda {
+
+static QudaVerbosity g_verbosity = QUDA_SUMMARIZE;
+static char g_prefix[128] = "";
+static FILE *g_out = nullptr;
+
+QudaVerbosity getVerbosity() { return g_verbosity; }
+void setVerbosityInternal(QudaVerbosity v, const char *prefix, FILE *f) {
+  g_verbosity = v;
+  if (prefix) { strncpy(g_prefix, prefix, sizeof(g_prefix) - 1); g_prefix[sizeof(g_prefix) - 1] = 0; }
+  if (f) g_out = f;
+}
+
+void qa_printf(const char *fmt, ...) {
+  if (commGrid().rank != 0) return;
+  FILE *f = g_out ? g_out : stdout;
+  fputs(g_prefix, f);
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(f, fmt, ap);
+  va_end(ap);
+  fflush(f);
+}
+
+void qa_warning(const char *fmt, ...) {
+  if (g_verbosity == QUDA_SILENT || commGrid().rank != 0) return;
+  FILE *f = g_out ? g_out : stdout;
+  fprintf(f, "%sWARNING: ", g_prefix);
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(f, fmt, ap);
+  va_end(ap);
+  fputc('\n', f);
+  fflush(f);
+}
+
+void qa_error(const char *file, int line, const char *func, const char *fmt, ...) {
+  FILE *f = g_out ? g_out : stderr;
+  fprintf(f, "%sERROR: ", g_prefix);
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(f, fmt, ap);
+  va_end(ap);
+  fprintf(f, " (rank %d, %s:%d in %s())\n", commGrid().rank, file, line, func);
+  fflush(f);
+  exit(1);  // comm_abort(1) of the reference, lib/comm_single.cpp:58-63
+}
+
+CommGrid &commGrid() {
+  static CommGrid g;
+  return g;
+}
+
+static hipStream_t g_compute = nullptr, g_comm = nullptr;
+void createStreams() {
+  if (!g_compute) HIP_CHECK(hipStreamCreateWithFlags(&g_compute, hipStreamNonBlocking));
+  if (!g_comm) HIP_CHECK(hipStreamCreateWithFlags(&g_comm, hipStreamNonBlocking));
+}
+void destroyStreams() {
+  if (g_compute) (void)hipStreamDestroy(g_compute);
+  if (g_comm) (void)hipStreamDestroy(g_comm);
+  g_compute = g_comm = nullptr;
+}
+hipStream_t computeStream() { return g_compute; }
+hipStream_t commStream() { return g_comm; }
+
+}  // namespace quda
