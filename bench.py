@@ -161,6 +161,8 @@ def main():
             cores = len(os.sched_getaffinity(0))
         except Exception:
             pass
+        # a one-GPU box owns a 16-core share of the host (more threads only oversubscribe it)
+        cores = int(os.environ.get("QUDA_AMD_CPU_THREADS", min(cores, 16)))
         Xc = Xl
         g_cpu = gauge if dist is None else gauge
         inp = src_h.copy()
