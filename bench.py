@@ -101,7 +101,7 @@ def main():
     dtype_name = {8: "f64", 4: "f32", 2: "i16+f32scale"}
     kinds = {"tm": qa.QUDA_TWISTED_MASS_DSLASH, "tmc": qa.QUDA_TWISTED_CLOVER_DSLASH, "wilson": qa.QUDA_WILSON_DSLASH}
 
-    gauge = make_gauge(X) if dist is None else dist.scatter_gauge(make_gauge(X) if rank == 0 else None)
+    gauge = make_gauge(X) if dist is None else dist.scatter_gauge(make_gauge(X))
     clover = None
     rng = np.random.default_rng(1234 + rank)
     src_h = rng.random(Vh_local * 24)

@@ -56,6 +56,16 @@ void qudaAmdBlasAxpy(double a, const void *x, void *y);
 long long qudaAmdDslashBytesPerSite(QudaInvertParam *inv_param, int which, int xpay);
 long long qudaAmdDslashFlopsPerSite(QudaInvertParam *inv_param, int xpay);
 
+/* RCCL bootstrap (the transport that replaces the reference's MPI layer, lib/comm_mpi.cpp:50-155): rank 0 obtains a
+ * 128-byte id, the launcher broadcasts it out of band, every rank calls qudaAmdCommInit BEFORE initCommsGridQuda / initQuda. */
+void qudaAmdCommGetUniqueId(void *out128);
+void qudaAmdCommInit(const void *id128, int rank, int size);
+int qudaAmdCommRank(void);
+int qudaAmdCommSize(void);
+void qudaAmdCommCoords(int coords[4]);
+void qudaAmdCommBarrier(void);
+void qudaAmdCommAllreduce(double *data, int n);   /* sum over ranks, in place */
+
 /* single-process emulation of a partitioned dimension (reference tests --partition, commDimPartitionedSet) */
 void qudaAmdSetPartitionMask(int mask);
 

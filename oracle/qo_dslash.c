@@ -361,3 +361,59 @@ void qo_clover_twisted_inverse_d(double *cinv, const double *clover, int V, doub
     pack_block(Inv, cinv + b * 36);
   }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Grid-decomposed host operator: the reference's MULTI_GPU branch
+ * (tests/wilson_dslash_reference.cpp:137-171; ghost lookup tests/dslash_util.h:214-394).
+ * ghost_gauge[d]: the -d neighbour's last slice of U_d, [parity][face index][18];
+ * fwd_ghost[d] / back_ghost[d]: full (unprojected) spinors of the +d / -d neighbour's first / last
+ * slice, input parity, [face index][24].  Face index = lexicographic index over the other three
+ * coordinates, halved.  partitioned[d] = 0 -> periodic wrap inside this rank.
+ * ------------------------------------------------------------------------------------------ */
+static int face_index(const int X[4], int d, int x1, int x2, int x3, int x4) {
+  switch (d) {
+    case 0: return ((x4 * X[2] + x3) * X[1] + x2) / 2;
+    case 1: return ((x4 * X[2] + x3) * X[0] + x1) / 2;
+    case 2: return ((x4 * X[1] + x2) * X[0] + x1) / 2;
+    default: return ((x3 * X[1] + x2) * X[0] + x1) / 2;
+  }
+}
+
+void qo_wil_dslash_halo_d(double *res, double *const gauge[4], double *const ghost_gauge[4], const double *in,
+                          double *const fwd_ghost[4], double *const back_ghost[4], int oddBit, int dagger, const int X[4],
+                          const int partitioned[4]) {
+  const int Vh = X[0] * X[1] * X[2] * X[3] / 2;
+  for (long k = 0; k < (long)Vh * 24; k++) res[k] = 0.0;
+  for (int i = 0; i < Vh; i++) {
+    const int Y = qo_full_lattice_index(X, i, oddBit);
+    const int c[4] = {Y % X[0], (Y / X[0]) % X[1], (Y / (X[1] * X[0])) % X[2], Y / (X[2] * X[1] * X[0])};
+    for (int dir = 0; dir < 8; dir++) {
+      const int d = dir / 2, fwd = (dir % 2 == 0);
+      const int f = face_index(X, d, c[0], c[1], c[2], c[3]);
+      const double *U, *psi;
+      if (fwd) {
+        U = gauge[d] + ((long)oddBit * Vh + i) * 18;
+        if (partitioned[d] && c[d] == X[d] - 1) psi = fwd_ghost[d] + (long)f * 24;
+        else psi = in + (long)nbr_of_d(X, i, dir, oddBit) * 24;
+      } else {
+        if (partitioned[d] && c[d] == 0) {
+          const int faceCB = Vh / X[d];
+          U = ghost_gauge[d] + ((long)(1 - oddBit) * faceCB + f) * 18;
+          psi = back_ghost[d] + (long)f * 24;
+        } else {
+          U = link_of_d(X, Vh, i, dir, oddBit, gauge);
+          psi = in + (long)nbr_of_d(X, i, dir, oddBit) * 24;
+        }
+      }
+      double proj[24], hop[24];
+      const int projIdx = 2 * (dir / 2) + (dir + dagger) % 2;
+      project_d(proj, projIdx, psi);
+      for (int s = 0; s < 4; s++) {
+        if (fwd) su3_mul_d(&hop[s * 6], U, &proj[s * 6]);
+        else su3_tmul_d(&hop[s * 6], U, &proj[s * 6]);
+      }
+      double *o = res + (long)i * 24;
+      for (int k = 0; k < 24; k++) o[k] = o[k] + hop[k];
+    }
+  }
+}

@@ -59,6 +59,11 @@ void qo_tmc_mat_d(double *out, double *const gauge[4], const double *clover, con
 void qo_tmc_matpc_d(double *out, double *const gauge[4], const double *in, const double *clover, const double *cinv,
                     double kappa, double mu, int flavor, int matpc, int dagger, const int X[4]);
 
+/* grid-decomposed variant (reference MULTI_GPU branch), see qo_dslash.c */
+void qo_wil_dslash_halo_d(double *res, double *const gauge[4], double *const ghost_gauge[4], const double *in,
+                          double *const fwd_ghost[4], double *const back_ghost[4], int oddBit, int dagger, const int X[4],
+                          const int partitioned[4]);
+
 /* ---- single precision (same loop nests, float arithmetic) ---- */
 void qo_wil_dslash_f(float *res, float *const gauge[4], const float *in, int oddBit, int dagger, const int X[4]);
 void qo_twist_gamma5_f(float *out, const float *in, int dagger, float kappa, float mu, int flavor, int nsites, int twist);

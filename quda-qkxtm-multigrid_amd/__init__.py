@@ -114,7 +114,8 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
                  "qudaAmdSpinorSetTwist", "qudaAmdDiracCreate", "qudaAmdDiracDestroy", "qudaAmdDiracDslash", "qudaAmdDiracDslashXpay",
                  "qudaAmdDiracM", "qudaAmdDiracMdag", "qudaAmdDiracMdagM", "qudaAmdDiracFlops", "qudaAmdTimeDslash", "qudaAmdTimeM",
                  "qudaAmdBlasNorm2", "qudaAmdBlasCDot", "qudaAmdBlasAxpy", "qudaAmdDslashBytesPerSite", "qudaAmdDslashFlopsPerSite",
-                 "qudaAmdSetPartitionMask", "qudaAmdComputeStream", "qudaAmdDeviceSynchronize"]
+                 "qudaAmdSetPartitionMask", "qudaAmdComputeStream", "qudaAmdDeviceSynchronize", "qudaAmdCommGetUniqueId",
+                 "qudaAmdCommInit", "qudaAmdCommRank", "qudaAmdCommSize", "qudaAmdCommCoords", "qudaAmdCommBarrier", "qudaAmdCommAllreduce"]
 
 _lib = None
 
@@ -168,6 +169,10 @@ def lib():
         L.cloverQuda.argtypes = [_p, _p, C.POINTER(QudaInvertParam), C.POINTER(_i), _i]
         L.loadGaugeQuda.argtypes = [_p, C.POINTER(QudaGaugeParam)]
         L.loadCloverQuda.argtypes = [_p, _p, C.POINTER(QudaInvertParam)]
+        L.qudaAmdCommInit.argtypes = [_p, _i, _i]
+        L.qudaAmdCommGetUniqueId.argtypes = [_p]
+        L.initCommsGridQuda.argtypes = [_i, C.POINTER(_i), _p, _p]
+        L.qudaAmdSetPartitionMask.argtypes = [_i]
         _lib = L
     return _lib
 

@@ -62,6 +62,7 @@ void cDotProduct(Complex *result, std::vector<ColorSpinorField *> &a, std::vecto
 
 // rank reductions (comm layer)
 void comm_allreduce(double *data, int n);
+void commAllreduceDevice(double *d_data, int n, hipStream_t s);
 void comm_allreduce_max(double *data, int n);
 
 }  // namespace quda

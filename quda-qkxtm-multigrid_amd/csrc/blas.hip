@@ -276,10 +276,10 @@ static void launch(const F &f, const ColorSpinorField &x, const ColorSpinorField
   }
   HIP_CHECK(hipGetLastError());
   if (F::nred > 0) {
+    if (g_global_reduction) commAllreduceDevice(d_red, F::nred, s);  // RCCL all-reduce of the partial sums, in stream order
     HIP_CHECK(hipMemcpyAsync(h_red, d_red, F::nred * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     for (int k = 0; k < F::nred; k++) out[k] = h_red[k];
-    if (g_global_reduction) comm_allreduce(out, F::nred);
   }
   const int nrd = F::rx + F::ry + F::rz + F::rw, nwr = F::wx + F::wy + F::wz + F::ww;
   bytes += (unsigned long long)(nrd + nwr) * x.RealLength() * x.Precision();

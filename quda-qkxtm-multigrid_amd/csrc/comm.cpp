@@ -1,25 +1,43 @@
-// comm.cpp — process topology and inter-rank transport.
+// comm.cpp — process topology and inter-rank transport: RCCL over xGMI, one process per GPU.
 //
-// Reference: lib/comm_common.cpp:94-196 (4-D topology, lexicographic rank map with t fastest,
-// lib/interface_quda.cpp:261-270), lib/comm_mpi.cpp:297-326 (allreduce).  Transport here is RCCL over
-// xGMI (one process per GPU); a single rank degenerates to no-ops.
+// What the reference does with MPI persistent point-to-point messages / CUDA-IPC copies and MPI_Allreduce
+// (lib/comm_common.cpp:94-196 topology, lib/comm_mpi.cpp:198-326, lib/cuda_color_spinor_field.cu:1212-1765) is
+// done here with ONE grouped ncclSend/ncclRecv per Dslash (every face of every partitioned dimension in a
+// single group, so on a 2x2x2 grid the <= 6 faces travel over 6 different xGMI links concurrently) and
+// ncclAllReduce for the 8-24-byte global sums.  The communicator is bootstrapped by the launcher: rank 0 calls
+// qudaAmdCommGetUniqueId, the id is broadcast out of band (torch.distributed / MPI / files), every rank calls
+// qudaAmdCommInit, then initCommsGridQuda fixes the 4-D grid (rank = ((x*Ny + y)*Nz + z)*Nt + t, t fastest,
+// reference lib/interface_quda.cpp:261-270).  A single rank needs none of this and degenerates to local copies.
+#include <rccl/rccl.h>
+
 #include <cstring>
+#include <vector>
 
 #include "blas.h"
+#include "halo.h"
 #include "interface_internal.h"
+#include "quda_amd_ext.h"
 
 namespace quda {
+
+static ncclComm_t g_nccl = nullptr;
+
+#define NCCL_CHECK(cmd)                                                                   \
+  do {                                                                                    \
+    ncclResult_t r_ = (cmd);                                                              \
+    if (r_ != ncclSuccess) errorQuda("RCCL call '%s' failed: %s", #cmd, ncclGetErrorString(r_)); \
+  } while (0)
 
 void commInit(const int *dims, QudaCommsMap func, void *fdata) {
   CommGrid &g = commGrid();
   int n = 1;
   for (int d = 0; d < 4; d++) { g.dims[d] = dims[d]; n *= dims[d]; }
-  if (n != g.size) errorQuda("process grid %d x %d x %d x %d needs %d ranks but the communicator has %d", dims[0], dims[1], dims[2], dims[3], n, g.size);
-  // default map: rank = ((x*Ny + y)*Nz + z)*Nt + t  (t fastest)
+  if (n != g.size) errorQuda("process grid %d x %d x %d x %d needs %d ranks but the communicator has %d (call qudaAmdCommInit first)", dims[0], dims[1], dims[2], dims[3], n, g.size);
   int r = g.rank;
   for (int d = 3; d >= 0; d--) { g.coords[d] = r % dims[d]; r /= dims[d]; }
+  g.user_map = func;
+  g.user_data = fdata;
   if (func) {
-    // user map: find the coordinates that map to this rank
     int c[4];
     bool found = false;
     for (c[0] = 0; c[0] < dims[0] && !found; c[0]++)
@@ -31,20 +49,123 @@ void commInit(const int *dims, QudaCommsMap func, void *fdata) {
   }
 }
 
-void commFinalize() {}
-
-void comm_allreduce(double *, int) {
-  if (commGrid().size == 1) return;
-  errorQuda("multi-rank reductions: RCCL transport not initialised");
-}
-void comm_allreduce_max(double *, int) {
-  if (commGrid().size == 1) return;
-  errorQuda("multi-rank reductions: RCCL transport not initialised");
+int commRankFromCoords(const int *c) {
+  const CommGrid &g = commGrid();
+  if (g.user_map) return g.user_map(c, g.user_data);
+  return ((c[0] * g.dims[1] + c[1]) * g.dims[2] + c[2]) * g.dims[3] + c[3];
 }
 
-void loadGaugeWithHalo(GaugeField &U, void *const h_gauge[4], QudaPrecision cpu_prec) {
-  if (commGrid().size == 1) { U.loadQDP(h_gauge, cpu_prec); return; }
-  errorQuda("multi-rank gauge load not built yet");
+int commNeighborRank(int dim, int dir) {
+  const CommGrid &g = commGrid();
+  int c[4];
+  for (int d = 0; d < 4; d++) c[d] = g.coords[d];
+  c[dim] = (c[dim] + dir + g.dims[dim]) % g.dims[dim];
+  return commRankFromCoords(c);
+}
+
+void commFinalize() {
+  freeHaloBuffers();
+  if (g_nccl) { (void)ncclCommDestroy(g_nccl); g_nccl = nullptr; }
+  CommGrid &g = commGrid();
+  g.rank = 0; g.size = 1;
+  for (int d = 0; d < 4; d++) { g.dims[d] = 1; g.coords[d] = 0; g.forced[d] = false; }
+}
+
+// ---- reductions ----
+static double *d_scratch = nullptr;
+static double *h_scratch = nullptr;
+static void ensureScratch() {
+  if (!d_scratch) HIP_CHECK(hipMalloc((void **)&d_scratch, 64 * sizeof(double)));
+  if (!h_scratch) HIP_CHECK(hipHostMalloc((void **)&h_scratch, 64 * sizeof(double), hipHostMallocDefault));
+}
+
+void commAllreduceDevice(double *d_data, int n, hipStream_t s) {
+  if (commGrid().size == 1) return;
+  NCCL_CHECK(ncclAllReduce(d_data, d_data, n, ncclDouble, ncclSum, g_nccl, s));
+}
+
+static void hostAllreduce(double *data, int n, ncclRedOp_t op) {
+  if (commGrid().size == 1) return;
+  if (n > 64) errorQuda("allreduce of %d doubles exceeds the scratch buffer", n);
+  ensureScratch();
+  hipStream_t s = computeStream();
+  memcpy(h_scratch, data, n * sizeof(double));
+  HIP_CHECK(hipMemcpyAsync(d_scratch, h_scratch, n * sizeof(double), hipMemcpyHostToDevice, s));
+  NCCL_CHECK(ncclAllReduce(d_scratch, d_scratch, n, ncclDouble, op, g_nccl, s));
+  HIP_CHECK(hipMemcpyAsync(h_scratch, d_scratch, n * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  memcpy(data, h_scratch, n * sizeof(double));
+}
+void comm_allreduce(double *data, int n) { hostAllreduce(data, n, ncclSum); }
+void comm_allreduce_max(double *data, int n) { hostAllreduce(data, n, ncclMax); }
+
+// ---- neighbour exchange: all (dim, dir) messages of one halo in a single RCCL group ----
+void commExchange(const std::vector<HaloMsg> &msgs, hipStream_t s) {
+  const CommGrid &g = commGrid();
+  bool remote = false;
+  for (const HaloMsg &m : msgs) {
+    const int to = commNeighborRank(m.dim, m.dir), from = commNeighborRank(m.dim, -m.dir);
+    if (to == g.rank && from == g.rank) {
+      // self neighbour (unpartitioned-but-forced dimension): the message lands in this rank's own ghost zone
+      HIP_CHECK(hipMemcpyAsync(m.recv, m.send, m.bytes, hipMemcpyDeviceToDevice, s));
+    } else {
+      remote = true;
+    }
+  }
+  if (!remote) return;
+  if (!g_nccl) errorQuda("multi-rank halo exchange without an RCCL communicator (qudaAmdCommInit)");
+  NCCL_CHECK(ncclGroupStart());
+  // order inside a (dim) pair: send forward, send backward, receive from behind, receive from ahead — with only two ranks
+  // along a dimension both neighbours are the same peer and RCCL matches messages to one peer in posting order
+  for (const HaloMsg &m : msgs) {
+    const int to = commNeighborRank(m.dim, m.dir);
+    if (to == g.rank) continue;
+    NCCL_CHECK(ncclSend(m.send, m.bytes, ncclChar, to, g_nccl, s));
+  }
+  for (const HaloMsg &m : msgs) {
+    const int from = commNeighborRank(m.dim, -m.dir);
+    if (from == g.rank) continue;
+    NCCL_CHECK(ncclRecv(m.recv, m.bytes, ncclChar, from, g_nccl, s));
+  }
+  NCCL_CHECK(ncclGroupEnd());
+}
+
+void loadGaugeWithHalo(GaugeField &U, void *const h_gauge[4], QudaPrecision cpu_prec) { U.loadQDP(h_gauge, cpu_prec); }
+
+void commBarrier() {
+  if (commGrid().size == 1) return;
+  double one = 1.0;
+  comm_allreduce(&one, 1);
 }
 
 }  // namespace quda
+
+using namespace quda;
+
+extern "C" {
+
+void qudaAmdCommGetUniqueId(void *out128) {
+  ncclUniqueId id;
+  NCCL_CHECK(ncclGetUniqueId(&id));
+  static_assert(sizeof(id) == 128, "unique id size");
+  memcpy(out128, &id, sizeof(id));
+}
+
+void qudaAmdCommInit(const void *id128, int rank, int size) {
+  CommGrid &g = commGrid();
+  if (size < 1 || rank < 0 || rank >= size) errorQuda("bad rank/size %d/%d", rank, size);
+  g.rank = rank;
+  g.size = size;
+  if (size == 1) return;
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  NCCL_CHECK(ncclCommInitRank(&g_nccl, size, id, rank));
+}
+
+int qudaAmdCommRank(void) { return commGrid().rank; }
+int qudaAmdCommSize(void) { return commGrid().size; }
+void qudaAmdCommCoords(int coords[4]) { for (int d = 0; d < 4; d++) coords[d] = commGrid().coords[d]; }
+void qudaAmdCommBarrier(void) { commBarrier(); }
+void qudaAmdCommAllreduce(double *data, int n) { comm_allreduce(data, n); }
+
+}

@@ -48,12 +48,12 @@ template <typename T, int NR> __device__ __forceinline__ __amdgpu_buffer_rsrc_t 
 }
 
 template <int NR> struct Planar<double, NR> {
-  static __device__ __forceinline__ void load(double *r, const void *base, int stride, int x, const float *, int) {
+  template <int AUX = 0> static __device__ __forceinline__ void load(double *r, const void *base, int stride, int x, const float *, int) {
     const __amdgpu_buffer_rsrc_t rs = planar_rsrc<double, NR>(base, stride);
     const int off = x * 16;
 #pragma unroll
     for (int k = 0; k < NR / 2; k++) {
-      const double2 t = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, off, k * stride * 16, 0));
+      const double2 t = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, off, k * stride * 16, AUX));
       r[2 * k] = t.x;
       r[2 * k + 1] = t.y;
     }
@@ -68,16 +68,16 @@ template <int NR> struct Planar<double, NR> {
 };
 
 template <int NR> struct Planar<float, NR> {
-  static __device__ __forceinline__ void load(float *r, const void *base, int stride, int x, const float *, int) {
+  template <int AUX = 0> static __device__ __forceinline__ void load(float *r, const void *base, int stride, int x, const float *, int) {
     const __amdgpu_buffer_rsrc_t rs = planar_rsrc<float, NR>(base, stride);
     const int off = x * 16;
 #pragma unroll
     for (int k = 0; k < NR / 4; k++) {
-      const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, k * stride * 16, 0));
+      const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, k * stride * 16, AUX));
       r[4 * k] = t.x; r[4 * k + 1] = t.y; r[4 * k + 2] = t.z; r[4 * k + 3] = t.w;
     }
     if (NR % 4) {  // trailing float2 plane (18-real links)
-      const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, x * 8, (NR / 4) * stride * 16, 0));
+      const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, x * 8, (NR / 4) * stride * 16, AUX));
       r[NR - 2] = t.x; r[NR - 1] = t.y;
     }
   }
@@ -94,17 +94,17 @@ template <int NR> struct Planar<float, NR> {
 
 // 16-bit fixed point.  norm == nullptr: fixed unit scale (links); else per-site scale at norm[nidx].
 template <int NR> struct Planar<short, NR> {
-  static __device__ __forceinline__ void load(float *r, const void *base, int stride, int x, const float *norm, int nidx) {
+  template <int AUX = 0> static __device__ __forceinline__ void load(float *r, const void *base, int stride, int x, const float *norm, int nidx) {
     const float s = norm ? norm[nidx] * kShortInv : kShortInv;
     const __amdgpu_buffer_rsrc_t rs = planar_rsrc<short, NR>(base, stride);
     const int off = x * 8;
 #pragma unroll
     for (int k = 0; k < NR / 4; k++) {
-      const short4 t = __builtin_bit_cast(short4, __builtin_amdgcn_raw_buffer_load_b64(rs, off, k * stride * 8, 0));
+      const short4 t = __builtin_bit_cast(short4, __builtin_amdgcn_raw_buffer_load_b64(rs, off, k * stride * 8, AUX));
       r[4 * k] = t.x * s; r[4 * k + 1] = t.y * s; r[4 * k + 2] = t.z * s; r[4 * k + 3] = t.w * s;
     }
     if (NR % 4) {
-      const short2 t = __builtin_bit_cast(short2, __builtin_amdgcn_raw_buffer_load_b32(rs, x * 4, (NR / 4) * stride * 8, 0));
+      const short2 t = __builtin_bit_cast(short2, __builtin_amdgcn_raw_buffer_load_b32(rs, x * 4, (NR / 4) * stride * 8, AUX));
       r[NR - 2] = t.x * s; r[NR - 1] = t.y * s;
     }
   }
@@ -139,8 +139,8 @@ template <typename T> __host__ __device__ constexpr size_t storeSize() { return 
 // tests/test_util.cpp:283-296 / lib/read_gauge.h) ----
 template <typename T, int R> struct Link {
   using real = typename Store<T>::real;
-  static __device__ __forceinline__ void load(real *U, const void *blk, int stride, int x, real sign) {
-    Planar<T, R>::load(U, blk, stride, x, nullptr, 0);
+  template <int AUX = 0> static __device__ __forceinline__ void load(real *U, const void *blk, int stride, int x, real sign) {
+    Planar<T, R>::template load<AUX>(U, blk, stride, x, nullptr, 0);
     if (R == 12) {
       // c = conj(a x b)
 #define QA_CROSS(i, j, k)                                                                               \

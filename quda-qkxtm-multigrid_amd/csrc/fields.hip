@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "device_io.h"
+#include "halo.h"
 
 namespace quda {
 
@@ -381,10 +382,34 @@ GaugeField::GaugeField(const LatticeGeom &g, QudaPrecision prec, QudaReconstruct
 }
 GaugeField::~GaugeField() { if (data) (void)hipFree(data); }
 
-// one thread per (parity, site): builds the 8 matrices the stencil needs at that site
+// boundary slice x_d = L_d - 1 of U_d (both parities) -> contiguous [parity][face index][18] block for the +d neighbour
+template <typename THost>
+__global__ void gauge_face_pack_kernel(THost *out, const THost *h, LatticeGeom g, int d) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nf = g.faceCB[d];
+  if (tid >= 2 * nf) return;
+  const int q = tid >= nf, f = tid - q * nf;
+  int c[4], L[3], o[3], n = 0;
+  for (int k = 0; k < 4; k++) if (k != d) { L[n] = g.X[k]; o[n] = k; n++; }
+  int l = 2 * f;
+  const int c0 = l % L[0]; l /= L[0];
+  const int c1 = l % L[1]; const int c2 = l / L[1];
+  c[d] = g.X[d] - 1;
+  c[o[0]] = c0; c[o[1]] = c1; c[o[2]] = c2;
+  c[o[0]] += (q + c[0] + c[1] + c[2] + c[3]) & 1;
+  const int idx = (((c[3] * g.X[2] + c[2]) * g.X[1] + c[1]) * g.X[0] + c[0]) >> 1;
+  const THost *src = h + ((size_t)q * g.Vh + idx) * 18;
+  THost *dst = out + (size_t)tid * 18;
+  for (int k = 0; k < 18; k++) dst[k] = src[k];
+}
+
+// one thread per (parity, site): builds the 8 matrices the stencil needs at that site.  ghost[d] != nullptr: the
+// backward link of a site on the x_d = 0 face lives on the -d neighbour rank and is taken from its packed last slice.
+template <typename THost> struct GhostLinks { const THost *g[4]; };
+
 template <typename TDev, int R, typename THost>
 __global__ void gauge_load_kernel(char *data, size_t link_bytes, int stride, const THost *h0, const THost *h1, const THost *h2, const THost *h3,
-                                  LatticeGeom g) {
+                                  LatticeGeom g, GhostLinks<THost> ghost) {
   using real = typename Store<TDev>::real;
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= 2 * g.Vh) return;
@@ -396,12 +421,18 @@ __global__ void gauge_load_kernel(char *data, size_t link_bytes, int stride, con
   const int t = (int)g.dZ.div(zb);
   const int z = (int)zb - t * g.X[2];
   const int xodd = (y + z + t + parity) & 1;
+  const int xf = 2 * xh + xodd;
   const int Xh = g.Xh, sy = Xh, sz = Xh * g.X[1], st = Xh * g.X[1] * g.X[2];
-  int nb[4];
+  int nb[4], face[4];
   nb[0] = xodd ? idx : (xh == 0 ? idx + (Xh - 1) : idx - 1);
   nb[1] = y == 0 ? idx + (g.X[1] - 1) * sy : idx - sy;
   nb[2] = z == 0 ? idx + (g.X[2] - 1) * sz : idx - sz;
   nb[3] = t == 0 ? idx + (g.X[3] - 1) * st : idx - st;
+  face[0] = ((t * g.X[2] + z) * g.X[1] + y) >> 1;
+  face[1] = ((t * g.X[2] + z) * g.X[0] + xf) >> 1;
+  face[2] = ((t * g.X[1] + y) * g.X[0] + xf) >> 1;
+  face[3] = ((z * g.X[1] + y) * g.X[0] + xf) >> 1;
+  const int coord[4] = {xf, y, z, t};
   const THost *h[4] = {h0, h1, h2, h3};
   char *base = data + (size_t)parity * 8 * link_bytes;
 #pragma unroll
@@ -411,7 +442,8 @@ __global__ void gauge_load_kernel(char *data, size_t link_bytes, int stride, con
 #pragma unroll
     for (int k = 0; k < 18; k++) U[k] = (real)f[k];
     Planar<TDev, R>::store(U, base + (size_t)(2 * mu) * link_bytes, stride, idx, nullptr, 0);
-    const THost *bk = h[mu] + ((size_t)(1 - parity) * g.Vh + nb[mu]) * 18;
+    const THost *bk = (ghost.g[mu] && coord[mu] == 0) ? ghost.g[mu] + ((size_t)(1 - parity) * g.faceCB[mu] + face[mu]) * 18
+                                                       : h[mu] + ((size_t)(1 - parity) * g.Vh + nb[mu]) * 18;
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
@@ -424,18 +456,41 @@ __global__ void gauge_load_kernel(char *data, size_t link_bytes, int stride, con
 }
 
 template <typename TDev, int R, typename THost> static void gaugeLoad(GaugeField &U, void *const h_gauge[4]) {
-  const size_t n = (size_t)U.geom.V * 18 * sizeof(THost);
-  char *stage = (char *)stagingBuffer(4 * n);
-  for (int d = 0; d < 4; d++) HIP_CHECK(hipMemcpyAsync(stage + d * n, h_gauge[d], n, hipMemcpyHostToDevice, computeStream()));
-  const int bs = 256, nb = (2 * U.geom.Vh + bs - 1) / bs;
-  hipLaunchKernelGGL((gauge_load_kernel<TDev, R, THost>), dim3(nb), dim3(bs), 0, computeStream(), (char *)U.data, U.link_bytes, U.stride,
-                     (const THost *)stage, (const THost *)(stage + n), (const THost *)(stage + 2 * n), (const THost *)(stage + 3 * n), U.geom);
+  const LatticeGeom &g = U.geom;
+  const size_t n = (size_t)g.V * 18 * sizeof(THost);
+  size_t ghost_bytes = 0;
+  // links of the -d neighbour are needed wherever dimension d is split over ranks; QUDA_AMD_FORCE_GAUGE_HALO=1 also sends a
+  // self-partitioned dimension (qudaAmdSetPartitionMask) through the same pack / exchange / ghost-index path, for testing
+  static const bool force = getenv("QUDA_AMD_FORCE_GAUGE_HALO") != nullptr;
+  auto split = [&](int d) { return commGrid().dims[d] > 1 || (force && commGrid().forced[d]); };
+  for (int d = 0; d < 4; d++) if (split(d)) ghost_bytes += 2 * (size_t)2 * g.faceCB[d] * 18 * sizeof(THost);
+  char *stage = (char *)stagingBuffer(4 * n + ghost_bytes);
+  hipStream_t s = computeStream();
+  for (int d = 0; d < 4; d++) HIP_CHECK(hipMemcpyAsync(stage + d * n, h_gauge[d], n, hipMemcpyHostToDevice, s));
+  GhostLinks<THost> ghost;
+  std::vector<HaloMsg> msgs;
+  char *p = stage + 4 * n;
+  for (int d = 0; d < 4; d++) {
+    ghost.g[d] = nullptr;
+    if (!split(d)) continue;
+    const size_t fb = (size_t)2 * g.faceCB[d] * 18 * sizeof(THost);
+    THost *sendb = (THost *)p; p += fb;
+    THost *recvb = (THost *)p; p += fb;
+    const int nt = 2 * g.faceCB[d];
+    hipLaunchKernelGGL((gauge_face_pack_kernel<THost>), dim3((nt + 255) / 256), dim3(256), 0, s, sendb, (const THost *)(stage + d * n), g, d);
+    HIP_CHECK(hipGetLastError());
+    msgs.push_back({d, +1, sendb, recvb, fb});  // my last slice goes forward; I receive my -d neighbour's last slice
+    ghost.g[d] = recvb;
+  }
+  if (!msgs.empty()) commExchange(msgs, s);
+  const int bs = 256, nb = (2 * g.Vh + bs - 1) / bs;
+  hipLaunchKernelGGL((gauge_load_kernel<TDev, R, THost>), dim3(nb), dim3(bs), 0, s, (char *)U.data, U.link_bytes, U.stride, (const THost *)stage,
+                     (const THost *)(stage + n), (const THost *)(stage + 2 * n), (const THost *)(stage + 3 * n), g, ghost);
   HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipStreamSynchronize(computeStream()));
+  HIP_CHECK(hipStreamSynchronize(s));
 }
 
 void GaugeField::loadQDP(void *const h_gauge[4], QudaPrecision cpu_prec) {
-  if (commGrid().size > 1) errorQuda("multi-rank gauge load goes through loadGaugeQuda's halo path");
 #define QA_GL(TD, RR)                                                     \
   if (cpu_prec == QUDA_DOUBLE_PRECISION) gaugeLoad<TD, RR, double>(*this, h_gauge); \
   else gaugeLoad<TD, RR, float>(*this, h_gauge);

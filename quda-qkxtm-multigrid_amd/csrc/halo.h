@@ -1,0 +1,53 @@
+// halo.h — spinor halo (ghost zone) machinery for the fine-grid stencil when the lattice is grid-decomposed.
+//
+// Reference: cudaColorSpinorField::{pack,gather,sendStart,commsQuery,scatter} (lib/cuda_color_spinor_field.cu:1465-1860),
+// packFaceWilsonKernel / packTwistedFaceWilsonKernel (lib/dslash_pack.cu:272, :610), the overlap policies of
+// lib/dslash_policy.cuh:148-297.  Re-designed: one pack launch for every face, one grouped RCCL send/recv on the comms
+// stream, the interior kernel on the compute stream meanwhile, then ONE exterior launch over the precomputed list of
+// boundary sites which does all 8 hops of such a site (ghost-aware) and the fused epilogue — every site is produced by
+// exactly one kernel, there is no partial-sum read-modify-write pass.
+#pragma once
+
+#include <vector>
+
+#include "fields.h"
+
+namespace quda {
+
+struct HaloMsg {
+  int dim, dir;   // dir = +1: sent to the +dim neighbour (and the matching receive comes from the -dim neighbour)
+  void *send, *recv;
+  size_t bytes;
+};
+
+// comm.cpp
+void commExchange(const std::vector<HaloMsg> &msgs, hipStream_t s);
+int commNeighborRank(int dim, int dir);
+void commBarrier();
+
+// per-precision ghost storage for spin-projected half spinors (12 reals / face site, planar, + fp32 scales for 16-bit)
+struct HaloBuffers {
+  QudaPrecision precision = QUDA_INVALID_PRECISION;
+  int faceCB[4] = {0, 0, 0, 0};
+  size_t face_bytes[4] = {0, 0, 0, 0};   // payload of one face (12 reals x faceCB) incl. norms, 16-byte aligned
+  size_t norm_offset[4] = {0, 0, 0, 0};  // byte offset of the fp32 scales inside a face block (16-bit only)
+  char *send[4][2] = {};                 // [dim][0: to -dim neighbour, 1: to +dim neighbour]
+  char *ghost[4][2] = {};                // [dim][0: from -dim neighbour, 1: from +dim neighbour]
+  char *pool = nullptr;
+  size_t pool_bytes = 0;
+};
+
+HaloBuffers &haloBuffers(const LatticeGeom &g, QudaPrecision prec);
+void freeHaloBuffers();
+
+// list of checkerboard indices (per output parity) that touch a partitioned boundary
+struct BoundaryList {
+  int *d_idx[2] = {nullptr, nullptr};
+  int count[2] = {0, 0};
+  int mask = -1;
+  int X[4] = {0, 0, 0, 0};
+};
+const BoundaryList &boundaryList(const LatticeGeom &g, int mask);
+void freeBoundaryLists();
+
+}  // namespace quda

@@ -81,6 +81,8 @@ struct CommGrid {
   int rank = 0, size = 1;
   bool partitioned(int d) const { return dims[d] > 1 || forced[d]; }
   bool forced[4] = {false, false, false, false};  // single-process self-neighbour emulation (reference --partition)
+  QudaCommsMap user_map = nullptr;
+  void *user_data = nullptr;
 };
 CommGrid &commGrid();
 

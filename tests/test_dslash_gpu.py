@@ -183,3 +183,24 @@ def test_resident_operator_api_and_properties_at_full_size(qa, oracle):
     for f in (x, y, mx, my, t):
         f.free()
     d.free()
+
+
+@pytest.mark.parametrize("mask", [1, 2, 4, 8, 6, 9, 15])
+def test_partitioned_dslash_self_neighbour(qa, mask):
+    """The reference's own way of testing the halo path without a cluster (tests/test_util.cpp:2047-2065 --partition):
+    a single process treats dimension d as partitioned and talks to itself — pack kernel, ghost-zone exchange,
+    interior + exterior kernels — and must reproduce the golden vectors exactly like the unpartitioned kernel."""
+    z, X, kappa, mu, gauge = qc.load(qc.FILES[1])  # 6x4x2x8: includes an extent-2 dimension
+    names = ["wil_dslash_p0_d0", "wil_dslash_p1_d1", "tm_dslash_fp_ee_d0_p0", "tm_dslash_fm_oo_d1_p0", "tm_dslash_fp_ee_d1_p0",
+             "tmc_dslash_fp_ee_d0_p0", "tmc_dslash_fm_ooasym_d1_p0", "tm_matpc_fp_ee_d0", "tm_matpc_fp_oo_d1", "tm_mat_fp_d0", "tmc_matpc_fm_eeasym_d1", "tmc_matpc_fm_ee_d1"]
+    os.environ["QUDA_AMD_FORCE_GAUGE_HALO"] = "1"  # the link ghost exchange of loadGaugeQuda goes through the same self path
+    try:
+        for prec, recon in ((8, 18), (4, 12), (2, 18)):
+            qa.lib().qudaAmdSetPartitionMask(mask)
+            _load_fields(qa, gauge, z["clover"], X, kappa, mu, prec, recon)
+            for name in names:
+                got = qc.run_abi(qa, name, z["spinor"], X, kappa, mu, prec)
+                assert qc.rel_err(got, z[name]) < TOL[prec], (name, prec, mask)
+            qa.lib().qudaAmdSetPartitionMask(0)
+    finally:
+        qa.lib().qudaAmdSetPartitionMask(0)
