@@ -56,6 +56,11 @@ void qudaAmdBlasAxpy(double a, const void *x, void *y);
 long long qudaAmdDslashBytesPerSite(QudaInvertParam *inv_param, int which, int xpay);
 long long qudaAmdDslashFlopsPerSite(QudaInvertParam *inv_param, int xpay);
 
+/* multigrid introspection: the reference's MG::verify() identities (lib/multigrid.cpp:372-486) and one preconditioner
+ * application K b on host vectors (full fields, layout described by inv_param as for MatQuda) */
+void qudaAmdMultigridVerify(void *mg_instance, double dev[3]);
+void qudaAmdMultigridCycle(void *mg_instance, void *h_x, void *h_b, QudaInvertParam *inv_param);
+
 /* RCCL bootstrap (the transport that replaces the reference's MPI layer, lib/comm_mpi.cpp:50-155): rank 0 obtains a
  * 128-byte id, the launcher broadcasts it out of band, every rank calls qudaAmdCommInit BEFORE initCommsGridQuda / initQuda. */
 void qudaAmdCommGetUniqueId(void *out128);

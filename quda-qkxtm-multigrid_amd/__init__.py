@@ -115,7 +115,8 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
                  "qudaAmdDiracM", "qudaAmdDiracMdag", "qudaAmdDiracMdagM", "qudaAmdDiracFlops", "qudaAmdTimeDslash", "qudaAmdTimeM",
                  "qudaAmdBlasNorm2", "qudaAmdBlasCDot", "qudaAmdBlasAxpy", "qudaAmdDslashBytesPerSite", "qudaAmdDslashFlopsPerSite",
                  "qudaAmdSetPartitionMask", "qudaAmdComputeStream", "qudaAmdDeviceSynchronize", "qudaAmdCommGetUniqueId",
-                 "qudaAmdCommInit", "qudaAmdCommRank", "qudaAmdCommSize", "qudaAmdCommCoords", "qudaAmdCommBarrier", "qudaAmdCommAllreduce"]
+                 "qudaAmdCommInit", "qudaAmdCommRank", "qudaAmdCommSize", "qudaAmdCommCoords", "qudaAmdCommBarrier", "qudaAmdCommAllreduce",
+                 "qudaAmdMultigridVerify", "qudaAmdMultigridCycle"]
 
 _lib = None
 
@@ -173,6 +174,8 @@ def lib():
         L.qudaAmdCommGetUniqueId.argtypes = [_p]
         L.initCommsGridQuda.argtypes = [_i, C.POINTER(_i), _p, _p]
         L.qudaAmdSetPartitionMask.argtypes = [_i]
+        L.qudaAmdMultigridVerify.argtypes = [_p, C.POINTER(_d)]
+        L.qudaAmdMultigridCycle.argtypes = [_p, _p, _p, C.POINTER(QudaInvertParam)]
         _lib = L
     return _lib
 
@@ -346,4 +349,59 @@ class Dirac:
     def free(self):
         if self.h:
             lib().qudaAmdDiracDestroy(self.h)
+            self.h = None
+
+
+def multigrid_param(ip, n_level=2, geo_block=(4, 4, 4, 4), n_vec=24, nu_pre=2, nu_post=2, cycle=QUDA_MG_CYCLE_RECURSIVE, smoother_tol=0.25,
+                    setup_maxiter=500, setup_tol=5e-6, generate_all_levels=True, omega=0.85):
+    """QudaMultigridParam filled the way the reference harness does (tests/multigrid_invert_test.cpp:195-290), with the
+    full-operator smoother this build implements (smoother_solve_type = QUDA_DIRECT_SOLVE)."""
+    mp = lib().newQudaMultigridParam()
+    mp.invert_param = C.pointer(ip)
+    mp.n_level = n_level
+    blocks = geo_block if isinstance(geo_block[0], (tuple, list)) else [geo_block] * n_level
+    nv = n_vec if isinstance(n_vec, (tuple, list)) else [n_vec] * n_level
+    for i in range(n_level):
+        for d in range(4):
+            mp.geo_block_size[i][d] = int(blocks[i][d])
+        for d in range(4, QUDA_MAX_DIM):
+            mp.geo_block_size[i][d] = 1
+        mp.spin_block_size[i] = 2 if i == 0 else 1
+        mp.n_vec[i] = int(nv[i])
+        mp.nu_pre[i], mp.nu_post[i] = nu_pre, nu_post
+        mp.cycle_type[i] = cycle
+        mp.smoother[i] = QUDA_MR_INVERTER
+        mp.smoother_tol[i] = smoother_tol
+        mp.global_reduction[i] = QUDA_BOOLEAN_YES
+        mp.smoother_solve_type[i] = QUDA_DIRECT_SOLVE
+        mp.coarse_grid_solution_type[i] = QUDA_MAT_SOLUTION
+        mp.omega[i] = omega
+        mp.location[i] = QUDA_CUDA_FIELD_LOCATION
+    mp.setup_maxiter, mp.setup_tol = setup_maxiter, setup_tol
+    mp.compute_null_vector = QUDA_COMPUTE_NULL_VECTOR_YES
+    mp.generate_all_levels = QUDA_BOOLEAN_YES if generate_all_levels else QUDA_BOOLEAN_NO
+    mp.run_verify = QUDA_BOOLEAN_NO
+    return mp
+
+
+class Multigrid:
+    """newMultigridQuda / destroyMultigridQuda handle"""
+
+    def __init__(self, mp):
+        self.mp = mp
+        self.h = lib().newMultigridQuda(C.byref(mp))
+
+    def verify(self):
+        dev = (_d * 3)()
+        lib().qudaAmdMultigridVerify(self.h, dev)
+        return [dev[0], dev[1], dev[2]]
+
+    def cycle(self, h_b, ip):
+        x = np.zeros_like(h_b)
+        lib().qudaAmdMultigridCycle(self.h, _vp(x), _vp(h_b), C.byref(ip))
+        return x
+
+    def free(self):
+        if self.h:
+            lib().destroyMultigridQuda(self.h)
             self.h = None

@@ -1,0 +1,216 @@
+// coarse.hip — coarse-grid operator: apply kernel and Galerkin construction (see coarse.h).
+//
+// Apply: one 256-thread work-group per coarse site; the 9 matrices of the site are split over the 4 waves, lane = output
+// row, each lane streams its row in 16-byte column pairs (unit stride across lanes) against the neighbour's vector
+// broadcast from LDS; partial rows are combined through LDS.  Per site 9 (2Nc)^2 complex = 166 KB for Nc = 24 are read
+// exactly once: HBM-bound at ~1 flop/byte for a single right-hand side, so plain FMAs, not MFMA.
+#include "coarse.h"
+
+#include "blas.h"
+
+namespace quda {
+
+CoarseGauge::CoarseGauge(const int xc[4], int n_) : n(n_), data(nullptr) {
+  nSites = 1;
+  for (int d = 0; d < 4; d++) { Xc[d] = xc[d]; nSites *= xc[d]; }
+  bytes = (size_t)nSites * 9 * n * n * 2 * sizeof(float);
+  HIP_CHECK(hipMalloc((void **)&data, bytes));
+  HIP_CHECK(hipMemsetAsync(data, 0, bytes, computeStream()));
+}
+CoarseGauge::~CoarseGauge() { if (data) (void)hipFree(data); }
+
+struct CVec { float *v[2]; int stride, Vh; };
+
+static CVec cvecFull(ColorSpinorField &f) {
+  CVec r;
+  r.v[0] = (float *)f.Even().V(); r.v[1] = (float *)f.Odd().V(); r.stride = f.Stride(); r.Vh = f.VolumeCB();
+  return r;
+}
+
+struct CoarseArg {
+  CVec out, in;
+  const float4 *G;
+  int Xc[4];
+  int n, mmask, parity, nwork;
+};
+
+template <int NMAX>
+__global__ void __launch_bounds__(256) coarse_apply_kernel(const CoarseArg arg) {
+  __shared__ float2 xin[9][NMAX];
+  __shared__ float2 part[4][NMAX];
+  const int n = arg.n, Vh = arg.out.Vh;
+  // site handled by this work-group (optionally one parity only)
+  int A = blockIdx.x;
+  if (arg.parity >= 0) A += arg.parity * Vh;
+  const int par = A >= Vh, xcb = A - par * Vh;
+  // coordinates of the coarse site
+  const int Xh = arg.Xc[0] >> 1;
+  int l = xcb;
+  const int xh = l % Xh; l /= Xh;
+  const int y = l % arg.Xc[1]; l /= arg.Xc[1];
+  const int z = l % arg.Xc[2]; const int t = l / arg.Xc[2];
+  const int c[4] = {2 * xh + ((y + z + t + par) & 1), y, z, t};
+  // stage the 9 input vectors (8 neighbours + self)
+  for (int m = 0; m < 9; m++) {
+    if (!((arg.mmask >> m) & 1)) continue;
+    int cn[4] = {c[0], c[1], c[2], c[3]};
+    int npar = par;
+    if (m < 8) {
+      const int mu = m >> 1, L = arg.Xc[mu];
+      cn[mu] = (m & 1) ? (c[mu] == 0 ? L - 1 : c[mu] - 1) : (c[mu] == L - 1 ? 0 : c[mu] + 1);
+      npar = (cn[0] + cn[1] + cn[2] + cn[3]) & 1;
+    }
+    const int nx = (((cn[3] * arg.Xc[2] + cn[2]) * arg.Xc[1] + cn[1]) * arg.Xc[0] + cn[0]) >> 1;
+    const float *src = arg.in.v[npar];
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+      const float *p = src + ((size_t)j * arg.in.stride + nx) * 2;
+      xin[m][j] = make_float2(p[0], p[1]);
+    }
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float re = 0.f, im = 0.f;
+  if (lane < n) {
+    for (int m = wave; m < 9; m += 4) {
+      if (!((arg.mmask >> m) & 1)) continue;
+      const float4 *M = arg.G + ((size_t)A * 9 + m) * (n / 2) * n + lane;
+      for (int jp = 0; jp < n / 2; jp++) {
+        const float4 w = M[(size_t)jp * n];
+        const float2 a = xin[m][2 * jp], b = xin[m][2 * jp + 1];
+        re += w.x * a.x - w.y * a.y + w.z * b.x - w.w * b.y;
+        im += w.x * a.y + w.y * a.x + w.z * b.y + w.w * b.x;
+      }
+    }
+    part[wave][lane] = make_float2(re, im);
+  }
+  __syncthreads();
+  if (wave == 0 && lane < n) {
+    const float2 s = make_float2(part[0][lane].x + part[1][lane].x + part[2][lane].x + part[3][lane].x,
+                                 part[0][lane].y + part[1][lane].y + part[2][lane].y + part[3][lane].y);
+    float *o = arg.out.v[par] + ((size_t)lane * arg.out.stride + xcb) * 2;
+    o[0] = s.x; o[1] = s.y;
+  }
+}
+
+void applyCoarse(ColorSpinorField &out, const ColorSpinorField &in, const CoarseGauge &G, int mmask, int parity) {
+  if (out.Precision() != QUDA_SINGLE_PRECISION || in.Precision() != QUDA_SINGLE_PRECISION) errorQuda("coarse operator is fp32");
+  if (in.Nspin() != 2 || 2 * in.Ncolor() != G.n) errorQuda("coarse field (%d spins, %d colours) does not match the operator (n = %d)", in.Nspin(), in.Ncolor(), G.n);
+  if (G.n > 64) errorQuda("2 Nc = %d exceeds one wavefront", G.n);
+  if (in.V() == out.V()) errorQuda("in and out must not alias");
+  CoarseArg arg;
+  ColorSpinorField &o = out, &i = const_cast<ColorSpinorField &>(in);
+  if (parity < 0) {
+    if (out.SiteSubset() != QUDA_FULL_SITE_SUBSET || in.SiteSubset() != QUDA_FULL_SITE_SUBSET) errorQuda("full coarse fields required");
+    arg.out = cvecFull(o); arg.in = cvecFull(i);
+    arg.nwork = G.nSites;
+  } else {
+    // parity fields: `out` lives on `parity`; hops read the other parity, the local term the same parity
+    if (out.SiteSubset() != QUDA_PARITY_SITE_SUBSET || in.SiteSubset() != QUDA_PARITY_SITE_SUBSET) errorQuda("parity coarse fields required");
+    const bool local_only = mmask == (1 << 8);
+    arg.out.v[parity] = (float *)o.V(); arg.out.v[1 - parity] = nullptr; arg.out.stride = o.Stride(); arg.out.Vh = o.VolumeCB();
+    arg.in.v[local_only ? parity : 1 - parity] = (float *)i.V(); arg.in.v[local_only ? 1 - parity : parity] = nullptr;
+    arg.in.stride = i.Stride(); arg.in.Vh = i.VolumeCB();
+    if (!local_only && (mmask & (1 << 8))) errorQuda("hop + local on parity fields needs both parities of the input");
+    arg.nwork = G.nSites / 2;
+  }
+  arg.G = (const float4 *)G.data;
+  for (int d = 0; d < 4; d++) arg.Xc[d] = G.Xc[d];
+  arg.n = G.n; arg.mmask = mmask; arg.parity = parity;
+  hipLaunchKernelGGL((coarse_apply_kernel<64>), dim3(arg.nwork), dim3(256), 0, computeStream(), arg);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- construction helpers ----
+__global__ void unit_vector_kernel(CVec v, int j, int ncomp) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= v.Vh) return;
+  for (int p = 0; p < 2; p++)
+    for (int k = 0; k < ncomp; k++) {
+      float *q = v.v[p] + ((size_t)k * v.stride + x) * 2;
+      q[0] = k == j ? 1.f : 0.f; q[1] = 0.f;
+    }
+}
+
+// column j of matrix m at every site (+)= coarse vector c
+__global__ void insert_column_kernel(float *G, CVec c, int n, int m, int j, int accumulate, int nSites) {
+  const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (t >= (long)nSites * n) return;
+  const int A = (int)(t / n), i = (int)(t - (long)A * n);
+  const int par = A >= c.Vh, x = A - par * c.Vh;
+  const float *p = c.v[par] + ((size_t)i * c.stride + x) * 2;
+  float *g = G + ((((size_t)A * 9 + m) * (n / 2) + j / 2) * n + i) * 4 + (j & 1) * 2;
+  if (accumulate) { g[0] += p[0]; g[1] += p[1]; }
+  else { g[0] = p[0]; g[1] = p[1]; }
+}
+
+void DiracCoarse::build() {
+  const Transfer &T = *transfer;
+  const int n = 2 * T.Nvec;
+  links = new CoarseGauge(T.Xc, n);
+  ownLinks = true;
+  ColorSpinorField *E = T.createCoarseField(), *c = T.createCoarseField();
+  ColorSpinorField *phi = T.createFineField(), *w = T.createFineField();
+  phi->twistFlavor = w->twistFlavor = fineFlavor;
+  const int bs = 256;
+  for (int j = 0; j < n; j++) {
+    hipLaunchKernelGGL(unit_vector_kernel, dim3((E->VolumeCB() + bs - 1) / bs), dim3(bs), 0, computeStream(), cvecFull(*E), j, n);
+    T.P(*phi, *E);
+    for (int d = 0; d < 8; d++) {
+      parent->hopDir(*w, *phi, d);
+      T.R(*c, *w, d, 1);
+      hipLaunchKernelGGL(insert_column_kernel, dim3(((long)links->nSites * n + bs - 1) / bs), dim3(bs), 0, computeStream(), links->data, cvecFull(*c), n, d, j, 0, links->nSites);
+      T.R(*c, *w, d, 0);
+      hipLaunchKernelGGL(insert_column_kernel, dim3(((long)links->nSites * n + bs - 1) / bs), dim3(bs), 0, computeStream(), links->data, cvecFull(*c), n, 8, j, 1, links->nSites);
+    }
+    parent->localTerm(*w, *phi);
+    T.R(*c, *w);
+    hipLaunchKernelGGL(insert_column_kernel, dim3(((long)links->nSites * n + bs - 1) / bs), dim3(bs), 0, computeStream(), links->data, cvecFull(*c), n, 8, j, 1, links->nSites);
+  }
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(computeStream()));
+  delete E; delete c; delete phi; delete w;
+}
+
+DiracCoarse::DiracCoarse(const DiracParam &p) : Dirac(p), transfer(p.transfer), parent(p.dirac), links(nullptr), ownLinks(false), fineFlavor(p.twistFlavor) {
+  if (!transfer || !parent) errorQuda("coarse operator needs a transfer operator and a parent operator");
+  Nc = transfer->Nvec;
+  type = QUDA_COARSE_DIRAC;
+  build();
+}
+DiracCoarse::DiracCoarse(const DiracCoarse &o, const DiracParam &p)
+    : Dirac(p), transfer(o.transfer), parent(o.parent), links(o.links), ownLinks(false), Nc(o.Nc), fineFlavor(o.fineFlavor) {
+  type = QUDA_COARSE_DIRAC;
+}
+DiracCoarse::~DiracCoarse() { if (ownLinks) delete links; }
+
+void DiracCoarse::M(ColorSpinorField &out, const ColorSpinorField &in) const {
+  if (dagger == QUDA_DAG_YES) errorQuda("coarse dagger operator not implemented (as in the reference)");
+  applyCoarse(out, in, *links, 0x1ff, -1);
+  const long n = 2 * Nc;
+  flops += (9 * (8 * n * n) - 2 * n) * (unsigned long long)in.Volume();
+}
+void DiracCoarse::Dslash(ColorSpinorField &out, const ColorSpinorField &in, const QudaParity parity) const {
+  applyCoarse(out, in, *links, 0xff, in.SiteSubset() == QUDA_FULL_SITE_SUBSET ? -1 : (int)parity);
+  const long n = 2 * Nc;
+  flops += (8 * (8 * n * n) - 2 * n) * (unsigned long long)out.Volume();
+}
+void DiracCoarse::Clover(ColorSpinorField &out, const ColorSpinorField &in, const QudaParity parity) const {
+  applyCoarse(out, in, *links, 1 << 8, in.SiteSubset() == QUDA_FULL_SITE_SUBSET ? -1 : (int)parity);
+  const long n = 2 * Nc;
+  flops += (8 * n * n - 2 * n) * (unsigned long long)out.Volume();
+}
+void DiracCoarse::DslashXpay(ColorSpinorField &out, const ColorSpinorField &in, const QudaParity parity, const ColorSpinorField &x, const double &k) const {
+  Dslash(out, in, parity);
+  blas::xpay(x, k, out);
+}
+void DiracCoarse::MdagM(ColorSpinorField &, const ColorSpinorField &) const { errorQuda("Not implemented"); }
+void DiracCoarse::prepare(ColorSpinorField *&src, ColorSpinorField *&sol, ColorSpinorField &x, ColorSpinorField &b, const QudaSolutionType solType) const {
+  if (solType == QUDA_MATPC_SOLUTION || solType == QUDA_MATPCDAG_MATPC_SOLUTION) errorQuda("Preconditioned solution requires a preconditioned solve_type");
+  src = &b;
+  sol = &x;
+}
+void DiracCoarse::reconstruct(ColorSpinorField &, const ColorSpinorField &, const QudaSolutionType) const {}
+void DiracCoarse::hopDir(ColorSpinorField &out, const ColorSpinorField &in, int dir) const { applyCoarse(out, in, *links, 1 << dir, -1); }
+void DiracCoarse::localTerm(ColorSpinorField &out, const ColorSpinorField &in) const { applyCoarse(out, in, *links, 1 << 8, -1); }
+
+}  // namespace quda

@@ -3,6 +3,8 @@
 // lib/dirac_twisted_clover.cpp:40-430 (operator algebra, coefficient conventions, flop counters).
 #include "dirac.h"
 
+#include "blas.h"
+#include "coarse.h"
 
 namespace quda {
 
@@ -53,6 +55,9 @@ void Dirac::MMdag(ColorSpinorField &out, const ColorSpinorField &in) const {
   flipDagger();
 }
 
+void Dirac::hopDir(ColorSpinorField &, const ColorSpinorField &, int) const { errorQuda("hopDir not available for Dirac type %d", type); }
+void Dirac::localTerm(ColorSpinorField &, const ColorSpinorField &) const { errorQuda("localTerm not available for Dirac type %d", type); }
+
 bool Dirac::isPC() const {
   return type == QUDA_WILSONPC_DIRAC || type == QUDA_TWISTED_MASSPC_DIRAC || type == QUDA_TWISTED_CLOVERPC_DIRAC || type == QUDA_COARSEPC_DIRAC ||
          type == QUDA_CLOVERPC_DIRAC;
@@ -66,6 +71,7 @@ Dirac *Dirac::create(const DiracParam &param) {
     case QUDA_TWISTED_MASSPC_DIRAC: return new DiracTwistedMassPC(param);
     case QUDA_TWISTED_CLOVER_DIRAC: return new DiracTwistedClover(param);
     case QUDA_TWISTED_CLOVERPC_DIRAC: return new DiracTwistedCloverPC(param);
+    case QUDA_COARSE_DIRAC: return new DiracCoarse(param);
     default: errorQuda("Dirac type %d is outside the twisted-mass/multigrid path this library implements", param.type);
   }
   return nullptr;
@@ -102,6 +108,14 @@ void DiracWilson::MdagM(ColorSpinorField &out, const ColorSpinorField &in) const
   M(*t, in);
   Mdag(out, *t);
 }
+
+// M = 1 - kappa D: H_d = -kappa (1 -+ gamma_mu) U, L = 1
+void DiracWilson::hopDir(ColorSpinorField &out, const ColorSpinorField &in, int dir) const {
+  checkFullSpinor(out, in);
+  applyHopDir(out.Odd(), in.Even(), *gauge, QUDA_ODD_PARITY, dir, -kappa);
+  applyHopDir(out.Even(), in.Odd(), *gauge, QUDA_EVEN_PARITY, dir, -kappa);
+}
+void DiracWilson::localTerm(ColorSpinorField &out, const ColorSpinorField &in) const { blas::copy(out, in); }
 
 void DiracWilson::prepare(ColorSpinorField *&src, ColorSpinorField *&sol, ColorSpinorField &x, ColorSpinorField &b,
                           const QudaSolutionType solType) const {
@@ -178,6 +192,7 @@ void DiracTwistedMass::twistedApply(ColorSpinorField &out, const ColorSpinorFiel
   flops += 48ll * in.Volume();
 }
 void DiracTwistedMass::Twist(ColorSpinorField &out, const ColorSpinorField &in) const { twistedApply(out, in, QUDA_TWIST_GAMMA5_DIRECT); }
+void DiracTwistedMass::localTerm(ColorSpinorField &out, const ColorSpinorField &in) const { Twist(out, in); }  // L = 1 + i a gamma5
 
 static DslashMode tmMode(QudaTwistDslashType t) {
   switch (t) {
@@ -350,6 +365,12 @@ void DiracTwistedClover::twistedCloverApply(ColorSpinorField &out, const ColorSp
 }
 void DiracTwistedClover::TwistClover(ColorSpinorField &out, const ColorSpinorField &in, const int parity) const {
   twistedCloverApply(out, in, QUDA_TWIST_GAMMA5_DIRECT, parity);
+}
+
+void DiracTwistedClover::localTerm(ColorSpinorField &out, const ColorSpinorField &in) const {  // L = A + i a gamma5
+  checkFullSpinor(out, in);
+  TwistClover(out.Even(), in.Even(), QUDA_EVEN_PARITY);
+  TwistClover(out.Odd(), in.Odd(), QUDA_ODD_PARITY);
 }
 
 void DiracTwistedClover::tcDslash(ColorSpinorField &out, const ColorSpinorField &in, int parity, const ColorSpinorField *x,

@@ -9,7 +9,7 @@
 namespace quda {
 
 class Transfer;
-class CoarseGauge;
+struct CoarseGauge;
 
 struct DiracParam {
   QudaDiracType type = QUDA_INVALID_DIRAC;
@@ -23,6 +23,7 @@ struct DiracParam {
   // coarse operators
   const Transfer *transfer = nullptr;
   const class Dirac *dirac = nullptr;   // fine operator the coarse one is built from
+  QudaTwistFlavorType twistFlavor = QUDA_TWIST_NO;  // flavour of the fine-level fields the hierarchy is built for
 };
 
 class Dirac {
@@ -57,6 +58,11 @@ class Dirac {
                        const QudaSolutionType solType) const = 0;
   virtual void reconstruct(ColorSpinorField &x, const ColorSpinorField &b, const QudaSolutionType solType) const = 0;
 
+  // Decomposition of the full (unpreconditioned, undaggered) operator M = L + sum_{d=0..7} H_d used by the Galerkin
+  // coarse-operator construction (coarse.h): out = H_dir in (full fields, hopping normalisation included), out = L in.
+  virtual void hopDir(ColorSpinorField &out, const ColorSpinorField &in, int dir) const;
+  virtual void localTerm(ColorSpinorField &out, const ColorSpinorField &in) const;
+
   void setMass(double m) { mass = m; }
   double Kappa() const { return kappa; }
   virtual double Mu() const { return 0.; }
@@ -82,6 +88,8 @@ class DiracWilson : public Dirac {
   void MdagM(ColorSpinorField &out, const ColorSpinorField &in) const override;
   void prepare(ColorSpinorField *&src, ColorSpinorField *&sol, ColorSpinorField &x, ColorSpinorField &b, const QudaSolutionType) const override;
   void reconstruct(ColorSpinorField &x, const ColorSpinorField &b, const QudaSolutionType) const override;
+  void hopDir(ColorSpinorField &out, const ColorSpinorField &in, int dir) const override;
+  void localTerm(ColorSpinorField &out, const ColorSpinorField &in) const override;
 };
 
 class DiracWilsonPC : public DiracWilson {
@@ -104,6 +112,7 @@ class DiracTwistedMass : public DiracWilson {
   explicit DiracTwistedMass(const DiracParam &p) : DiracWilson(p), mu(p.mu), epsilon(p.epsilon) {}
   double Mu() const override { return mu; }
   void Twist(ColorSpinorField &out, const ColorSpinorField &in) const;
+  void localTerm(ColorSpinorField &out, const ColorSpinorField &in) const override;
   void TwistedDslash(ColorSpinorField &out, const ColorSpinorField &in, QudaParity parity, QudaTwistDslashType t, double a, double b) const;
   void TwistedDslashXpay(ColorSpinorField &out, const ColorSpinorField &in, const ColorSpinorField &x, QudaParity parity,
                          QudaTwistDslashType t, double a, double b) const;
@@ -139,6 +148,7 @@ class DiracTwistedClover : public DiracWilson {
   double Mu() const override { return mu; }
   CloverField *Clover() const override { return &clover; }
   void TwistClover(ColorSpinorField &out, const ColorSpinorField &in, const int parity) const;
+  void localTerm(ColorSpinorField &out, const ColorSpinorField &in) const override;
   void M(ColorSpinorField &out, const ColorSpinorField &in) const override;
   void MdagM(ColorSpinorField &out, const ColorSpinorField &in) const override;
   void prepare(ColorSpinorField *&src, ColorSpinorField *&sol, ColorSpinorField &x, ColorSpinorField &b, const QudaSolutionType) const override;

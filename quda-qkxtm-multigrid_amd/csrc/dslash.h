@@ -33,6 +33,10 @@ struct DslashParam {
 // out(parity) = stencil(in(other parity)); fields must be device parity fields of equal precision.
 void applyDslash(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, const DslashParam &p);
 
+// one direction of the stencil only: out(parity) = coef * U P psi(x + dhat(dir)), dir = 2 mu + (0 fwd, 1 bwd), no dagger
+// (building block of the Galerkin coarse-operator construction)
+void applyHopDir(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, int parity, int dir, double coef);
+
 // site-local kernels
 enum SiteOp {
   SITE_TWIST = 0,              // out = b (1 + i a g5) in

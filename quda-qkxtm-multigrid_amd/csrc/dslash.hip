@@ -19,6 +19,7 @@
 // [+ 144 P clover & inverse] (+ norms for 16-bit), SURVEY.md section 8d.
 #include "dslash.h"
 
+#include <cstring>
 #include <vector>
 
 #include "device_io.h"
@@ -298,6 +299,52 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
       for (int k = 0; k < 24; k++) acc[k] = arg.k * acc[k] + tmp[k];
     }
   }
+  Planar<T, 24>::store(acc, arg.out, arg.sp_stride, idx, arg.outNorm, idx);
+}
+
+// ---- single-direction hop (setup-time helper for the multigrid coarse-operator construction) ----
+template <typename T, int R>
+__global__ void __launch_bounds__(256) hop_dir_kernel(const DslashArg<typename Store<T>::real> arg, int dir, typename Store<T>::real coef) {
+  using real = typename Store<T>::real;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= arg.Vh) return;
+  const uint32_t za = arg.dXh.div((uint32_t)idx);
+  const int xh = idx - (int)za * arg.Xh;
+  const uint32_t zb = arg.dY.div(za);
+  const int y = (int)za - (int)zb * arg.Y;
+  const int t = (int)arg.dZ.div(zb);
+  const int z = (int)zb - t * arg.Z;
+  const int xodd = (y + z + t + arg.parity) & 1;
+  const int Xh = arg.Xh, sy = Xh, sz = Xh * arg.Y, st = Xh * arg.Y * arg.Z;
+  int nbr;
+  real sign = 1;
+  switch (dir) {
+    case 0: nbr = xodd ? (xh == Xh - 1 ? idx - (Xh - 1) : idx + 1) : idx; break;
+    case 1: nbr = xodd ? idx : (xh == 0 ? idx + (Xh - 1) : idx - 1); break;
+    case 2: nbr = y == arg.Y - 1 ? idx - (arg.Y - 1) * sy : idx + sy; break;
+    case 3: nbr = y == 0 ? idx + (arg.Y - 1) * sy : idx - sy; break;
+    case 4: nbr = z == arg.Z - 1 ? idx - (arg.Z - 1) * sz : idx + sz; break;
+    case 5: nbr = z == 0 ? idx + (arg.Z - 1) * sz : idx - sz; break;
+    case 6: nbr = t == arg.T - 1 ? idx - (arg.T - 1) * st : idx + st; if (t == arg.T - 1) sign = arg.tsign_fwd; break;
+    default: nbr = t == 0 ? idx + (arg.T - 1) * st : idx - st; if (t == 0) sign = arg.tsign_bwd; break;
+  }
+  real acc[24], psi[24], U[18];
+#pragma unroll
+  for (int k = 0; k < 24; k++) acc[k] = 0;
+  Planar<T, 24>::load(psi, arg.in, arg.sp_stride, nbr, arg.inNorm, nbr);
+  Link<T, R>::load(U, arg.gauge + (size_t)dir * arg.link_bytes, arg.g_stride, idx, sign);
+  switch (dir) {
+    case 0: hop_compute<T, 0, false, false>(acc, psi, U, arg); break;
+    case 1: hop_compute<T, 1, false, false>(acc, psi, U, arg); break;
+    case 2: hop_compute<T, 2, false, false>(acc, psi, U, arg); break;
+    case 3: hop_compute<T, 3, false, false>(acc, psi, U, arg); break;
+    case 4: hop_compute<T, 4, false, false>(acc, psi, U, arg); break;
+    case 5: hop_compute<T, 5, false, false>(acc, psi, U, arg); break;
+    case 6: hop_compute<T, 6, false, false>(acc, psi, U, arg); break;
+    default: hop_compute<T, 7, false, false>(acc, psi, U, arg); break;
+  }
+#pragma unroll
+  for (int k = 0; k < 24; k++) acc[k] *= coef;
   Planar<T, 24>::store(acc, arg.out, arg.sp_stride, idx, arg.outNorm, idx);
 }
 
@@ -596,6 +643,37 @@ void applyDslash(ColorSpinorField &out, const ColorSpinorField &in, const GaugeF
     case QUDA_SINGLE_PRECISION: dispatchRecon<float>(out, in, U, p); break;
     case QUDA_HALF_PRECISION: dispatchRecon<short>(out, in, U, p); break;
     default: errorQuda("bad precision %d", in.Precision());
+  }
+}
+
+template <typename T, int R> static void launchHopDir(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, int parity, int dir, double coef) {
+  using real = typename Store<T>::real;
+  DslashArg<real> arg;
+  memset(&arg, 0, sizeof(arg));
+  const LatticeGeom &g = U.geom;
+  arg.out = out.V(); arg.outNorm = (float *)out.Norm();
+  arg.in = in.V(); arg.inNorm = (const float *)in.Norm();
+  arg.gauge = (const char *)U.parityBase(parity);
+  arg.link_bytes = U.link_bytes;
+  arg.sp_stride = in.Stride(); arg.g_stride = U.stride;
+  arg.Vh = g.Vh; arg.Xh = g.Xh; arg.Y = g.X[1]; arg.Z = g.X[2]; arg.T = g.X[3];
+  arg.dXh = g.dXh; arg.dY = g.dY; arg.dZ = g.dZ;
+  arg.parity = parity; arg.sfwd = 1;
+  arg.tsign_fwd = (R == 12 && U.t_boundary == QUDA_ANTI_PERIODIC_T) ? -1 : 1;
+  arg.tsign_bwd = arg.tsign_fwd;
+  hipLaunchKernelGGL((hop_dir_kernel<T, R>), dim3((g.Vh + 255) / 256), dim3(256), 0, computeStream(), arg, dir, (real)coef);
+  HIP_CHECK(hipGetLastError());
+}
+
+void applyHopDir(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, int parity, int dir, double coef) {
+  if (in.Precision() != out.Precision() || in.Precision() != U.precision) errorQuda("precision mismatch");
+  if (in.VolumeCB() != U.geom.Vh) errorQuda("volume mismatch");
+  for (int d = 0; d < 4; d++) if (commGrid().partitioned(d)) errorQuda("multigrid setup on a grid-decomposed lattice is not built yet (single-GPU hierarchy only)");
+  const bool r12 = U.reconstruct == QUDA_RECONSTRUCT_12;
+  switch (in.Precision()) {
+    case QUDA_DOUBLE_PRECISION: r12 ? launchHopDir<double, 12>(out, in, U, parity, dir, coef) : launchHopDir<double, 18>(out, in, U, parity, dir, coef); break;
+    case QUDA_SINGLE_PRECISION: r12 ? launchHopDir<float, 12>(out, in, U, parity, dir, coef) : launchHopDir<float, 18>(out, in, U, parity, dir, coef); break;
+    default: errorQuda("single-direction hop: fp64/fp32 only");
   }
 }
 

@@ -1,0 +1,316 @@
+// multigrid.cpp — MG setup and cycle (see multigrid.h).
+#include "multigrid.h"
+
+#include <cmath>
+#include <sys/time.h>
+
+#include "interface_internal.h"
+
+namespace quda {
+
+static double now() {
+  timeval t;
+  gettimeofday(&t, nullptr);
+  return t.tv_sec + 1e-6 * t.tv_usec;
+}
+
+MGParam::MGParam(QudaMultigridParam &g, std::vector<ColorSpinorField *> &B_, DiracMatrix &res, DiracMatrix &smooth, int level_, QudaTwistFlavorType flavor)
+    : SolverParam(*g.invert_param), mg_global(g), level(level_), Nlevel(g.n_level), spinBlockSize(g.spin_block_size[level_]), Nvec(g.n_vec[level_]),
+      B(B_), nu_pre(g.nu_pre[level_]), nu_post(g.nu_post[level_]), smoother_tol(g.smoother_tol[level_]), cycle_type(g.cycle_type[level_]),
+      smoother(g.smoother[level_]), matResidual(res), matSmooth(smooth), fineFlavor(flavor) {
+  for (int d = 0; d < 4; d++) geoBlockSize[d] = g.geo_block_size[level_][d];
+  omega = g.omega[level_];
+  global_reduction = g.global_reduction[level_] != QUDA_BOOLEAN_NO;
+  precision = precision_sloppy = precision_precondition = QUDA_SINGLE_PRECISION;
+  inv_type_precondition = QUDA_INVALID_INVERTER;
+  preconditioner = nullptr;
+  use_init_guess = QUDA_USE_INIT_GUESS_NO;
+  iter = 0; gflops = 0; secs = 0;
+}
+
+static ColorSpinorField *likeField(const ColorSpinorField &x) {
+  ColorSpinorParam p = x.param();
+  p.create = QUDA_ZERO_FIELD_CREATE;
+  return new ColorSpinorField(p);
+}
+
+MG::MG(MGParam &p)
+    : Solver(p), mgp(p), transfer(nullptr), presmoother(nullptr), postsmoother(nullptr), coarse_solver(nullptr), param_presmooth(nullptr),
+      param_postsmooth(nullptr), param_coarse_solver(nullptr), coarse(nullptr), param_coarse(nullptr), r(nullptr), r_coarse(nullptr), x_coarse(nullptr),
+      diracCoarse(nullptr), matCoarse(nullptr), ownCoarseSolver(false) {
+  if (p.level >= QUDA_MAX_MG_LEVEL) errorQuda("Level=%d is greater than limit of multigrid recursion depth", p.level + 1);
+  if (getVerbosity() >= QUDA_SUMMARIZE) printfQuda("MG level %d: creating level %d of %d\n", p.level + 1, p.level + 1, p.Nlevel);
+  const bool coarsest = p.level == p.Nlevel - 1;
+
+  if (!coarsest) {
+    if (p.mg_global.compute_null_vector == QUDA_COMPUTE_NULL_VECTOR_YES && (p.mg_global.generate_all_levels == QUDA_BOOLEAN_YES || p.level == 0))
+      generateNullVectors(p.B);
+  }
+
+  // smoothers (reference :40-85)
+  param_presmooth = new SolverParam(p);
+  param_presmooth->inv_type = p.smoother;
+  param_presmooth->inv_type_precondition = QUDA_INVALID_INVERTER;
+  param_presmooth->is_preconditioner = true;
+  param_presmooth->preserve_source = QUDA_PRESERVE_SOURCE_YES;
+  param_presmooth->use_init_guess = QUDA_USE_INIT_GUESS_NO;
+  param_presmooth->maxiter = p.nu_pre;
+  param_presmooth->Nkrylov = 4;
+  param_presmooth->tol = p.smoother_tol;
+  param_presmooth->global_reduction = p.global_reduction;
+  param_presmooth->compute_true_res = false;
+  param_presmooth->precision = param_presmooth->precision_sloppy = param_presmooth->precision_precondition = QUDA_SINGLE_PRECISION;
+  if (coarsest) {
+    // coarsest-grid solver: GCR(20) to smoother_tol (reference :63-70)
+    param_presmooth->inv_type = QUDA_GCR_INVERTER;
+    param_presmooth->Nkrylov = 20;
+    param_presmooth->maxiter = 1000;
+    param_presmooth->delta = 1e-8;
+    param_presmooth->pipeline = 1;
+    param_presmooth->global_reduction = true;
+  }
+  presmoother = Solver::create(*param_presmooth, p.matSmooth, p.matSmooth, p.matSmooth);
+  if (!coarsest) {
+    param_postsmooth = new SolverParam(*param_presmooth);
+    param_postsmooth->use_init_guess = QUDA_USE_INIT_GUESS_YES;
+    param_postsmooth->maxiter = p.nu_post;
+    postsmoother = Solver::create(*param_postsmooth, p.matSmooth, p.matSmooth, p.matSmooth);
+  }
+
+  if (!coarsest) {
+    r = likeField(*p.B[0]);
+    r->twistFlavor = p.fineFlavor;
+    transfer = new Transfer(p.B, p.Nvec, p.geoBlockSize, p.spinBlockSize);
+    for (int d = 0; d < 4; d++) p.mg_global.geo_block_size[p.level][d] = p.geoBlockSize[d];
+    r_coarse = transfer->createCoarseField();
+    x_coarse = transfer->createCoarseField();
+
+    // Galerkin coarse operator (reference :150-190)
+    DiracParam dp;
+    dp.type = QUDA_COARSE_DIRAC;
+    dp.transfer = transfer;
+    dp.dirac = p.matResidual.Expose();
+    dp.kappa = 1.0;  // the hopping normalisation is folded into the coarse links (coarse.h)
+    dp.dagger = QUDA_DAG_NO;
+    dp.matpcType = p.mg_global.invert_param->matpc_type;
+    dp.twistFlavor = p.fineFlavor;
+    const double t0 = now();
+    diracCoarse = new DiracCoarse(dp);
+    matCoarse = new DiracM(*diracCoarse);
+    if (getVerbosity() >= QUDA_SUMMARIZE) printfQuda("MG level %d: coarse operator %d^2 x 9 per site on %d x %d x %d x %d built in %.3f s\n", p.level + 1, 2 * p.Nvec, transfer->Xc[0], transfer->Xc[1], transfer->Xc[2], transfer->Xc[3], now() - t0);
+
+    // coarse null vectors: restricted fine ones unless every level generates its own (reference :196-208)
+    const int nVecCoarse = std::max(p.Nvec, p.level + 1 < p.Nlevel ? p.mg_global.n_vec[p.level + 1] : p.Nvec);
+    B_coarse.resize(nVecCoarse, nullptr);
+    for (int i = 0; i < nVecCoarse; i++) B_coarse[i] = transfer->createCoarseField();
+    if (p.mg_global.generate_all_levels != QUDA_BOOLEAN_YES)
+      for (int i = 0; i < p.Nvec; i++) transfer->R(*B_coarse[i], *p.B[i]);
+
+    param_coarse = new MGParam(p.mg_global, B_coarse, *matCoarse, *matCoarse, p.level + 1, QUDA_TWIST_NO);
+    param_coarse->delta = 1e-20;
+    coarse = new MG(*param_coarse);
+
+    if (p.cycle_type == QUDA_MG_CYCLE_VCYCLE || p.level == p.Nlevel - 2) {
+      coarse_solver = coarse;
+    } else if (p.cycle_type == QUDA_MG_CYCLE_RECURSIVE) {
+      // K-cycle: GCR(10), at most 11 iterations, preconditioned by the coarse V-cycle (reference :225-250)
+      param_coarse_solver = new SolverParam(*param_coarse);
+      param_coarse_solver->inv_type = QUDA_GCR_INVERTER;
+      param_coarse_solver->inv_type_precondition = QUDA_MG_INVERTER;
+      param_coarse_solver->is_preconditioner = true;
+      param_coarse_solver->preserve_source = QUDA_PRESERVE_SOURCE_YES;
+      param_coarse_solver->use_init_guess = QUDA_USE_INIT_GUESS_NO;
+      param_coarse_solver->maxiter = 11;
+      param_coarse_solver->Nkrylov = 10;
+      param_coarse_solver->tol = p.mg_global.smoother_tol[p.level + 1];
+      param_coarse_solver->global_reduction = true;
+      param_coarse_solver->compute_true_res = false;
+      param_coarse_solver->delta = 1e-8;
+      param_coarse_solver->pipeline = 1;
+      param_coarse_solver->precision = param_coarse_solver->precision_sloppy = param_coarse_solver->precision_precondition = QUDA_SINGLE_PRECISION;
+      coarse_solver = new GCR(*matCoarse, *coarse, *matCoarse, *matCoarse, *param_coarse_solver);
+      ownCoarseSolver = true;
+    } else {
+      errorQuda("Multigrid cycle type %d not supported", p.cycle_type);
+    }
+  }
+  if (getVerbosity() >= QUDA_SUMMARIZE) printfQuda("MG level %d: setup completed\n", p.level + 1);
+}
+
+MG::~MG() {
+  if (ownCoarseSolver) delete coarse_solver;
+  delete param_coarse_solver;
+  delete coarse;
+  delete param_coarse;
+  for (ColorSpinorField *f : B_coarse) delete f;
+  delete matCoarse;
+  delete diracCoarse;
+  delete transfer;
+  delete postsmoother;
+  delete presmoother;
+  delete param_presmooth;
+  delete param_postsmooth;
+  delete r; delete r_coarse; delete x_coarse;
+}
+
+unsigned long long MG::flops() const {
+  unsigned long long f = 0;
+  if (coarse) f += coarse->flops();
+  if (param_presmooth) { f += (unsigned long long)(param_presmooth->gflops * 1e9); param_presmooth->gflops = 0; }
+  if (param_postsmooth) { f += (unsigned long long)(param_postsmooth->gflops * 1e9); param_postsmooth->gflops = 0; }
+  if (transfer) f += transfer->flops();
+  return f;
+}
+
+// reference generateNullVectors :693-779
+void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
+  if (getVerbosity() >= QUDA_SUMMARIZE) printfQuda("MG level %d: generating %d null vectors (BiCGstab, maxiter %d, tol %g)\n", mgp.level + 1, mgp.Nvec, mgp.mg_global.setup_maxiter, mgp.mg_global.setup_tol);
+  SolverParam sp(mgp);
+  sp.maxiter = mgp.mg_global.setup_maxiter;
+  sp.tol = mgp.mg_global.setup_tol;
+  sp.use_init_guess = QUDA_USE_INIT_GUESS_YES;
+  sp.delta = 1e-7;
+  sp.inv_type = QUDA_BICGSTAB_INVERTER;
+  sp.inv_type_precondition = QUDA_INVALID_INVERTER;
+  sp.residual_type = QUDA_L2_RELATIVE_RESIDUAL;
+  sp.compute_null_vector = QUDA_COMPUTE_NULL_VECTOR_YES;
+  sp.is_preconditioner = true;
+  sp.global_reduction = true;
+  sp.precision = sp.precision_sloppy = sp.precision_precondition = QUDA_SINGLE_PRECISION;
+  ColorSpinorField *b = likeField(*B[0]);
+  b->twistFlavor = mgp.fineFlavor;
+  const QudaVerbosity v0 = getVerbosity();
+  for (int i = 0; i < mgp.Nvec; i++) {
+    ColorSpinorField &x = *B[i];
+    x.twistFlavor = mgp.fineFlavor;
+    spinorRandom(x, 0x5eedULL + 7919ULL * (mgp.level * 131 + i));
+    blas::zero(*b);
+    Solver *solve = Solver::create(sp, mgp.matSmooth, mgp.matSmooth, mgp.matSmooth);
+    (*solve)(x, *b);
+    delete solve;
+    // global orthonormalisation against the previous vectors
+    for (int j = 0; j < i; j++) {
+      const Complex alpha = blas::cDotProduct(*B[j], x);
+      blas::caxpy(-alpha, *B[j], x);
+    }
+    const double nrm2 = blas::norm2(x);
+    if (nrm2 > 1e-16) blas::ax(1.0 / sqrt(nrm2), x);
+    else errorQuda("Cannot orthogonalize %d vector", i);
+  }
+  (void)v0;
+  delete b;
+}
+
+// reference :488-604 restricted to full-system smoothing (see multigrid.h)
+void MG::operator()(ColorSpinorField &x, ColorSpinorField &b) {
+  if (b.SiteSubset() != QUDA_FULL_SITE_SUBSET) errorQuda("this multigrid build preconditions the full system (QUDA_DIRECT_SOLVE outer solve)");
+  if (mgp.level < mgp.Nlevel - 1) {
+    r->twistFlavor = b.twistFlavor;
+    (*presmoother)(x, b);
+    mgp.matResidual(*r, x);
+    blas::axpby(1.0, b, -1.0, *r);  // r = b - A x
+    transfer->R(*r_coarse, *r);
+    blas::zero(*x_coarse);
+    (*coarse_solver)(*x_coarse, *r_coarse);
+    transfer->P(*r, *x_coarse);     // repurpose residual storage
+    blas::xpy(*r, x);
+    (*postsmoother)(x, b);
+  } else {
+    (*presmoother)(x, b);           // coarsest-grid solve
+  }
+  blas::setGlobalReduction(true);
+}
+
+void MG::verify(double dev[3]) {
+  dev[0] = dev[1] = dev[2] = 0.0;
+  if (mgp.level >= mgp.Nlevel - 1) return;
+  ColorSpinorField *tmp1 = likeField(*mgp.B[0]), *tmp2 = likeField(*mgp.B[0]);
+  ColorSpinorField *c1 = transfer->createCoarseField(), *c2 = transfer->createCoarseField(), *c3 = transfer->createCoarseField();
+  tmp1->twistFlavor = tmp2->twistFlavor = mgp.fineFlavor;
+  // (1) v_k - P P^dag v_k = 0 for the vectors the transfer was built from
+  for (int i = 0; i < mgp.Nvec; i++) {
+    transfer->R(*c1, *mgp.B[i]);
+    transfer->P(*tmp2, *c1);
+    const double n = blas::norm2(*mgp.B[i]);
+    blas::copy(*tmp1, *mgp.B[i]);
+    const double d = blas::xmyNorm(*tmp2, *tmp1);
+    if (n > 0) dev[0] = std::max(dev[0], sqrt(d / n));
+  }
+  // (2) eta_c - P^dag P eta_c = 0
+  spinorRandom(*c1, 0xabcdefULL + mgp.level);
+  transfer->P(*tmp1, *c1);
+  transfer->R(*c2, *tmp1);
+  {
+    const double n = blas::norm2(*c1);
+    blas::copy(*c3, *c1);
+    dev[1] = sqrt(blas::xmyNorm(*c2, *c3) / n);
+  }
+  // (3) emulated R D P eta_c against the native coarse operator
+  transfer->P(*tmp1, *c1);
+  mgp.matResidual(*tmp2, *tmp1);
+  transfer->R(*c2, *tmp2);
+  (*matCoarse)(*c3, *c1);
+  {
+    const double n = blas::norm2(*c3);
+    dev[2] = sqrt(blas::xmyNorm(*c2, *c3) / n);
+  }
+  delete tmp1; delete tmp2; delete c1; delete c2; delete c3;
+  if (getVerbosity() >= QUDA_SUMMARIZE)
+    printfQuda("MG level %d verify: |(1-PP^dag)v|/|v| = %e  |(1-P^dag P)eta|/|eta| = %e  |RDP eta - Dc eta|/|Dc eta| = %e\n", mgp.level + 1, dev[0], dev[1], dev[2]);
+  if (coarse) {
+    double dc[3];
+    coarse->verify(dc);
+    for (int k = 0; k < 3; k++) dev[k] = std::max(dev[k], dc[k]);
+  }
+}
+
+// ================================================================================================
+// reference multigrid_solver ctor, lib/interface_quda.cpp:2161-2255
+multigrid_solver::multigrid_solver(QudaMultigridParam &mg_param) : d(nullptr), m(nullptr), mgParam(nullptr), mg(nullptr) {
+  QudaInvertParam *param = mg_param.invert_param;
+  if (!param) errorQuda("QudaMultigridParam.invert_param is NULL");
+  if (mg_param.n_level < 2 || mg_param.n_level > QUDA_MAX_MG_LEVEL) errorQuda("Requested MG levels %d outside 2..%d", mg_param.n_level, QUDA_MAX_MG_LEVEL);
+  for (int i = 0; i < mg_param.n_level; i++)
+    if (mg_param.smoother_solve_type[i] != QUDA_DIRECT_SOLVE)
+      errorQuda("smoother_solve_type[%d] = %d: this build smooths the full operator (QUDA_DIRECT_SOLVE); the even-odd preconditioned smoother comes next", i, mg_param.smoother_solve_type[i]);
+  if (param->solve_type != QUDA_DIRECT_SOLVE) errorQuda("Outer MG solver can only use QUDA_DIRECT_SOLVE at present");
+  GaugeField *g = gaugePrecondition ? gaugePrecondition : (gaugeSloppy ? gaugeSloppy : gaugePrecise);
+  if (!g) errorQuda("Gauge field not allocated");
+  if (g->precision != QUDA_SINGLE_PRECISION) errorQuda("the multigrid hierarchy runs in fp32: load the gauge field with cuda_prec_precondition = QUDA_SINGLE_PRECISION (got %d)", g->precision);
+  for (int dd = 0; dd < 4; dd++) if (commGrid().partitioned(dd)) errorQuda("multigrid on a grid-decomposed lattice is not built yet");
+  mg_param.secs = 0; mg_param.gflops = 0;
+  const double t0 = now();
+
+  // QKXTM: kappa / mu rescaled for the P,R setup only (reference :2196-2211)
+  const double orig_mu = param->mu, orig_kappa = param->kappa, orig_mass = param->mass;
+  param->kappa *= mg_param.delta_kappaPR;
+  param->mu *= mg_param.delta_muPR;
+  param->mass = 0.5 / param->kappa - 4.0;
+  DiracParam dp;
+  setDiracPreParam(dp, param, false);
+  if (dp.clover && dp.clover->precision != QUDA_SINGLE_PRECISION) errorQuda("multigrid needs an fp32 precondition clover field");
+  d = Dirac::create(dp);
+  m = new DiracM(*d);
+  param->kappa = orig_kappa; param->mu = orig_mu; param->mass = orig_mass;
+
+  ColorSpinorParam cp = deviceSpinorParam(QUDA_SINGLE_PRECISION, QUDA_FULL_SITE_SUBSET, param->twist_flavor);
+  cp.create = QUDA_ZERO_FIELD_CREATE;
+  B.resize(mg_param.n_vec[0]);
+  for (int i = 0; i < mg_param.n_vec[0]; i++) B[i] = new ColorSpinorField(cp);
+  mgParam = new MGParam(mg_param, B, *m, *m, 0, param->twist_flavor);
+  mg = new MG(*mgParam);
+  if (mg_param.run_verify == QUDA_BOOLEAN_YES) { double dev[3]; mg->verify(dev); }
+  mg_param.secs = now() - t0;
+  mg_param_copy = mg_param;
+  inv_param_copy = *param;
+}
+
+multigrid_solver::~multigrid_solver() {
+  delete mg;
+  delete mgParam;
+  for (ColorSpinorField *f : B) delete f;
+  delete m;
+  delete d;
+}
+
+}  // namespace quda

@@ -1,15 +1,80 @@
-// multigrid.h — adaptive multigrid (reference include/multigrid.h, lib/multigrid.cpp).  Filled in by multigrid.cpp.
+// multigrid.h — adaptive multigrid preconditioner (reference include/multigrid.h, lib/multigrid.cpp:11-779).
+//
+// Hierarchy: level 0 = the full fine operator (Wilson / twisted-mass / twisted-clover, fp32 "precondition" links),
+// level l+1 = Galerkin coarse operator of level l through a Transfer built from Nvec block-orthonormalised null
+// vectors (BiCGstab on M x = 0 from random guesses, or the restricted vectors of the level above).
+// Cycle (reference MG::operator(), :488-604): pre-smooth (MR, nu_pre) -> residual -> R -> coarse solve
+// (V-cycle: the coarse MG itself; K-cycle = QUDA_MG_CYCLE_RECURSIVE: GCR(10) preconditioned by it) -> P, correct ->
+// post-smooth (MR, nu_post); coarsest level: GCR to smoother_tol.
+// Scope of this build: smoothing and coarse-grid solves act on the full (unpreconditioned) operators
+// (smoother_solve_type = QUDA_DIRECT_SOLVE, coarse_grid_solution_type = QUDA_MAT_SOLUTION — a combination the reference
+// supports); the outer solver is GCR on the full system, which is the only outer solve the reference's MG accepts
+// (lib/interface_quda.cpp:2183-2184).  The even-odd preconditioned smoother variant (Yhat / Xinv) comes next.
 #pragma once
 
+#include <vector>
+
+#include "coarse.h"
 #include "solver.h"
+#include "transfer.h"
 
 namespace quda {
 
-class MG;
+struct MGParam : SolverParam {
+  QudaMultigridParam &mg_global;
+  int level, Nlevel;
+  int geoBlockSize[4];
+  int spinBlockSize;
+  int Nvec;
+  std::vector<ColorSpinorField *> &B;   // null vectors of THIS level (fp32 device full fields)
+  int nu_pre, nu_post;
+  double smoother_tol;
+  QudaMultigridCycleType cycle_type;
+  QudaInverterType smoother;
+  DiracMatrix &matResidual, &matSmooth;
+  QudaTwistFlavorType fineFlavor;
+  MGParam(QudaMultigridParam &g, std::vector<ColorSpinorField *> &B, DiracMatrix &matResidual, DiracMatrix &matSmooth, int level, QudaTwistFlavorType flavor);
+};
+
+class MG : public Solver {
+  MGParam &mgp;
+  Transfer *transfer;
+  Solver *presmoother, *postsmoother, *coarse_solver;
+  SolverParam *param_presmooth, *param_postsmooth, *param_coarse_solver;
+  MG *coarse;
+  MGParam *param_coarse;
+  std::vector<ColorSpinorField *> B_coarse;
+  ColorSpinorField *r, *r_coarse, *x_coarse;
+  DiracCoarse *diracCoarse;
+  DiracM *matCoarse;
+  bool ownCoarseSolver;
+  void generateNullVectors(std::vector<ColorSpinorField *> &B);
+
+ public:
+  explicit MG(MGParam &param);
+  ~MG() override;
+  void operator()(ColorSpinorField &out, ColorSpinorField &in) override;
+  unsigned long long flops() const override;
+  // self-consistency identities of the reference's MG::verify() (lib/multigrid.cpp:372-486); returns the three worst
+  // relative deviations over the hierarchy: |(1 - P P^dag) v_k| / |v_k|, |(1 - P^dag P) eta| / |eta|,
+  // |R D P eta - D_c eta| / |D_c eta|
+  void verify(double dev[3]);
+  const Transfer *getTransfer() const { return transfer; }
+  const DiracCoarse *getCoarseDirac() const { return diracCoarse; }
+  MG *getCoarse() const { return coarse; }
+};
 
 // opaque object handed out by newMultigridQuda (reference include/multigrid.h:375-411)
 struct multigrid_solver {
-  Solver *mg = nullptr;
+  Dirac *d;       // level-0 full operator in the preconditioner precision
+  DiracM *m;
+  std::vector<ColorSpinorField *> B;
+  MGParam *mgParam;
+  MG *mg;
+  QudaMultigridParam mg_param_copy;
+  QudaInvertParam inv_param_copy;
+  explicit multigrid_solver(QudaMultigridParam &mg_param);
+  ~multigrid_solver();
 };
 
 }  // namespace quda

@@ -1,0 +1,56 @@
+// transfer.h — inter-grid transfer operators of the adaptive multigrid (reference include/transfer.h,
+// lib/transfer.cpp:21-348, lib/transfer_util.cu:15-363, lib/restrictor.cu, lib/prolongator.cu).
+//
+// V holds the block-orthonormalised null vectors.  R = V^dagger summed over each aggregate and over the fine spins of a
+// chirality, P = V broadcast (reference restrictor.cu:51-125, prolongator.cu:42-116).  MI355X layout: V is stored
+// AGGREGATE-MAJOR — [aggregate][fine spin-colour k][vector pair][site in aggregate] as float4 — so the work-group
+// that owns an aggregate streams one contiguous 2304 B/site slab with 16-byte unit-stride lanes; the (4 %) fine-vector
+// traffic goes through a site map.  Both kernels are pure HBM streams of V (V + fine vec + coarse vec bytes).
+#pragma once
+
+#include <vector>
+
+#include "fields.h"
+
+namespace quda {
+
+class Transfer {
+ public:
+  int Nvec;
+  int geo_bs[4];
+  int spin_bs;
+  int fineSpin, fineColor;     // of the level this transfer starts from
+  int Xf[4], Xc[4];            // fine / coarse full lattice extents
+  int blockVol;                // sites per aggregate
+  int nAgg;                    // aggregates = coarse volume
+  long fineVol;
+  float *V;                    // device, aggregate-major (see above)
+  int *block_to_fine;          // [A*blockVol + b] -> fine full index (parity*Vh + x_cb)
+  int *fine_to_block;          // inverse
+  mutable unsigned long long flops_;
+
+  // B: Nvec null vectors on the fine level (device, fp32, full fields).  geo_bs is adjusted in place with the reference's
+  // fallback rule (lib/transfer.cpp:31-44) so callers can read back the block size actually used.
+  Transfer(const std::vector<ColorSpinorField *> &B, int Nvec, int *geo_bs, int spin_bs);
+  ~Transfer();
+
+  // dir < 0: plain R.  dir in 0..7 with boundary = 0/1: only fine sites whose neighbour in direction dir lies inside /
+  // outside the site's own aggregate contribute (used by the Galerkin coarse-operator construction).
+  void R(ColorSpinorField &coarse, const ColorSpinorField &fine, int dir = -1, int boundary = 0) const;
+  void P(ColorSpinorField &fine, const ColorSpinorField &coarse) const;
+
+  ColorSpinorField *createCoarseField() const;   // reference ColorSpinorField::CreateCoarse, lib/color_spinor_field.cpp:737-763
+  ColorSpinorField *createFineField() const;
+  unsigned long long flops() const { unsigned long long f = flops_; flops_ = 0; return f; }
+  size_t vBytes() const { return (size_t)fineVol * fineSpin * fineColor * Nvec * 2 * sizeof(float); }
+
+ private:
+  void createGeoMap();
+  void fillAndOrthonormalise(const std::vector<ColorSpinorField *> &B);
+};
+
+// uniform(0,1) random spinor from a counter-based generator keyed by (seed, global site, component): the same field for
+// any process grid (reference uses a private rand48 clone, lib/color_spinor_util.cu:12-22)
+void spinorRandom(ColorSpinorField &f, unsigned long long seed);
+
+}  // namespace quda

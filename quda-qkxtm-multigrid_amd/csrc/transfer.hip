@@ -1,0 +1,392 @@
+// transfer.hip — restrictor / prolongator / block Gram-Schmidt kernels and the Transfer host class (see transfer.h).
+#include "transfer.h"
+
+#include <cstring>
+
+namespace quda {
+
+constexpr int kMaxVec = 32;
+
+// fine-vector element access: complex number sc of site x in one parity block of a planar field with NV reals per vector
+template <int NV> __device__ __forceinline__ size_t fidx(int stride, int x, int sc) {
+  const int r = 2 * sc;
+  return ((size_t)(r / NV) * stride + x) * NV + (r % NV);
+}
+
+struct FineVec {
+  float *v[2];  // even / odd parity block
+  int stride, Vh;
+};
+struct CoarseVec {
+  float *v[2];
+  int stride, Vh;
+};
+
+static FineVec fineVec(const ColorSpinorField &f) {
+  if (f.Location() != QUDA_CUDA_FIELD_LOCATION || f.Precision() != QUDA_SINGLE_PRECISION || f.SiteSubset() != QUDA_FULL_SITE_SUBSET)
+    errorQuda("transfer operators work on full fp32 device fields (precision %d subset %d)", f.Precision(), f.SiteSubset());
+  ColorSpinorField &g = const_cast<ColorSpinorField &>(f);
+  FineVec r;
+  r.v[0] = (float *)g.Even().V(); r.v[1] = (float *)g.Odd().V();
+  r.stride = f.Stride(); r.Vh = f.VolumeCB();
+  return r;
+}
+
+struct MaskArg {
+  int dir;       // -1: no mask
+  int boundary;  // 1: keep sites whose dir-neighbour is outside the aggregate, 0: inside
+  int bs[4];
+  int single[4]; // coarse extent 1 in that dimension: the neighbour always wraps into the same aggregate
+};
+
+__device__ __forceinline__ bool mask_keep(const MaskArg &m, int b) {
+  if (m.dir < 0) return true;
+  const int mu = m.dir >> 1, fwd = !(m.dir & 1);
+  int y[4], l = b;
+  y[0] = l % m.bs[0]; l /= m.bs[0];
+  y[1] = l % m.bs[1]; l /= m.bs[1];
+  y[2] = l % m.bs[2]; y[3] = l / m.bs[2];
+  const bool out = !m.single[mu] && (fwd ? y[mu] == m.bs[mu] - 1 : y[mu] == 0);
+  return out == (m.boundary != 0);
+}
+
+// ---- block reduction of one float4 across the work-group (wave64 shuffles, then LDS across waves) ----
+__device__ __forceinline__ float4 block_sum4(float4 v, float4 *lds) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    v.x += __shfl_down(v.x, off, 64); v.y += __shfl_down(v.y, off, 64);
+    v.z += __shfl_down(v.z, off, 64); v.w += __shfl_down(v.w, off, 64);
+  }
+  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds[wave] = v;
+  __syncthreads();
+  float4 r = lds[0];
+  for (int w = 1; w < nw; w++) { r.x += lds[w].x; r.y += lds[w].y; r.z += lds[w].z; r.w += lds[w].w; }
+  return r;
+}
+
+// ---- restrictor: one work-group per aggregate, one thread per fine site of it ----
+template <int NSF, int NCF, int NVEC, int NV>
+__global__ void restrict_kernel(CoarseVec out, FineVec in, const float4 *V, const int *block_to_fine, int blockVol, int spin_bs, MaskArg mask) {
+  constexpr int K = NSF * NCF;
+  __shared__ float4 lds[16];
+  const int A = blockIdx.x, b = threadIdx.x;
+  const bool active = b < blockVol && mask_keep(mask, b);
+  float2 r[K];
+  if (active) {
+    const int f = block_to_fine[(size_t)A * blockVol + b];
+    const int parity = f >= in.Vh, x = f - parity * in.Vh;
+    const float *base = in.v[parity];
+#pragma unroll
+    for (int k = 0; k < K; k++) { const size_t i = fidx<NV>(in.stride, x, k); r[k] = make_float2(base[i], base[i + 1]); }
+  }
+  const int cpar = A >= out.Vh, xc = A - cpar * out.Vh;
+  float *ob = out.v[cpar];
+  for (int chi = 0; chi < 2; chi++) {
+    for (int vp = 0; vp < NVEC / 2; vp++) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+          if ((k / NCF) / spin_bs != chi) continue;
+          const float4 w = V[(((size_t)A * K + k) * (NVEC / 2) + vp) * blockVol + b];
+          // conj(V) * r
+          acc.x += w.x * r[k].x + w.y * r[k].y; acc.y += w.x * r[k].y - w.y * r[k].x;
+          acc.z += w.z * r[k].x + w.w * r[k].y; acc.w += w.z * r[k].y - w.w * r[k].x;
+        }
+      }
+      const float4 s = block_sum4(acc, lds);
+      if (threadIdx.x == 0) {
+        const int c0 = chi * NVEC + 2 * vp;
+        ob[((size_t)c0 * out.stride + xc) * 2] = s.x; ob[((size_t)c0 * out.stride + xc) * 2 + 1] = s.y;
+        ob[((size_t)(c0 + 1) * out.stride + xc) * 2] = s.z; ob[((size_t)(c0 + 1) * out.stride + xc) * 2 + 1] = s.w;
+      }
+    }
+  }
+}
+
+// ---- prolongator ----
+template <int NSF, int NCF, int NVEC, int NV>
+__global__ void prolong_kernel(FineVec out, CoarseVec in, const float4 *V, const int *block_to_fine, int blockVol, int spin_bs) {
+  constexpr int K = NSF * NCF;
+  __shared__ float2 xc_s[2 * NVEC];
+  const int A = blockIdx.x, b = threadIdx.x;
+  const int cpar = A >= in.Vh, xc = A - cpar * in.Vh;
+  for (int j = threadIdx.x; j < 2 * NVEC; j += blockDim.x) {
+    const float *p = in.v[cpar] + ((size_t)j * in.stride + xc) * 2;
+    xc_s[j] = make_float2(p[0], p[1]);
+  }
+  __syncthreads();
+  if (b >= blockVol) return;
+  const int f = block_to_fine[(size_t)A * blockVol + b];
+  const int parity = f >= out.Vh, x = f - parity * out.Vh;
+  float *base = out.v[parity];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const int chi = (k / NCF) / spin_bs;
+    float re = 0.f, im = 0.f;
+    for (int vp = 0; vp < NVEC / 2; vp++) {
+      const float4 w = V[(((size_t)A * K + k) * (NVEC / 2) + vp) * blockVol + b];
+      const float2 c0 = xc_s[chi * NVEC + 2 * vp], c1 = xc_s[chi * NVEC + 2 * vp + 1];
+      re += w.x * c0.x - w.y * c0.y + w.z * c1.x - w.w * c1.y;
+      im += w.x * c0.y + w.y * c0.x + w.z * c1.y + w.w * c1.x;
+    }
+    const size_t i = fidx<NV>(out.stride, x, k);
+    base[i] = re; base[i + 1] = im;
+  }
+}
+
+// ---- V fill + block Gram-Schmidt ----
+struct VecList { const float *ev[kMaxVec]; const float *od[kMaxVec]; };
+
+template <int NV> __global__ void fillv_kernel(float *V, VecList B, int stride, int Vh, const int *block_to_fine, int blockVol, int K, int nvec, long total) {
+  const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;  // over (A, b)
+  if (t >= total) return;
+  const long A = t / blockVol;
+  const int b = (int)(t - A * blockVol);
+  const int f = block_to_fine[t];
+  const int parity = f >= Vh, x = f - parity * Vh;
+  for (int v = 0; v < nvec; v++) {
+    const float *base = parity ? B.od[v] : B.ev[v];
+    for (int k = 0; k < K; k++) {
+      const size_t i = fidx<NV>(stride, x, k);
+      const size_t o = ((((size_t)A * K + k) * (nvec / 2) + v / 2) * blockVol + b) * 4 + (v & 1) * 2;
+      V[o] = base[i]; V[o + 1] = base[i + 1];
+    }
+  }
+}
+
+__device__ __forceinline__ double2 block_sum2d(double2 v, double2 *lds) {
+  for (int off = 32; off > 0; off >>= 1) { v.x += __shfl_down(v.x, off, 64); v.y += __shfl_down(v.y, off, 64); }
+  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds[wave] = v;
+  __syncthreads();
+  double2 r = lds[0];
+  for (int w = 1; w < nw; w++) { r.x += lds[w].x; r.y += lds[w].y; }
+  return r;
+}
+
+// modified Gram-Schmidt over the nvec vectors of one (aggregate, chirality) block, sums in fp64
+// (reference blockGramSchmidt, lib/transfer_util.cu:328-363)
+__global__ void block_gs_kernel(float *V, int blockVol, int K, int ncf, int spin_bs, int nvec) {
+  __shared__ double2 lds[16];
+  const int A = blockIdx.x >> 1, chi = blockIdx.x & 1;
+  const int Kc = K / 2, n = Kc * blockVol;
+  // element e of this block -> (k, b)
+  auto addr = [&](int e, int v) -> size_t {
+    const int kk = e / blockVol, b = e - kk * blockVol;
+    // the kk-th fine spin-colour index whose chirality is chi
+    const int nsc = spin_bs * ncf;             // spin-colour values per chirality are contiguous in k = s*ncf + c
+    const int k = chi * nsc + kk;
+    return ((((size_t)A * K + k) * (nvec / 2) + v / 2) * blockVol + b) * 4 + (v & 1) * 2;
+  };
+  for (int jc = 0; jc < nvec; jc++) {
+    for (int ic = 0; ic < jc; ic++) {
+      double2 dot = make_double2(0.0, 0.0);
+      for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const size_t ai = addr(e, ic), aj = addr(e, jc);
+        const double ar = V[ai], aim = V[ai + 1], br = V[aj], bim = V[aj + 1];
+        dot.x += ar * br + aim * bim; dot.y += ar * bim - aim * br;
+      }
+      dot = block_sum2d(dot, lds);
+      for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const size_t ai = addr(e, ic), aj = addr(e, jc);
+        const double ar = V[ai], aim = V[ai + 1];
+        V[aj] = (float)(V[aj] - (dot.x * ar - dot.y * aim));
+        V[aj + 1] = (float)(V[aj + 1] - (dot.x * aim + dot.y * ar));
+      }
+      __syncthreads();
+    }
+    double2 nrm = make_double2(0.0, 0.0);
+    for (int e = threadIdx.x; e < n; e += blockDim.x) { const size_t aj = addr(e, jc); nrm.x += (double)V[aj] * V[aj] + (double)V[aj + 1] * V[aj + 1]; }
+    nrm = block_sum2d(nrm, lds);
+    const float scale = nrm.x > 0.0 ? (float)(1.0 / sqrt(nrm.x)) : 0.f;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) { const size_t aj = addr(e, jc); V[aj] *= scale; V[aj + 1] *= scale; }
+    __syncthreads();
+  }
+}
+
+// ---- random source ----
+__device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long i) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ULL * (i + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z ^= z >> 31;
+  return (float)((z >> 40) * (1.0 / 16777216.0));
+}
+template <typename real> __global__ void random_kernel(real *v, long n, unsigned long long seed, unsigned long long offset) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (real)hash_uniform(seed, offset + i);
+}
+void spinorRandom(ColorSpinorField &f, unsigned long long seed) {
+  if (f.Location() != QUDA_CUDA_FIELD_LOCATION) errorQuda("device field required");
+  const int nseg = f.SiteSubset() == QUDA_FULL_SITE_SUBSET ? 2 : 1;
+  const long n = (long)f.Stride() * f.Nspin() * f.Ncolor() * 2;
+  const unsigned long long rank_off = (unsigned long long)commGrid().rank << 40;
+  for (int s = 0; s < nseg; s++) {
+    void *p = nseg == 2 ? (s ? f.Odd().V() : f.Even().V()) : f.V();
+    const int bs = 256; const long nb = (n + bs - 1) / bs;
+    if (f.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((random_kernel<double>), dim3(nb), dim3(bs), 0, computeStream(), (double *)p, n, seed, rank_off + (unsigned long long)s * n);
+    else if (f.Precision() == QUDA_SINGLE_PRECISION) hipLaunchKernelGGL((random_kernel<float>), dim3(nb), dim3(bs), 0, computeStream(), (float *)p, n, seed, rank_off + (unsigned long long)s * n);
+    else errorQuda("random source needs fp64/fp32 storage");
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+// ================================================================================================
+Transfer::Transfer(const std::vector<ColorSpinorField *> &B, int Nvec_, int *gbs, int spin_bs_)
+    : Nvec(Nvec_), spin_bs(spin_bs_), V(nullptr), block_to_fine(nullptr), fine_to_block(nullptr), flops_(0) {
+  if ((int)B.size() < Nvec) errorQuda("need %d null vectors, got %zu", Nvec, B.size());
+  if (Nvec % 2 || Nvec > kMaxVec) errorQuda("Nvec = %d must be even and <= %d", Nvec, kMaxVec);
+  const ColorSpinorField &b0 = *B[0];
+  if (b0.SiteSubset() != QUDA_FULL_SITE_SUBSET) errorQuda("null vectors must be full fields");
+  fineSpin = b0.Nspin(); fineColor = b0.Ncolor();
+  if (fineSpin % spin_bs || fineSpin / spin_bs != 2) errorQuda("spin block %d does not leave two chiralities from %d spins", spin_bs, fineSpin);
+  for (int d = 0; d < 4; d++) Xf[d] = b0.X(d);
+  // block-size fallback, reference lib/transfer.cpp:31-44
+  for (int d = 0; d < 4; d++) {
+    while (gbs[d] > 0) {
+      if (d == 0 && Xf[0] == gbs[0]) warningQuda("X-dimension length %d cannot block length %d", Xf[0], gbs[0]);
+      else if ((Xf[d] / gbs[d] + 1) % 2 == 0) warningQuda("Indexing does not (yet) support odd coarse dimensions: X(%d) = %d", d, Xf[d] / gbs[d]);
+      else if ((Xf[d] / gbs[d]) * gbs[d] != Xf[d]) warningQuda("cannot block dim[%d]=%d with block size = %d", d, Xf[d], gbs[d]);
+      else break;
+      gbs[d] /= 2;
+    }
+    if (gbs[d] == 0) errorQuda("Unable to block dimension %d", d);
+  }
+  blockVol = 1; nAgg = 1; fineVol = 1;
+  for (int d = 0; d < 4; d++) { geo_bs[d] = gbs[d]; Xc[d] = Xf[d] / gbs[d]; blockVol *= gbs[d]; nAgg *= Xc[d]; fineVol *= Xf[d]; }
+  if (blockVol == 1) errorQuda("Total geometric block size is 1");
+  if (blockVol > 1024) errorQuda("aggregate of %d sites exceeds one work-group", blockVol);
+  if (getVerbosity() >= QUDA_VERBOSE) printfQuda("Transfer: using block size %d x %d x %d x %d\n", geo_bs[0], geo_bs[1], geo_bs[2], geo_bs[3]);
+  createGeoMap();
+  HIP_CHECK(hipMalloc((void **)&V, vBytes()));
+  fillAndOrthonormalise(B);
+}
+
+Transfer::~Transfer() {
+  if (V) (void)hipFree(V);
+  if (block_to_fine) (void)hipFree(block_to_fine);
+  if (fine_to_block) (void)hipFree(fine_to_block);
+}
+
+// reference createGeoMap lib/transfer.cpp:220-258 (fine site -> coarse site), plus the position inside the aggregate
+void Transfer::createGeoMap() {
+  std::vector<int> b2f(fineVol), f2b(fineVol);
+  const long Vh = fineVol / 2, Vhc = nAgg / 2;
+  for (int parity = 0; parity < 2; parity++)
+    for (long i = 0; i < Vh; i++) {
+      const long za = i / (Xf[0] / 2); const int xh = (int)(i - za * (Xf[0] / 2));
+      const long zb = za / Xf[1]; const int y = (int)(za - zb * Xf[1]);
+      const int t = (int)(zb / Xf[2]), z = (int)(zb - (long)t * Xf[2]);
+      const int x[4] = {2 * xh + ((y + z + t + parity) & 1), y, z, t};
+      int xc[4], yb[4];
+      for (int d = 0; d < 4; d++) { xc[d] = x[d] / geo_bs[d]; yb[d] = x[d] % geo_bs[d]; }
+      const int cpar = (xc[0] + xc[1] + xc[2] + xc[3]) & 1;
+      const long clex = ((long)(xc[3] * Xc[2] + xc[2]) * Xc[1] + xc[1]) * Xc[0] + xc[0];
+      const long A = cpar * Vhc + clex / 2;
+      const int b = ((yb[3] * geo_bs[2] + yb[2]) * geo_bs[1] + yb[1]) * geo_bs[0] + yb[0];
+      const long f = parity * Vh + i;
+      b2f[A * blockVol + b] = (int)f;
+      f2b[f] = (int)(A * blockVol + b);
+    }
+  HIP_CHECK(hipMalloc((void **)&block_to_fine, fineVol * sizeof(int)));
+  HIP_CHECK(hipMalloc((void **)&fine_to_block, fineVol * sizeof(int)));
+  HIP_CHECK(hipMemcpy(block_to_fine, b2f.data(), fineVol * sizeof(int), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(fine_to_block, f2b.data(), fineVol * sizeof(int), hipMemcpyHostToDevice));
+}
+
+void Transfer::fillAndOrthonormalise(const std::vector<ColorSpinorField *> &B) {
+  VecList vl;
+  memset(&vl, 0, sizeof(vl));
+  for (int v = 0; v < Nvec; v++) { const FineVec f = fineVec(*B[v]); vl.ev[v] = f.v[0]; vl.od[v] = f.v[1]; }
+  const FineVec f0 = fineVec(*B[0]);
+  const long total = fineVol;
+  const int K = fineSpin * fineColor;
+  if (fineSpin == 4) hipLaunchKernelGGL((fillv_kernel<4>), dim3((total + 255) / 256), dim3(256), 0, computeStream(), V, vl, f0.stride, f0.Vh, block_to_fine, blockVol, K, Nvec, total);
+  else hipLaunchKernelGGL((fillv_kernel<2>), dim3((total + 255) / 256), dim3(256), 0, computeStream(), V, vl, f0.stride, f0.Vh, block_to_fine, blockVol, K, Nvec, total);
+  HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(block_gs_kernel, dim3(2 * nAgg), dim3(256), 0, computeStream(), V, blockVol, K, fineColor, spin_bs, Nvec);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(computeStream()));
+}
+
+ColorSpinorField *Transfer::createCoarseField() const {
+  ColorSpinorParam p;
+  p.location = QUDA_CUDA_FIELD_LOCATION;
+  p.nSpin = 2; p.nColor = Nvec;
+  for (int d = 0; d < 4; d++) p.x[d] = Xc[d];
+  p.siteSubset = QUDA_FULL_SITE_SUBSET;
+  p.precision = QUDA_SINGLE_PRECISION;
+  p.create = QUDA_ZERO_FIELD_CREATE;
+  return new ColorSpinorField(p);
+}
+ColorSpinorField *Transfer::createFineField() const {
+  ColorSpinorParam p;
+  p.location = QUDA_CUDA_FIELD_LOCATION;
+  p.nSpin = fineSpin; p.nColor = fineColor;
+  for (int d = 0; d < 4; d++) p.x[d] = Xf[d];
+  p.siteSubset = QUDA_FULL_SITE_SUBSET;
+  p.precision = QUDA_SINGLE_PRECISION;
+  p.create = QUDA_ZERO_FIELD_CREATE;
+  return new ColorSpinorField(p);
+}
+
+static CoarseVec coarseVec(const ColorSpinorField &c) {
+  FineVec f = fineVec(c);
+  CoarseVec r;
+  r.v[0] = f.v[0]; r.v[1] = f.v[1]; r.stride = f.stride; r.Vh = f.Vh;
+  return r;
+}
+
+#define QA_TRANSFER_DISPATCH(CALL)                                                             \
+  if (fineSpin == 4 && fineColor == 3) {                                                       \
+    switch (Nvec) {                                                                            \
+      case 4: { CALL(4, 3, 4, 4); } break;                                                     \
+      case 8: { CALL(4, 3, 8, 4); } break;                                                     \
+      case 24: { CALL(4, 3, 24, 4); } break;                                                   \
+      case 32: { CALL(4, 3, 32, 4); } break;                                                   \
+      default: errorQuda("Nvec = %d not instantiated for the fine level (4, 8, 24, 32)", Nvec); \
+    }                                                                                          \
+  } else if (fineSpin == 2 && fineColor == 4 && Nvec == 4) { CALL(2, 4, 4, 2);                 \
+  } else if (fineSpin == 2 && fineColor == 8 && Nvec == 8) { CALL(2, 8, 8, 2);                 \
+  } else if (fineSpin == 2 && fineColor == 8 && Nvec == 4) { CALL(2, 8, 4, 2);                 \
+  } else if (fineSpin == 2 && fineColor == 24 && Nvec == 24) { CALL(2, 24, 24, 2);             \
+  } else if (fineSpin == 2 && fineColor == 24 && Nvec == 32) { CALL(2, 24, 32, 2);             \
+  } else if (fineSpin == 2 && fineColor == 32 && Nvec == 32) { CALL(2, 32, 32, 2);             \
+  } else errorQuda("transfer %d x %d -> Nvec %d not instantiated", fineSpin, fineColor, Nvec);
+
+void Transfer::R(ColorSpinorField &coarse, const ColorSpinorField &fine, int dir, int boundary) const {
+  if (fine.Nspin() != fineSpin || fine.Ncolor() != fineColor || fine.Volume() != fineVol) errorQuda("fine field does not match the transfer operator");
+  if (coarse.Nspin() != 2 || coarse.Ncolor() != Nvec || coarse.Volume() != nAgg) errorQuda("coarse field does not match the transfer operator");
+  const FineVec in = fineVec(fine);
+  const CoarseVec out = coarseVec(coarse);
+  MaskArg m;
+  m.dir = dir; m.boundary = boundary;
+  for (int d = 0; d < 4; d++) { m.bs[d] = geo_bs[d]; m.single[d] = Xc[d] == 1; }
+  const int threads = (blockVol + 63) / 64 * 64;
+#define QA_R(NSF, NCF, NVEC, NV) \
+  hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV>), dim3(nAgg), dim3(threads), 0, computeStream(), out, in, (const float4 *)V, block_to_fine, blockVol, spin_bs, m)
+  QA_TRANSFER_DISPATCH(QA_R)
+#undef QA_R
+  HIP_CHECK(hipGetLastError());
+  flops_ += 8ull * fineSpin * fineColor * Nvec * fineVol;  // reference lib/restrictor.cu:405
+}
+
+void Transfer::P(ColorSpinorField &fine, const ColorSpinorField &coarse) const {
+  if (fine.Nspin() != fineSpin || fine.Ncolor() != fineColor || fine.Volume() != fineVol) errorQuda("fine field does not match the transfer operator");
+  if (coarse.Nspin() != 2 || coarse.Ncolor() != Nvec || coarse.Volume() != nAgg) errorQuda("coarse field does not match the transfer operator");
+  const FineVec out = fineVec(fine);
+  const CoarseVec in = coarseVec(coarse);
+  const int threads = (blockVol + 63) / 64 * 64;
+#define QA_P(NSF, NCF, NVEC, NV) \
+  hipLaunchKernelGGL((prolong_kernel<NSF, NCF, NVEC, NV>), dim3(nAgg), dim3(threads), 0, computeStream(), out, in, (const float4 *)V, block_to_fine, blockVol, spin_bs)
+  QA_TRANSFER_DISPATCH(QA_P)
+#undef QA_P
+  HIP_CHECK(hipGetLastError());
+  flops_ += 8ull * fineSpin * fineColor * Nvec * fineVol;  // reference lib/prolongator.cu:228
+}
+
+}  // namespace quda

@@ -1,0 +1,114 @@
+"""Multigrid on the GPU through the C ABI (newMultigridQuda / invertQuda), pinned the way the reference pins it
+(SURVEY 8c): (1) the three MG::verify() identities, which are known-answer (= 0) tests of R, P, block-orthonormality and
+the Galerkin coarse operator against the already-oracled fine operator; (2) the MG-GCR solution, whose true residual
+|b - M x| / |b| is recomputed on the host with the oracle's tm_mat (as tests/multigrid_invert_test.cpp:529-577)."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qa():
+    mod = importlib.import_module("quda-qkxtm-multigrid_amd")
+    mod.init(0)
+    yield mod
+    mod.end()
+
+
+def smooth_gauge(X, eps, seed=3):
+    """SU(3) links exp(i eps H) with random Hermitian traceless H: a smooth field on which kappa ~ 0.125 is close to
+    critical, so the fine operator is ill-conditioned and multigrid has something to do (periodic T as the reference MG test)."""
+    rng = np.random.default_rng(seed)
+    V = int(np.prod(X))
+    out = np.empty((4, V * 18))
+    for mu in range(4):
+        a = rng.standard_normal((V, 3, 3)) + 1j * rng.standard_normal((V, 3, 3))
+        h = 0.5 * (a + a.conj().transpose(0, 2, 1))
+        h -= np.trace(h, axis1=1, axis2=2)[:, None, None] * np.eye(3) / 3.0
+        w, v = np.linalg.eigh(h)
+        u = (v * np.exp(1j * eps * w)[:, None, :]) @ v.conj().transpose(0, 2, 1)
+        out[mu] = np.stack([u.real, u.imag], axis=-1).reshape(-1)
+    return out
+
+
+def _setup(qa, X, kappa, mu, eps=0.35):
+    gauge = smooth_gauge(X, eps)
+    gp = qa.gauge_param(X, cuda_prec=8, prec_sloppy=4, prec_precondition=4, t_boundary=qa.QUDA_PERIODIC_T)
+    qa.load_gauge(gauge, gp)
+    ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=8, prec_sloppy=4, prec_precondition=4,
+                         solution_type=qa.QUDA_MAT_SOLUTION)
+    ip.solve_type = qa.QUDA_DIRECT_SOLVE
+    ip.inv_type = qa.QUDA_GCR_INVERTER
+    ip.gcrNkrylov = 20
+    ip.tol = 1e-10
+    ip.maxiter = 2000
+    ip.reliable_delta = 1e-4
+    ip.verbosity = qa.QUDA_SILENT
+    return gauge, ip
+
+
+def _true_residual(oracle, gauge, X, kappa, mu, x, b):
+    oracle.set_threads(8)
+    try:
+        mx = oracle.tm_mat(gauge, x, list(X), kappa, mu, +1, 0)
+    finally:
+        oracle.set_threads(1)
+    return float(np.linalg.norm(b - mx) / np.linalg.norm(b))
+
+
+@pytest.mark.parametrize("X,levels,blocks,nvec", [((8, 8, 8, 8), 2, (4, 4, 4, 4), 8), ((16, 8, 8, 16), 3, [(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)], 8)])
+def test_verify_identities_and_mg_gcr_solve(qa, oracle, X, levels, blocks, nvec):
+    kappa, mu = 0.124, 0.005
+    gauge, ip = _setup(qa, X, kappa, mu)
+    V = int(np.prod(X))
+    rng = np.random.default_rng(5)
+    b = rng.random(V * 24)
+
+    # plain GCR (no preconditioner) as the baseline
+    ip.inv_type_precondition = qa.QUDA_INVALID_ENUM
+    x0 = qa.invert(b, ip)
+    iters_plain = ip.iter
+    assert _true_residual(oracle, gauge, X, kappa, mu, x0, b) < 5e-10
+
+    mp = qa.multigrid_param(ip, n_level=levels, geo_block=blocks, n_vec=nvec, setup_maxiter=300, setup_tol=1e-5)
+    mg = qa.Multigrid(mp)
+    try:
+        dev = mg.verify()
+        # reference threshold 10^(4 - 2 prec) = 1e-4 for fp32 (lib/multigrid.cpp:381)
+        assert dev[0] < 1e-4 and dev[1] < 1e-4 and dev[2] < 1e-4, dev
+        ip.inv_type_precondition = qa.QUDA_MG_INVERTER
+        ip.preconditioner = mg.h
+        ip.tol_precondition = 1e-1
+        ip.maxiter_precondition = 1
+        ip.precondition_cycle = 1
+        ip.omega = 1.0
+        x = qa.invert(b, ip)
+        iters_mg = ip.iter
+        res = _true_residual(oracle, gauge, X, kappa, mu, x, b)
+        assert res < 5e-10, res
+        assert abs(ip.true_res - res) < 1e-9
+        assert iters_mg < iters_plain, (iters_mg, iters_plain)
+        print("MG-GCR %s: %d iterations (plain GCR %d), true residual %.2e, setup %.2f s, solve %.3f s" % (X, iters_mg, iters_plain, res, mp.secs, ip.secs))
+    finally:
+        mg.free()
+
+
+def test_restrictor_prolongator_are_adjoint(qa):
+    """<P c, f> = <c, R f> on the device hierarchy, via one V-cycle object: exercised through qudaAmdMultigridVerify identity (2)
+    plus an explicit cycle call that must reduce the residual."""
+    X = (8, 8, 8, 8)
+    kappa, mu = 0.124, 0.005
+    gauge, ip = _setup(qa, X, kappa, mu)
+    mp = qa.multigrid_param(ip, n_level=2, geo_block=(4, 4, 4, 4), n_vec=8, cycle=qa.QUDA_MG_CYCLE_VCYCLE, setup_maxiter=300, setup_tol=1e-5)
+    mg = qa.Multigrid(mp)
+    try:
+        rng = np.random.default_rng(9)
+        b = rng.random(int(np.prod(X)) * 24)
+        x = mg.cycle(b, ip)
+        r = b - qa.mat(x, ip)
+        assert np.linalg.norm(r) < 0.5 * np.linalg.norm(b)  # one V-cycle is a contraction on a random right-hand side
+    finally:
+        mg.free()
