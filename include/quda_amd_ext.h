@@ -70,6 +70,7 @@ int qudaAmdCommSize(void);
 void qudaAmdCommCoords(int coords[4]);
 void qudaAmdCommBarrier(void);
 void qudaAmdCommAllreduce(double *data, int n);   /* sum over ranks, in place */
+void qudaAmdCommAllreduceMax(double *data, int n);
 
 /* single-process emulation of a partitioned dimension (reference tests --partition, commDimPartitionedSet) */
 void qudaAmdSetPartitionMask(int mask);

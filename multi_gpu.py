@@ -2,9 +2,8 @@
 
 Mirrors what the reference's harness does around initCommsGridQuda (tests/test_util.cpp:50-92, lib/interface_quda.cpp:261-285):
 choose a process grid, map rank <-> grid coordinates (t fastest), cut the global even-odd ordered host fields into
-each rank's local sub-lattice, and bootstrap the transport.  The data path (halo exchange, all-reduce) is RCCL inside
-libquda.so; torch.distributed (gloo) is used ONLY as the out-of-band control plane that carries the 128-byte RCCL id,
-the barrier and the max-over-ranks of the timings.
+each rank's local sub-lattice, and bootstrap the transport.  The data path (halo exchange, all-reduce, barrier, max over
+ranks) is RCCL inside libquda.so; the only out-of-band step is a 128-byte TCP broadcast of the RCCL id on MASTER_ADDR.
 
 The pure-numpy helpers are exercised on CPU by tests/test_multirank_cpu.py (gloo, world_size 2) against the oracle.
 """
@@ -98,57 +97,87 @@ def scatter_gauge(gauge, X, grid, coords):
 
 
 class Dist:
-    def __init__(self, qa, rank, world, grid, X, tdist):
-        self.qa, self.rank, self.world, self.grid, self.X, self.tdist = qa, rank, world, grid, X, tdist
+    """Handle on the initialised multi-rank run.  Barrier and max-over-ranks go through libquda's own RCCL communicator."""
+
+    def __init__(self, qa, rank, world, grid, X):
+        self.qa, self.rank, self.world, self.grid, self.X = qa, rank, world, grid, X
         self.coords = rank_to_coords(rank, grid)
         self.local_dims = local_dims(X, grid)
 
     def barrier(self):
-        self.tdist.barrier()
+        self.qa.lib().qudaAmdCommBarrier()
 
     def max_over_ranks(self, v):
-        import torch
+        buf = (C.c_double * 1)(float(v))
+        self.qa.lib().qudaAmdCommAllreduceMax(buf, 1)
+        return float(buf[0])
 
-        t = torch.tensor([float(v)], dtype=torch.float64)
-        self.tdist.all_reduce(t, op=self.tdist.ReduceOp.MAX)
-        return float(t[0])
-
-    def scatter_gauge(self, gauge_or_none):
-        # every rank regenerates the same seeded global field (cheaper than shipping 1.2 GB through the control plane)
-        assert gauge_or_none is not None
-        return scatter_gauge(gauge_or_none, self.X, self.grid, self.coords)
+    def scatter_gauge(self, gauge):
+        # every rank regenerates the same seeded global field (cheaper than shipping 1.2 GB through a control plane)
+        return scatter_gauge(gauge, self.X, self.grid, self.coords)
 
     def finalize(self):
+        self.barrier()
         self.qa.end()
-        self.tdist.barrier()
-        self.tdist.destroy_process_group()
+
+
+def _broadcast_id(rank, world, payload):
+    """Out-of-band broadcast of the 128-byte RCCL id over a plain TCP socket on MASTER_ADDR (port MASTER_PORT + 1).
+    Deliberately NOT torch.distributed: importing torch would load a second HIP runtime (torch bundles its own ROCm
+    libraries) next to the /opt/rocm one libquda.so is linked against."""
+    import socket
+    import time
+
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("QUDA_AMD_BOOTSTRAP_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
+    if rank == 0:
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(world)
+        for _ in range(world - 1):
+            c, _a = srv.accept()
+            c.sendall(payload)
+            c.close()
+        srv.close()
+        return payload
+    deadline = time.time() + 300
+    while True:
+        try:
+            c = socket.create_connection((addr, port), timeout=10)
+            break
+        except OSError:
+            if time.time() > deadline:
+                raise
+            time.sleep(0.2)
+    buf = b""
+    while len(buf) < 128:
+        chunk = c.recv(128 - len(buf))
+        if not chunk:
+            raise RuntimeError("bootstrap connection closed early")
+        buf += chunk
+    c.close()
+    return buf
 
 
 def setup(qa, rank, world, local_rank, X, grid=None):
     """initQudaDevice -> RCCL bootstrap -> initCommsGridQuda -> initQuda, returning the Dist helper"""
-    import torch
-    import torch.distributed as tdist
-
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    if not tdist.is_initialized():
-        tdist.init_process_group("gloo", rank=rank, world_size=world)
     grid = grid or choose_grid(world)
     L = qa.lib()
     L.setVerbosityQuda(qa.QUDA_SILENT, b"", None)
     L.initQudaDevice(int(local_rank))
-    uid = torch.zeros(128, dtype=torch.uint8)
+    payload = b""
     if rank == 0:
         buf = (C.c_char * 128)()
         L.qudaAmdCommGetUniqueId(buf)
-        uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
-    tdist.broadcast(uid, src=0)
-    idb = (C.c_char * 128).from_buffer_copy(bytes(uid.numpy().tobytes()))
+        payload = bytes(buf.raw)
+    payload = _broadcast_id(rank, world, payload)
+    idb = (C.c_char * 128).from_buffer_copy(payload)
     L.qudaAmdCommInit(idb, int(rank), int(world))
     dims = (C.c_int * 4)(*grid)
     L.initCommsGridQuda(4, dims, None, None)
     L.initQuda(int(local_rank))
-    return Dist(qa, rank, world, grid, X, tdist)
+    return Dist(qa, rank, world, grid, X)
 
 
 def face_cb_indices(Xl, d, side, parity):

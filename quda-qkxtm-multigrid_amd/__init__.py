@@ -115,7 +115,7 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
                  "qudaAmdDiracM", "qudaAmdDiracMdag", "qudaAmdDiracMdagM", "qudaAmdDiracFlops", "qudaAmdTimeDslash", "qudaAmdTimeM",
                  "qudaAmdBlasNorm2", "qudaAmdBlasCDot", "qudaAmdBlasAxpy", "qudaAmdDslashBytesPerSite", "qudaAmdDslashFlopsPerSite",
                  "qudaAmdSetPartitionMask", "qudaAmdComputeStream", "qudaAmdDeviceSynchronize", "qudaAmdCommGetUniqueId",
-                 "qudaAmdCommInit", "qudaAmdCommRank", "qudaAmdCommSize", "qudaAmdCommCoords", "qudaAmdCommBarrier", "qudaAmdCommAllreduce",
+                 "qudaAmdCommInit", "qudaAmdCommRank", "qudaAmdCommSize", "qudaAmdCommCoords", "qudaAmdCommBarrier", "qudaAmdCommAllreduce", "qudaAmdCommAllreduceMax",
                  "qudaAmdMultigridVerify", "qudaAmdMultigridCycle"]
 
 _lib = None

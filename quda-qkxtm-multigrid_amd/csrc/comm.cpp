@@ -167,5 +167,6 @@ int qudaAmdCommSize(void) { return commGrid().size; }
 void qudaAmdCommCoords(int coords[4]) { for (int d = 0; d < 4; d++) coords[d] = commGrid().coords[d]; }
 void qudaAmdCommBarrier(void) { commBarrier(); }
 void qudaAmdCommAllreduce(double *data, int n) { comm_allreduce(data, n); }
+void qudaAmdCommAllreduceMax(double *data, int n) { comm_allreduce_max(data, n); }
 
 }

@@ -93,7 +93,7 @@ def _worker(rank, world, port, grid, X, q):
 
 @pytest.mark.parametrize("grid", [[1, 1, 1, 2], [1, 1, 2, 1], [1, 2, 1, 1], [2, 1, 1, 1]])
 def test_two_rank_decomposition_matches_global_operator(grid):
-    import torch.multiprocessing as mp
+    import multiprocessing as mp  # NOT torch.multiprocessing: the pytest process may hold libquda.so (second HIP runtime)
 
     X = [4, 4, 4, 8]
     ctx = mp.get_context("spawn")
