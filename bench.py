@@ -182,6 +182,20 @@ def main():
                    sample="%d x tm_dslash fp64 on %s (oracle/liboracle.so, outer parallel-for over sites); 1 thread = %.3f GFLOP/s"
                    % (n_all, "x".join(str(v) for v in Xc), 1368.0 * Vh_local / t1 * 1e-9))
 
+    traffic = None
+    if rank == 0 and world == 1:
+        # HBM bytes per launch of the same kernel from the committed rocprofv3 PMC summary (tools/summarize_profiles.py)
+        import glob
+        tname = {8: "double", 4: "float", 2: "short"}[args.prec]
+        variant = {"tm": 0, "wilson": 0, "tmc": 2}[args.dslash]
+        key = "dslash_kernel<%s, %d, %d," % (tname, args.recon, variant)
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
+            try:
+                for k, v in json.load(open(path))["kernels"].items():
+                    if key in k and "hbm_bytes_per_launch" in v and X == [32, 32, 32, 32]:
+                        traffic = {"bytes_per_launch": round(v["hbm_bytes_per_launch"]), "source": os.path.basename(path)}
+            except Exception:
+                pass
     if rank == 0:
         out = {
             "metric": "twisted-mass Dslash GFLOP/s (even-odd, 32^4)" if X == [32, 32, 32, 32] else "twisted-mass Dslash GFLOP/s",
@@ -192,7 +206,7 @@ def main():
                        % ({"tm": "twisted-mass", "tmc": "twisted-clover", "wilson": "Wilson"}[args.dslash], kappa, mu, "x".join(map(str, X)), args.recon),
                        "local_lattice": Xl, "process_grid": dist.grid if dist else [1, 1, 1, 1], "flops_per_site": r["flops_site"]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "bytes_per_site": r["bytes_site"], "kernel_us": round(1e6 * r["sec"], 3)},
+                         "traffic": traffic, "bytes_per_site": r["bytes_site"], "kernel_us": round(1e6 * r["sec"], 3)},
             "cpu_baseline": cpu,
             "extra": extra,
         }

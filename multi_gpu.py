@@ -165,6 +165,7 @@ def setup(qa, rank, world, local_rank, X, grid=None):
     grid = grid or choose_grid(world)
     L = qa.lib()
     L.setVerbosityQuda(qa.QUDA_SILENT, b"", None)
+    local_rank = int(os.environ.get("QUDA_AMD_FORCE_DEVICE", local_rank))  # rehearsal of N ranks on fewer GPUs
     L.initQudaDevice(int(local_rank))
     payload = b""
     if rank == 0:

@@ -46,6 +46,7 @@ template <typename real> struct DslashArg {
   real a, b, k;
   real tsign_fwd, tsign_bwd;  // recon-12: sign of the reconstructed row of t-links on the boundary slices
   int nblocks, xcd_q, xcd_r;
+  int ts, bps;                // time-slab interleave: ts slices per slab, bps blocks per time slice (ts = 0: off)
   // grid-decomposed lattices (halo.h)
   int commMask;               // bit d set: dimension d is partitioned
   const int *blist;           // exterior kernel: checkerboard indices of the boundary sites
@@ -163,7 +164,14 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
     // contiguous range of logical blocks (a slab of time slices) so t/z neighbours hit its own L2.
     const int b = blockIdx.x;
     const int xcd = b & 7, within = b >> 3;
-    const int lb = (xcd < arg.xcd_r ? xcd * (arg.xcd_q + 1) : arg.xcd_r * (arg.xcd_q + 1) + (xcd - arg.xcd_r) * arg.xcd_q) + within;
+    int lb = (xcd < arg.xcd_r ? xcd * (arg.xcd_q + 1) : arg.xcd_r * (arg.xcd_q + 1) + (xcd - arg.xcd_r) * arg.xcd_q) + within;
+    if (arg.ts > 0) {
+      // inside an XCD's slab of ts time slices walk t fastest: consecutive blocks are the same (y,z) chunk on ts successive
+      // slices, so the +-t neighbours of a chunk are touched within a few blocks of each other (L2-resident) instead of a
+      // whole 3 MB slice apart
+      const int per = arg.bps * arg.ts, s = lb / per, w = lb - s * per, c = w / arg.ts, tt = w - c * arg.ts;
+      lb = (s * arg.ts + tt) * arg.bps + c;
+    }
     idx = lb * blockDim.x + threadIdx.x;
     if (idx >= arg.Vh) return;
   }
@@ -551,6 +559,17 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
   const int bs = dslashBlockSize();
   const int nb = (g.Vh + bs - 1) / bs;
   arg.nblocks = nb; arg.xcd_q = nb / 8; arg.xcd_r = nb % 8;
+  {
+    static int order = -1;
+    if (order < 0) { const char *e = getenv("QUDA_AMD_DSLASH_ORDER"); order = e ? atoi(e) : 1; }
+    const int slice = g.Vh / g.X[3];
+    arg.ts = 0; arg.bps = 0;
+    if (order > 0 && slice % bs == 0 && g.X[3] % 8 == 0 && nb % 8 == 0) {
+      arg.bps = slice / bs;
+      arg.ts = order == 1 ? g.X[3] / 8 : order;   // order > 1: explicit slab thickness (must divide T/8)
+      if ((g.X[3] / 8) % arg.ts != 0) arg.ts = g.X[3] / 8;
+    }
+  }
   arg.commMask = 0; arg.blist = nullptr; arg.nboundary = 0;
   for (int d = 0; d < 4; d++) { arg.ghost[d][0] = arg.ghost[d][1] = nullptr; arg.faceCB[d] = g.faceCB[d]; arg.ghostNormOff[d] = 0; }
   // link/clover stream cache policy: nt for the 16-byte-per-lane formats (measured on 32^4: fp64 4.67 -> 5.2 TB/s, fp32
