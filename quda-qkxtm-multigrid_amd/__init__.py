@@ -353,9 +353,9 @@ class Dirac:
 
 
 def multigrid_param(ip, n_level=2, geo_block=(4, 4, 4, 4), n_vec=24, nu_pre=2, nu_post=2, cycle=QUDA_MG_CYCLE_RECURSIVE, smoother_tol=0.25,
-                    setup_maxiter=500, setup_tol=5e-6, generate_all_levels=True, omega=0.85):
+                    setup_maxiter=500, setup_tol=5e-6, generate_all_levels=True, omega=0.85, smoother_pc=False):
     """QudaMultigridParam filled the way the reference harness does (tests/multigrid_invert_test.cpp:195-290), with the
-    full-operator smoother this build implements (smoother_solve_type = QUDA_DIRECT_SOLVE)."""
+    smoother on the full operator (QUDA_DIRECT_SOLVE) or, smoother_pc=True, the reference default QUDA_DIRECT_PC_SOLVE."""
     mp = lib().newQudaMultigridParam()
     mp.invert_param = C.pointer(ip)
     mp.n_level = n_level
@@ -373,7 +373,7 @@ def multigrid_param(ip, n_level=2, geo_block=(4, 4, 4, 4), n_vec=24, nu_pre=2, n
         mp.smoother[i] = QUDA_MR_INVERTER
         mp.smoother_tol[i] = smoother_tol
         mp.global_reduction[i] = QUDA_BOOLEAN_YES
-        mp.smoother_solve_type[i] = QUDA_DIRECT_SOLVE
+        mp.smoother_solve_type[i] = QUDA_DIRECT_PC_SOLVE if smoother_pc else QUDA_DIRECT_SOLVE
         mp.coarse_grid_solution_type[i] = QUDA_MAT_SOLUTION
         mp.omega[i] = omega
         mp.location[i] = QUDA_CUDA_FIELD_LOCATION

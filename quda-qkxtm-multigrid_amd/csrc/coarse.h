@@ -56,6 +56,25 @@ class DiracCoarse : public Dirac {
   void localTerm(ColorSpinorField &out, const ColorSpinorField &in) const override;
   const CoarseGauge &Links() const { return *links; }
   int Ncolor() const { return Nc; }
+  // preconditioned links: slots 0..7 = Xinv H_d, slot 8 = Xinv (reference Yhat / Xinv, lib/coarse_op.cuh:1217-1278, :1468-1475);
+  // built on first use by a dense batched Gauss-Jordan inverse + batched matrix products on the device
+  const CoarseGauge &HatLinks() const;
+  void CloverInv(ColorSpinorField &out, const ColorSpinorField &in, const QudaParity parity) const;
+
+ protected:
+  mutable CoarseGauge *hat;
+  mutable bool ownHat;
+};
+
+// even-odd preconditioned coarse operator (reference DiracCoarsePC, lib/dirac_coarse.cpp:237-372)
+class DiracCoarsePC : public DiracCoarse {
+ public:
+  DiracCoarsePC(const DiracCoarse &other, const DiracParam &p);
+  void Dslash(ColorSpinorField &out, const ColorSpinorField &in, const QudaParity parity) const override;   // A^-1 D
+  void DslashXpay(ColorSpinorField &out, const ColorSpinorField &in, const QudaParity parity, const ColorSpinorField &x, const double &k) const override;
+  void M(ColorSpinorField &out, const ColorSpinorField &in) const override;
+  void prepare(ColorSpinorField *&src, ColorSpinorField *&sol, ColorSpinorField &x, ColorSpinorField &b, const QudaSolutionType) const override;
+  void reconstruct(ColorSpinorField &x, const ColorSpinorField &b, const QudaSolutionType) const override;
 };
 
 // mmask: bit m set = include matrix m (0..7 hops, 8 local); parity: -1 both, else only that output parity

@@ -171,17 +171,189 @@ void DiracCoarse::build() {
   delete E; delete c; delete phi; delete w;
 }
 
-DiracCoarse::DiracCoarse(const DiracParam &p) : Dirac(p), transfer(p.transfer), parent(p.dirac), links(nullptr), ownLinks(false), fineFlavor(p.twistFlavor) {
+// ---- preconditioned links: batched dense inverse and products ----
+// one work-group per coarse site: Gauss-Jordan with partial pivoting on [X | 1] held in LDS (n <= 64: 64 x 128 complex fp32 = 64 KiB)
+__global__ void __launch_bounds__(256) coarse_invert_kernel(float *hat, const float *G, int n, int *fail) {
+  extern __shared__ float2 aug[];  // [n][2n] row-major
+  __shared__ int piv;
+  __shared__ float2 pinv;
+  const size_t A = blockIdx.x;
+  const int W = 2 * n;
+  const float4 *X4 = reinterpret_cast<const float4 *>(G) + (A * 9 + 8) * (size_t)(n / 2) * n;
+  for (int e = threadIdx.x; e < n * (n / 2); e += blockDim.x) {
+    const int jp = e / n, i = e - jp * n;
+    const float4 w = X4[(size_t)jp * n + i];
+    aug[i * W + 2 * jp] = make_float2(w.x, w.y);
+    aug[i * W + 2 * jp + 1] = make_float2(w.z, w.w);
+  }
+  for (int e = threadIdx.x; e < n * n; e += blockDim.x) { const int i = e / n, j = e - i * n; aug[i * W + n + j] = make_float2(i == j ? 1.f : 0.f, 0.f); }
+  __syncthreads();
+  for (int p = 0; p < n; p++) {
+    if (threadIdx.x == 0) {
+      int best = p; float bm = -1.f;
+      for (int r = p; r < n; r++) { const float2 v = aug[r * W + p]; const float m = v.x * v.x + v.y * v.y; if (m > bm) { bm = m; best = r; } }
+      piv = best;
+      const float2 v = aug[best * W + p];
+      if (bm <= 0.f) { *fail = 1; pinv = make_float2(0.f, 0.f); }
+      else pinv = make_float2(v.x / bm, -v.y / bm);
+    }
+    __syncthreads();
+    const int pr = piv;
+    if (pr != p) for (int c = threadIdx.x; c < W; c += blockDim.x) { const float2 t = aug[p * W + c]; aug[p * W + c] = aug[pr * W + c]; aug[pr * W + c] = t; }
+    __syncthreads();
+    const float2 ip = pinv;
+    for (int c = threadIdx.x; c < W; c += blockDim.x) { const float2 v = aug[p * W + c]; aug[p * W + c] = make_float2(v.x * ip.x - v.y * ip.y, v.x * ip.y + v.y * ip.x); }
+    __syncthreads();
+    // eliminate column p from every other row: thread -> (row r, column c)
+    for (int e = threadIdx.x; e < n * W; e += blockDim.x) {
+      const int r = e / W, c = e - r * W;
+      if (r == p || c == p) continue;
+      const float2 f = aug[r * W + p], v = aug[p * W + c];
+      float2 &t = aug[r * W + c];
+      t.x -= f.x * v.x - f.y * v.y; t.y -= f.x * v.y + f.y * v.x;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < n; r += blockDim.x) if (r != p) aug[r * W + p] = make_float2(0.f, 0.f);
+    __syncthreads();
+  }
+  float4 *O4 = reinterpret_cast<float4 *>(hat) + (A * 9 + 8) * (size_t)(n / 2) * n;
+  for (int e = threadIdx.x; e < n * (n / 2); e += blockDim.x) {
+    const int jp = e / n, i = e - jp * n;
+    const float2 a = aug[i * W + n + 2 * jp], b = aug[i * W + n + 2 * jp + 1];
+    O4[(size_t)jp * n + i] = make_float4(a.x, a.y, b.x, b.y);
+  }
+}
+
+// hat[d] = Xinv * H_d for d = 0..7 (one work-group per (site, d))
+__global__ void __launch_bounds__(256) coarse_hat_kernel(float *hat, const float *G, int n) {
+  extern __shared__ float2 sm[];  // Xinv [n][n] then H [n][n], row-major
+  float2 *Xi = sm, *H = sm + n * n;
+  const size_t A = blockIdx.x >> 3;
+  const int d = blockIdx.x & 7;
+  const float4 *X4 = reinterpret_cast<const float4 *>(hat) + (A * 9 + 8) * (size_t)(n / 2) * n;
+  const float4 *H4 = reinterpret_cast<const float4 *>(G) + (A * 9 + d) * (size_t)(n / 2) * n;
+  for (int e = threadIdx.x; e < n * (n / 2); e += blockDim.x) {
+    const int jp = e / n, i = e - jp * n;
+    const float4 x = X4[(size_t)jp * n + i], h = H4[(size_t)jp * n + i];
+    Xi[i * n + 2 * jp] = make_float2(x.x, x.y); Xi[i * n + 2 * jp + 1] = make_float2(x.z, x.w);
+    H[i * n + 2 * jp] = make_float2(h.x, h.y); H[i * n + 2 * jp + 1] = make_float2(h.z, h.w);
+  }
+  __syncthreads();
+  float4 *O4 = reinterpret_cast<float4 *>(hat) + (A * 9 + d) * (size_t)(n / 2) * n;
+  for (int e = threadIdx.x; e < n * (n / 2); e += blockDim.x) {
+    const int jp = e / n, i = e - jp * n;
+    float2 a = make_float2(0.f, 0.f), b = make_float2(0.f, 0.f);
+    for (int k = 0; k < n; k++) {
+      const float2 x = Xi[i * n + k], h0 = H[k * n + 2 * jp], h1 = H[k * n + 2 * jp + 1];
+      a.x += x.x * h0.x - x.y * h0.y; a.y += x.x * h0.y + x.y * h0.x;
+      b.x += x.x * h1.x - x.y * h1.y; b.y += x.x * h1.y + x.y * h1.x;
+    }
+    O4[(size_t)jp * n + i] = make_float4(a.x, a.y, b.x, b.y);
+  }
+}
+
+const CoarseGauge &DiracCoarse::HatLinks() const {
+  if (hat) return *hat;
+  const int n = links->n;
+  hat = new CoarseGauge(links->Xc, n);
+  ownHat = true;
+  int *d_fail = nullptr, h_fail = 0;
+  HIP_CHECK(hipMalloc((void **)&d_fail, sizeof(int)));
+  HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(int), computeStream()));
+  HIP_CHECK(hipFuncSetAttribute((const void *)coarse_invert_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  HIP_CHECK(hipFuncSetAttribute((const void *)coarse_hat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+  hipLaunchKernelGGL(coarse_invert_kernel, dim3(links->nSites), dim3(256), (size_t)n * 2 * n * sizeof(float2), computeStream(), hat->data, links->data, n, d_fail);
+  hipLaunchKernelGGL(coarse_hat_kernel, dim3(links->nSites * 8), dim3(256), (size_t)2 * n * n * sizeof(float2), computeStream(), hat->data, links->data, n);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(&h_fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, computeStream()));
+  HIP_CHECK(hipStreamSynchronize(computeStream()));
+  HIP_CHECK(hipFree(d_fail));
+  if (h_fail) errorQuda("singular coarse local matrix X: cannot build the preconditioned coarse operator");
+  return *hat;
+}
+
+DiracCoarse::DiracCoarse(const DiracParam &p) : Dirac(p), transfer(p.transfer), parent(p.dirac), links(nullptr), ownLinks(false), fineFlavor(p.twistFlavor), hat(nullptr), ownHat(false) {
   if (!transfer || !parent) errorQuda("coarse operator needs a transfer operator and a parent operator");
   Nc = transfer->Nvec;
   type = QUDA_COARSE_DIRAC;
   build();
 }
 DiracCoarse::DiracCoarse(const DiracCoarse &o, const DiracParam &p)
-    : Dirac(p), transfer(o.transfer), parent(o.parent), links(o.links), ownLinks(false), Nc(o.Nc), fineFlavor(o.fineFlavor) {
+    : Dirac(p), transfer(o.transfer), parent(o.parent), links(o.links), ownLinks(false), Nc(o.Nc), fineFlavor(o.fineFlavor), hat(nullptr), ownHat(false) {
   type = QUDA_COARSE_DIRAC;
+  hat = const_cast<CoarseGauge *>(&o.HatLinks());  // shared with (and owned by) the operator the links came from
 }
-DiracCoarse::~DiracCoarse() { if (ownLinks) delete links; }
+DiracCoarse::~DiracCoarse() { if (ownLinks) delete links; if (ownHat) delete hat; }
+
+void DiracCoarse::CloverInv(ColorSpinorField &out, const ColorSpinorField &in, const QudaParity parity) const {
+  applyCoarse(out, in, HatLinks(), 1 << 8, in.SiteSubset() == QUDA_FULL_SITE_SUBSET ? -1 : (int)parity);
+  const long n = 2 * Nc;
+  flops += (8 * n * n - 2 * n) * (unsigned long long)out.Volume();
+}
+
+// ---- even-odd preconditioned coarse operator: M = 1 - (A^-1 D)_{p pbar} (A^-1 D)_{pbar p}  (reference :237-372) ----
+DiracCoarsePC::DiracCoarsePC(const DiracCoarse &o, const DiracParam &p) : DiracCoarse(o, p) { type = QUDA_COARSEPC_DIRAC; }
+
+void DiracCoarsePC::Dslash(ColorSpinorField &out, const ColorSpinorField &in, const QudaParity parity) const {
+  applyCoarse(out, in, HatLinks(), 0xff, (int)parity);
+  const long n = 2 * Nc;
+  flops += (8 * (8 * n * n) - 2 * n) * (unsigned long long)out.Volume();
+}
+void DiracCoarsePC::DslashXpay(ColorSpinorField &out, const ColorSpinorField &in, const QudaParity parity, const ColorSpinorField &x, const double &k) const {
+  Dslash(out, in, parity);
+  blas::xpay(x, k, out);
+}
+void DiracCoarsePC::M(ColorSpinorField &out, const ColorSpinorField &in) const {
+  if (in.SiteSubset() == QUDA_FULL_SITE_SUBSET || out.SiteSubset() == QUDA_FULL_SITE_SUBSET) errorQuda("Cannot apply preconditioned operator to full field");
+  if (dagger != QUDA_DAG_NO) errorQuda("Dagger operator not implemented");
+  ColorSpinorField *t = getTmp(tmp1, own1, in);
+  if (matpcType == QUDA_MATPC_EVEN_EVEN) {
+    Dslash(*t, in, QUDA_ODD_PARITY);
+    DslashXpay(out, *t, QUDA_EVEN_PARITY, in, -1.0);
+  } else if (matpcType == QUDA_MATPC_ODD_ODD) {
+    Dslash(*t, in, QUDA_EVEN_PARITY);
+    DslashXpay(out, *t, QUDA_ODD_PARITY, in, -1.0);
+  } else {
+    errorQuda("matpcType %d: the coarse preconditioned operator is built for the symmetric types", matpcType);
+  }
+}
+void DiracCoarsePC::prepare(ColorSpinorField *&src, ColorSpinorField *&sol, ColorSpinorField &x, ColorSpinorField &b, const QudaSolutionType solType) const {
+  if (solType == QUDA_MATPC_SOLUTION || solType == QUDA_MATPCDAG_MATPC_SOLUTION) { src = &b; sol = &x; return; }
+  ColorSpinorField *t = getTmp(tmp1, own1, b.Even());
+  if (matpcType == QUDA_MATPC_EVEN_EVEN) {  // src = A_ee^-1 (b_e - D_eo A_oo^-1 b_o)
+    src = &(x.Odd());
+    CloverInv(*src, b.Odd(), QUDA_ODD_PARITY);
+    DiracCoarse::Dslash(*t, *src, QUDA_EVEN_PARITY);
+    blas::xpay(b.Even(), -1.0, *t);
+    CloverInv(*src, *t, QUDA_EVEN_PARITY);
+    sol = &(x.Even());
+  } else if (matpcType == QUDA_MATPC_ODD_ODD) {
+    src = &(x.Even());
+    CloverInv(*src, b.Even(), QUDA_EVEN_PARITY);
+    DiracCoarse::Dslash(*t, *src, QUDA_ODD_PARITY);
+    blas::xpay(b.Odd(), -1.0, *t);
+    CloverInv(*src, *t, QUDA_ODD_PARITY);
+    sol = &(x.Odd());
+  } else {
+    errorQuda("MatPCType %d not valid for DiracCoarsePC", matpcType);
+  }
+}
+void DiracCoarsePC::reconstruct(ColorSpinorField &x, const ColorSpinorField &b, const QudaSolutionType solType) const {
+  if (solType == QUDA_MATPC_SOLUTION || solType == QUDA_MATPCDAG_MATPC_SOLUTION) return;
+  checkFullSpinor(x, b);
+  ColorSpinorField *t = getTmp(tmp1, own1, b.Even());
+  if (matpcType == QUDA_MATPC_EVEN_EVEN) {  // x_o = A_oo^-1 (b_o - D_oe x_e)
+    DiracCoarse::Dslash(*t, x.Even(), QUDA_ODD_PARITY);
+    blas::xpay(b.Odd(), -1.0, *t);
+    CloverInv(x.Odd(), *t, QUDA_ODD_PARITY);
+  } else if (matpcType == QUDA_MATPC_ODD_ODD) {
+    DiracCoarse::Dslash(*t, x.Odd(), QUDA_EVEN_PARITY);
+    blas::xpay(b.Even(), -1.0, *t);
+    CloverInv(x.Even(), *t, QUDA_EVEN_PARITY);
+  } else {
+    errorQuda("MatPCType %d not valid for DiracCoarsePC", matpcType);
+  }
+}
 
 void DiracCoarse::M(ColorSpinorField &out, const ColorSpinorField &in) const {
   if (dagger == QUDA_DAG_YES) errorQuda("coarse dagger operator not implemented (as in the reference)");

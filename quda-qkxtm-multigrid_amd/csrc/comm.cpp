@@ -10,7 +10,10 @@
 // reference lib/interface_quda.cpp:261-270).  A single rank needs none of this and degenerates to local copies.
 #include <rccl/rccl.h>
 
+#include <unistd.h>
+
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "blas.h"
@@ -21,6 +24,38 @@
 namespace quda {
 
 static ncclComm_t g_nccl = nullptr;
+
+// ---- rehearsal transport (QUDA_AMD_TRANSPORT=shm): messages as files in a shared directory, staged through the host.
+// Exists only so that N ranks can be rehearsed on ONE GPU (RCCL refuses duplicate devices); it follows the same posting
+// order / per-peer FIFO matching as the RCCL path, so neighbour maps, face ordering and the two-ranks-per-dimension case
+// are exercised end to end.  Never used unless the environment variable is set. ----
+static bool g_shm = false;
+static std::string g_shm_dir;
+static std::vector<unsigned long> g_seq_send, g_seq_recv;
+static unsigned long g_seq_red = 0;
+
+static void shmWrite(const std::string &name, const void *p, size_t n) {
+  const std::string tmp = g_shm_dir + "/." + name + ".tmp", fin = g_shm_dir + "/" + name;
+  FILE *f = fopen(tmp.c_str(), "wb");
+  if (!f || fwrite(p, 1, n, f) != n) errorQuda("shm transport: cannot write %s", tmp.c_str());
+  fclose(f);
+  if (rename(tmp.c_str(), fin.c_str())) errorQuda("shm transport: rename failed for %s", fin.c_str());
+}
+static void shmRead(const std::string &name, void *p, size_t n, bool consume) {
+  const std::string fin = g_shm_dir + "/" + name;
+  for (long spins = 0;; spins++) {
+    FILE *f = fopen(fin.c_str(), "rb");
+    if (f) {
+      const size_t got = fread(p, 1, n, f);
+      fclose(f);
+      if (got != n) errorQuda("shm transport: short read on %s (%zu of %zu)", fin.c_str(), got, n);
+      if (consume) remove(fin.c_str());
+      return;
+    }
+    if (spins > 600000) errorQuda("shm transport: timed out waiting for %s", fin.c_str());
+    usleep(100);
+  }
+}
 
 #define NCCL_CHECK(cmd)                                                                   \
   do {                                                                                    \
@@ -66,6 +101,7 @@ int commNeighborRank(int dim, int dir) {
 void commFinalize() {
   freeHaloBuffers();
   if (g_nccl) { (void)ncclCommDestroy(g_nccl); g_nccl = nullptr; }
+  g_shm = false;
   CommGrid &g = commGrid();
   g.rank = 0; g.size = 1;
   for (int d = 0; d < 4; d++) { g.dims[d] = 1; g.coords[d] = 0; g.forced[d] = false; }
@@ -79,14 +115,39 @@ static void ensureScratch() {
   if (!h_scratch) HIP_CHECK(hipHostMalloc((void **)&h_scratch, 64 * sizeof(double), hipHostMallocDefault));
 }
 
+static void shmAllreduce(double *data, int n, bool is_max) {
+  const CommGrid &g = commGrid();
+  const unsigned long seq = g_seq_red++;
+  shmWrite("red_" + std::to_string(seq) + "_" + std::to_string(g.rank), data, n * sizeof(double));
+  std::vector<double> acc(data, data + n), tmp(n);
+  for (int r = 0; r < g.size; r++) {
+    if (r == g.rank) continue;
+    shmRead("red_" + std::to_string(seq) + "_" + std::to_string(r), tmp.data(), n * sizeof(double), false);
+    for (int k = 0; k < n; k++) acc[k] = is_max ? (tmp[k] > acc[k] ? tmp[k] : acc[k]) : acc[k] + tmp[k];
+  }
+  // everyone has read round seq-1 once it writes round seq: clean up our own file of the previous round
+  if (seq > 0) remove((g_shm_dir + "/red_" + std::to_string(seq - 1) + "_" + std::to_string(g.rank)).c_str());
+  for (int k = 0; k < n; k++) data[k] = acc[k];
+}
+
 void commAllreduceDevice(double *d_data, int n, hipStream_t s) {
   if (commGrid().size == 1) return;
+  if (g_shm) {
+    double h[64];
+    HIP_CHECK(hipMemcpyAsync(h, d_data, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    shmAllreduce(h, n, false);
+    HIP_CHECK(hipMemcpyAsync(d_data, h, n * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    return;
+  }
   NCCL_CHECK(ncclAllReduce(d_data, d_data, n, ncclDouble, ncclSum, g_nccl, s));
 }
 
 static void hostAllreduce(double *data, int n, ncclRedOp_t op) {
   if (commGrid().size == 1) return;
   if (n > 64) errorQuda("allreduce of %d doubles exceeds the scratch buffer", n);
+  if (g_shm) { shmAllreduce(data, n, op == ncclMax); return; }
   ensureScratch();
   hipStream_t s = computeStream();
   memcpy(h_scratch, data, n * sizeof(double));
@@ -113,6 +174,26 @@ void commExchange(const std::vector<HaloMsg> &msgs, hipStream_t s) {
     }
   }
   if (!remote) return;
+  if (g_shm) {
+    // same posting order as the RCCL group below; per-peer FIFO matching through per-pair sequence numbers
+    HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<char> host;
+    for (const HaloMsg &m : msgs) {
+      const int to = commNeighborRank(m.dim, m.dir);
+      if (to == g.rank) continue;
+      host.resize(m.bytes);
+      HIP_CHECK(hipMemcpy(host.data(), m.send, m.bytes, hipMemcpyDeviceToHost));
+      shmWrite("msg_" + std::to_string(g.rank) + "_" + std::to_string(to) + "_" + std::to_string(g_seq_send[to]++), host.data(), m.bytes);
+    }
+    for (const HaloMsg &m : msgs) {
+      const int from = commNeighborRank(m.dim, -m.dir);
+      if (from == g.rank) continue;
+      host.resize(m.bytes);
+      shmRead("msg_" + std::to_string(from) + "_" + std::to_string(g.rank) + "_" + std::to_string(g_seq_recv[from]++), host.data(), m.bytes, true);
+      HIP_CHECK(hipMemcpy(m.recv, host.data(), m.bytes, hipMemcpyHostToDevice));
+    }
+    return;
+  }
   if (!g_nccl) errorQuda("multi-rank halo exchange without an RCCL communicator (qudaAmdCommInit)");
   NCCL_CHECK(ncclGroupStart());
   // order inside a (dim) pair: send forward, send backward, receive from behind, receive from ahead — with only two ranks
@@ -157,6 +238,17 @@ void qudaAmdCommInit(const void *id128, int rank, int size) {
   g.rank = rank;
   g.size = size;
   if (size == 1) return;
+  const char *tr = getenv("QUDA_AMD_TRANSPORT");
+  if (tr && !strcmp(tr, "shm")) {
+    const char *dir = getenv("QUDA_AMD_SHM_DIR");
+    if (!dir) errorQuda("QUDA_AMD_TRANSPORT=shm needs QUDA_AMD_SHM_DIR");
+    g_shm = true;
+    g_shm_dir = dir;
+    g_seq_send.assign(size, 0);
+    g_seq_recv.assign(size, 0);
+    g_seq_red = 0;
+    return;
+  }
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
   NCCL_CHECK(ncclCommInitRank(&g_nccl, size, id, rank));

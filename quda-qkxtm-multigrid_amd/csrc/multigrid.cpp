@@ -37,10 +37,13 @@ static ColorSpinorField *likeField(const ColorSpinorField &x) {
 MG::MG(MGParam &p)
     : Solver(p), mgp(p), transfer(nullptr), presmoother(nullptr), postsmoother(nullptr), coarse_solver(nullptr), param_presmooth(nullptr),
       param_postsmooth(nullptr), param_coarse_solver(nullptr), coarse(nullptr), param_coarse(nullptr), r(nullptr), r_coarse(nullptr), x_coarse(nullptr),
-      diracCoarse(nullptr), matCoarse(nullptr), ownCoarseSolver(false) {
+      b_tilde(nullptr), diracCoarse(nullptr), diracCoarseSmoother(nullptr), matCoarse(nullptr), matCoarseSmoother(nullptr), pcSmooth(false),
+      ownCoarseSolver(false) {
   if (p.level >= QUDA_MAX_MG_LEVEL) errorQuda("Level=%d is greater than limit of multigrid recursion depth", p.level + 1);
   if (getVerbosity() >= QUDA_SUMMARIZE) printfQuda("MG level %d: creating level %d of %d\n", p.level + 1, p.level + 1, p.Nlevel);
   const bool coarsest = p.level == p.Nlevel - 1;
+  pcSmooth = p.mg_global.smoother_solve_type[p.level] == QUDA_DIRECT_PC_SOLVE;
+  if (pcSmooth != p.matSmooth.isPC()) errorQuda("smoother_solve_type[%d] and the smoother operator disagree about even-odd preconditioning", p.level);
 
   if (!coarsest) {
     if (p.mg_global.compute_null_vector == QUDA_COMPUTE_NULL_VECTOR_YES && (p.mg_global.generate_all_levels == QUDA_BOOLEAN_YES || p.level == 0))
@@ -77,9 +80,15 @@ MG::MG(MGParam &p)
     postsmoother = Solver::create(*param_postsmooth, p.matSmooth, p.matSmooth, p.matSmooth);
   }
 
+  r = likeField(*p.B[0]);
+  r->twistFlavor = p.fineFlavor;
+  if (pcSmooth) {
+    ColorSpinorParam bp = r->Even().param();
+    bp.create = QUDA_ZERO_FIELD_CREATE;
+    b_tilde = new ColorSpinorField(bp);
+    b_tilde->twistFlavor = p.fineFlavor;
+  }
   if (!coarsest) {
-    r = likeField(*p.B[0]);
-    r->twistFlavor = p.fineFlavor;
     transfer = new Transfer(p.B, p.Nvec, p.geoBlockSize, p.spinBlockSize);
     for (int d = 0; d < 4; d++) p.mg_global.geo_block_size[p.level][d] = p.geoBlockSize[d];
     r_coarse = transfer->createCoarseField();
@@ -106,7 +115,15 @@ MG::MG(MGParam &p)
     if (p.mg_global.generate_all_levels != QUDA_BOOLEAN_YES)
       for (int i = 0; i < p.Nvec; i++) transfer->R(*B_coarse[i], *p.B[i]);
 
-    param_coarse = new MGParam(p.mg_global, B_coarse, *matCoarse, *matCoarse, p.level + 1, QUDA_TWIST_NO);
+    // smoother operator of the next level: the coarse operator itself or its even-odd preconditioned form (reference :184-190)
+    if (p.mg_global.smoother_solve_type[p.level + 1] == QUDA_DIRECT_PC_SOLVE) {
+      DiracParam dps = dp;
+      dps.type = QUDA_COARSEPC_DIRAC;
+      if (dps.matpcType != QUDA_MATPC_EVEN_EVEN && dps.matpcType != QUDA_MATPC_ODD_ODD) dps.matpcType = QUDA_MATPC_EVEN_EVEN;
+      diracCoarseSmoother = new DiracCoarsePC(*diracCoarse, dps);
+      matCoarseSmoother = new DiracM(*diracCoarseSmoother);
+    }
+    param_coarse = new MGParam(p.mg_global, B_coarse, *matCoarse, matCoarseSmoother ? *matCoarseSmoother : *matCoarse, p.level + 1, QUDA_TWIST_NO);
     param_coarse->delta = 1e-20;
     coarse = new MG(*param_coarse);
 
@@ -143,6 +160,8 @@ MG::~MG() {
   delete coarse;
   delete param_coarse;
   for (ColorSpinorField *f : B_coarse) delete f;
+  delete matCoarseSmoother;
+  delete diracCoarseSmoother;
   delete matCoarse;
   delete diracCoarse;
   delete transfer;
@@ -150,7 +169,7 @@ MG::~MG() {
   delete presmoother;
   delete param_presmooth;
   delete param_postsmooth;
-  delete r; delete r_coarse; delete x_coarse;
+  delete r; delete r_coarse; delete x_coarse; delete b_tilde;
 }
 
 unsigned long long MG::flops() const {
@@ -185,7 +204,7 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
     x.twistFlavor = mgp.fineFlavor;
     spinorRandom(x, 0x5eedULL + 7919ULL * (mgp.level * 131 + i));
     blas::zero(*b);
-    Solver *solve = Solver::create(sp, mgp.matSmooth, mgp.matSmooth, mgp.matSmooth);
+    Solver *solve = Solver::create(sp, mgp.matResidual, mgp.matResidual, mgp.matResidual);
     (*solve)(x, *b);
     delete solve;
     // global orthonormalisation against the previous vectors
@@ -201,22 +220,42 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
   delete b;
 }
 
-// reference :488-604 restricted to full-system smoothing (see multigrid.h)
+// reference :488-604 (outer and inner solution type QUDA_MAT_SOLUTION; smoother full or even-odd preconditioned)
 void MG::operator()(ColorSpinorField &x, ColorSpinorField &b) {
-  if (b.SiteSubset() != QUDA_FULL_SITE_SUBSET) errorQuda("this multigrid build preconditions the full system (QUDA_DIRECT_SOLVE outer solve)");
+  if (b.SiteSubset() != QUDA_FULL_SITE_SUBSET) errorQuda("the multigrid cycle preconditions the full system (QUDA_DIRECT_SOLVE outer solve)");
+  const Dirac &dirac = *mgp.matSmooth.Expose();
+  ColorSpinorField *out = nullptr, *in = nullptr;
+  r->twistFlavor = b.twistFlavor;
+  x.twistFlavor = b.twistFlavor;
   if (mgp.level < mgp.Nlevel - 1) {
-    r->twistFlavor = b.twistFlavor;
-    (*presmoother)(x, b);
+    blas::copy(*r, b);  // the source is copied: prepare() of a preconditioned smoother builds its source from it
+    dirac.prepare(in, out, x, *r, QUDA_MAT_SOLUTION);
+    if (pcSmooth) { b_tilde->twistFlavor = b.twistFlavor; blas::copy(*b_tilde, *in); }  // keep the prepared source for the post-smoother
+    (*presmoother)(*out, *in);
+    dirac.reconstruct(x, b, QUDA_MAT_SOLUTION);
     mgp.matResidual(*r, x);
-    blas::axpby(1.0, b, -1.0, *r);  // r = b - A x
+    blas::axpby(1.0, b, -1.0, *r);  // r = b - A x   (full residual: coarse_grid_solution_type = MAT)
     transfer->R(*r_coarse, *r);
     blas::zero(*x_coarse);
     (*coarse_solver)(*x_coarse, *r_coarse);
     transfer->P(*r, *x_coarse);     // repurpose residual storage
     blas::xpy(*r, x);
-    (*postsmoother)(x, b);
+    if (pcSmooth) {
+      in = b_tilde;
+      out = dirac.getMatPCType() == QUDA_MATPC_ODD_ODD || dirac.getMatPCType() == QUDA_MATPC_ODD_ODD_ASYMMETRIC ? &x.Odd() : &x.Even();
+    } else {
+      blas::copy(*r, b);
+      in = r;
+      out = &x;
+    }
+    (*postsmoother)(*out, *in);
+    dirac.reconstruct(x, b, QUDA_MAT_SOLUTION);
   } else {
-    (*presmoother)(x, b);           // coarsest-grid solve
+    // coarsest-grid solve
+    blas::copy(*r, b);
+    dirac.prepare(in, out, x, *r, QUDA_MAT_SOLUTION);
+    (*presmoother)(*out, *in);
+    dirac.reconstruct(x, b, QUDA_MAT_SOLUTION);
   }
   blas::setGlobalReduction(true);
 }
@@ -266,13 +305,16 @@ void MG::verify(double dev[3]) {
 
 // ================================================================================================
 // reference multigrid_solver ctor, lib/interface_quda.cpp:2161-2255
-multigrid_solver::multigrid_solver(QudaMultigridParam &mg_param) : d(nullptr), m(nullptr), mgParam(nullptr), mg(nullptr) {
+multigrid_solver::multigrid_solver(QudaMultigridParam &mg_param) : d(nullptr), m(nullptr), dSmooth(nullptr), mSmooth(nullptr), mgParam(nullptr), mg(nullptr) {
   QudaInvertParam *param = mg_param.invert_param;
   if (!param) errorQuda("QudaMultigridParam.invert_param is NULL");
   if (mg_param.n_level < 2 || mg_param.n_level > QUDA_MAX_MG_LEVEL) errorQuda("Requested MG levels %d outside 2..%d", mg_param.n_level, QUDA_MAX_MG_LEVEL);
-  for (int i = 0; i < mg_param.n_level; i++)
-    if (mg_param.smoother_solve_type[i] != QUDA_DIRECT_SOLVE)
-      errorQuda("smoother_solve_type[%d] = %d: this build smooths the full operator (QUDA_DIRECT_SOLVE); the even-odd preconditioned smoother comes next", i, mg_param.smoother_solve_type[i]);
+  for (int i = 0; i < mg_param.n_level; i++) {
+    if (mg_param.smoother_solve_type[i] != QUDA_DIRECT_SOLVE && mg_param.smoother_solve_type[i] != QUDA_DIRECT_PC_SOLVE)
+      errorQuda("Unsupported smoother solve type %d on level %d", mg_param.smoother_solve_type[i], i);
+    if (mg_param.coarse_grid_solution_type[i] != QUDA_MAT_SOLUTION)
+      errorQuda("coarse_grid_solution_type[%d] = %d: this build restricts the full residual (QUDA_MAT_SOLUTION)", i, mg_param.coarse_grid_solution_type[i]);
+  }
   if (param->solve_type != QUDA_DIRECT_SOLVE) errorQuda("Outer MG solver can only use QUDA_DIRECT_SOLVE at present");
   GaugeField *g = gaugePrecondition ? gaugePrecondition : (gaugeSloppy ? gaugeSloppy : gaugePrecise);
   if (!g) errorQuda("Gauge field not allocated");
@@ -291,13 +333,19 @@ multigrid_solver::multigrid_solver(QudaMultigridParam &mg_param) : d(nullptr), m
   if (dp.clover && dp.clover->precision != QUDA_SINGLE_PRECISION) errorQuda("multigrid needs an fp32 precondition clover field");
   d = Dirac::create(dp);
   m = new DiracM(*d);
+  if (mg_param.smoother_solve_type[0] == QUDA_DIRECT_PC_SOLVE) {
+    DiracParam dps;
+    setDiracPreParam(dps, param, true);
+    dSmooth = Dirac::create(dps);
+    mSmooth = new DiracM(*dSmooth);
+  }
   param->kappa = orig_kappa; param->mu = orig_mu; param->mass = orig_mass;
 
   ColorSpinorParam cp = deviceSpinorParam(QUDA_SINGLE_PRECISION, QUDA_FULL_SITE_SUBSET, param->twist_flavor);
   cp.create = QUDA_ZERO_FIELD_CREATE;
   B.resize(mg_param.n_vec[0]);
   for (int i = 0; i < mg_param.n_vec[0]; i++) B[i] = new ColorSpinorField(cp);
-  mgParam = new MGParam(mg_param, B, *m, *m, 0, param->twist_flavor);
+  mgParam = new MGParam(mg_param, B, *m, mSmooth ? *mSmooth : *m, 0, param->twist_flavor);
   mg = new MG(*mgParam);
   if (mg_param.run_verify == QUDA_BOOLEAN_YES) { double dev[3]; mg->verify(dev); }
   mg_param.secs = now() - t0;
@@ -309,6 +357,8 @@ multigrid_solver::~multigrid_solver() {
   delete mg;
   delete mgParam;
   for (ColorSpinorField *f : B) delete f;
+  delete mSmooth;
+  delete dSmooth;
   delete m;
   delete d;
 }

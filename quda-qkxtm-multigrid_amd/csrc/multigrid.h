@@ -6,10 +6,11 @@
 // Cycle (reference MG::operator(), :488-604): pre-smooth (MR, nu_pre) -> residual -> R -> coarse solve
 // (V-cycle: the coarse MG itself; K-cycle = QUDA_MG_CYCLE_RECURSIVE: GCR(10) preconditioned by it) -> P, correct ->
 // post-smooth (MR, nu_post); coarsest level: GCR to smoother_tol.
-// Scope of this build: smoothing and coarse-grid solves act on the full (unpreconditioned) operators
-// (smoother_solve_type = QUDA_DIRECT_SOLVE, coarse_grid_solution_type = QUDA_MAT_SOLUTION — a combination the reference
-// supports); the outer solver is GCR on the full system, which is the only outer solve the reference's MG accepts
-// (lib/interface_quda.cpp:2183-2184).  The even-odd preconditioned smoother variant (Yhat / Xinv) comes next.
+// Smoother per level: the full operator (smoother_solve_type = QUDA_DIRECT_SOLVE) or — the reference's default — the
+// even-odd preconditioned one (QUDA_DIRECT_PC_SOLVE: DiracTwistedMassPC / DiracTwistedCloverPC / DiracWilsonPC on level 0,
+// DiracCoarsePC with Xinv / Yhat on coarse levels) wrapped in Dirac::prepare / reconstruct exactly as the reference's
+// cycle does.  Coarse-grid solution type is QUDA_MAT_SOLUTION (full residual restricted); the outer solver is GCR on the
+// full system, the only outer solve the reference's MG accepts (lib/interface_quda.cpp:2183-2184).
 #pragma once
 
 #include <vector>
@@ -44,9 +45,11 @@ class MG : public Solver {
   MG *coarse;
   MGParam *param_coarse;
   std::vector<ColorSpinorField *> B_coarse;
-  ColorSpinorField *r, *r_coarse, *x_coarse;
+  ColorSpinorField *r, *r_coarse, *x_coarse, *b_tilde;
   DiracCoarse *diracCoarse;
-  DiracM *matCoarse;
+  DiracCoarse *diracCoarseSmoother;
+  DiracM *matCoarse, *matCoarseSmoother;
+  bool pcSmooth;
   bool ownCoarseSolver;
   void generateNullVectors(std::vector<ColorSpinorField *> &B);
 
@@ -68,6 +71,8 @@ class MG : public Solver {
 struct multigrid_solver {
   Dirac *d;       // level-0 full operator in the preconditioner precision
   DiracM *m;
+  Dirac *dSmooth; // level-0 smoother operator (== d, or its even-odd preconditioned form)
+  DiracM *mSmooth;
   std::vector<ColorSpinorField *> B;
   MGParam *mgParam;
   MG *mg;

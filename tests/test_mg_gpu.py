@@ -59,8 +59,9 @@ def _true_residual(oracle, gauge, X, kappa, mu, x, b):
     return float(np.linalg.norm(b - mx) / np.linalg.norm(b))
 
 
+@pytest.mark.parametrize("smoother_pc", [False, True], ids=["full-smoother", "pc-smoother"])
 @pytest.mark.parametrize("X,levels,blocks,nvec", [((8, 8, 8, 8), 2, (4, 4, 4, 4), 8), ((16, 8, 8, 16), 3, [(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)], 8)])
-def test_verify_identities_and_mg_gcr_solve(qa, oracle, X, levels, blocks, nvec):
+def test_verify_identities_and_mg_gcr_solve(qa, oracle, X, levels, blocks, nvec, smoother_pc):
     kappa, mu = 0.124, 0.005
     gauge, ip = _setup(qa, X, kappa, mu)
     V = int(np.prod(X))
@@ -73,7 +74,7 @@ def test_verify_identities_and_mg_gcr_solve(qa, oracle, X, levels, blocks, nvec)
     iters_plain = ip.iter
     assert _true_residual(oracle, gauge, X, kappa, mu, x0, b) < 5e-10
 
-    mp = qa.multigrid_param(ip, n_level=levels, geo_block=blocks, n_vec=nvec, setup_maxiter=300, setup_tol=1e-5)
+    mp = qa.multigrid_param(ip, n_level=levels, geo_block=blocks, n_vec=nvec, setup_maxiter=300, setup_tol=1e-5, smoother_pc=smoother_pc)
     mg = qa.Multigrid(mp)
     try:
         dev = mg.verify()
@@ -91,7 +92,7 @@ def test_verify_identities_and_mg_gcr_solve(qa, oracle, X, levels, blocks, nvec)
         assert res < 5e-10, res
         assert abs(ip.true_res - res) < 1e-9
         assert iters_mg < iters_plain, (iters_mg, iters_plain)
-        print("MG-GCR %s: %d iterations (plain GCR %d), true residual %.2e, setup %.2f s, solve %.3f s" % (X, iters_mg, iters_plain, res, mp.secs, ip.secs))
+        print("MG-GCR %s pc=%s: %d iterations (plain GCR %d), true residual %.2e, setup %.2f s, solve %.3f s" % (X, smoother_pc, iters_mg, iters_plain, res, mp.secs, ip.secs))
     finally:
         mg.free()
 
