@@ -30,38 +30,44 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def random_su3(rng, n):
-    g = rng.standard_normal((n, 3, 3)) + 1j * rng.standard_normal((n, 3, 3))
-    q, r = np.linalg.qr(g)
-    d = np.diagonal(r, axis1=-2, axis2=-1)
-    q = q * (d / np.abs(d))[..., None, :]
-    q = q / np.linalg.det(q)[..., None, None] ** (1.0 / 3.0)
-    return q
+from synth import make_clover, make_gauge, smooth_gauge  # noqa: E402
 
 
-def make_gauge(X, seed=137, antiperiodic=True):
-    """random SU(3) links in the host QDP order (4, V*18): even sites then odd, anti-periodic T folded into the last slice"""
-    rng = np.random.default_rng(seed)
-    V = int(np.prod(X))
-    out = np.empty((4, V * 18))
-    for mu in range(4):
-        q = random_su3(rng, V)
-        out[mu] = np.stack([q.real, q.imag], axis=-1).reshape(-1)
-    if antiperiodic:
-        Vh = V // 2
-        lo = (X[0] // 2) * X[1] * X[2] * (X[3] - 1)
-        g3 = out[3].reshape(2, Vh, 18)
-        g3[:, lo:, :] *= -1.0
+def run_mg(qa, X=(16, 16, 16, 16)):
+    """MG-preconditioned GCR to |r|/|b| <= 1e-10 (the second half of the metric) on one GPU: 3-level K-cycle, 24 null
+    vectors, 4^4 then 2^4 aggregates, even-odd preconditioned MR smoother — the reference harness' default shape
+    (tests/multigrid_invert_test.cpp:224-286) on a 16^4 warm-start gauge field at kappa close to critical.  Setup (null
+    vectors + Galerkin operators) and solve are timed separately; the residual is re-computed with MatQuda."""
+    kappa, mu = 0.124, 0.005
+    gauge = smooth_gauge(X, 0.35)
+    gp = qa.gauge_param(X, cuda_prec=8, prec_sloppy=4, prec_precondition=4, t_boundary=qa.QUDA_PERIODIC_T)
+    qa.load_gauge(gauge, gp)
+    ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=8, prec_sloppy=4, prec_precondition=4,
+                         solution_type=qa.QUDA_MAT_SOLUTION)
+    ip.solve_type = qa.QUDA_DIRECT_SOLVE
+    ip.inv_type = qa.QUDA_GCR_INVERTER
+    ip.gcrNkrylov = 20
+    ip.tol = 1e-10
+    ip.maxiter = 5000
+    b = np.random.default_rng(5).random(int(np.prod(X)) * 24)
+    ip.inv_type_precondition = qa.QUDA_INVALID_ENUM
+    t0 = time.perf_counter()
+    qa.invert(b, ip)
+    plain = dict(iters=ip.iter, secs=round(time.perf_counter() - t0, 4))
+    mp = qa.multigrid_param(ip, n_level=3, geo_block=[(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)], n_vec=24, setup_maxiter=500, setup_tol=5e-6,
+                            smoother_pc=True)
+    mg = qa.Multigrid(mp)
+    ip.inv_type_precondition = qa.QUDA_MG_INVERTER
+    ip.preconditioner = mg.h
+    ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
+    t0 = time.perf_counter()
+    x = qa.invert(b, ip)
+    solve = time.perf_counter() - t0
+    res = float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b))
+    out = dict(lattice="x".join(map(str, X)), kappa=kappa, mu=mu, levels=3, n_vec=24, setup_secs=round(mp.secs, 3), solve_secs=round(solve, 4),
+               iters=ip.iter, true_res=res, plain_gcr=plain)
+    mg.free()
     return out
-
-
-def make_clover(X, seed=11):
-    rng = np.random.default_rng(seed)
-    V = int(np.prod(X))
-    c = rng.uniform(-0.1, 0.1, size=(V, 72))
-    c[:, 0:6] += 1.0
-    c[:, 36:42] += 1.0
-    return c.reshape(-1)
 
 
 def main():
@@ -151,6 +157,9 @@ def main():
             extra["%s_%s_r%d" % (kind, dtype_name[prec].split("+")[0], recon)] = dict(
                 gflops=round(e["flops_site"] * Vh_global / e["sec"] * 1e-9, 1), hbm_gbs=round(e["bytes_site"] * Vh_local / e["sec"] * 1e-9, 1),
                 frac=round(e["bytes_site"] * Vh_local / e["sec"] * 1e-9 / HBM_PEAK_GBS, 4), bytes_per_site=e["bytes_site"], us=round(1e6 * e["sec"], 2))
+
+    if not args.no_extra and rank == 0 and world == 1:
+        extra["mg_gcr"] = run_mg(qa)
 
     cpu = None
     if rank == 0 and not args.no_cpu:

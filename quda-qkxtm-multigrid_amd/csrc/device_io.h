@@ -58,12 +58,12 @@ template <int NR> struct Planar<double, NR> {
       r[2 * k + 1] = t.y;
     }
   }
-  static __device__ __forceinline__ void store(const double *r, void *base, int stride, int x, float *, int) {
+  template <int AUX = 0> static __device__ __forceinline__ void store(const double *r, void *base, int stride, int x, float *, int) {
     const __amdgpu_buffer_rsrc_t rs = planar_rsrc<double, NR>(base, stride);
     const int off = x * 16;
 #pragma unroll
     for (int k = 0; k < NR / 2; k++)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, make_double2(r[2 * k], r[2 * k + 1])), rs, off, k * stride * 16, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, make_double2(r[2 * k], r[2 * k + 1])), rs, off, k * stride * 16, AUX);
   }
 };
 
@@ -81,14 +81,14 @@ template <int NR> struct Planar<float, NR> {
       r[NR - 2] = t.x; r[NR - 1] = t.y;
     }
   }
-  static __device__ __forceinline__ void store(const float *r, void *base, int stride, int x, float *, int) {
+  template <int AUX = 0> static __device__ __forceinline__ void store(const float *r, void *base, int stride, int x, float *, int) {
     const __amdgpu_buffer_rsrc_t rs = planar_rsrc<float, NR>(base, stride);
     const int off = x * 16;
 #pragma unroll
     for (int k = 0; k < NR / 4; k++)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, make_float4(r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3])), rs, off,
-                                             k * stride * 16, 0);
-    if (NR % 4) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, make_float2(r[NR - 2], r[NR - 1])), rs, x * 8, (NR / 4) * stride * 16, 0);
+                                             k * stride * 16, AUX);
+    if (NR % 4) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, make_float2(r[NR - 2], r[NR - 1])), rs, x * 8, (NR / 4) * stride * 16, AUX);
   }
 };
 
@@ -109,7 +109,7 @@ template <int NR> struct Planar<short, NR> {
     }
   }
   static __device__ __forceinline__ short q16(float v) { return (short)__float2int_rn(fminf(fmaxf(v, -kShortMax), kShortMax)); }
-  static __device__ __forceinline__ void store(const float *r, void *base, int stride, int x, float *norm, int nidx) {
+  template <int AUX = 0> static __device__ __forceinline__ void store(const float *r, void *base, int stride, int x, float *norm, int nidx) {
     float s = kShortMax;
     if (norm) {
       float m = 0.f;
@@ -124,10 +124,10 @@ template <int NR> struct Planar<short, NR> {
     for (int k = 0; k < NR / 4; k++)
       __builtin_amdgcn_raw_buffer_store_b64(
           __builtin_bit_cast(u32x2_t, make_short4(q16(r[4 * k] * s), q16(r[4 * k + 1] * s), q16(r[4 * k + 2] * s), q16(r[4 * k + 3] * s))), rs, off,
-          k * stride * 8, 0);
+          k * stride * 8, AUX);
     if (NR % 4)
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, make_short2(q16(r[NR - 2] * s), q16(r[NR - 1] * s))), rs, x * 4,
-                                            (NR / 4) * stride * 8, 0);
+                                            (NR / 4) * stride * 8, AUX);
   }
 };
 

@@ -151,7 +151,7 @@ __device__ __forceinline__ void hop_compute(real *acc, real *psi, const real *U,
 // KT: 0 = every site, all neighbours local (periodic wrap inside this rank);
 //     1 = interior pass of a grid-decomposed lattice: sites that touch a partitioned boundary are left to the exterior pass;
 //     2 = exterior pass: one thread per boundary site (arg.blist), off-node neighbours come from the ghost zone.
-template <typename T, int R, int VARIANT, int GAUX, int KT>
+template <typename T, int R, int VARIANT, int GAUX, int KT, int SAUX = 0>
 __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename Store<T>::real> arg) {
   using real = typename Store<T>::real;
   int idx;
@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
       for (int k = 0; k < 24; k++) acc[k] = arg.k * acc[k] + tmp[k];
     }
   }
-  Planar<T, 24>::store(acc, arg.out, arg.sp_stride, idx, arg.outNorm, idx);
+  Planar<T, 24>::template store<SAUX>(acc, arg.out, arg.sp_stride, idx, arg.outNorm, idx);
 }
 
 // ---- single-direction hop (setup-time helper for the multigrid coarse-operator construction) ----
@@ -485,7 +485,10 @@ HaloBuffers &haloBuffers(const LatticeGeom &g, QudaPrecision prec) {
     total += 4 * h.face_bytes[d];
   }
   HIP_CHECK(hipMalloc((void **)&h.pool, total));
-  HIP_CHECK(hipMemset(h.pool, 0, total));
+  // hipMemset on the null stream may still be in flight when it returns and does not order against the non-blocking
+  // compute/comm streams: a late memset would wipe a freshly packed send buffer, so zero on the compute stream and drain
+  HIP_CHECK(hipMemsetAsync(h.pool, 0, total, computeStream()));
+  HIP_CHECK(hipStreamSynchronize(computeStream()));
   h.pool_bytes = total;
   char *p = h.pool;
   for (int d = 0; d < 4; d++)
@@ -580,7 +583,10 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
   for (int d = 0; d < 4; d++) if (commGrid().partitioned(d)) mask |= 1 << d;
   hipStream_t cs = computeStream();
   if (mask == 0) {
-    hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 0>), dim3(nb), dim3(bs), 0, cs, arg);
+    static int saux = -1;
+    if (saux < 0) { const char *e = getenv("QUDA_AMD_STORE_AUX"); saux = e ? atoi(e) : 0; }
+    if (saux == 2) hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 0, 2>), dim3(nb), dim3(bs), 0, cs, arg);
+    else hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 0>), dim3(nb), dim3(bs), 0, cs, arg);
     HIP_CHECK(hipGetLastError());
     return;
   }

@@ -18,20 +18,7 @@ def qa():
     mod.end()
 
 
-def smooth_gauge(X, eps, seed=3):
-    """SU(3) links exp(i eps H) with random Hermitian traceless H: a smooth field on which kappa ~ 0.125 is close to
-    critical, so the fine operator is ill-conditioned and multigrid has something to do (periodic T as the reference MG test)."""
-    rng = np.random.default_rng(seed)
-    V = int(np.prod(X))
-    out = np.empty((4, V * 18))
-    for mu in range(4):
-        a = rng.standard_normal((V, 3, 3)) + 1j * rng.standard_normal((V, 3, 3))
-        h = 0.5 * (a + a.conj().transpose(0, 2, 1))
-        h -= np.trace(h, axis1=1, axis2=2)[:, None, None] * np.eye(3) / 3.0
-        w, v = np.linalg.eigh(h)
-        u = (v * np.exp(1j * eps * w)[:, None, :]) @ v.conj().transpose(0, 2, 1)
-        out[mu] = np.stack([u.real, u.imag], axis=-1).reshape(-1)
-    return out
+from synth import smooth_gauge  # noqa: E402
 
 
 def _setup(qa, X, kappa, mu, eps=0.35):

@@ -42,7 +42,8 @@ def main():
             full[parity * nh_g:(parity + 1) * nh_g] = full_parity_field
             return mg.scatter_field(full, X, grid, dist.coords, 24)[parity * nh_l:(parity + 1) * nh_l]
 
-        for prec, tol in ((8, 1e-12), (4, 2e-5), (2, 1e-2)):
+        order = ((8, 1e-12), (4, 2e-5), (2, 1e-2)) if not os.environ.get("MGPU_REVERSE") else ((4, 2e-5), (8, 1e-12), (2, 1e-2))
+        for prec, tol in order:
             qa.load_gauge(g_loc, qa.gauge_param(Xl, cuda_prec=prec))
             ipc = qa.invert_param(qa.QUDA_TWISTED_CLOVER_DSLASH, kappa, mu, cuda_prec=prec)
             qa.load_clover(c_loc, None, ipc)
@@ -52,7 +53,14 @@ def main():
                     ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", dagger, cuda_prec=prec)
                     got = qa.dslash(s_loc[pin * nh_l:(pin + 1) * nh_l].copy(), ip, parity)
                     want_g = oracle.tm_dslash(gauge, spinor[pin * nh_g:(pin + 1) * nh_g].copy(), X, kappa, mu, +1, parity, "ee", dagger)
-                    err = np.max(np.abs(got - local_part(want_g, parity))) / np.max(np.abs(want_g))
+                    want_l = local_part(want_g, parity)
+                    err = np.max(np.abs(got - want_l)) / np.max(np.abs(want_g))
+                    if err >= tol:
+                        bad = np.nonzero(np.max(np.abs(got - want_l).reshape(-1, 24), axis=1) > tol * np.max(np.abs(want_g)))[0]
+                        x, y, z, t = mg.cb_coords(Xl, parity)
+                        print("rank %d FAIL tm_dslash prec %d dagger %d parity %d: %d bad sites of %d; coords (x,y,z,t) of first: %s; z in %s t in %s" % (
+                            rank, prec, dagger, parity, bad.size, got.size // 24, [(int(x[i]), int(y[i]), int(z[i]), int(t[i])) for i in bad[:6]],
+                            sorted(set(int(v) for v in z[bad])), sorted(set(int(v) for v in t[bad]))), flush=True)
                     assert err < tol, ("tm_dslash", X, grid, prec, dagger, parity, err)
             ipf = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, -1, "ee", 0, cuda_prec=prec, solution_type=qa.QUDA_MAT_SOLUTION)
             got = qa.mat(s_loc.copy(), ipf)

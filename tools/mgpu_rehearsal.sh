@@ -7,7 +7,7 @@ export MASTER_ADDR=127.0.0.1 MASTER_PORT=29611 WORLD_SIZE=$N QUDA_AMD_FORCE_DEVI
 export QUDA_AMD_TRANSPORT=shm QUDA_AMD_SHM_DIR=$(mktemp -d /dev/shm/quda_amd_XXXXXX)
 pids=()
 for r in $(seq 0 $((N-1))); do
-  RANK=$r LOCAL_RANK=$r timeout -k 5 200 python3 tools/mgpu_check.py $N > ${LOG}.rank$r 2>&1 &
+  RANK=$r LOCAL_RANK=$r timeout -k 5 120 python3 tools/mgpu_check.py $N > ${LOG}.rank$r 2>&1 &
   pids+=($!)
 done
 rc=0
