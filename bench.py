@@ -39,6 +39,7 @@ def run_mg(qa, X=(16, 16, 16, 16)):
     (tests/multigrid_invert_test.cpp:224-286) on a 16^4 warm-start gauge field at kappa close to critical.  Setup (null
     vectors + Galerkin operators) and solve are timed separately; the residual is re-computed with MatQuda."""
     kappa, mu = 0.124, 0.005
+    qa.lib().freeCloverQuda()
     gauge = smooth_gauge(X, 0.35)
     gp = qa.gauge_param(X, cuda_prec=8, prec_sloppy=4, prec_precondition=4, t_boundary=qa.QUDA_PERIODIC_T)
     qa.load_gauge(gauge, gp)
@@ -158,6 +159,13 @@ def main():
                 gflops=round(e["flops_site"] * Vh_global / e["sec"] * 1e-9, 1), hbm_gbs=round(e["bytes_site"] * Vh_local / e["sec"] * 1e-9, 1),
                 frac=round(e["bytes_site"] * Vh_local / e["sec"] * 1e-9 / HBM_PEAK_GBS, 4), bytes_per_site=e["bytes_site"], us=round(1e6 * e["sec"], 2))
 
+        # streaming yardstick: y += a x on full-lattice fp64 fields (3 x 201 MB per call, beyond the 256 MB Infinity Cache)
+        sx, sy = qa.Spinor(8, qa.QUDA_FULL_SITE_SUBSET), qa.Spinor(8, qa.QUDA_FULL_SITE_SUBSET)
+        qa.lib().qudaAmdTimeAxpy(0.5, sx.h, sy.h, 5)
+        sec = qa.lib().qudaAmdTimeAxpy(0.5, sx.h, sy.h, 50)
+        extra["stream_axpy_f64"] = dict(hbm_gbs=round(3 * 2 * Vh_local * 24 * 8 / sec * 1e-9, 1), us=round(1e6 * sec, 2))
+        sx.free(); sy.free()
+
     if not args.no_extra and rank == 0 and world == 1:
         extra["mg_gcr"] = run_mg(qa)
 
@@ -191,7 +199,7 @@ def main():
                    sample="%d x tm_dslash fp64 on %s (oracle/liboracle.so, outer parallel-for over sites); 1 thread = %.3f GFLOP/s"
                    % (n_all, "x".join(str(v) for v in Xc), 1368.0 * Vh_local / t1 * 1e-9))
 
-    traffic = None
+    traffic, traffic_source = None, None
     if rank == 0 and world == 1:
         # HBM bytes per launch of the same kernel from the committed rocprofv3 PMC summary (tools/summarize_profiles.py)
         import glob
@@ -202,7 +210,7 @@ def main():
             try:
                 for k, v in json.load(open(path))["kernels"].items():
                     if key in k and "hbm_bytes_per_launch" in v and X == [32, 32, 32, 32]:
-                        traffic = {"bytes_per_launch": round(v["hbm_bytes_per_launch"]), "source": os.path.basename(path)}
+                        traffic, traffic_source = round(v["hbm_bytes_per_launch"]), os.path.basename(path)
             except Exception:
                 pass
     if rank == 0:
@@ -215,7 +223,7 @@ def main():
                        % ({"tm": "twisted-mass", "tmc": "twisted-clover", "wilson": "Wilson"}[args.dslash], kappa, mu, "x".join(map(str, X)), args.recon),
                        "local_lattice": Xl, "process_grid": dist.grid if dist else [1, 1, 1, 1], "flops_per_site": r["flops_site"]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "bytes_per_site": r["bytes_site"], "kernel_us": round(1e6 * r["sec"], 3)},
+                         "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": traffic_source, "bytes_per_site": r["bytes_site"], "kernel_us": round(1e6 * r["sec"], 3)},
             "cpu_baseline": cpu,
             "extra": extra,
         }

@@ -51,6 +51,7 @@ double qudaAmdTimeM(void *dirac, void *out, const void *in, int niter);
 double qudaAmdBlasNorm2(const void *field);
 void qudaAmdBlasCDot(const void *x, const void *y, double result[2]);
 void qudaAmdBlasAxpy(double a, const void *x, void *y);
+double qudaAmdTimeAxpy(double a, const void *x, void *y, int niter);   /* seconds per y += a x, device-event timed */
 
 /* algorithmic work model of the stencil kernel behind Dirac::Dslash */
 long long qudaAmdDslashBytesPerSite(QudaInvertParam *inv_param, int which, int xpay);
@@ -60,6 +61,20 @@ long long qudaAmdDslashFlopsPerSite(QudaInvertParam *inv_param, int xpay);
  * application K b on host vectors (full fields, layout described by inv_param as for MatQuda) */
 void qudaAmdMultigridVerify(void *mg_instance, double dev[3]);
 void qudaAmdMultigridCycle(void *mg_instance, void *h_x, void *h_b, QudaInvertParam *inv_param);
+
+/* Read-only access to a hierarchy built by newMultigridQuda — what a C++ test of the reference reaches through
+ * multigrid_solver->mg (include/multigrid.h:108-330: B, transfer, diracCoarse).  Host layouts are the reference's CPU
+ * orders, fp32: vectors site-major (parity*Vh + x_cb, spin, colour, re/im), DeGrand-Rossi basis on level 0; V as
+ * (site, spin, colour, vector) (lib/transfer_util.cu:15-36); coarse links as QDP-ordered
+ * Y[dim 0-3 backward | 4-7 forward][site][row][col] and X[site][row][col] (lib/dslash_coarse.cu:50-64) with the
+ * operator's -kappa already multiplied into Y.  `level` names the finer of the two levels a transfer connects. */
+int qudaAmdMultigridLevels(void *mg_instance);
+void qudaAmdMultigridLevelInfo(void *mg_instance, int level, int info[18]); /* Xf[4] Xc[4] fineSpin fineColor Nvec geo_bs[4] spin_bs 0 0 */
+void qudaAmdMultigridGetNullVector(void *mg_instance, int level, int k, float *h_out);
+void qudaAmdMultigridGetV(void *mg_instance, int level, float *h_out);
+void qudaAmdMultigridGetCoarseLinks(void *mg_instance, int level, float *h_Y, float *h_X);
+/* op 0: R (level -> level+1; lib/restrictor.cu), 1: P (level+1 -> level; lib/prolongator.cu), 2: M of `level` */
+void qudaAmdMultigridApply(void *mg_instance, int level, int op, float *h_out, const float *h_in);
 
 /* RCCL bootstrap (the transport that replaces the reference's MPI layer, lib/comm_mpi.cpp:50-155): rank 0 obtains a
  * 128-byte id, the launcher broadcasts it out of band, every rank calls qudaAmdCommInit BEFORE initCommsGridQuda / initQuda. */

@@ -116,7 +116,8 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
                  "qudaAmdBlasNorm2", "qudaAmdBlasCDot", "qudaAmdBlasAxpy", "qudaAmdDslashBytesPerSite", "qudaAmdDslashFlopsPerSite",
                  "qudaAmdSetPartitionMask", "qudaAmdComputeStream", "qudaAmdDeviceSynchronize", "qudaAmdCommGetUniqueId",
                  "qudaAmdCommInit", "qudaAmdCommRank", "qudaAmdCommSize", "qudaAmdCommCoords", "qudaAmdCommBarrier", "qudaAmdCommAllreduce", "qudaAmdCommAllreduceMax",
-                 "qudaAmdMultigridVerify", "qudaAmdMultigridCycle"]
+                 "qudaAmdMultigridVerify", "qudaAmdMultigridCycle", "qudaAmdTimeAxpy", "qudaAmdMultigridLevels", "qudaAmdMultigridLevelInfo",
+                 "qudaAmdMultigridGetNullVector", "qudaAmdMultigridGetV", "qudaAmdMultigridGetCoarseLinks", "qudaAmdMultigridApply"]
 
 _lib = None
 
@@ -176,6 +177,14 @@ def lib():
         L.qudaAmdSetPartitionMask.argtypes = [_i]
         L.qudaAmdMultigridVerify.argtypes = [_p, C.POINTER(_d)]
         L.qudaAmdMultigridCycle.argtypes = [_p, _p, _p, C.POINTER(QudaInvertParam)]
+        L.qudaAmdTimeAxpy.argtypes = [_d, _p, _p, _i]
+        L.qudaAmdTimeAxpy.restype = _d
+        L.qudaAmdMultigridLevels.argtypes = [_p]
+        L.qudaAmdMultigridLevelInfo.argtypes = [_p, _i, C.POINTER(_i)]
+        L.qudaAmdMultigridGetNullVector.argtypes = [_p, _i, _i, _p]
+        L.qudaAmdMultigridGetV.argtypes = [_p, _i, _p]
+        L.qudaAmdMultigridGetCoarseLinks.argtypes = [_p, _i, _p, _p]
+        L.qudaAmdMultigridApply.argtypes = [_p, _i, _i, _p, _p]
         _lib = L
     return _lib
 
@@ -400,6 +409,52 @@ class Multigrid:
         x = np.zeros_like(h_b)
         lib().qudaAmdMultigridCycle(self.h, _vp(x), _vp(h_b), C.byref(ip))
         return x
+
+    # ---- introspection (include/quda_amd_ext.h): reference CPU orders, fp32 complex ----
+    def levels(self):
+        return lib().qudaAmdMultigridLevels(self.h)
+
+    def level_info(self, level):
+        a = (_i * 18)()
+        lib().qudaAmdMultigridLevelInfo(self.h, level, a)
+        v = list(a)
+        return dict(Xf=v[0:4], Xc=v[4:8], fineSpin=v[8], fineColor=v[9], Nvec=v[10], geo_bs=v[11:15], spin_bs=v[15])
+
+    def null_vector(self, level, k):
+        i = self.level_info(level)
+        out = np.zeros((int(np.prod(i["Xf"])), i["fineSpin"], i["fineColor"]), dtype=np.complex64)
+        lib().qudaAmdMultigridGetNullVector(self.h, level, k, _vp(out))
+        return out
+
+    def V(self, level):
+        i = self.level_info(level)
+        out = np.zeros((int(np.prod(i["Xf"])), i["fineSpin"], i["fineColor"], i["Nvec"]), dtype=np.complex64)
+        lib().qudaAmdMultigridGetV(self.h, level, _vp(out))
+        return out
+
+    def coarse_links(self, level):
+        i = self.level_info(level)
+        Vc, n = int(np.prod(i["Xc"])), 2 * i["Nvec"]
+        Y = np.zeros((8, Vc, n, n), dtype=np.complex64)
+        X = np.zeros((Vc, n, n), dtype=np.complex64)
+        lib().qudaAmdMultigridGetCoarseLinks(self.h, level, _vp(Y), _vp(X))
+        return Y, X
+
+    def apply(self, level, op, h_in):
+        """op 'R' (level -> level+1), 'P' (level+1 -> level), 'M' (operator of `level`); fields as (sites, spin, colour) complex64"""
+        i = self.level_info(level) if op != "M" or level < self.levels() - 1 else None
+        if i is None:
+            j = self.level_info(level - 1)
+            fine_shape = (int(np.prod(j["Xc"])), 2, j["Nvec"])
+            coarse_shape = None
+        else:
+            fine_shape = (int(np.prod(i["Xf"])), i["fineSpin"], i["fineColor"])
+            coarse_shape = (int(np.prod(i["Xc"])), 2, i["Nvec"])
+        shape_in, shape_out = {"R": (fine_shape, coarse_shape), "P": (coarse_shape, fine_shape), "M": (fine_shape, fine_shape)}[op]
+        h_in = np.ascontiguousarray(h_in, dtype=np.complex64).reshape(shape_in)
+        out = np.zeros(shape_out, dtype=np.complex64)
+        lib().qudaAmdMultigridApply(self.h, level, {"R": 0, "P": 1, "M": 2}[op], _vp(out), _vp(h_in))
+        return out
 
     def free(self):
         if self.h:

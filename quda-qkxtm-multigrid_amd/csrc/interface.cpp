@@ -494,6 +494,21 @@ void qudaAmdBlasCDot(const void *x, const void *y, double r[2]) {
   r[0] = c.real(); r[1] = c.imag();
 }
 void qudaAmdBlasAxpy(double a, const void *x, void *y) { blas::axpy(a, *(const ColorSpinorField *)x, *(ColorSpinorField *)y); }
+// device-event timed y += a x loop: the streaming-bandwidth yardstick printed beside the stencil numbers
+double qudaAmdTimeAxpy(double a, const void *x, void *y, int niter) {
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0));
+  HIP_CHECK(hipEventCreate(&e1));
+  HIP_CHECK(hipEventRecord(e0, computeStream()));
+  for (int i = 0; i < niter; i++) blas::axpy(a, *(const ColorSpinorField *)x, *(ColorSpinorField *)y);
+  HIP_CHECK(hipEventRecord(e1, computeStream()));
+  HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  HIP_CHECK(hipEventDestroy(e0));
+  HIP_CHECK(hipEventDestroy(e1));
+  return 1e-3 * ms / niter;
+}
 
 static DslashMode pcDslashMode(QudaInvertParam *inv) {
   const bool asym = inv->matpc_type == QUDA_MATPC_EVEN_EVEN_ASYMMETRIC || inv->matpc_type == QUDA_MATPC_ODD_ODD_ASYMMETRIC;

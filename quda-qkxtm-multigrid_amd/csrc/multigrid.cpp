@@ -330,7 +330,7 @@ multigrid_solver::multigrid_solver(QudaMultigridParam &mg_param) : d(nullptr), m
   param->mass = 0.5 / param->kappa - 4.0;
   DiracParam dp;
   setDiracPreParam(dp, param, false);
-  if (dp.clover && dp.clover->precision != QUDA_SINGLE_PRECISION) errorQuda("multigrid needs an fp32 precondition clover field");
+  if (param->dslash_type == QUDA_TWISTED_CLOVER_DSLASH && dp.clover && dp.clover->precision != QUDA_SINGLE_PRECISION) errorQuda("multigrid needs an fp32 precondition clover field");
   d = Dirac::create(dp);
   m = new DiracM(*d);
   if (mg_param.smoother_solve_type[0] == QUDA_DIRECT_PC_SOLVE) {

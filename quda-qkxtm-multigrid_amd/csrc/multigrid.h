@@ -65,6 +65,8 @@ class MG : public Solver {
   const Transfer *getTransfer() const { return transfer; }
   const DiracCoarse *getCoarseDirac() const { return diracCoarse; }
   MG *getCoarse() const { return coarse; }
+  const std::vector<ColorSpinorField *> &nullVectors() const { return mgp.B; }
+  DiracMatrix &residualMatrix() const { return mgp.matResidual; }
 };
 
 // opaque object handed out by newMultigridQuda (reference include/multigrid.h:375-411)

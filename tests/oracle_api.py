@@ -150,6 +150,59 @@ class Oracle:
     def norm2(self, a):
         return self.lib.qo_norm2_d(_p(a), C.c_long(a.size))
 
+    # -- multigrid pieces (oracle/qo_mg.c); complex128 arrays in the reference CPU orders
+    @staticmethod
+    def _c(a):
+        a = np.ascontiguousarray(a, dtype=np.complex128)
+        return a, a.ctypes.data_as(_dp)
+
+    def mg_block_orthogonalize(self, V, X, geo_bs, Ns, Nc, Nvec, spin_bs):
+        V, pv = self._c(np.array(V, dtype=np.complex128))
+        self.lib.qo_mg_block_orthogonalize(pv, _x(X), _x(geo_bs), Ns, Nc, Nvec, spin_bs)
+        return V
+
+    def mg_restrict(self, inp, V, X, geo_bs, Ns, Nc, Nvec, spin_bs):
+        Vc = int(np.prod(X)) // int(np.prod(geo_bs))
+        out = np.zeros((Vc, Ns // spin_bs, Nvec), dtype=np.complex128)
+        inp, pi = self._c(inp)
+        V, pv = self._c(V)
+        self.lib.qo_mg_restrict(out.ctypes.data_as(_dp), pi, pv, _x(X), _x(geo_bs), Ns, Nc, Nvec, spin_bs)
+        return out
+
+    def mg_prolongate(self, inp, V, X, geo_bs, Ns, Nc, Nvec, spin_bs):
+        out = np.zeros((int(np.prod(X)), Ns, Nc), dtype=np.complex128)
+        inp, pi = self._c(inp)
+        V, pv = self._c(V)
+        self.lib.qo_mg_prolongate(out.ctypes.data_as(_dp), pi, pv, _x(X), _x(geo_bs), Ns, Nc, Nvec, spin_bs)
+        return out
+
+    def mg_coarse_op_fine(self, V, gauge, clover, kappa, mu_tilde, X, geo_bs, Nvec):
+        Vc, n = int(np.prod(X)) // int(np.prod(geo_bs)), 2 * Nvec
+        Y = np.zeros((8, Vc, n, n), dtype=np.complex128)
+        Xm = np.zeros((Vc, n, n), dtype=np.complex128)
+        V, pv = self._c(V)
+        self.lib.qo_mg_coarse_op_fine(Y.ctypes.data_as(_dp), Xm.ctypes.data_as(_dp), pv, _g(gauge), _p(clover) if clover is not None else None,
+                                      C.c_double(kappa), C.c_double(mu_tilde), _x(X), _x(geo_bs), Nvec)
+        return Y, Xm
+
+    def mg_coarse_op_coarse(self, V, Yf, Xf, kappa, X, geo_bs, NcF, Nvec):
+        Vc, n = int(np.prod(X)) // int(np.prod(geo_bs)), 2 * Nvec
+        Y = np.zeros((8, Vc, n, n), dtype=np.complex128)
+        Xm = np.zeros((Vc, n, n), dtype=np.complex128)
+        V, pv = self._c(V)
+        Yf, py = self._c(Yf)
+        Xf, px = self._c(Xf)
+        self.lib.qo_mg_coarse_op_coarse(Y.ctypes.data_as(_dp), Xm.ctypes.data_as(_dp), pv, py, px, C.c_double(kappa), _x(X), _x(geo_bs), NcF, Nvec)
+        return Y, Xm
+
+    def mg_coarse_apply(self, inp, Y, Xm, kappa, Xc, Nvec):
+        inp, pi = self._c(inp)
+        Y, py = self._c(Y)
+        Xm, px = self._c(Xm)
+        out = np.zeros((int(np.prod(Xc)), 2, Nvec), dtype=np.complex128)
+        self.lib.qo_mg_coarse_apply(out.ctypes.data_as(_dp), pi, py, px, C.c_double(kappa), _x(Xc), Nvec)
+        return out
+
 
 def build():
     subprocess.check_call(["make", "-s", "-C", ODIR, "liboracle.so"])

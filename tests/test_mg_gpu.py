@@ -100,3 +100,56 @@ def test_restrictor_prolongator_are_adjoint(qa):
         assert np.linalg.norm(r) < 0.5 * np.linalg.norm(b)  # one V-cycle is a contraction on a random right-hand side
     finally:
         mg.free()
+
+
+def test_hierarchy_against_oracle_restatement(qa, oracle):
+    """Every piece of a 3-level hierarchy against the CPU restatement of the reference's algorithms (oracle/qo_mg.c):
+    block Gram-Schmidt of the device's own null vectors, the Galerkin links (calculateY, both the fine and the
+    from-coarse variants), R, P and the coarse operator apply.  fp32 device arithmetic vs fp64 oracle; tolerances are
+    relative to the largest element: 2e-5 for single kernels, 2e-4 after the 8-deep Gram-Schmidt recursion."""
+    X, kappa, mu = (8, 8, 8, 16), 0.124, 0.005
+    gauge, ip = _setup(qa, X, kappa, mu)
+    nvec = [8, 8]
+    mp = qa.multigrid_param(ip, n_level=3, geo_block=[(4, 4, 4, 4), (1, 1, 1, 2), (2, 2, 2, 2)], n_vec=8, setup_maxiter=100, setup_tol=1e-4)
+    mg = qa.Multigrid(mp)
+    rng = np.random.default_rng(17)
+
+    def rel(a, b):
+        return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+    try:
+        assert mg.levels() == 3
+        Yprev = Xprev = None
+        for level in range(2):
+            i = mg.level_info(level)
+            Xf, Xc, bs, Ns, Nc, Nv, sbs = i["Xf"], i["Xc"], i["geo_bs"], i["fineSpin"], i["fineColor"], i["Nvec"], i["spin_bs"]
+            assert Nv == nvec[level] and [Xf[d] // bs[d] for d in range(4)] == Xc
+            # block orthonormalisation of the device's null vectors (lib/transfer_util.cu:168-363)
+            B = np.stack([mg.null_vector(level, k) for k in range(Nv)], axis=-1)
+            Vd = mg.V(level).astype(np.complex128)
+            Vo = oracle.mg_block_orthogonalize(B, Xf, bs, Ns, Nc, Nv, sbs)
+            assert rel(Vd, Vo) < 2e-4, (level, rel(Vd, Vo))
+            # R and P with the device's V (lib/restrictor.cu:51-125, lib/prolongator.cu:42-116)
+            phi = (rng.standard_normal((int(np.prod(Xf)), Ns, Nc)) + 1j * rng.standard_normal((int(np.prod(Xf)), Ns, Nc)))
+            eta = (rng.standard_normal((int(np.prod(Xc)), 2, Nv)) + 1j * rng.standard_normal((int(np.prod(Xc)), 2, Nv)))
+            assert rel(mg.apply(level, "R", phi), oracle.mg_restrict(phi, Vd, Xf, bs, Ns, Nc, Nv, sbs)) < 2e-5
+            assert rel(mg.apply(level, "P", eta), oracle.mg_prolongate(eta, Vd, Xf, bs, Ns, Nc, Nv, sbs)) < 2e-5
+            # Galerkin links (lib/coarse_op.cuh:1310-1498); the device stores -kappa Y
+            Yd, Xd = mg.coarse_links(level)
+            if level == 0:
+                Yo, Xo = oracle.mg_coarse_op_fine(Vd, gauge, None, kappa, 2 * kappa * mu, Xf, bs, Nv)
+            else:
+                Yo, Xo = oracle.mg_coarse_op_coarse(Vd, Yprev, Xprev, kappa, Xf, bs, Nc, Nv)
+            assert rel(Xd, Xo) < 2e-5, (level, rel(Xd, Xo))
+            assert rel(Yd, -kappa * Yo) < 2e-5, (level, rel(Yd, -kappa * Yo))
+            # coarse operator apply (lib/dslash_coarse.cu:50-290) with the device's own links
+            Yref = Yd.astype(np.complex128) / (-kappa)
+            want = oracle.mg_coarse_apply(eta, Yref, Xd.astype(np.complex128), kappa, Xc, Nv)
+            assert rel(mg.apply(level + 1, "M", eta), want) < 2e-5
+            Yprev, Xprev = Yref, Xd.astype(np.complex128)
+        # the level-0 operator of the hierarchy is the oracle's tm_mat
+        phi = rng.standard_normal((int(np.prod(X)), 4, 3)) + 1j * rng.standard_normal((int(np.prod(X)), 4, 3))
+        want = oracle.tm_mat(gauge, np.ascontiguousarray(phi).view(np.float64).reshape(-1), list(X), kappa, mu, +1, 0).view(np.complex128).reshape(-1, 4, 3)
+        assert rel(mg.apply(0, "M", phi), want) < 2e-5
+    finally:
+        mg.free()

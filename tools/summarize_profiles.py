@@ -17,7 +17,7 @@ import sys
 
 
 def counters(d):
-    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     agg = collections.defaultdict(list)
     for path in f:
         for r in csv.DictReader(open(path)):
@@ -28,7 +28,7 @@ def counters(d):
 def main():
     tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
     os.makedirs("profiles", exist_ok=True)
-    st = glob.glob(os.path.join(stats_dir, "*", "*kernel_stats.csv"))
+    st = glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True)
     if st:
         shutil.copy(st[0], "profiles/%s_kernel_stats.csv" % tag)
     fetch, write = counters(fetch_dir), counters(write_dir)
