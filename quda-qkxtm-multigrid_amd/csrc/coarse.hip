@@ -5,6 +5,7 @@
 // broadcast from LDS; partial rows are combined through LDS.  Per site 9 (2Nc)^2 complex = 166 KB for Nc = 24 are read
 // exactly once: HBM-bound at ~1 flop/byte for a single right-hand side, so plain FMAs, not MFMA.
 #include "coarse.h"
+#include "halo.h"
 
 #include "blas.h"
 
@@ -32,6 +33,11 @@ struct CoarseArg {
   const float4 *G;
   int Xc[4];
   int n, mmask, parity, nwork;
+  // grid-decomposed lattice: ghost[m] = the neighbour rank's face needed by hop m (full coarse spinors, both or one
+  // parity, [q][component][face site] float2); commMask bit mu = dimension mu is partitioned
+  const float2 *ghost[8];
+  int faceCB[4];
+  int commMask, ghostSingle;
 };
 
 template <int NMAX>
@@ -60,11 +66,25 @@ __global__ void __launch_bounds__(256) coarse_apply_kernel(const CoarseArg arg) 
       cn[mu] = (m & 1) ? (c[mu] == 0 ? L - 1 : c[mu] - 1) : (c[mu] == L - 1 ? 0 : c[mu] + 1);
       npar = (cn[0] + cn[1] + cn[2] + cn[3]) & 1;
     }
-    const int nx = (((cn[3] * arg.Xc[2] + cn[2]) * arg.Xc[1] + cn[1]) * arg.Xc[0] + cn[0]) >> 1;
-    const float *src = arg.in.v[npar];
-    for (int j = threadIdx.x; j < n; j += blockDim.x) {
-      const float *p = src + ((size_t)j * arg.in.stride + nx) * 2;
-      xin[m][j] = make_float2(p[0], p[1]);
+    bool cross = false;
+    if (m < 8 && ((arg.commMask >> (m >> 1)) & 1)) {
+      const int mu = m >> 1;
+      cross = (m & 1) ? c[mu] == 0 : c[mu] == arg.Xc[mu] - 1;
+    }
+    if (cross) {
+      const int mu = m >> 1;
+      int l = 0, mul = 1;
+      for (int k = 0; k < 4; k++) if (k != mu) { l += cn[k] * mul; mul *= arg.Xc[k]; }
+      const int f = l >> 1, q = arg.ghostSingle ? 0 : npar;
+      const float2 *src = arg.ghost[m] + (size_t)q * n * arg.faceCB[mu] + f;
+      for (int j = threadIdx.x; j < n; j += blockDim.x) xin[m][j] = src[(size_t)j * arg.faceCB[mu]];
+    } else {
+      const int nx = (((cn[3] * arg.Xc[2] + cn[2]) * arg.Xc[1] + cn[1]) * arg.Xc[0] + cn[0]) >> 1;
+      const float *src = arg.in.v[npar];
+      for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        const float *p = src + ((size_t)j * arg.in.stride + nx) * 2;
+        xin[m][j] = make_float2(p[0], p[1]);
+      }
     }
   }
   __syncthreads();
@@ -92,6 +112,96 @@ __global__ void __launch_bounds__(256) coarse_apply_kernel(const CoarseArg arg) 
   }
 }
 
+// ---- ghost zones of coarse fields (reference: full coarse spinors exchanged blocking, lib/dslash_coarse.cu:68-137, :707) ----
+struct CoarseGhost {
+  int Xc[4], n;
+  int faceCB[4];
+  float2 *pool;
+  float2 *send[4][2], *ghost[4][2];   // [mu][0: x_mu = 0 face / from the -mu neighbour, 1: x_mu = L-1 face / from the +mu neighbour]
+};
+static std::vector<CoarseGhost> g_cghosts;
+void freeCoarseGhosts() {
+  for (CoarseGhost &c : g_cghosts) if (c.pool) (void)hipFree(c.pool);
+  g_cghosts.clear();
+}
+static CoarseGhost &coarseGhost(const int Xc[4], int n) {
+  for (CoarseGhost &c : g_cghosts)
+    if (c.n == n && c.Xc[0] == Xc[0] && c.Xc[1] == Xc[1] && c.Xc[2] == Xc[2] && c.Xc[3] == Xc[3]) return c;
+  CoarseGhost c;
+  c.n = n;
+  size_t total = 0;
+  const int Vh = Xc[0] * Xc[1] * Xc[2] * Xc[3] / 2;
+  for (int d = 0; d < 4; d++) { c.Xc[d] = Xc[d]; c.faceCB[d] = Vh / Xc[d]; total += (size_t)4 * 2 * n * c.faceCB[d]; }
+  HIP_CHECK(hipMalloc((void **)&c.pool, total * sizeof(float2)));
+  HIP_CHECK(hipMemsetAsync(c.pool, 0, total * sizeof(float2), computeStream()));
+  float2 *p = c.pool;
+  for (int d = 0; d < 4; d++)
+    for (int k = 0; k < 2; k++) { c.send[d][k] = p; p += (size_t)2 * n * c.faceCB[d]; c.ghost[d][k] = p; p += (size_t)2 * n * c.faceCB[d]; }
+  g_cghosts.push_back(c);
+  return g_cghosts.back();
+}
+
+struct CoarsePackArg {
+  CVec in;
+  float2 *send[8];   // slot 2 mu + (0: x_mu = 0 face, 1: x_mu = L-1 face); nullptr = not packed
+  int start[9];
+  int Xc[4], faceCB[4];
+  int n, single;     // single >= 0: only that parity of `in` exists
+};
+__global__ void __launch_bounds__(256) coarse_pack_kernel(const CoarsePackArg arg) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= arg.start[8]) return;
+  int slot = 0;
+  for (int k = 1; k < 8; k++) slot += tid >= arg.start[k];
+  const int mu = slot >> 1, nf = arg.faceCB[mu];
+  const int local = tid - arg.start[slot];
+  const int q = local / nf, f = local - q * nf;
+  const int par = arg.single >= 0 ? arg.single : q;
+  int c[4], L[3], o[3], k3 = 0;
+  for (int k = 0; k < 4; k++) if (k != mu) { L[k3] = arg.Xc[k]; o[k3] = k; k3++; }
+  int l = 2 * f;
+  const int c0 = l % L[0]; l /= L[0];
+  const int c1 = l % L[1]; const int c2 = l / L[1];
+  c[mu] = (slot & 1) ? arg.Xc[mu] - 1 : 0;
+  c[o[0]] = c0; c[o[1]] = c1; c[o[2]] = c2;
+  c[o[0]] += (par + c[0] + c[1] + c[2] + c[3]) & 1;
+  const int idx = (((c[3] * arg.Xc[2] + c[2]) * arg.Xc[1] + c[1]) * arg.Xc[0] + c[0]) >> 1;
+  const float2 *src = reinterpret_cast<const float2 *>(arg.in.v[par]) + idx;
+  float2 *dst = arg.send[slot] + (size_t)q * arg.n * nf + f;
+  for (int j = 0; j < arg.n; j++) dst[(size_t)j * nf] = src[(size_t)j * arg.in.stride];
+}
+
+// exchange the faces of `in` the masked hops need; fills arg.ghost / commMask
+static void exchangeCoarseGhost(CoarseArg &arg, const CoarseGauge &G, int single) {
+  arg.commMask = 0; arg.ghostSingle = single >= 0;
+  for (int m = 0; m < 8; m++) arg.ghost[m] = nullptr;
+  int mask = 0;
+  for (int d = 0; d < 4; d++) if (commGrid().partitioned(d) && ((arg.mmask >> (2 * d)) & 3)) mask |= 1 << d;
+  for (int d = 0; d < 4; d++) arg.faceCB[d] = G.nSites / 2 / G.Xc[d];
+  if (!mask) return;
+  CoarseGhost &cg = coarseGhost(G.Xc, G.n);
+  CoarsePackArg pa;
+  pa.in = arg.in; pa.n = G.n; pa.single = single;
+  const int nq = single >= 0 ? 1 : 2;
+  int nt = 0;
+  std::vector<HaloMsg> msgs;
+  for (int d = 0; d < 4; d++) {
+    pa.Xc[d] = G.Xc[d]; pa.faceCB[d] = cg.faceCB[d];
+    const size_t bytes = (size_t)nq * G.n * cg.faceCB[d] * sizeof(float2);
+    // hop 2d (forward) reads the +d neighbour's x_d = 0 face: every rank sends that face backward
+    const bool needFwd = ((mask >> d) & 1) && ((arg.mmask >> (2 * d)) & 1), needBwd = ((mask >> d) & 1) && ((arg.mmask >> (2 * d + 1)) & 1);
+    pa.send[2 * d] = cg.send[d][0]; pa.start[2 * d] = nt; if (needFwd) nt += nq * cg.faceCB[d];
+    pa.send[2 * d + 1] = cg.send[d][1]; pa.start[2 * d + 1] = nt; if (needBwd) nt += nq * cg.faceCB[d];
+    if (needBwd) { msgs.push_back({d, +1, cg.send[d][1], cg.ghost[d][0], bytes}); arg.ghost[2 * d + 1] = cg.ghost[d][0]; }
+    if (needFwd) { msgs.push_back({d, -1, cg.send[d][0], cg.ghost[d][1], bytes}); arg.ghost[2 * d] = cg.ghost[d][1]; }
+  }
+  pa.start[8] = nt;
+  hipLaunchKernelGGL(coarse_pack_kernel, dim3((nt + 255) / 256), dim3(256), 0, computeStream(), pa);
+  HIP_CHECK(hipGetLastError());
+  commExchange(msgs, computeStream());
+  arg.commMask = mask;
+}
+
 void applyCoarse(ColorSpinorField &out, const ColorSpinorField &in, const CoarseGauge &G, int mmask, int parity) {
   if (out.Precision() != QUDA_SINGLE_PRECISION || in.Precision() != QUDA_SINGLE_PRECISION) errorQuda("coarse operator is fp32");
   if (in.Nspin() != 2 || 2 * in.Ncolor() != G.n) errorQuda("coarse field (%d spins, %d colours) does not match the operator (n = %d)", in.Nspin(), in.Ncolor(), G.n);
@@ -116,6 +226,7 @@ void applyCoarse(ColorSpinorField &out, const ColorSpinorField &in, const Coarse
   arg.G = (const float4 *)G.data;
   for (int d = 0; d < 4; d++) arg.Xc[d] = G.Xc[d];
   arg.n = G.n; arg.mmask = mmask; arg.parity = parity;
+  exchangeCoarseGhost(arg, G, parity < 0 ? -1 : 1 - parity);
   hipLaunchKernelGGL((coarse_apply_kernel<64>), dim3(arg.nwork), dim3(256), 0, computeStream(), arg);
   HIP_CHECK(hipGetLastError());
 }

@@ -312,7 +312,8 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
 
 // ---- single-direction hop (setup-time helper for the multigrid coarse-operator construction) ----
 template <typename T, int R>
-__global__ void __launch_bounds__(256) hop_dir_kernel(const DslashArg<typename Store<T>::real> arg, int dir, typename Store<T>::real coef) {
+__global__ void __launch_bounds__(256) hop_dir_kernel(const DslashArg<typename Store<T>::real> arg, int dir, typename Store<T>::real coef,
+                                                      const void *ghost, int ghostFaceCB) {
   using real = typename Store<T>::real;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= arg.Vh) return;
@@ -339,7 +340,21 @@ __global__ void __launch_bounds__(256) hop_dir_kernel(const DslashArg<typename S
   real acc[24], psi[24], U[18];
 #pragma unroll
   for (int k = 0; k < 24; k++) acc[k] = 0;
-  Planar<T, 24>::load(psi, arg.in, arg.sp_stride, nbr, arg.inNorm, nbr);
+  // grid-decomposed direction: the neighbour of a face site lives on the adjacent rank; its full spinor was exchanged into
+  // `ghost` (face index = lexicographic index of the other three coordinates, halved — same convention as pack_kernel)
+  bool cross = false;
+  int f = 0;
+  if (ghost) {
+    const int xf = 2 * xh + xodd, X0 = 2 * Xh;
+    switch (dir >> 1) {
+      case 0: cross = (dir & 1) ? xf == 0 : xf == X0 - 1; f = (y + arg.Y * (z + arg.Z * t)) >> 1; break;
+      case 1: cross = (dir & 1) ? y == 0 : y == arg.Y - 1; f = (xf + X0 * (z + arg.Z * t)) >> 1; break;
+      case 2: cross = (dir & 1) ? z == 0 : z == arg.Z - 1; f = (xf + X0 * (y + arg.Y * t)) >> 1; break;
+      default: cross = (dir & 1) ? t == 0 : t == arg.T - 1; f = (xf + X0 * (y + arg.Y * z)) >> 1; break;
+    }
+  }
+  if (cross) Planar<T, 24>::load(psi, ghost, ghostFaceCB, f, nullptr, f);
+  else Planar<T, 24>::load(psi, arg.in, arg.sp_stride, nbr, arg.inNorm, nbr);
   Link<T, R>::load(U, arg.gauge + (size_t)dir * arg.link_bytes, arg.g_stride, idx, sign);
   switch (dir) {
     case 0: hop_compute<T, 0, false, false>(acc, psi, U, arg); break;
@@ -495,9 +510,13 @@ HaloBuffers &haloBuffers(const LatticeGeom &g, QudaPrecision prec) {
     for (int dir = 0; dir < 2; dir++) { h.send[d][dir] = p; p += h.face_bytes[d]; h.ghost[d][dir] = p; p += h.face_bytes[d]; }
   return h;
 }
+void freeFullFaceBuffers();
+void freeCoarseGhosts();  // coarse.hip
 void freeHaloBuffers() {
   for (HaloBuffers &h : g_halo) { if (h.pool) (void)hipFree(h.pool); h = HaloBuffers(); }
   freeBoundaryLists();
+  freeFullFaceBuffers();
+  freeCoarseGhosts();
 }
 
 const BoundaryList &boundaryList(const LatticeGeom &g, int mask) {
@@ -671,6 +690,36 @@ void applyDslash(ColorSpinorField &out, const ColorSpinorField &in, const GaugeF
   }
 }
 
+// full (unprojected) spinors of the face x_d = face_coord of the parity_in checkerboard -> planar block of stride faceCB
+template <typename T>
+__global__ void __launch_bounds__(256) face_full_pack_kernel(void *dst, const void *in, const float *inNorm, int sp_stride, int X0, int X1, int X2, int X3,
+                                                             int d, int face_coord, int parity_in, int faceCB) {
+  using real = typename Store<T>::real;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= faceCB) return;
+  const int X[4] = {X0, X1, X2, X3};
+  int c[4], L[3], o[3], n = 0;
+  for (int k = 0; k < 4; k++) if (k != d) { L[n] = X[k]; o[n] = k; n++; }
+  int l = 2 * f;
+  const int c0 = l % L[0]; l /= L[0];
+  const int c1 = l % L[1]; const int c2 = l / L[1];
+  c[d] = face_coord;
+  c[o[0]] = c0; c[o[1]] = c1; c[o[2]] = c2;
+  c[o[0]] += (parity_in + c[0] + c[1] + c[2] + c[3]) & 1;
+  const int idx = (((c[3] * X[2] + c[2]) * X[1] + c[1]) * X[0] + c[0]) >> 1;
+  real psi[24];
+  Planar<T, 24>::load(psi, in, sp_stride, idx, inNorm, idx);
+  Planar<T, 24>::store(psi, dst, faceCB, f, nullptr, f);
+}
+
+static char *g_ffSend = nullptr, *g_ffGhost = nullptr;
+static size_t g_ffBytes = 0;
+void freeFullFaceBuffers() {
+  if (g_ffSend) (void)hipFree(g_ffSend);
+  if (g_ffGhost) (void)hipFree(g_ffGhost);
+  g_ffSend = g_ffGhost = nullptr; g_ffBytes = 0;
+}
+
 template <typename T, int R> static void launchHopDir(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, int parity, int dir, double coef) {
   using real = typename Store<T>::real;
   DslashArg<real> arg;
@@ -684,16 +733,37 @@ template <typename T, int R> static void launchHopDir(ColorSpinorField &out, con
   arg.Vh = g.Vh; arg.Xh = g.Xh; arg.Y = g.X[1]; arg.Z = g.X[2]; arg.T = g.X[3];
   arg.dXh = g.dXh; arg.dY = g.dY; arg.dZ = g.dZ;
   arg.parity = parity; arg.sfwd = 1;
-  arg.tsign_fwd = (R == 12 && U.t_boundary == QUDA_ANTI_PERIODIC_T) ? -1 : 1;
-  arg.tsign_bwd = arg.tsign_fwd;
-  hipLaunchKernelGGL((hop_dir_kernel<T, R>), dim3((g.Vh + 255) / 256), dim3(256), 0, computeStream(), arg, dir, (real)coef);
+  const bool first_t = commGrid().coords[3] == 0, last_t = commGrid().coords[3] == commGrid().dims[3] - 1;
+  arg.tsign_fwd = (R == 12 && U.t_boundary == QUDA_ANTI_PERIODIC_T && last_t) ? -1 : 1;
+  arg.tsign_bwd = (R == 12 && U.t_boundary == QUDA_ANTI_PERIODIC_T && first_t) ? -1 : 1;
+  const int mu = dir >> 1;
+  const void *ghost = nullptr;
+  if (commGrid().partitioned(mu)) {
+    // a forward hop needs the x_mu = 0 face of the +mu neighbour (it sends it backward), a backward hop the x_mu = L-1 face
+    // of the -mu neighbour; setup-time path, so one blocking exchange on the compute stream
+    const size_t bytes = (size_t)g.faceCB[mu] * 24 * sizeof(real);
+    if (bytes > g_ffBytes) {
+      freeFullFaceBuffers();
+      HIP_CHECK(hipMalloc((void **)&g_ffSend, bytes));
+      HIP_CHECK(hipMalloc((void **)&g_ffGhost, bytes));
+      g_ffBytes = bytes;
+    }
+    const bool fwd = !(dir & 1);
+    hipLaunchKernelGGL((face_full_pack_kernel<T>), dim3((g.faceCB[mu] + 255) / 256), dim3(256), 0, computeStream(), (void *)g_ffSend, in.V(), (const float *)in.Norm(),
+                       in.Stride(), g.X[0], g.X[1], g.X[2], g.X[3], mu, fwd ? 0 : g.X[mu] - 1, 1 - parity, g.faceCB[mu]);
+    HIP_CHECK(hipGetLastError());
+    std::vector<HaloMsg> msgs;
+    msgs.push_back({mu, fwd ? -1 : +1, g_ffSend, g_ffGhost, bytes});
+    commExchange(msgs, computeStream());
+    ghost = g_ffGhost;
+  }
+  hipLaunchKernelGGL((hop_dir_kernel<T, R>), dim3((g.Vh + 255) / 256), dim3(256), 0, computeStream(), arg, dir, (real)coef, ghost, g.faceCB[mu]);
   HIP_CHECK(hipGetLastError());
 }
 
 void applyHopDir(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, int parity, int dir, double coef) {
   if (in.Precision() != out.Precision() || in.Precision() != U.precision) errorQuda("precision mismatch");
   if (in.VolumeCB() != U.geom.Vh) errorQuda("volume mismatch");
-  for (int d = 0; d < 4; d++) if (commGrid().partitioned(d)) errorQuda("multigrid setup on a grid-decomposed lattice is not built yet (single-GPU hierarchy only)");
   const bool r12 = U.reconstruct == QUDA_RECONSTRUCT_12;
   switch (in.Precision()) {
     case QUDA_DOUBLE_PRECISION: r12 ? launchHopDir<double, 12>(out, in, U, parity, dir, coef) : launchHopDir<double, 18>(out, in, U, parity, dir, coef); break;

@@ -319,7 +319,6 @@ multigrid_solver::multigrid_solver(QudaMultigridParam &mg_param) : d(nullptr), m
   GaugeField *g = gaugePrecondition ? gaugePrecondition : (gaugeSloppy ? gaugeSloppy : gaugePrecise);
   if (!g) errorQuda("Gauge field not allocated");
   if (g->precision != QUDA_SINGLE_PRECISION) errorQuda("the multigrid hierarchy runs in fp32: load the gauge field with cuda_prec_precondition = QUDA_SINGLE_PRECISION (got %d)", g->precision);
-  for (int dd = 0; dd < 4; dd++) if (commGrid().partitioned(dd)) errorQuda("multigrid on a grid-decomposed lattice is not built yet");
   mg_param.secs = 0; mg_param.gflops = 0;
   const double t0 = now();
 

@@ -102,12 +102,18 @@ def test_restrictor_prolongator_are_adjoint(qa):
         mg.free()
 
 
-def test_hierarchy_against_oracle_restatement(qa, oracle):
-    """Every piece of a 3-level hierarchy against the CPU restatement of the reference's algorithms (oracle/qo_mg.c):
+@pytest.mark.parametrize("mask", [0, 15, 9], ids=["unpartitioned", "self-neighbour-xyzt", "self-neighbour-xt"])
+def test_hierarchy_against_oracle_restatement(qa, oracle, mask):
+    """mask != 0: every dimension in the mask is treated as grid-decomposed with the process as its own neighbour, so
+    the Galerkin probing (ghost-aware single-direction hops), the coarse-operator halo exchange and the solver's
+    global reductions run through the multi-rank code path and must reproduce the same hierarchy.
+
+    Every piece of a 3-level hierarchy against the CPU restatement of the reference's algorithms (oracle/qo_mg.c):
     block Gram-Schmidt of the device's own null vectors, the Galerkin links (calculateY, both the fine and the
     from-coarse variants), R, P and the coarse operator apply.  fp32 device arithmetic vs fp64 oracle; tolerances are
     relative to the largest element: 2e-5 for single kernels, 2e-4 after the 8-deep Gram-Schmidt recursion."""
     X, kappa, mu = (8, 8, 8, 16), 0.124, 0.005
+    qa.lib().qudaAmdSetPartitionMask(mask)
     gauge, ip = _setup(qa, X, kappa, mu)
     nvec = [8, 8]
     mp = qa.multigrid_param(ip, n_level=3, geo_block=[(4, 4, 4, 4), (1, 1, 1, 2), (2, 2, 2, 2)], n_vec=8, setup_maxiter=100, setup_tol=1e-4)
@@ -151,5 +157,14 @@ def test_hierarchy_against_oracle_restatement(qa, oracle):
         phi = rng.standard_normal((int(np.prod(X)), 4, 3)) + 1j * rng.standard_normal((int(np.prod(X)), 4, 3))
         want = oracle.tm_mat(gauge, np.ascontiguousarray(phi).view(np.float64).reshape(-1), list(X), kappa, mu, +1, 0).view(np.complex128).reshape(-1, 4, 3)
         assert rel(mg.apply(0, "M", phi), want) < 2e-5
+        # and the preconditioned solve through the same (possibly partitioned) path
+        b = rng.random(int(np.prod(X)) * 24)
+        ip.inv_type_precondition = qa.QUDA_MG_INVERTER
+        ip.preconditioner = mg.h
+        ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
+        x = qa.invert(b, ip)
+        assert _true_residual(oracle, gauge, X, kappa, mu, x, b) < 5e-10
+        assert ip.iter < 40, ip.iter
     finally:
         mg.free()
+        qa.lib().qudaAmdSetPartitionMask(0)

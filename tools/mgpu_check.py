@@ -93,6 +93,44 @@ def main():
         # (xg holds only this rank's piece; the oracle result is exact on sites whose 8 neighbours are local)
         if rank == 0:
             print("OK lattice %s grid %s: dslash/mat/matpc parity in 3 precisions; GCR %d iterations, global |r|/|b| = %.2e" % (X, grid, ip.iter, rel))
+        # ---- multigrid on the decomposed lattice: ghost-aware Galerkin probing, coarse halo exchange, global reductions ----
+        from synth import smooth_gauge
+        kmg, mumg = 0.124, 0.005
+        gs = smooth_gauge(X, 0.35)
+        gs_loc = mg.scatter_gauge(gs, X, grid, dist.coords)
+        qa.load_gauge(gs_loc, qa.gauge_param(Xl, cuda_prec=8, prec_sloppy=4, prec_precondition=4, t_boundary=qa.QUDA_PERIODIC_T))
+        ipm = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kmg, mumg, +1, "ee", 0, cuda_prec=8, prec_sloppy=4, prec_precondition=4,
+                              solution_type=qa.QUDA_MAT_SOLUTION)
+        ipm.solve_type = qa.QUDA_DIRECT_SOLVE
+        ipm.inv_type = qa.QUDA_GCR_INVERTER
+        ipm.gcrNkrylov = 20
+        ipm.tol = 1e-10
+        ipm.maxiter = 2000
+        ipm.reliable_delta = 1e-4
+        bg = np.random.default_rng(5).random(spinor.size)
+        bm_loc = mg.scatter_field(bg, X, grid, dist.coords, 24)
+        ipm.inv_type_precondition = qa.QUDA_INVALID_ENUM
+        qa.invert(bm_loc, ipm)
+        it_plain = ipm.iter
+        for pc in (False, True):
+            mp = qa.multigrid_param(ipm, n_level=2, geo_block=(4, 4, 4, 4), n_vec=8, setup_maxiter=300, setup_tol=1e-5, smoother_pc=pc)
+            h = qa.Multigrid(mp)
+            dev = h.verify()
+            assert max(dev) < 1e-4, ("mg verify", X, grid, dev)
+            ipm.inv_type_precondition = qa.QUDA_MG_INVERTER
+            ipm.preconditioner = h.h
+            ipm.tol_precondition, ipm.maxiter_precondition, ipm.precondition_cycle, ipm.omega = 1e-1, 1, 1, 1.0
+            xm_loc = qa.invert(bm_loc, ipm)
+            res = bm_loc - qa.mat(xm_loc, ipm)
+            n2 = np.array([np.dot(res, res), np.dot(bm_loc, bm_loc)])
+            qa.lib().qudaAmdCommAllreduce(n2.ctypes.data_as(C.POINTER(C.c_double)), 2)
+            relm = float(np.sqrt(n2[0] / n2[1]))
+            assert relm < 5e-10 and ipm.iter < it_plain // 2, ("mg-gcr", X, grid, relm, ipm.iter, it_plain)
+            if rank == 0:
+                print("OK lattice %s grid %s: MG-GCR (pc smoother %s) %d iterations (plain GCR %d), verify %.1e %.1e %.1e, global |r|/|b| = %.2e"
+                      % (X, grid, pc, ipm.iter, it_plain, dev[0], dev[1], dev[2], relm), flush=True)
+            ipm.inv_type_precondition = qa.QUDA_INVALID_ENUM
+            h.free()
         oracle.set_threads(1)
         dist.finalize()
     print("rank %d: all checks passed" % rank)
