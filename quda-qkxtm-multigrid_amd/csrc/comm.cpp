@@ -19,6 +19,7 @@
 #include "blas.h"
 #include "halo.h"
 #include "interface_internal.h"
+#include "p2p.h"
 #include "quda_amd_ext.h"
 
 namespace quda {
@@ -30,6 +31,10 @@ static ncclComm_t g_nccl = nullptr;
 // order / per-peer FIFO matching as the RCCL path, so neighbour maps, face ordering and the two-ranks-per-dimension case
 // are exercised end to end.  Never used unless the environment variable is set. ----
 static bool g_shm = false;
+// QUDA_AMD_RCCL_SELFTEST=1 with a one-rank communicator: self-neighbour messages and reductions go through the real
+// ncclSend/ncclRecv/ncclAllReduce calls (peer = own rank) instead of the local shortcuts, so the RCCL call sequence of
+// the multi-GPU path can be validated on a one-GPU box
+static bool g_rccl_self = false;
 static std::string g_shm_dir;
 static std::vector<unsigned long> g_seq_send, g_seq_recv;
 static unsigned long g_seq_red = 0;
@@ -102,6 +107,8 @@ void commFinalize() {
   freeHaloBuffers();
   if (g_nccl) { (void)ncclCommDestroy(g_nccl); g_nccl = nullptr; }
   g_shm = false;
+  g_rccl_self = false;
+  p2pReset();
   CommGrid &g = commGrid();
   g.rank = 0; g.size = 1;
   for (int d = 0; d < 4; d++) { g.dims[d] = 1; g.coords[d] = 0; g.forced[d] = false; }
@@ -131,7 +138,7 @@ static void shmAllreduce(double *data, int n, bool is_max) {
 }
 
 void commAllreduceDevice(double *d_data, int n, hipStream_t s) {
-  if (commGrid().size == 1) return;
+  if (commGrid().size == 1 && !g_rccl_self) return;
   if (g_shm) {
     double h[64];
     HIP_CHECK(hipMemcpyAsync(h, d_data, n * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -145,7 +152,7 @@ void commAllreduceDevice(double *d_data, int n, hipStream_t s) {
 }
 
 static void hostAllreduce(double *data, int n, ncclRedOp_t op) {
-  if (commGrid().size == 1) return;
+  if (commGrid().size == 1 && !g_rccl_self) return;
   if (n > 64) errorQuda("allreduce of %d doubles exceeds the scratch buffer", n);
   if (g_shm) { shmAllreduce(data, n, op == ncclMax); return; }
   ensureScratch();
@@ -160,13 +167,34 @@ static void hostAllreduce(double *data, int n, ncclRedOp_t op) {
 void comm_allreduce(double *data, int n) { hostAllreduce(data, n, ncclSum); }
 void comm_allreduce_max(double *data, int n) { hostAllreduce(data, n, ncclMax); }
 
+// every rank contributes n bytes; all[r*n ..] = rank r's blob (IPC handles of the peer-mapped halo windows)
+void commAllgatherBytes(const void *mine, void *all, size_t n) {
+  const CommGrid &g = commGrid();
+  if (g.size == 1) { memcpy(all, mine, n); return; }
+  if (g_shm) {
+    static unsigned long seq = 0;
+    const unsigned long q = seq++;
+    shmWrite("ag_" + std::to_string(q) + "_" + std::to_string(g.rank), mine, n);
+    for (int r = 0; r < g.size; r++) shmRead("ag_" + std::to_string(q) + "_" + std::to_string(r), (char *)all + (size_t)r * n, n, false);
+    return;
+  }
+  char *d = nullptr;
+  HIP_CHECK(hipMalloc((void **)&d, n * (g.size + 1)));
+  hipStream_t s = computeStream();
+  HIP_CHECK(hipMemcpyAsync(d, mine, n, hipMemcpyHostToDevice, s));
+  NCCL_CHECK(ncclAllGather(d, d + n, n, ncclChar, g_nccl, s));
+  HIP_CHECK(hipMemcpyAsync(all, d + n, n * g.size, hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipStreamSynchronize(s));
+  HIP_CHECK(hipFree(d));
+}
+
 // ---- neighbour exchange: all (dim, dir) messages of one halo in a single RCCL group ----
 void commExchange(const std::vector<HaloMsg> &msgs, hipStream_t s) {
   const CommGrid &g = commGrid();
   bool remote = false;
   for (const HaloMsg &m : msgs) {
     const int to = commNeighborRank(m.dim, m.dir), from = commNeighborRank(m.dim, -m.dir);
-    if (to == g.rank && from == g.rank) {
+    if (to == g.rank && from == g.rank && !g_rccl_self) {
       // self neighbour (unpartitioned-but-forced dimension): the message lands in this rank's own ghost zone
       HIP_CHECK(hipMemcpyAsync(m.recv, m.send, m.bytes, hipMemcpyDeviceToDevice, s));
     } else {
@@ -200,12 +228,12 @@ void commExchange(const std::vector<HaloMsg> &msgs, hipStream_t s) {
   // along a dimension both neighbours are the same peer and RCCL matches messages to one peer in posting order
   for (const HaloMsg &m : msgs) {
     const int to = commNeighborRank(m.dim, m.dir);
-    if (to == g.rank) continue;
+    if (to == g.rank && !g_rccl_self) continue;
     NCCL_CHECK(ncclSend(m.send, m.bytes, ncclChar, to, g_nccl, s));
   }
   for (const HaloMsg &m : msgs) {
     const int from = commNeighborRank(m.dim, -m.dir);
-    if (from == g.rank) continue;
+    if (from == g.rank && !g_rccl_self) continue;
     NCCL_CHECK(ncclRecv(m.recv, m.bytes, ncclChar, from, g_nccl, s));
   }
   NCCL_CHECK(ncclGroupEnd());
@@ -237,7 +265,9 @@ void qudaAmdCommInit(const void *id128, int rank, int size) {
   if (size < 1 || rank < 0 || rank >= size) errorQuda("bad rank/size %d/%d", rank, size);
   g.rank = rank;
   g.size = size;
-  if (size == 1) return;
+  const char *st = getenv("QUDA_AMD_RCCL_SELFTEST");
+  g_rccl_self = size == 1 && st && atoi(st) != 0;
+  if (size == 1 && !g_rccl_self) return;
   const char *tr = getenv("QUDA_AMD_TRANSPORT");
   if (tr && !strcmp(tr, "shm")) {
     const char *dir = getenv("QUDA_AMD_SHM_DIR");

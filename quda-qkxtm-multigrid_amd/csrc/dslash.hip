@@ -27,6 +27,24 @@
 
 namespace quda {
 
+// ---- face packing: spin-project the boundary sites of the INPUT field into the send buffers of every partitioned
+// dimension in one launch (reference packFaceWilsonKernel / packTwistedFaceWilsonKernel, lib/dslash_pack.cu:272, :610) ----
+template <typename real> struct PackArg {
+  const void *in;
+  const float *inNorm;
+  int sp_stride;
+  int X[4];         // full local extents
+  int parity_in;    // parity of the input field
+  real sfwd, a;
+  char *send[4][2]; // [dim][0: to the -dim neighbour, 1: to the +dim neighbour]
+  int faceCB[4];
+  int normOff[4];
+  int start[9];     // prefix offsets of the 8 (dim, dir) thread ranges
+  // peer-store transport: send[][] point into the NEIGHBOURS' ghost zones; the last block to finish raises the flags there
+  unsigned *peerFlag[8];   // the neighbours' site counters of the faces this rank sends
+  int staux;        // cache-policy bits of the face stores (experiment switch QUDA_AMD_PACK_AUX; 17 = sc0 sc1)
+};
+
 template <typename real> struct DslashArg {
   void *out;
   float *outNorm;
@@ -54,6 +72,17 @@ template <typename real> struct DslashArg {
   const char *ghost[4][2];    // [dim][0: from the -dim neighbour, 1: from the +dim neighbour] spin-projected half spinors
   int faceCB[4];
   int ghostNormOff[4];        // byte offset of the fp32 scales inside a ghost block (16-bit storage)
+  // peer-store transport (p2p.h): the exterior pass polls these flags (one per incoming face, raised by the neighbour's pack
+  // kernel) until they reach waitSeq before it touches the ghost zone; waitSeq = 0: the data arrived in stream order
+  const unsigned *waitFlag[8];
+  unsigned waitCount[8];      // value each incoming-face site counter must have reached (cumulative, compared modulo 2^32)
+  unsigned waitSeq;
+  unsigned long long waitTicks;
+  int *errWord;
+  // peer-store transport: the first packBlocks blocks of the interior launch pack the faces (pack_body) while the rest of
+  // the grid does the interior stencil — one launch, the faces leave at time zero and travel during the interior pass
+  int packBlocks;
+  PackArg<real> pack;
 };
 
 // ---- spin projection / reconstruction in the chiral basis; s = +1 selects projector[2 mu], -1 projector[2 mu + 1]
@@ -123,124 +152,90 @@ template <typename real> __device__ __forceinline__ void twist_inplace(real *p, 
 // hoists all 8 directions' loads to the top (fp64: 512 registers + scratch spills, 1 wave/SIMD) nor serialises them.
 // GAUX: cache policy of the link stream (0 default, 2 = nt: read-once data that should not displace the spinor
 // working set from L2 / Infinity Cache).
-template <typename T, int R, int DIR, int GAUX, typename real>
-__device__ __forceinline__ void hop_load(real *psi, real *U, const DslashArg<real> &arg, int idx, int nbr, real sign) {
-  Planar<T, 24>::load(psi, arg.in, arg.sp_stride, nbr, arg.inNorm, nbr);
+// GH: 0 = every neighbour is local; 1 = off-node neighbours are read from the ghost zone (exterior pass); 2 = off-node hops are
+// skipped here and done by ghost_hop() once the faces have arrived (single-launch peer-store path)
+template <typename T, int R, int DIR, int GAUX, int GH = 0, typename real>
+__device__ __forceinline__ void hop_load(real *psi, real *U, const DslashArg<real> &arg, int idx, int nbr, real sign, bool off_node = false, int face = 0) {
+  constexpr int MU = DIR / 2;
+  if (GH == 2 && off_node) return;
+  if (GH == 1 && off_node) {
+    // the neighbour lives on another rank: its (pre-twisted,) spin-projected half spinor was packed there with the same
+    // projector sign; it goes into the first 12 slots of the buffer.  Issued here, with the other loads of the hop, so it
+    // does not cost a dependent round trip in the compute phase.  sc0 sc1 (system-scope) loads: the zone may have been
+    // written by another GPU while this kernel was running.
+    const char *gb = arg.ghost[MU][(DIR & 1) ? 0 : 1];
+    Planar<T, 12>::template load<17>(psi, gb, arg.faceCB[MU], face, reinterpret_cast<const float *>(gb + arg.ghostNormOff[MU]), face);
+  } else {
+    Planar<T, 24>::load(psi, arg.in, arg.sp_stride, nbr, arg.inNorm, nbr);
+  }
   Link<T, R>::template load<GAUX>(U, arg.gauge + (size_t)DIR * arg.link_bytes, arg.g_stride, idx, sign);
 }
-template <typename T, int DIR, bool PRETWIST, bool GHOST, typename real>
+template <typename T, int DIR, bool PRETWIST, int GH, typename real>
 __device__ __forceinline__ void hop_compute(real *acc, real *psi, const real *U, const DslashArg<real> &arg, bool off_node = false, int face = 0) {
   constexpr int MU = DIR / 2;
+  if (GH == 2 && off_node) return;
   real h[12], g[12];
-  if (PRETWIST) twist_inplace(psi, arg.a);  // QUDA_DEG_TWIST_INV_DSLASH: A^-1 applied to the neighbour before the hop
   const real s = (DIR & 1) ? -arg.sfwd : arg.sfwd;
-  spin_project<MU>(h, psi, s);
-  if (GHOST && off_node) {
-    // the neighbour lives on another rank: its (pre-twisted,) spin-projected half spinor was packed there with the same s
-    const char *gb = arg.ghost[MU][(DIR & 1) ? 0 : 1];
-    Planar<T, 12>::load(h, gb, arg.faceCB[MU], face, reinterpret_cast<const float *>(gb + arg.ghostNormOff[MU]), face);
+  if (GH == 1 && off_node) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) h[k] = psi[k];
+  } else {
+    if (PRETWIST) twist_inplace(psi, arg.a);  // QUDA_DEG_TWIST_INV_DSLASH: A^-1 applied to the neighbour before the hop
+    spin_project<MU>(h, psi, s);
   }
   su3_mv(g, U, h);
   su3_mv(g + 6, U, h + 6);
   spin_reconstruct<MU>(acc, g, s);
 }
 
-// VARIANT: 0 = Wilson / twist epilogues, 1 = twist applied to the neighbours first (TWIST_INV_DSLASH), 2 = clover epilogues.
-// Compile-time so the 8-hop pipeline below is one straight-line basic block (a wave-uniform runtime branch per hop
-// made hipcc split it into ~80 blocks and shuttle the double buffers through AGPRs).
-// KT: 0 = every site, all neighbours local (periodic wrap inside this rank);
-//     1 = interior pass of a grid-decomposed lattice: sites that touch a partitioned boundary are left to the exterior pass;
-//     2 = exterior pass: one thread per boundary site (arg.blist), off-node neighbours come from the ghost zone.
-template <typename T, int R, int VARIANT, int GAUX, int KT, int SAUX = 0>
-__global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename Store<T>::real> arg) {
-  using real = typename Store<T>::real;
-  int idx;
-  if (KT == 2) {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= arg.nboundary) return;
-    idx = arg.blist[tid];
-  } else {
-    // XCD-aware block remap: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch); give each XCD a
-    // contiguous range of logical blocks (a slab of time slices) so t/z neighbours hit its own L2.
-    const int b = blockIdx.x;
-    const int xcd = b & 7, within = b >> 3;
-    int lb = (xcd < arg.xcd_r ? xcd * (arg.xcd_q + 1) : arg.xcd_r * (arg.xcd_q + 1) + (xcd - arg.xcd_r) * arg.xcd_q) + within;
-    if (arg.ts > 0) {
-      // inside an XCD's slab of ts time slices walk t fastest: consecutive blocks are the same (y,z) chunk on ts successive
-      // slices, so the +-t neighbours of a chunk are touched within a few blocks of each other (L2-resident) instead of a
-      // whole 3 MB slice apart
-      const int per = arg.bps * arg.ts, s = lb / per, w = lb - s * per, c = w / arg.ts, tt = w - c * arg.ts;
-      lb = (s * arg.ts + tt) * arg.bps + c;
+// one off-node hop from the ghost zone (half spinor packed by the neighbour + this site's link), for the lanes that need it
+template <typename T, int R, int DIR, int GAUX, typename real>
+__device__ __forceinline__ void ghost_hop(real *acc, const DslashArg<real> &arg, int idx, bool off_node, int face, real sign) {
+  constexpr int MU = DIR / 2;
+  if (!off_node) return;
+  real h[12], g[12], U[18];
+  const char *gb = arg.ghost[MU][(DIR & 1) ? 0 : 1];
+  Planar<T, 12>::template load<17>(h, gb, arg.faceCB[MU], face, reinterpret_cast<const float *>(gb + arg.ghostNormOff[MU]), face);
+  Link<T, R>::template load<GAUX>(U, arg.gauge + (size_t)DIR * arg.link_bytes, arg.g_stride, idx, sign);
+  const real s = (DIR & 1) ? -arg.sfwd : arg.sfwd;
+  su3_mv(g, U, h);
+  su3_mv(g + 6, U, h + 6);
+  spin_reconstruct<MU>(acc, g, s);
+}
+
+// wave-level variant of wait_for_faces (no block barrier: only the waves that own boundary sites wait)
+template <typename real> __device__ __forceinline__ void wait_for_faces_wave(const DslashArg<real> &arg) {
+  if (!arg.waitSeq) return;
+  const int lane = threadIdx.x & 63;
+  if (lane < 8 && arg.waitFlag[lane]) {
+    const unsigned long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(arg.waitFlag[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - arg.waitCount[lane]) < 0) {
+      if (wall_clock64() - t0 > arg.waitTicks) { *arg.errWord = 1 + lane; break; }
+      __builtin_amdgcn_s_sleep(1);
     }
-    idx = lb * blockDim.x + threadIdx.x;
-    if (idx >= arg.Vh) return;
   }
+}
 
-  // checkerboard index -> coordinates (tests/test_util.cpp:419-443)
-  const uint32_t za = arg.dXh.div((uint32_t)idx);
-  const int xh = idx - (int)za * arg.Xh;
-  const uint32_t zb = arg.dY.div(za);
-  const int y = (int)za - (int)zb * arg.Y;
-  const int t = (int)arg.dZ.div(zb);
-  const int z = (int)zb - t * arg.Z;
-  const int xodd = (y + z + t + arg.parity) & 1;
-  const int xf = 2 * xh + xodd;  // full x coordinate
-  // which hops leave this rank (KT != 0 only)
-  const bool gx = (arg.commMask & 1) != 0, gy = (arg.commMask & 2) != 0, gz = (arg.commMask & 4) != 0, gt = (arg.commMask & 8) != 0;
-  const bool o_xp = gx && xf == 2 * arg.Xh - 1, o_xm = gx && xf == 0, o_yp = gy && y == arg.Y - 1, o_ym = gy && y == 0;
-  const bool o_zp = gz && z == arg.Z - 1, o_zm = gz && z == 0, o_tp = gt && t == arg.T - 1, o_tm = gt && t == 0;
-  if (KT == 1 && (o_xp || o_xm || o_yp || o_ym || o_zp || o_zm || o_tp || o_tm)) return;
-  // face (ghost-zone) indices: lexicographic over the three other coordinates, halved (reference tests/dslash_util.h:291-394)
-  const int X1 = 2 * arg.Xh;
-  const int f_x = ((t * arg.Z + z) * arg.Y + y) >> 1, f_y = ((t * arg.Z + z) * X1 + xf) >> 1;
-  const int f_z = ((t * arg.Y + y) * X1 + xf) >> 1, f_t = ((z * arg.Y + y) * X1 + xf) >> 1;
+// Peer-store transport: threads 0-7 of the block poll one incoming-face flag each (relaxed system-scope loads: an acquire
+// load would invalidate the caches on EVERY poll, and 2700 waves doing that made this pass 4x slower); the rest of the block
+// waits at the barrier.  No cache maintenance is needed afterwards: the ghost zone is fine-grained (uncached) memory and is
+// read with system-scope loads, and it cannot have been read earlier in this kernel.
+template <typename real> __device__ __forceinline__ void wait_for_faces(const DslashArg<real> &arg) {
+  if (!arg.waitSeq) return;
+  if (threadIdx.x < 8 && arg.waitFlag[threadIdx.x]) {
+    const unsigned long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(arg.waitFlag[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - arg.waitCount[threadIdx.x]) < 0) {
+      if (wall_clock64() - t0 > arg.waitTicks) { *arg.errWord = 1 + (int)threadIdx.x; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+}
 
-  const int Xh = arg.Xh, sy = Xh, sz = Xh * arg.Y, st = Xh * arg.Y * arg.Z;
-  const int n_xp = xodd ? (xh == Xh - 1 ? idx - (Xh - 1) : idx + 1) : idx;
-  const int n_xm = xodd ? idx : (xh == 0 ? idx + (Xh - 1) : idx - 1);
-  const int n_yp = y == arg.Y - 1 ? idx - (arg.Y - 1) * sy : idx + sy;
-  const int n_ym = y == 0 ? idx + (arg.Y - 1) * sy : idx - sy;
-  const int n_zp = z == arg.Z - 1 ? idx - (arg.Z - 1) * sz : idx + sz;
-  const int n_zm = z == 0 ? idx + (arg.Z - 1) * sz : idx - sz;
-  const int n_tp = t == arg.T - 1 ? idx - (arg.T - 1) * st : idx + st;
-  const int n_tm = t == 0 ? idx + (arg.T - 1) * st : idx - st;
-
-  real acc[24];
-#pragma unroll
-  for (int k = 0; k < 24; k++) acc[k] = 0;
-
-  constexpr bool PT = VARIANT == 1;
+// fused epilogue of the stencil: twist / inverse twist / xpay / clover-twist (+ inverse), then the store of the site
+template <typename T, int VARIANT, int GAUX, int SAUX, typename real>
+__device__ __forceinline__ void dslash_epilogue(real *acc, const DslashArg<real> &arg, int idx) {
   constexpr bool CLOVER = VARIANT == 2;
-  const real one = 1;
-  const real sg_tp = t == arg.T - 1 ? arg.tsign_fwd : one, sg_tm = t == 0 ? arg.tsign_bwd : one;
-  // direction order: dir = 2 mu + (0 forward, 1 backward), as the reference (tests/dslash_util.h:131-140)
-  real pA[24], uA[18], pB[24], uB[18];
-  // QA_FENCE: nothing may be scheduled across (machine scheduler).  QA_PIN: an empty volatile asm that "modifies" the
-  // accumulators, so LLVM's IR-level sinking cannot push a hop's arithmetic past the following loads either (without it
-  // all 8 hops' FMAs sink below the last fence and every loaded register stays live: 390-512 registers, scratch spills).
-#define QA_FENCE() __builtin_amdgcn_sched_barrier(0)
-#define QA_PIN()                                                   \
-  _Pragma("unroll") for (int k_ = 0; k_ < 24; k_++) asm volatile("" : "+v"(acc[k_]))
-  hop_load<T, R, 0, GAUX>(pA, uA, arg, idx, n_xp, one);
-  hop_load<T, R, 1, GAUX>(pB, uB, arg, idx, n_xm, one);
-  QA_FENCE(); hop_compute<T, 0, PT, KT == 2>(acc, pA, uA, arg, o_xp, f_x); QA_PIN(); QA_FENCE();
-  hop_load<T, R, 2, GAUX>(pA, uA, arg, idx, n_yp, one);
-  QA_FENCE(); hop_compute<T, 1, PT, KT == 2>(acc, pB, uB, arg, o_xm, f_x); QA_PIN(); QA_FENCE();
-  hop_load<T, R, 3, GAUX>(pB, uB, arg, idx, n_ym, one);
-  QA_FENCE(); hop_compute<T, 2, PT, KT == 2>(acc, pA, uA, arg, o_yp, f_y); QA_PIN(); QA_FENCE();
-  hop_load<T, R, 4, GAUX>(pA, uA, arg, idx, n_zp, one);
-  QA_FENCE(); hop_compute<T, 3, PT, KT == 2>(acc, pB, uB, arg, o_ym, f_y); QA_PIN(); QA_FENCE();
-  hop_load<T, R, 5, GAUX>(pB, uB, arg, idx, n_zm, one);
-  QA_FENCE(); hop_compute<T, 4, PT, KT == 2>(acc, pA, uA, arg, o_zp, f_z); QA_PIN(); QA_FENCE();
-  hop_load<T, R, 6, GAUX>(pA, uA, arg, idx, n_tp, sg_tp);
-  QA_FENCE(); hop_compute<T, 5, PT, KT == 2>(acc, pB, uB, arg, o_zm, f_z); QA_PIN(); QA_FENCE();
-  hop_load<T, R, 7, GAUX>(pB, uB, arg, idx, n_tm, sg_tm);
-  QA_FENCE(); hop_compute<T, 6, PT, KT == 2>(acc, pA, uA, arg, o_tp, f_t); QA_PIN(); QA_FENCE();
-  hop_compute<T, 7, PT, KT == 2>(acc, pB, uB, arg, o_tm, f_t);
-#undef QA_FENCE
-#undef QA_PIN
-
-  // ---- epilogue ----
   real xs[24];
   if (arg.xpay) Planar<T, 24>::load(xs, arg.x, arg.sp_stride, idx, arg.xNorm, idx);
 
@@ -310,6 +305,181 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
   Planar<T, 24>::template store<SAUX>(acc, arg.out, arg.sp_stride, idx, arg.outNorm, idx);
 }
 
+// ---- face packing (reference packFaceWilsonKernel / packTwistedFaceWilsonKernel, lib/dslash_pack.cu:272, :610) ----
+// P2P: the send pointers are peer-mapped ghost zones — system-scope write-through stores (sc0 sc1), completion counter, flags
+template <typename T, bool PRETWIST, bool P2P, typename real> __device__ __forceinline__ void pack_body(const PackArg<real> &arg, int bid, int nblk) {
+  const int tid = bid * blockDim.x + threadIdx.x;
+  if (tid < arg.start[8]) {
+    int slot = 0;
+#pragma unroll
+    for (int k = 1; k < 8; k++) slot += tid >= arg.start[k];
+    const int d = slot >> 1, to_fwd = slot & 1, f = tid - arg.start[slot];
+    // other three coordinates from the face index (lexicographic, halved), then the site's full index
+    int c[4], L[3], o[3], n = 0;
+    for (int k = 0; k < 4; k++) if (k != d) { L[n] = arg.X[k]; o[n] = k; n++; }
+    int l = 2 * f;
+    const int c0 = l % L[0]; l /= L[0];
+    const int c1 = l % L[1]; const int c2 = l / L[1];
+    c[d] = to_fwd ? arg.X[d] - 1 : 0;
+    c[o[0]] = c0; c[o[1]] = c1; c[o[2]] = c2;
+    c[o[0]] += (arg.parity_in + c[0] + c[1] + c[2] + c[3]) & 1;  // pick the site of the pair that has the input parity
+    const int idx = (((c[3] * arg.X[2] + c[2]) * arg.X[1] + c[1]) * arg.X[0] + c[0]) >> 1;
+    real psi[24], h[12];
+    Planar<T, 24>::load(psi, arg.in, arg.sp_stride, idx, arg.inNorm, idx);
+    if (PRETWIST) twist_inplace(psi, arg.a);
+    // the receiver uses this face for its hop in direction -d (if we send forward) / +d (if we send backward)
+    const real s = to_fwd ? -arg.sfwd : arg.sfwd;
+    switch (d) {
+      case 0: spin_project<0>(h, psi, s); break;
+      case 1: spin_project<1>(h, psi, s); break;
+      case 2: spin_project<2>(h, psi, s); break;
+      default: spin_project<3>(h, psi, s); break;
+    }
+    char *sb = arg.send[d][to_fwd];
+    if (P2P && arg.staux == 17) Planar<T, 12>::template store<17>(h, sb, arg.faceCB[d], f, reinterpret_cast<float *>(sb + arg.normOff[d]), f);
+    else if (P2P && arg.staux == 2) Planar<T, 12>::template store<2>(h, sb, arg.faceCB[d], f, reinterpret_cast<float *>(sb + arg.normOff[d]), f);
+    else Planar<T, 12>::template store<0>(h, sb, arg.faceCB[d], f, reinterpret_cast<float *>(sb + arg.normOff[d]), f);
+  }
+  if (P2P) {
+    // Signalling: every incoming face has a cumulative SITE COUNTER in the receiver's window.  A block waits until its own
+    // stores are acknowledged (the zones are fine-grained memory and the stores write-through at system scope, so nothing
+    // lingers in this GPU's L2: s_waitcnt vmcnt(0), i.e. a work-group-scope release, is all it takes — a system-scope fence
+    // would also write back the whole dirty L2, 10 us per launch when every wave did it), then adds the number of sites it
+    // packed for each face to that face's counter with a fire-and-forget remote atomic.  No completion counter, no last
+    // block, no returning atomic: under a saturated memory system every dependent round trip costs microseconds.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x < 8 && arg.peerFlag[threadIdx.x]) {
+      const int beg = bid * (int)blockDim.x, end = beg + (int)blockDim.x;
+      const int lo = beg > arg.start[threadIdx.x] ? beg : arg.start[threadIdx.x];
+      const int hi = end < arg.start[threadIdx.x + 1] ? end : arg.start[threadIdx.x + 1];
+      if (hi > lo) (void)__hip_atomic_fetch_add(arg.peerFlag[threadIdx.x], (unsigned)(hi - lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// VARIANT: 0 = Wilson / twist epilogues, 1 = twist applied to the neighbours first (TWIST_INV_DSLASH), 2 = clover epilogues.
+// Compile-time so the 8-hop pipeline below is one straight-line basic block (a wave-uniform runtime branch per hop
+// made hipcc split it into ~80 blocks and shuttle the double buffers through AGPRs).
+// All 8 hops + epilogue of one site.  KT: 0 = every neighbour is local (periodic wrap inside this rank); 1 = interior pass of a
+// grid-decomposed lattice (sites that touch a partitioned boundary are skipped); 2 = exterior pass (boundary site, off-node
+// neighbours from the ghost zone); 3 = single-launch peer-store path: local hops first, then the off-node hops once the
+// neighbours' faces have arrived.
+template <typename T, int R, int VARIANT, int GAUX, int KT, int SAUX, typename real>
+__device__ __forceinline__ void stencil_site(const DslashArg<real> &arg, const int idx) {
+  // checkerboard index -> coordinates (tests/test_util.cpp:419-443)
+  const uint32_t za = arg.dXh.div((uint32_t)idx);
+  const int xh = idx - (int)za * arg.Xh;
+  const uint32_t zb = arg.dY.div(za);
+  const int y = (int)za - (int)zb * arg.Y;
+  const int t = (int)arg.dZ.div(zb);
+  const int z = (int)zb - t * arg.Z;
+  const int xodd = (y + z + t + arg.parity) & 1;
+  const int xf = 2 * xh + xodd;  // full x coordinate
+  // which hops leave this rank (KT != 0 only)
+  const bool gx = (arg.commMask & 1) != 0, gy = (arg.commMask & 2) != 0, gz = (arg.commMask & 4) != 0, gt = (arg.commMask & 8) != 0;
+  const bool o_xp = gx && xf == 2 * arg.Xh - 1, o_xm = gx && xf == 0, o_yp = gy && y == arg.Y - 1, o_ym = gy && y == 0;
+  const bool o_zp = gz && z == arg.Z - 1, o_zm = gz && z == 0, o_tp = gt && t == arg.T - 1, o_tm = gt && t == 0;
+  if (KT == 1 && (o_xp || o_xm || o_yp || o_ym || o_zp || o_zm || o_tp || o_tm)) return;
+  // face (ghost-zone) indices: lexicographic over the three other coordinates, halved (reference tests/dslash_util.h:291-394)
+  const int X1 = 2 * arg.Xh;
+  const int f_x = ((t * arg.Z + z) * arg.Y + y) >> 1, f_y = ((t * arg.Z + z) * X1 + xf) >> 1;
+  const int f_z = ((t * arg.Y + y) * X1 + xf) >> 1, f_t = ((z * arg.Y + y) * X1 + xf) >> 1;
+
+  const int Xh = arg.Xh, sy = Xh, sz = Xh * arg.Y, st = Xh * arg.Y * arg.Z;
+  const int n_xp = xodd ? (xh == Xh - 1 ? idx - (Xh - 1) : idx + 1) : idx;
+  const int n_xm = xodd ? idx : (xh == 0 ? idx + (Xh - 1) : idx - 1);
+  const int n_yp = y == arg.Y - 1 ? idx - (arg.Y - 1) * sy : idx + sy;
+  const int n_ym = y == 0 ? idx + (arg.Y - 1) * sy : idx - sy;
+  const int n_zp = z == arg.Z - 1 ? idx - (arg.Z - 1) * sz : idx + sz;
+  const int n_zm = z == 0 ? idx + (arg.Z - 1) * sz : idx - sz;
+  const int n_tp = t == arg.T - 1 ? idx - (arg.T - 1) * st : idx + st;
+  const int n_tm = t == 0 ? idx + (arg.T - 1) * st : idx - st;
+
+  real acc[24];
+#pragma unroll
+  for (int k = 0; k < 24; k++) acc[k] = 0;
+
+  constexpr bool PT = VARIANT == 1;
+  const real one = 1;
+  const real sg_tp = t == arg.T - 1 ? arg.tsign_fwd : one, sg_tm = t == 0 ? arg.tsign_bwd : one;
+  // direction order: dir = 2 mu + (0 forward, 1 backward), as the reference (tests/dslash_util.h:131-140)
+  real pA[24], uA[18], pB[24], uB[18];
+  // QA_FENCE: nothing may be scheduled across (machine scheduler).  QA_PIN: an empty volatile asm that "modifies" the
+  // accumulators, so LLVM's IR-level sinking cannot push a hop's arithmetic past the following loads either (without it
+  // all 8 hops' FMAs sink below the last fence and every loaded register stays live: 390-512 registers, scratch spills).
+#define QA_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define QA_PIN()                                                   \
+  _Pragma("unroll") for (int k_ = 0; k_ < 24; k_++) asm volatile("" : "+v"(acc[k_]))
+  hop_load<T, R, 0, GAUX, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(pA, uA, arg, idx, n_xp, one, o_xp, f_x);
+  hop_load<T, R, 1, GAUX, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(pB, uB, arg, idx, n_xm, one, o_xm, f_x);
+  QA_FENCE(); hop_compute<T, 0, PT, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(acc, pA, uA, arg, o_xp, f_x); QA_PIN(); QA_FENCE();
+  hop_load<T, R, 2, GAUX, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(pA, uA, arg, idx, n_yp, one, o_yp, f_y);
+  QA_FENCE(); hop_compute<T, 1, PT, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(acc, pB, uB, arg, o_xm, f_x); QA_PIN(); QA_FENCE();
+  hop_load<T, R, 3, GAUX, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(pB, uB, arg, idx, n_ym, one, o_ym, f_y);
+  QA_FENCE(); hop_compute<T, 2, PT, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(acc, pA, uA, arg, o_yp, f_y); QA_PIN(); QA_FENCE();
+  hop_load<T, R, 4, GAUX, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(pA, uA, arg, idx, n_zp, one, o_zp, f_z);
+  QA_FENCE(); hop_compute<T, 3, PT, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(acc, pB, uB, arg, o_ym, f_y); QA_PIN(); QA_FENCE();
+  hop_load<T, R, 5, GAUX, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(pB, uB, arg, idx, n_zm, one, o_zm, f_z);
+  QA_FENCE(); hop_compute<T, 4, PT, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(acc, pA, uA, arg, o_zp, f_z); QA_PIN(); QA_FENCE();
+  hop_load<T, R, 6, GAUX, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(pA, uA, arg, idx, n_tp, sg_tp, o_tp, f_t);
+  QA_FENCE(); hop_compute<T, 5, PT, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(acc, pB, uB, arg, o_zm, f_z); QA_PIN(); QA_FENCE();
+  hop_load<T, R, 7, GAUX, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(pB, uB, arg, idx, n_tm, sg_tm, o_tm, f_t);
+  QA_FENCE(); hop_compute<T, 6, PT, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(acc, pA, uA, arg, o_tp, f_t); QA_PIN(); QA_FENCE();
+  hop_compute<T, 7, PT, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(acc, pB, uB, arg, o_tm, f_t);
+#undef QA_FENCE
+#undef QA_PIN
+
+  if (KT == 3) {
+    // the hops that leave this rank: wait (only the waves that own boundary sites) until the neighbours' faces are in, then add them
+    const bool anyoff = o_xp || o_xm || o_yp || o_ym || o_zp || o_zm || o_tp || o_tm;
+    if (__builtin_amdgcn_ballot_w64(anyoff) != 0) {
+      wait_for_faces_wave(arg);
+      ghost_hop<T, R, 0, GAUX>(acc, arg, idx, o_xp, f_x, one);
+      ghost_hop<T, R, 1, GAUX>(acc, arg, idx, o_xm, f_x, one);
+      ghost_hop<T, R, 2, GAUX>(acc, arg, idx, o_yp, f_y, one);
+      ghost_hop<T, R, 3, GAUX>(acc, arg, idx, o_ym, f_y, one);
+      ghost_hop<T, R, 4, GAUX>(acc, arg, idx, o_zp, f_z, one);
+      ghost_hop<T, R, 5, GAUX>(acc, arg, idx, o_zm, f_z, one);
+      ghost_hop<T, R, 6, GAUX>(acc, arg, idx, o_tp, f_t, sg_tp);
+      ghost_hop<T, R, 7, GAUX>(acc, arg, idx, o_tm, f_t, sg_tm);
+    }
+  }
+  dslash_epilogue<T, VARIANT, GAUX, SAUX>(acc, arg, idx);
+}
+
+template <typename T, int R, int VARIANT, int GAUX, int KT, int SAUX = 0>
+__global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename Store<T>::real> arg) {
+  if (KT == 2) {
+    wait_for_faces(arg);
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= arg.nboundary) return;
+    stencil_site<T, R, VARIANT, GAUX, 2, SAUX>(arg, arg.blist[tid]);
+    return;
+  }
+  int b = blockIdx.x;
+  if (KT == 3) {
+    // single-launch peer-store path: [pack blocks | every site]; boundary sites do their local hops first, then poll the
+    // incoming-face counters and add the off-node hops (stencil_site, KT == 3)
+    if (b < arg.packBlocks) { pack_body<T, VARIANT == 1, true>(arg.pack, b, arg.packBlocks); return; }
+    b -= arg.packBlocks;
+  }
+  // XCD-aware block remap: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch); give each XCD a
+  // contiguous range of logical blocks (a slab of time slices) so t/z neighbours hit its own L2.
+  const int xcd = b & 7, within = b >> 3;
+  int lb = (xcd < arg.xcd_r ? xcd * (arg.xcd_q + 1) : arg.xcd_r * (arg.xcd_q + 1) + (xcd - arg.xcd_r) * arg.xcd_q) + within;
+  if (arg.ts > 0) {
+    // inside an XCD's slab of ts time slices walk t fastest: consecutive blocks are the same (y,z) chunk on ts successive
+    // slices, so the +-t neighbours of a chunk are touched within a few blocks of each other (L2-resident) instead of a
+    // whole 3 MB slice apart
+    const int per = arg.bps * arg.ts, s = lb / per, w = lb - s * per, c = w / arg.ts, tt = w - c * arg.ts;
+    lb = (s * arg.ts + tt) * arg.bps + c;
+  }
+  const int idx = lb * blockDim.x + threadIdx.x;
+  if (idx >= arg.Vh) return;
+  stencil_site<T, R, VARIANT, GAUX, KT, SAUX>(arg, idx);
+}
+
 // ---- single-direction hop (setup-time helper for the multigrid coarse-operator construction) ----
 template <typename T, int R>
 __global__ void __launch_bounds__(256) hop_dir_kernel(const DslashArg<typename Store<T>::real> arg, int dir, typename Store<T>::real coef,
@@ -357,14 +527,14 @@ __global__ void __launch_bounds__(256) hop_dir_kernel(const DslashArg<typename S
   else Planar<T, 24>::load(psi, arg.in, arg.sp_stride, nbr, arg.inNorm, nbr);
   Link<T, R>::load(U, arg.gauge + (size_t)dir * arg.link_bytes, arg.g_stride, idx, sign);
   switch (dir) {
-    case 0: hop_compute<T, 0, false, false>(acc, psi, U, arg); break;
-    case 1: hop_compute<T, 1, false, false>(acc, psi, U, arg); break;
-    case 2: hop_compute<T, 2, false, false>(acc, psi, U, arg); break;
-    case 3: hop_compute<T, 3, false, false>(acc, psi, U, arg); break;
-    case 4: hop_compute<T, 4, false, false>(acc, psi, U, arg); break;
-    case 5: hop_compute<T, 5, false, false>(acc, psi, U, arg); break;
-    case 6: hop_compute<T, 6, false, false>(acc, psi, U, arg); break;
-    default: hop_compute<T, 7, false, false>(acc, psi, U, arg); break;
+    case 0: hop_compute<T, 0, false, 0>(acc, psi, U, arg); break;
+    case 1: hop_compute<T, 1, false, 0>(acc, psi, U, arg); break;
+    case 2: hop_compute<T, 2, false, 0>(acc, psi, U, arg); break;
+    case 3: hop_compute<T, 3, false, 0>(acc, psi, U, arg); break;
+    case 4: hop_compute<T, 4, false, 0>(acc, psi, U, arg); break;
+    case 5: hop_compute<T, 5, false, 0>(acc, psi, U, arg); break;
+    case 6: hop_compute<T, 6, false, 0>(acc, psi, U, arg); break;
+    default: hop_compute<T, 7, false, 0>(acc, psi, U, arg); break;
   }
 #pragma unroll
   for (int k = 0; k < 24; k++) acc[k] *= coef;
@@ -432,64 +602,34 @@ static int dslashBlockSize() {
   return bs;
 }
 
-// ---- face packing: spin-project the boundary sites of the INPUT field into the send buffers of every partitioned
-// dimension in one launch (reference packFaceWilsonKernel / packTwistedFaceWilsonKernel, lib/dslash_pack.cu:272, :610) ----
-template <typename real> struct PackArg {
-  const void *in;
-  const float *inNorm;
-  int sp_stride;
-  int X[4];         // full local extents
-  int parity_in;    // parity of the input field
-  real sfwd, a;
-  char *send[4][2]; // [dim][0: to the -dim neighbour, 1: to the +dim neighbour]
-  int faceCB[4];
-  int normOff[4];
-  int start[9];     // prefix offsets of the 8 (dim, dir) thread ranges
-};
 
-template <typename T, bool PRETWIST> __global__ void __launch_bounds__(256) pack_kernel(const PackArg<typename Store<T>::real> arg) {
-  using real = typename Store<T>::real;
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= arg.start[8]) return;
-  int slot = 0;
-#pragma unroll
-  for (int k = 1; k < 8; k++) slot += tid >= arg.start[k];
-  const int d = slot >> 1, to_fwd = slot & 1, f = tid - arg.start[slot];
-  // other three coordinates from the face index (lexicographic, halved), then the site's full index
-  int c[4], L[3], o[3], n = 0;
-  for (int k = 0; k < 4; k++) if (k != d) { L[n] = arg.X[k]; o[n] = k; n++; }
-  int l = 2 * f;
-  const int c0 = l % L[0]; l /= L[0];
-  const int c1 = l % L[1]; const int c2 = l / L[1];
-  c[d] = to_fwd ? arg.X[d] - 1 : 0;
-  c[o[0]] = c0; c[o[1]] = c1; c[o[2]] = c2;
-  c[o[0]] += (arg.parity_in + c[0] + c[1] + c[2] + c[3]) & 1;  // pick the site of the pair that has the input parity
-  const int idx = (((c[3] * arg.X[2] + c[2]) * arg.X[1] + c[1]) * arg.X[0] + c[0]) >> 1;
-  real psi[24], h[12];
-  Planar<T, 24>::load(psi, arg.in, arg.sp_stride, idx, arg.inNorm, idx);
-  if (PRETWIST) twist_inplace(psi, arg.a);
-  // the receiver uses this face for its hop in direction -d (if we send forward) / +d (if we send backward)
-  const real s = to_fwd ? -arg.sfwd : arg.sfwd;
-  switch (d) {
-    case 0: spin_project<0>(h, psi, s); break;
-    case 1: spin_project<1>(h, psi, s); break;
-    case 2: spin_project<2>(h, psi, s); break;
-    default: spin_project<3>(h, psi, s); break;
-  }
-  char *sb = arg.send[d][to_fwd];
-  Planar<T, 12>::store(h, sb, arg.faceCB[d], f, reinterpret_cast<float *>(sb + arg.normOff[d]), f);
+template <typename T, bool PRETWIST, bool P2P = false> __global__ void __launch_bounds__(256) pack_kernel(const PackArg<typename Store<T>::real> arg) {
+  pack_body<T, PRETWIST, P2P>(arg, blockIdx.x, gridDim.x);
 }
 
 // ---- ghost-zone storage and the boundary-site lists ----
 static HaloBuffers g_halo[3];
 static std::vector<BoundaryList> g_blists;
 
+static void releaseHalo(HaloBuffers &h) {
+  if (h.window) {
+    // neighbours may still be storing into / polling this window: drain the device and meet them before unmapping
+    HIP_CHECK(hipDeviceSynchronize());
+    commBarrier();
+    commUnmapPeers(h.map);
+    commBarrier();
+    p2pFree(h.window);
+  }
+  if (h.pool) HIP_CHECK(hipFree(h.pool));
+  h = HaloBuffers();
+}
+
 HaloBuffers &haloBuffers(const LatticeGeom &g, QudaPrecision prec) {
   HaloBuffers &h = g_halo[prec == QUDA_DOUBLE_PRECISION ? 0 : (prec == QUDA_SINGLE_PRECISION ? 1 : 2)];
   bool same = h.precision == prec;
   for (int d = 0; d < 4; d++) same = same && h.faceCB[d] == g.faceCB[d];
   if (same && h.pool) return h;
-  if (h.pool) HIP_CHECK(hipFree(h.pool));
+  releaseHalo(h);
   h.precision = prec;
   size_t total = 0;
   for (int d = 0; d < 4; d++) {
@@ -508,12 +648,37 @@ HaloBuffers &haloBuffers(const LatticeGeom &g, QudaPrecision prec) {
   char *p = h.pool;
   for (int d = 0; d < 4; d++)
     for (int dir = 0; dir < 2; dir++) { h.send[d][dir] = p; p += h.face_bytes[d]; h.ghost[d][dir] = p; p += h.face_bytes[d]; }
+
+  // ---- peer-store transport: same offsets on every rank (same local lattice), so a neighbour address = its base + my offset
+  h.p2p = p2pHaloEnabled();
+  if (h.p2p) {
+    const size_t flags_off = total;               // 4 ghost blocks per dim (k x buf), then 16 flags
+    h.window = (char *)p2pAlloc(total + 256);
+    if (!commMapPeers(h.window, h.map)) errorQuda("peer mapping of a halo window failed after the transport probe succeeded");
+    HIP_CHECK(hipDeviceSynchronize());
+    size_t off = 0;
+    for (int d = 0; d < 4; d++)
+      for (int k = 0; k < 2; k++) {
+        // k = 0: zone filled by the -d neighbour (it sent forward), k = 1: by the +d neighbour (it sent backward)
+        const int to_fwd = k == 0 ? 1 : 0;                 // the sender's direction that fills zone k
+        const int slot = 2 * d + (to_fwd ? 1 : 0);         // MY neighbour in that direction receives my (d, to_fwd) face in ITS zone k
+        for (int buf = 0; buf < 2; buf++) {
+          h.ghostBuf[d][k][buf] = h.window + off;
+          h.peerGhost[d][to_fwd][buf] = (char *)h.map.peer[slot] + off;
+          off += h.face_bytes[d];
+        }
+        h.flag[d][k] = (unsigned *)(h.window + flags_off) + (2 * d + k) * 2;
+        h.peerFlag[d][to_fwd] = (unsigned *)((char *)h.map.peer[slot] + flags_off) + (2 * d + k) * 2;
+      }
+    h.seq = 0;
+    commBarrier();
+  }
   return h;
 }
 void freeFullFaceBuffers();
 void freeCoarseGhosts();  // coarse.hip
 void freeHaloBuffers() {
-  for (HaloBuffers &h : g_halo) { if (h.pool) (void)hipFree(h.pool); h = HaloBuffers(); }
+  for (HaloBuffers &h : g_halo) releaseHalo(h);
   freeBoundaryLists();
   freeFullFaceBuffers();
   freeCoarseGhosts();
@@ -550,6 +715,14 @@ void freeBoundaryLists() {
 }
 
 static hipEvent_t g_evIn = nullptr, g_evHalo = nullptr;
+
+template <typename T, int R, int VARIANT, int GAUX, typename Arg> static void launchExterior(const Arg &arg, hipStream_t s) {
+  if (arg.nboundary <= 0) return;
+  static int eb = 0;
+  if (!eb) { const char *e = getenv("QUDA_AMD_EXT_BLOCK"); eb = e ? atoi(e) : 64; }
+  hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 2>), dim3((arg.nboundary + eb - 1) / eb), dim3(eb), 0, s, arg);
+  HIP_CHECK(hipGetLastError());
+}
 
 template <typename T, int R, int VARIANT>
 static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, const DslashParam &p) {
@@ -593,6 +766,8 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
     }
   }
   arg.commMask = 0; arg.blist = nullptr; arg.nboundary = 0;
+  arg.waitSeq = 0; arg.waitTicks = 0; arg.errWord = nullptr; arg.packBlocks = 0;
+  for (int k = 0; k < 8; k++) { arg.waitFlag[k] = nullptr; arg.waitCount[k] = 0; }
   for (int d = 0; d < 4; d++) { arg.ghost[d][0] = arg.ghost[d][1] = nullptr; arg.faceCB[d] = g.faceCB[d]; arg.ghostNormOff[d] = 0; }
   // link/clover stream cache policy: nt for the 16-byte-per-lane formats (measured on 32^4: fp64 4.67 -> 5.2 TB/s, fp32
   // 4.68 -> 5.16 TB/s algorithmic; the read-once links no longer evict the re-used spinors), default for the 8-byte 16-bit format
@@ -610,18 +785,68 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
     return;
   }
 
-  // ---- grid-decomposed lattice: pack + RCCL exchange on the comms stream, interior stencil on the compute stream meanwhile,
-  // then the exterior pass over the boundary-site list (reference policy DslashCuda2 / DslashFusedExterior, lib/dslash_policy.cuh) ----
+  // ---- grid-decomposed lattice (reference policies DslashCuda2 / DslashFusedExterior, lib/dslash_policy.cuh) ----
   HaloBuffers &hb = haloBuffers(g, in.Precision());
   const BoundaryList &bl = boundaryList(g, mask);
-  if (!g_evIn) { HIP_CHECK(hipEventCreateWithFlags(&g_evIn, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&g_evHalo, hipEventDisableTiming)); }
-  hipStream_t ms = commStream();
-  HIP_CHECK(hipEventRecord(g_evIn, cs));            // `in` is complete and the previous exterior pass has released the ghost zone
-  HIP_CHECK(hipStreamWaitEvent(ms, g_evIn, 0));
   PackArg<real> pa;
   pa.in = in.V(); pa.inNorm = (const float *)in.Norm(); pa.sp_stride = in.Stride();
   for (int d = 0; d < 4; d++) pa.X[d] = g.X[d];
   pa.parity_in = 1 - p.parity; pa.sfwd = arg.sfwd; pa.a = arg.a;
+  { static int sa = -1; if (sa < 0) { const char *e = getenv("QUDA_AMD_PACK_AUX"); sa = e ? atoi(e) : 17; } pa.staux = sa; }
+  for (int k = 0; k < 8; k++) { pa.peerFlag[k] = nullptr; arg.waitFlag[k] = nullptr; arg.waitCount[k] = 0; }
+  arg.waitSeq = 0; arg.waitTicks = 0; arg.errWord = nullptr;
+  arg.commMask = mask;
+  arg.blist = bl.d_idx[p.parity]; arg.nboundary = bl.count[p.parity];
+
+  if (hb.p2p) {
+    // peer-store transport, ONE stream: the pack kernel stores every face straight into the neighbours' ghost zones and
+    // raises their flags; the interior pass runs while the faces travel; the exterior pass polls this rank's flags.
+    // Ghost zones are double-buffered by the parity of the exchange counter: a neighbour can be at most one exchange ahead
+    // (it needs OUR face of exchange k+1, packed after our exterior pass k, before it can finish k+1 and pack k+2).
+    const unsigned seq = ++hb.seq;
+    const int buf = seq & 1;
+    int nt = 0;
+    for (int d = 0; d < 4; d++) {
+      pa.faceCB[d] = g.faceCB[d]; pa.normOff[d] = (int)hb.norm_offset[d];
+      for (int dir = 0; dir < 2; dir++) {
+        pa.send[d][dir] = hb.peerGhost[d][dir][buf];
+        pa.start[2 * d + dir] = nt;
+        if ((mask >> d) & 1) { nt += g.faceCB[d]; pa.peerFlag[2 * d + dir] = hb.peerFlag[d][dir] + buf; }
+      }
+      if ((mask >> d) & 1) {
+        arg.ghost[d][0] = hb.ghostBuf[d][0][buf]; arg.ghost[d][1] = hb.ghostBuf[d][1][buf];
+        arg.ghostNormOff[d] = (int)hb.norm_offset[d];
+        arg.waitFlag[2 * d] = hb.flag[d][0] + buf; arg.waitFlag[2 * d + 1] = hb.flag[d][1] + buf;
+        // exchange seq uses buffer seq & 1 for the ((seq + 1) / 2)-th (odd) or (seq / 2)-th (even) time
+        arg.waitCount[2 * d] = arg.waitCount[2 * d + 1] = ((seq + 1) >> 1) * (unsigned)g.faceCB[d];
+      }
+    }
+    pa.start[8] = nt;
+    arg.waitSeq = seq; arg.waitTicks = p2pTimeoutTicks(); arg.errWord = p2pErrorWord();
+    static int fuse = -1;
+    if (fuse < 0) { const char *e = getenv("QUDA_AMD_FUSE"); fuse = e ? atoi(e) : 1; }
+    if (fuse) {
+      // ONE launch: [pack blocks | every site]; boundary sites add their off-node hops after polling the face counters
+      arg.packBlocks = (nt + bs - 1) / bs;
+      arg.pack = pa;
+      hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 3>), dim3(arg.packBlocks + nb), dim3(bs), 0, cs, arg);
+      HIP_CHECK(hipGetLastError());
+      return;
+    }
+    // QUDA_AMD_FUSE=0 (A/B measurements): pack, interior and exterior passes as three launches on the one stream
+    hipLaunchKernelGGL((pack_kernel<T, VARIANT == 1, true>), dim3((nt + 255) / 256), dim3(256), 0, cs, pa);
+    hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 1>), dim3(nb), dim3(bs), 0, cs, arg);   // interior
+    HIP_CHECK(hipGetLastError());
+    launchExterior<T, R, VARIANT, GAUX>(arg, cs);
+    return;
+  }
+
+  // staged transport: pack + ONE grouped RCCL send/recv on the comms stream, interior stencil on the compute stream meanwhile,
+  // then the exterior pass over the boundary-site list
+  if (!g_evIn) { HIP_CHECK(hipEventCreateWithFlags(&g_evIn, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&g_evHalo, hipEventDisableTiming)); }
+  hipStream_t ms = commStream();
+  HIP_CHECK(hipEventRecord(g_evIn, cs));            // `in` is complete and the previous exterior pass has released the ghost zone
+  HIP_CHECK(hipStreamWaitEvent(ms, g_evIn, 0));
   int nt = 0;
   std::vector<HaloMsg> msgs;
   for (int d = 0; d < 4; d++) {
@@ -645,15 +870,10 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
   commExchange(msgs, ms);
   HIP_CHECK(hipEventRecord(g_evHalo, ms));
 
-  arg.commMask = mask;
   hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 1>), dim3(nb), dim3(bs), 0, cs, arg);   // interior
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamWaitEvent(cs, g_evHalo, 0));
-  arg.blist = bl.d_idx[p.parity]; arg.nboundary = bl.count[p.parity];
-  if (arg.nboundary > 0) {
-    hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 2>), dim3((arg.nboundary + 127) / 128), dim3(128), 0, cs, arg);  // exterior
-    HIP_CHECK(hipGetLastError());
-  }
+  launchExterior<T, R, VARIANT, GAUX>(arg, cs);
 }
 
 template <typename T> static void dispatchRecon(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, const DslashParam &p) {

@@ -3,6 +3,7 @@
 // (geometry), lib/copy_color_spinor.cuh:49-91 (basis rotation), lib/cuda_color_spinor_field.cu:513-590
 // (load/save), lib/clover_invert.cu:56-85 (twisted inverse).
 #include "fields.h"
+#include "p2p.h"
 
 #include <cmath>
 #include <cstring>
@@ -303,6 +304,7 @@ template <typename TDev, typename THost> static void d2hParity(ColorSpinorField 
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipMemcpyAsync(dst.V(), stage, hbytes, hipMemcpyDeviceToHost, computeStream()));
   HIP_CHECK(hipStreamSynchronize(computeStream()));
+  p2pCheck("download of a result field");
 }
 
 template <typename TOut, typename TIn> static void d2dParity(ColorSpinorField &dst, const ColorSpinorField &src) {

@@ -9,6 +9,7 @@
 #include "blas.h"
 #include "dirac.h"
 #include "interface_internal.h"
+#include "p2p.h"
 #include "quda_amd_ext.h"
 
 namespace quda {
@@ -467,6 +468,7 @@ double qudaAmdTimeDslash(void *d, void *out, const void *in, QudaParity parity, 
   for (int i = 0; i < niter; i++) ((Dirac *)d)->Dslash(*(ColorSpinorField *)out, *(const ColorSpinorField *)in, parity);
   HIP_CHECK(hipEventRecord(e1, computeStream()));
   HIP_CHECK(hipEventSynchronize(e1));
+  p2pCheck(__func__);
   float ms = 0;
   HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
   HIP_CHECK(hipEventDestroy(e0));
@@ -481,6 +483,7 @@ double qudaAmdTimeM(void *d, void *out, const void *in, int niter) {
   for (int i = 0; i < niter; i++) ((Dirac *)d)->M(*(ColorSpinorField *)out, *(const ColorSpinorField *)in);
   HIP_CHECK(hipEventRecord(e1, computeStream()));
   HIP_CHECK(hipEventSynchronize(e1));
+  p2pCheck(__func__);
   float ms = 0;
   HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
   HIP_CHECK(hipEventDestroy(e0));
@@ -503,6 +506,7 @@ double qudaAmdTimeAxpy(double a, const void *x, void *y, int niter) {
   for (int i = 0; i < niter; i++) blas::axpy(a, *(const ColorSpinorField *)x, *(ColorSpinorField *)y);
   HIP_CHECK(hipEventRecord(e1, computeStream()));
   HIP_CHECK(hipEventSynchronize(e1));
+  p2pCheck(__func__);
   float ms = 0;
   HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
   HIP_CHECK(hipEventDestroy(e0));
@@ -530,6 +534,6 @@ void qudaAmdSetPartitionMask(int mask) {
   for (int d = 0; d < 4; d++) commGrid().forced[d] = (mask >> d) & 1;
 }
 void *qudaAmdComputeStream(void) { return (void *)computeStream(); }
-void qudaAmdDeviceSynchronize(void) { HIP_CHECK(hipDeviceSynchronize()); }
+void qudaAmdDeviceSynchronize(void) { HIP_CHECK(hipDeviceSynchronize()); p2pCheck(__func__); }
 
 }  // extern "C"

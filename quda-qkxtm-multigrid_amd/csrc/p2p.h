@@ -1,0 +1,41 @@
+// p2p.h — peer-mapped halo windows: the pack kernel of one GPU stores its faces straight into the ghost zone of the
+// neighbouring GPU over xGMI and raises a flag there; the neighbour's exterior kernel polls the flag.  No host round
+// trip, no collective-library launch on the critical path (a grouped RCCL send/recv costs ~55 us per Dslash, measured;
+// the whole 32x16x16x16 interior kernel takes 18 us).  The reference's counterpart is its CUDA-IPC "p2p" policy
+// (lib/cuda_color_spinor_field.cu:1212-1400, lib/dslash_policy.cuh:838-998: cudaIpcOpenMemHandle'd ghost buffers,
+// cudaMemcpyAsync into the peer, IPC events); like the reference, the library falls back to the staged transport (RCCL
+// send/recv) when peer mapping is not possible.
+#pragma once
+
+#include <vector>
+
+#include "qa_core.h"
+
+namespace quda {
+
+// fine-grained (uncached, system-coherent) device memory: remote GPUs store into it while a local kernel polls / reads it
+void *p2pAlloc(size_t bytes);
+void p2pFree(void *p);
+
+struct PeerMap {
+  void *peer[8] = {};            // slot = 2 * dim + (1: the +dim neighbour, 0: the -dim neighbour); own pointer for a self neighbour
+  std::vector<void *> opened;    // IPC mappings to close
+};
+// Collective over all ranks.  false: some rank could not export / open a handle (nothing stays mapped).
+bool commMapPeers(void *local, PeerMap &m);
+void commUnmapPeers(PeerMap &m);
+void commAllgatherBytes(const void *mine, void *all, size_t n);
+
+// Decided once, collectively, at the first halo exchange: QUDA_AMD_HALO=rccl forces the staged transport; otherwise the
+// windows are mapped and a token round trip through them must succeed on every rank.
+bool p2pHaloEnabled();
+void p2pReset();
+
+// device word set by a wait that timed out (a neighbour never signalled); p2pCheck aborts with a message if it is set
+int *p2pErrorWord();
+void p2pCheck(const char *where);
+
+// 100 MHz constant-rate counter ticks a kernel waits for a neighbour before it gives up (QUDA_AMD_P2P_TIMEOUT_S, default 20 s)
+unsigned long long p2pTimeoutTicks();
+
+}  // namespace quda

@@ -1,0 +1,140 @@
+// p2p.hip — see p2p.h
+#include "p2p.h"
+
+#include <cstdlib>
+#include <cstring>
+
+#include "blas.h"
+#include "halo.h"
+#include "interface_internal.h"
+
+namespace quda {
+
+void *p2pAlloc(size_t bytes) {
+  void *p = nullptr;
+  HIP_CHECK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained));
+  HIP_CHECK(hipMemsetAsync(p, 0, bytes, computeStream()));
+  HIP_CHECK(hipStreamSynchronize(computeStream()));
+  return p;
+}
+void p2pFree(void *p) { if (p) (void)hipFree(p); }
+
+bool commMapPeers(void *local, PeerMap &m) {
+  const CommGrid &g = commGrid();
+  for (int s = 0; s < 8; s++) m.peer[s] = nullptr;
+  m.opened.clear();
+  double fail = 0;
+  hipIpcMemHandle_t mine;
+  memset(&mine, 0, sizeof(mine));
+  if (g.size > 1 && hipIpcGetMemHandle(&mine, local) != hipSuccess) { (void)hipGetLastError(); fail = 1; }
+  std::vector<hipIpcMemHandle_t> all(g.size);
+  if (g.size > 1) commAllgatherBytes(&mine, all.data(), sizeof(mine));
+  comm_allreduce(&fail, 1);
+  if (fail > 0) return false;
+  std::vector<void *> byRank(g.size, nullptr);
+  byRank[g.rank] = local;
+  for (int s = 0; s < 8; s++) {
+    const int r = commNeighborRank(s >> 1, (s & 1) ? +1 : -1);
+    if (!byRank[r]) {
+      void *p = nullptr;
+      if (hipIpcOpenMemHandle(&p, all[r], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); fail = 1; break; }
+      byRank[r] = p;
+      m.opened.push_back(p);
+    }
+    m.peer[s] = byRank[r];
+  }
+  comm_allreduce(&fail, 1);
+  if (fail > 0) { commUnmapPeers(m); return false; }
+  return true;
+}
+void commUnmapPeers(PeerMap &m) {
+  for (void *p : m.opened) (void)hipIpcCloseMemHandle(p);
+  m.opened.clear();
+  for (int s = 0; s < 8; s++) m.peer[s] = nullptr;
+}
+
+unsigned long long p2pTimeoutTicks() {
+  static unsigned long long t = 0;
+  if (!t) { const char *e = getenv("QUDA_AMD_P2P_TIMEOUT_S"); t = (unsigned long long)((e ? atof(e) : 20.0) * 1e8); if (!t) t = 1; }
+  return t;
+}
+
+static int *g_err = nullptr;
+int *p2pErrorWord() {
+  if (!g_err) {
+    HIP_CHECK(hipHostMalloc((void **)&g_err, sizeof(int), hipHostMallocMapped));
+    *g_err = 0;
+  }
+  return g_err;
+}
+void p2pCheck(const char *where) {
+  if (g_err && *(volatile int *)g_err) errorQuda("%s: a halo wait timed out (a neighbour rank never delivered its face; error word %d)", where, *g_err);
+}
+
+// ---- token round trip through the mapped windows ----
+struct ProbeWindow { unsigned data[8][16]; unsigned flag[8]; };
+
+__global__ void p2p_probe_send(ProbeWindow *const *peer, int rank) {
+  const int s = threadIdx.x;
+  if (s >= 8 || !peer[s]) return;
+  ProbeWindow *w = peer[s];
+  for (int k = 0; k < 16; k++) w->data[s][k] = 0x5eed0000u + (unsigned)rank * 64u + s * 16u + k;
+  __threadfence_system();
+  __hip_atomic_store(&w->flag[s], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void p2p_probe_recv(ProbeWindow *mine, const int *fromRank, unsigned long long ticks, int *result) {
+  const int s = threadIdx.x;
+  if (s >= 8) return;
+  const unsigned long long t0 = wall_clock64();
+  bool ok = true;
+  while (__hip_atomic_load(&mine->flag[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != 1u)
+    if (wall_clock64() - t0 > ticks) { ok = false; break; }
+  if (ok)
+    for (int k = 0; k < 16; k++) ok = ok && mine->data[s][k] == 0x5eed0000u + (unsigned)fromRank[s] * 64u + s * 16u + k;
+  if (!ok) atomicAdd(result, 1);
+}
+
+static int g_p2p = -1;
+void p2pReset() { g_p2p = -1; }
+
+bool p2pHaloEnabled() {
+  if (g_p2p >= 0) return g_p2p != 0;
+  const char *e = getenv("QUDA_AMD_HALO");
+  if (e && !strcmp(e, "rccl")) { g_p2p = 0; return false; }
+  const CommGrid &g = commGrid();
+  ProbeWindow *win = (ProbeWindow *)p2pAlloc(sizeof(ProbeWindow));
+  PeerMap pm;
+  double fail = 0;
+  if (!commMapPeers(win, pm)) {
+    fail = 1;
+  } else {
+    ProbeWindow **d_peer = nullptr;
+    int *d_from = nullptr, *d_res = nullptr, h_from[8], h_res = 0;
+    // window s is written by the rank that has me as its slot-s neighbour: its +dim neighbour (s odd) is me -> it is my -dim neighbour
+    for (int s = 0; s < 8; s++) h_from[s] = commNeighborRank(s >> 1, (s & 1) ? -1 : +1);
+    HIP_CHECK(hipMalloc((void **)&d_peer, 8 * sizeof(void *)));
+    HIP_CHECK(hipMalloc((void **)&d_from, 8 * sizeof(int)));
+    HIP_CHECK(hipMalloc((void **)&d_res, sizeof(int)));
+    HIP_CHECK(hipMemcpy(d_peer, pm.peer, 8 * sizeof(void *), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_from, h_from, 8 * sizeof(int), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemset(d_res, 0, sizeof(int)));
+    HIP_CHECK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(p2p_probe_send, dim3(1), dim3(64), 0, computeStream(), (ProbeWindow *const *)d_peer, g.rank);
+    hipLaunchKernelGGL(p2p_probe_recv, dim3(1), dim3(64), 0, computeStream(), win, d_from, (unsigned long long)5e8, d_res);
+    if (hipStreamSynchronize(computeStream()) != hipSuccess) { (void)hipGetLastError(); h_res = 1; }
+    else HIP_CHECK(hipMemcpy(&h_res, d_res, sizeof(int), hipMemcpyDeviceToHost));
+    fail = h_res ? 1 : 0;
+    (void)hipFree(d_peer); (void)hipFree(d_from); (void)hipFree(d_res);
+  }
+  comm_allreduce(&fail, 1);   // also keeps every rank's window alive until all neighbours have written it
+  commUnmapPeers(pm);
+  commBarrier();
+  p2pFree(win);
+  g_p2p = fail > 0 ? 0 : 1;
+  if (g.rank == 0 && getVerbosity() >= QUDA_SUMMARIZE)
+    printfQuda("halo transport: %s\n", g_p2p ? "direct peer stores (IPC-mapped ghost zones)" : "RCCL send/recv (peer mapping unavailable)");
+  if (!g_p2p && e && !strcmp(e, "p2p")) errorQuda("QUDA_AMD_HALO=p2p requested but the peer windows cannot be mapped / verified");
+  return g_p2p != 0;
+}
+
+}  // namespace quda

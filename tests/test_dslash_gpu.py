@@ -204,3 +204,13 @@ def test_partitioned_dslash_self_neighbour(qa, mask):
             qa.lib().qudaAmdSetPartitionMask(0)
     finally:
         qa.lib().qudaAmdSetPartitionMask(0)
+
+
+def test_rccl_call_sequence_self_loop():
+    """The real RCCL calls of the multi-GPU path (ncclCommInitRank, grouped ncclSend/ncclRecv, ncclAllReduce) on one GPU:
+    a one-rank communicator in self-test mode sends every halo message to itself through RCCL (tools/rccl_selftest.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_selftest.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL self-loop OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
