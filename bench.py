@@ -221,7 +221,7 @@ def main():
             "vs_baseline": None, "dtype": dtype_name[args.prec], "data": "synthetic",
             "config": {"workload": "%s even-odd Dslash (DiracTwistedMassPC::Dslash, kappa=%g mu=%g), %s lattice, recon-%d, fields resident in HBM"
                        % ({"tm": "twisted-mass", "tmc": "twisted-clover", "wilson": "Wilson"}[args.dslash], kappa, mu, "x".join(map(str, X)), args.recon),
-                       "local_lattice": Xl, "process_grid": dist.grid if dist else [1, 1, 1, 1], "flops_per_site": r["flops_site"]},
+                       "local_lattice": Xl, "halo_transport": {1: "direct peer stores (IPC-mapped ghost zones over xGMI)", 0: "RCCL send/recv", -1: "none (single rank)"}[int(qa.lib().qudaAmdHaloTransport())], "process_grid": dist.grid if dist else [1, 1, 1, 1], "flops_per_site": r["flops_site"]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": traffic_source, "bytes_per_site": r["bytes_site"], "kernel_us": round(1e6 * r["sec"], 3)},
             "cpu_baseline": cpu,

@@ -93,6 +93,9 @@ void qudaAmdSetPartitionMask(int mask);
 /* stream the kernels are launched on (hipStream_t), for callers that bracket work with their own events */
 void *qudaAmdComputeStream(void);
 void qudaAmdDeviceSynchronize(void);
+/* halo transport in use: -1 not decided yet (no partitioned Dslash so far), 0 staged RCCL send/recv, 1 direct peer stores
+ * into IPC-mapped ghost zones (the reference's "p2p" vs staged comms policies, lib/dslash_policy.cuh:838-998) */
+int qudaAmdHaloTransport(void);
 
 #ifdef __cplusplus
 }

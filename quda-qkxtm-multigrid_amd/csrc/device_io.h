@@ -95,7 +95,8 @@ template <int NR> struct Planar<float, NR> {
 // 16-bit fixed point.  norm == nullptr: fixed unit scale (links); else per-site scale at norm[nidx].
 template <int NR> struct Planar<short, NR> {
   template <int AUX = 0> static __device__ __forceinline__ void load(float *r, const void *base, int stride, int x, const float *norm, int nidx) {
-    const float s = norm ? norm[nidx] * kShortInv : kShortInv;
+    // AUX with sc1 (bit 4): the block may have been written by another GPU / process -> the scale is read at system scope too
+    const float s = norm ? ((AUX & 16) ? __hip_atomic_load(&norm[nidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : norm[nidx]) * kShortInv : kShortInv;
     const __amdgpu_buffer_rsrc_t rs = planar_rsrc<short, NR>(base, stride);
     const int off = x * 8;
 #pragma unroll
@@ -115,7 +116,8 @@ template <int NR> struct Planar<short, NR> {
       float m = 0.f;
 #pragma unroll
       for (int k = 0; k < NR; k++) m = fmaxf(m, fabsf(r[k]));
-      norm[nidx] = m;
+      if (AUX & 16) __hip_atomic_store(&norm[nidx], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // write-through like the payload
+      else norm[nidx] = m;
       s = m > 0.f ? kShortMax / m : 0.f;
     }
     const __amdgpu_buffer_rsrc_t rs = planar_rsrc<short, NR>(base, stride);

@@ -42,7 +42,7 @@ template <typename real> struct PackArg {
   int start[9];     // prefix offsets of the 8 (dim, dir) thread ranges
   // peer-store transport: send[][] point into the NEIGHBOURS' ghost zones; the last block to finish raises the flags there
   unsigned *peerFlag[8];   // the neighbours' site counters of the faces this rank sends
-  int staux;        // cache-policy bits of the face stores (experiment switch QUDA_AMD_PACK_AUX; 17 = sc0 sc1)
+  unsigned long long *timeline;
 };
 
 template <typename real> struct DslashArg {
@@ -83,6 +83,7 @@ template <typename real> struct DslashArg {
   // the grid does the interior stencil — one launch, the faces leave at time zero and travel during the interior pass
   int packBlocks;
   PackArg<real> pack;
+  unsigned long long *timeline;   // QUDA_AMD_TIMELINE=1: per-block wall_clock64 stamps (measurement aid), else nullptr
 };
 
 // ---- spin projection / reconstruction in the chiral basis; s = +1 selects projector[2 mu], -1 projector[2 mu + 1]
@@ -207,10 +208,10 @@ __device__ __forceinline__ void ghost_hop(real *acc, const DslashArg<real> &arg,
 template <typename real> __device__ __forceinline__ void wait_for_faces_wave(const DslashArg<real> &arg) {
   if (!arg.waitSeq) return;
   const int lane = threadIdx.x & 63;
-  if (lane < 8 && arg.waitFlag[lane]) {
+  if (lane < 8 && arg.waitFlag[lane] && !__hip_atomic_load(arg.errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
     const unsigned long long t0 = wall_clock64();
     while ((int)(__hip_atomic_load(arg.waitFlag[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - arg.waitCount[lane]) < 0) {
-      if (wall_clock64() - t0 > arg.waitTicks) { *arg.errWord = 1 + lane; break; }
+      if (wall_clock64() - t0 > arg.waitTicks) { __hip_atomic_store(arg.errWord, 1 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       __builtin_amdgcn_s_sleep(1);
     }
   }
@@ -222,10 +223,10 @@ template <typename real> __device__ __forceinline__ void wait_for_faces_wave(con
 // read with system-scope loads, and it cannot have been read earlier in this kernel.
 template <typename real> __device__ __forceinline__ void wait_for_faces(const DslashArg<real> &arg) {
   if (!arg.waitSeq) return;
-  if (threadIdx.x < 8 && arg.waitFlag[threadIdx.x]) {
+  if (threadIdx.x < 8 && arg.waitFlag[threadIdx.x] && !__hip_atomic_load(arg.errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
     const unsigned long long t0 = wall_clock64();
     while ((int)(__hip_atomic_load(arg.waitFlag[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - arg.waitCount[threadIdx.x]) < 0) {
-      if (wall_clock64() - t0 > arg.waitTicks) { *arg.errWord = 1 + (int)threadIdx.x; break; }
+      if (wall_clock64() - t0 > arg.waitTicks) { __hip_atomic_store(arg.errWord, 1 + (int)threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       __builtin_amdgcn_s_sleep(1);
     }
   }
@@ -309,6 +310,7 @@ __device__ __forceinline__ void dslash_epilogue(real *acc, const DslashArg<real>
 // P2P: the send pointers are peer-mapped ghost zones — system-scope write-through stores (sc0 sc1), completion counter, flags
 template <typename T, bool PRETWIST, bool P2P, typename real> __device__ __forceinline__ void pack_body(const PackArg<real> &arg, int bid, int nblk) {
   const int tid = bid * blockDim.x + threadIdx.x;
+  if (P2P && arg.timeline && threadIdx.x == 0) arg.timeline[bid] = wall_clock64();
   if (tid < arg.start[8]) {
     int slot = 0;
 #pragma unroll
@@ -336,9 +338,8 @@ template <typename T, bool PRETWIST, bool P2P, typename real> __device__ __force
       default: spin_project<3>(h, psi, s); break;
     }
     char *sb = arg.send[d][to_fwd];
-    if (P2P && arg.staux == 17) Planar<T, 12>::template store<17>(h, sb, arg.faceCB[d], f, reinterpret_cast<float *>(sb + arg.normOff[d]), f);
-    else if (P2P && arg.staux == 2) Planar<T, 12>::template store<2>(h, sb, arg.faceCB[d], f, reinterpret_cast<float *>(sb + arg.normOff[d]), f);
-    else Planar<T, 12>::template store<0>(h, sb, arg.faceCB[d], f, reinterpret_cast<float *>(sb + arg.normOff[d]), f);
+    // peer-mapped target: sc0 sc1 stores (system scope, write-through) — an IPC mapping need not be fine-grained on the writer's side
+    Planar<T, 12>::template store<P2P ? 17 : 0>(h, sb, arg.faceCB[d], f, reinterpret_cast<float *>(sb + arg.normOff[d]), f);
   }
   if (P2P) {
     // Signalling: every incoming face has a cumulative SITE COUNTER in the receiver's window.  A block waits until its own
@@ -355,6 +356,7 @@ template <typename T, bool PRETWIST, bool P2P, typename real> __device__ __force
       const int hi = end < arg.start[threadIdx.x + 1] ? end : arg.start[threadIdx.x + 1];
       if (hi > lo) (void)__hip_atomic_fetch_add(arg.peerFlag[threadIdx.x], (unsigned)(hi - lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    if (arg.timeline && threadIdx.x == 0) arg.timeline[1024 + bid] = wall_clock64();
   }
 }
 
@@ -434,7 +436,9 @@ __device__ __forceinline__ void stencil_site(const DslashArg<real> &arg, const i
     // the hops that leave this rank: wait (only the waves that own boundary sites) until the neighbours' faces are in, then add them
     const bool anyoff = o_xp || o_xm || o_yp || o_ym || o_zp || o_zm || o_tp || o_tm;
     if (__builtin_amdgcn_ballot_w64(anyoff) != 0) {
+      if (arg.timeline && (threadIdx.x & 63) == 0) arg.timeline[4096 + (blockIdx.x * 4 + (threadIdx.x >> 6))] = wall_clock64();
       wait_for_faces_wave(arg);
+      if (arg.timeline && (threadIdx.x & 63) == 0) arg.timeline[8192 + (blockIdx.x * 4 + (threadIdx.x >> 6))] = wall_clock64();
       ghost_hop<T, R, 0, GAUX>(acc, arg, idx, o_xp, f_x, one);
       ghost_hop<T, R, 1, GAUX>(acc, arg, idx, o_xm, f_x, one);
       ghost_hop<T, R, 2, GAUX>(acc, arg, idx, o_yp, f_y, one);
@@ -477,7 +481,9 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
   }
   const int idx = lb * blockDim.x + threadIdx.x;
   if (idx >= arg.Vh) return;
+  if (KT == 3 && arg.timeline && threadIdx.x == 0) arg.timeline[2048 + blockIdx.x] = wall_clock64();
   stencil_site<T, R, VARIANT, GAUX, KT, SAUX>(arg, idx);
+  if (KT == 3 && arg.timeline && threadIdx.x == 0) arg.timeline[12288 + blockIdx.x] = wall_clock64();
 }
 
 // ---- single-direction hop (setup-time helper for the multigrid coarse-operator construction) ----
@@ -792,7 +798,7 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
   pa.in = in.V(); pa.inNorm = (const float *)in.Norm(); pa.sp_stride = in.Stride();
   for (int d = 0; d < 4; d++) pa.X[d] = g.X[d];
   pa.parity_in = 1 - p.parity; pa.sfwd = arg.sfwd; pa.a = arg.a;
-  { static int sa = -1; if (sa < 0) { const char *e = getenv("QUDA_AMD_PACK_AUX"); sa = e ? atoi(e) : 17; } pa.staux = sa; }
+  pa.timeline = nullptr; arg.timeline = nullptr;
   for (int k = 0; k < 8; k++) { pa.peerFlag[k] = nullptr; arg.waitFlag[k] = nullptr; arg.waitCount[k] = 0; }
   arg.waitSeq = 0; arg.waitTicks = 0; arg.errWord = nullptr;
   arg.commMask = mask;
@@ -817,8 +823,8 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
         arg.ghost[d][0] = hb.ghostBuf[d][0][buf]; arg.ghost[d][1] = hb.ghostBuf[d][1][buf];
         arg.ghostNormOff[d] = (int)hb.norm_offset[d];
         arg.waitFlag[2 * d] = hb.flag[d][0] + buf; arg.waitFlag[2 * d + 1] = hb.flag[d][1] + buf;
-        // exchange seq uses buffer seq & 1 for the ((seq + 1) / 2)-th (odd) or (seq / 2)-th (even) time
-        arg.waitCount[2 * d] = arg.waitCount[2 * d + 1] = ((seq + 1) >> 1) * (unsigned)g.faceCB[d];
+        // the counters are cumulative per (dimension, buffer): expected value = times this buffer has been used x face sites
+        arg.waitCount[2 * d] = arg.waitCount[2 * d + 1] = ++hb.uses[d][buf] * (unsigned)g.faceCB[d];
       }
     }
     pa.start[8] = nt;
@@ -828,6 +834,30 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
     if (fuse) {
       // ONE launch: [pack blocks | every site]; boundary sites add their off-node hops after polling the face counters
       arg.packBlocks = (nt + bs - 1) / bs;
+      static unsigned long long *tl = nullptr;
+      static int tlmode = -1;
+      if (tlmode < 0) { const char *e = getenv("QUDA_AMD_TIMELINE"); tlmode = e ? atoi(e) : 0; if (tlmode) HIP_CHECK(hipHostMalloc((void **)&tl, 16384 * sizeof(unsigned long long), hipHostMallocMapped)); }
+      if (tlmode) {
+        static int calls = 0;
+        if (++calls == 60 && arg.packBlocks + nb <= 1024) {
+          HIP_CHECK(hipStreamSynchronize(cs));
+          memset(tl, 0, 16384 * sizeof(unsigned long long));
+          pa.timeline = tl; arg.timeline = tl; arg.pack = pa;
+          hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 3>), dim3(arg.packBlocks + nb), dim3(bs), 0, cs, arg);
+          HIP_CHECK(hipStreamSynchronize(cs));
+          unsigned long long t0 = ~0ull;
+          for (int i = 0; i < 16384; i++) if (tl[i] && tl[i] < t0) t0 = tl[i];
+          auto stat = [&](int off, int n, const char *name) {
+            double mn = 1e30, mx = 0, sum = 0; int c = 0;
+            for (int i = 0; i < n; i++) if (tl[off + i]) { const double v = (tl[off + i] - t0) * 0.01; mn = v < mn ? v : mn; mx = v > mx ? v : mx; sum += v; c++; }
+            if (c) printfQuda("timeline %-22s n=%4d  min %6.2f  mean %6.2f  max %6.2f us\n", name, c, mn, sum / c, mx);
+          };
+          stat(0, 1024, "pack block start"); stat(1024, 1024, "pack block end"); stat(2048, 1024, "stencil block start");
+          stat(4096, 4096, "boundary wave wait beg"); stat(8192, 4096, "boundary wave wait end"); stat(12288, 1024, "stencil block end");
+          return;
+        }
+      }
+      pa.timeline = nullptr; arg.timeline = nullptr;
       arg.pack = pa;
       hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 3>), dim3(arg.packBlocks + nb), dim3(bs), 0, cs, arg);
       HIP_CHECK(hipGetLastError());

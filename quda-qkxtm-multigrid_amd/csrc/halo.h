@@ -46,6 +46,7 @@ struct HaloBuffers {
   char *peerGhost[4][2][2] = {};   // [dim][to_fwd][buf]
   unsigned *peerFlag[4][2] = {};   // + buf
   unsigned seq = 0;
+  unsigned uses[4][2] = {};        // exchanges that used (dim, buf) so far
   PeerMap map;
 };
 

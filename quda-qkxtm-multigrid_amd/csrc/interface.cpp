@@ -534,6 +534,7 @@ void qudaAmdSetPartitionMask(int mask) {
   for (int d = 0; d < 4; d++) commGrid().forced[d] = (mask >> d) & 1;
 }
 void *qudaAmdComputeStream(void) { return (void *)computeStream(); }
+int qudaAmdHaloTransport(void) { return p2pTransport(); }
 void qudaAmdDeviceSynchronize(void) { HIP_CHECK(hipDeviceSynchronize()); p2pCheck(__func__); }
 
 }  // extern "C"

@@ -30,12 +30,13 @@ void commAllgatherBytes(const void *mine, void *all, size_t n);
 // windows are mapped and a token round trip through them must succeed on every rank.
 bool p2pHaloEnabled();
 void p2pReset();
+int p2pTransport();   // -1 not decided yet, 0 staged (RCCL send/recv), 1 direct peer stores
 
 // device word set by a wait that timed out (a neighbour never signalled); p2pCheck aborts with a message if it is set
 int *p2pErrorWord();
 void p2pCheck(const char *where);
 
-// 100 MHz constant-rate counter ticks a kernel waits for a neighbour before it gives up (QUDA_AMD_P2P_TIMEOUT_S, default 20 s)
+// 100 MHz constant-rate counter ticks a kernel waits for a neighbour before it gives up (QUDA_AMD_P2P_TIMEOUT_S, default 10 s)
 unsigned long long p2pTimeoutTicks();
 
 }  // namespace quda

@@ -55,20 +55,24 @@ void commUnmapPeers(PeerMap &m) {
 
 unsigned long long p2pTimeoutTicks() {
   static unsigned long long t = 0;
-  if (!t) { const char *e = getenv("QUDA_AMD_P2P_TIMEOUT_S"); t = (unsigned long long)((e ? atof(e) : 20.0) * 1e8); if (!t) t = 1; }
+  if (!t) { const char *e = getenv("QUDA_AMD_P2P_TIMEOUT_S"); t = (unsigned long long)((e ? atof(e) : 10.0) * 1e8); if (!t) t = 1; }
   return t;
 }
 
-static int *g_err = nullptr;
+static int *g_err = nullptr;   // device word: 0, or 1 + slot of the first wait that timed out (later waits then return at once)
 int *p2pErrorWord() {
   if (!g_err) {
-    HIP_CHECK(hipHostMalloc((void **)&g_err, sizeof(int), hipHostMallocMapped));
-    *g_err = 0;
+    HIP_CHECK(hipMalloc((void **)&g_err, sizeof(int)));
+    HIP_CHECK(hipMemset(g_err, 0, sizeof(int)));
+    HIP_CHECK(hipDeviceSynchronize());
   }
   return g_err;
 }
 void p2pCheck(const char *where) {
-  if (g_err && *(volatile int *)g_err) errorQuda("%s: a halo wait timed out (a neighbour rank never delivered its face; error word %d)", where, *g_err);
+  if (!g_err) return;
+  int h = 0;
+  HIP_CHECK(hipMemcpy(&h, g_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (h) errorQuda("%s: a halo wait timed out (a neighbour rank never delivered its face; error word %d)", where, h);
 }
 
 // ---- token round trip through the mapped windows ----
@@ -95,7 +99,11 @@ __global__ void p2p_probe_recv(ProbeWindow *mine, const int *fromRank, unsigned 
 }
 
 static int g_p2p = -1;
-void p2pReset() { g_p2p = -1; }
+void p2pReset() {
+  g_p2p = -1;
+  if (g_err) { (void)hipFree(g_err); g_err = nullptr; }
+}
+int p2pTransport() { return g_p2p; }
 
 bool p2pHaloEnabled() {
   if (g_p2p >= 0) return g_p2p != 0;

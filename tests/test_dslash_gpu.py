@@ -214,3 +214,20 @@ def test_rccl_call_sequence_self_loop():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_selftest.py")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL self-loop OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_two_process_decomposition_on_one_gpu():
+    """Two real processes (ranks) sharing this GPU, lattice split 1x1x1x2 / 1x1x2x1 / 2x1x1x1: halo through the IPC-mapped
+    peer-store transport (each rank's pack blocks store into the other PROCESS' ghost window), collectives through the file
+    transport (RCCL refuses two ranks on one device).  Dslash / Mat / MatPC in three precisions, distributed GCR and MG-GCR
+    against the single-lattice oracle (tools/mgpu_check.py)."""
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        log = os.path.join(tmp, "rehearsal.log")
+        env = dict(os.environ, QUDA_AMD_P2P_TIMEOUT_S="5")
+        subprocess.run([os.path.join(root, "tools", "mgpu_rehearsal.sh"), "2", log], cwd=root, env=env, timeout=400, check=True)
+        text = open(log).read()
+    assert "rank 0: all checks passed" in text and "rank 1: all checks passed" in text, text[-3000:]
+    assert text.count("MG-GCR") >= 6

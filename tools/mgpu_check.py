@@ -42,7 +42,8 @@ def main():
             full[parity * nh_g:(parity + 1) * nh_g] = full_parity_field
             return mg.scatter_field(full, X, grid, dist.coords, 24)[parity * nh_l:(parity + 1) * nh_l]
 
-        order = ((8, 1e-12), (4, 2e-5), (2, 1e-2)) if not os.environ.get("MGPU_REVERSE") else ((4, 2e-5), (8, 1e-12), (2, 1e-2))
+        tols = {8: 1e-12, 4: 2e-5, 2: 1e-2}
+        order = [(int(v), tols[int(v)]) for v in os.environ.get("MGPU_ORDER", "8,4,2").split(",")]
         for prec, tol in order:
             qa.load_gauge(g_loc, qa.gauge_param(Xl, cuda_prec=prec))
             ipc = qa.invert_param(qa.QUDA_TWISTED_CLOVER_DSLASH, kappa, mu, cuda_prec=prec)
