@@ -75,26 +75,34 @@ void p2pCheck(const char *where) {
   if (h) errorQuda("%s: a halo wait timed out (a neighbour rank never delivered its face; error word %d)", where, h);
 }
 
-// ---- token round trip through the mapped windows ----
+// ---- token round trips through the mapped windows, with the same access types as the halo protocol: system-scope
+// write-through stores for the payload, a fire-and-forget remote atomic add for the counter, system-scope polling and loads.
+// Several rounds over the SAME addresses, so a receiver that could serve a later round from a stale cache line fails here
+// and not in production. ----
 struct ProbeWindow { unsigned data[8][16]; unsigned flag[8]; };
 
-__global__ void p2p_probe_send(ProbeWindow *const *peer, int rank) {
-  const int s = threadIdx.x;
+__device__ __forceinline__ unsigned probe_token(int rank, int s, int k, int round) { return 0x5eed0000u + (unsigned)round * 4096u + (unsigned)rank * 128u + s * 16u + k; }
+
+__global__ void p2p_probe_send(ProbeWindow *const *peer, int rank, int round) {
+  const int s = threadIdx.x >> 4, k = threadIdx.x & 15;   // 8 slots x 16 words
   if (s >= 8 || !peer[s]) return;
   ProbeWindow *w = peer[s];
-  for (int k = 0; k < 16; k++) w->data[s][k] = 0x5eed0000u + (unsigned)rank * 64u + s * 16u + k;
-  __threadfence_system();
-  __hip_atomic_store(&w->flag[s], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&w->data[s][k], probe_token(rank, s, k, round), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (k == 0) (void)__hip_atomic_fetch_add(&w->flag[s], 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__global__ void p2p_probe_recv(ProbeWindow *mine, const int *fromRank, unsigned long long ticks, int *result) {
+__global__ void p2p_probe_recv(ProbeWindow *mine, const int *fromRank, unsigned long long ticks, int *result, int round) {
   const int s = threadIdx.x;
   if (s >= 8) return;
   const unsigned long long t0 = wall_clock64();
   bool ok = true;
-  while (__hip_atomic_load(&mine->flag[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != 1u)
+  while ((int)(__hip_atomic_load(&mine->flag[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - 16u * (unsigned)round) < 0) {
     if (wall_clock64() - t0 > ticks) { ok = false; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
   if (ok)
-    for (int k = 0; k < 16; k++) ok = ok && mine->data[s][k] == 0x5eed0000u + (unsigned)fromRank[s] * 64u + s * 16u + k;
+    for (int k = 0; k < 16; k++) ok = ok && __hip_atomic_load(&mine->data[s][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == probe_token(fromRank[s], s, k, round);
   if (!ok) atomicAdd(result, 1);
 }
 
@@ -127,11 +135,14 @@ bool p2pHaloEnabled() {
     HIP_CHECK(hipMemcpy(d_from, h_from, 8 * sizeof(int), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemset(d_res, 0, sizeof(int)));
     HIP_CHECK(hipDeviceSynchronize());
-    hipLaunchKernelGGL(p2p_probe_send, dim3(1), dim3(64), 0, computeStream(), (ProbeWindow *const *)d_peer, g.rank);
-    hipLaunchKernelGGL(p2p_probe_recv, dim3(1), dim3(64), 0, computeStream(), win, d_from, (unsigned long long)5e8, d_res);
-    if (hipStreamSynchronize(computeStream()) != hipSuccess) { (void)hipGetLastError(); h_res = 1; }
-    else HIP_CHECK(hipMemcpy(&h_res, d_res, sizeof(int), hipMemcpyDeviceToHost));
-    fail = h_res ? 1 : 0;
+    for (int round = 1; round <= 3 && fail == 0; round++) {
+      hipLaunchKernelGGL(p2p_probe_send, dim3(1), dim3(128), 0, computeStream(), (ProbeWindow *const *)d_peer, g.rank, round);
+      hipLaunchKernelGGL(p2p_probe_recv, dim3(1), dim3(64), 0, computeStream(), win, d_from, (unsigned long long)3e8, d_res, round);
+      if (hipStreamSynchronize(computeStream()) != hipSuccess) { (void)hipGetLastError(); h_res = 1; }
+      else HIP_CHECK(hipMemcpy(&h_res, d_res, sizeof(int), hipMemcpyDeviceToHost));
+      fail = h_res ? 1 : 0;
+      comm_allreduce(&fail, 1);   // every rank has verified this round before anyone overwrites the tokens
+    }
     (void)hipFree(d_peer); (void)hipFree(d_from); (void)hipFree(d_res);
   }
   comm_allreduce(&fail, 1);   // also keeps every rank's window alive until all neighbours have written it
