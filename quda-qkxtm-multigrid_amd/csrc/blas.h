@@ -62,6 +62,7 @@ void cDotProduct(Complex *result, std::vector<ColorSpinorField *> &a, std::vecto
 
 // rank reductions (comm layer)
 void comm_allreduce(double *data, int n);
+bool commReductionsNeeded();   // more than one rank (or the RCCL self-test mode): sums must go through the all-reduce
 void commAllreduceDevice(double *d_data, int n, hipStream_t s);
 void comm_allreduce_max(double *data, int n);
 

@@ -4,7 +4,10 @@
 // double-precision partial sums it produces.  Every operand is streamed once with 16-byte per-lane
 // accesses (HBM-bound: (n_in + n_out) x field bytes); sums are accumulated in fp64 regardless of the
 // storage precision (reference QudaSumFloat, lib/reduce_quda.cu:61-63), reduced by wave shuffles
-// (64 lanes) -> LDS -> one fp64 atomic per block, and read back through pinned host memory.
+// (64 lanes) -> LDS -> one fp64 partial per block; the last block to finish (completion counter) adds the partials in block
+// order — bit-reproducible, unlike fp64 atomics — and writes the result straight into pinned host memory (single rank) or
+// into the device word RCCL all-reduces.  No memset before and no copy after the kernel: a reduction is ONE launch + one
+// stream synchronisation (the memset/copy pair cost ~7 us per reduction and 35 ms of the 16^4 MG setup+solve profile).
 // fp64/fp32 fields of any spin/colour are treated as flat arrays (complex pairs stay adjacent in the
 // FLOAT2/FLOAT4 planar orders); 16-bit fields go site by site because of their per-site scale.
 #include "blas.h"
@@ -17,19 +20,35 @@ namespace blas {
 unsigned long long flops = 0;
 unsigned long long bytes = 0;
 
-static double *d_red = nullptr;   // device accumulators
-static double *h_red = nullptr;   // pinned host copy
+static double *d_red = nullptr;   // device results (what RCCL all-reduces)
+static double *h_red = nullptr;   // pinned, device-mapped host results
+static double *h_red_dev = nullptr;  // device address of h_red
+static double *d_part = nullptr;  // per-block partial sums
+static unsigned *d_count = nullptr;  // completion counter (zero between launches)
+constexpr int kMaxBlocks = 4096;
 static bool g_global_reduction = true;
 constexpr int kMaxRed = 64;
 
 void init() {
   if (!d_red) HIP_CHECK(hipMalloc((void **)&d_red, kMaxRed * sizeof(double)));
-  if (!h_red) HIP_CHECK(hipHostMalloc((void **)&h_red, kMaxRed * sizeof(double), hipHostMallocDefault));
+  if (!h_red) {
+    HIP_CHECK(hipHostMalloc((void **)&h_red, kMaxRed * sizeof(double), hipHostMallocMapped));
+    HIP_CHECK(hipHostGetDevicePointer((void **)&h_red_dev, h_red, 0));
+  }
+  if (!d_part) HIP_CHECK(hipMalloc((void **)&d_part, (size_t)kMaxBlocks * 4 * sizeof(double)));
+  if (!d_count) {
+    HIP_CHECK(hipMalloc((void **)&d_count, sizeof(unsigned)));
+    HIP_CHECK(hipMemset(d_count, 0, sizeof(unsigned)));
+    HIP_CHECK(hipDeviceSynchronize());
+  }
 }
 void end() {
   if (d_red) (void)hipFree(d_red);
   if (h_red) (void)hipHostFree(h_red);
-  d_red = h_red = nullptr;
+  if (d_part) (void)hipFree(d_part);
+  if (d_count) (void)hipFree(d_count);
+  d_red = h_red = h_red_dev = d_part = nullptr;
+  d_count = nullptr;
 }
 void setGlobalReduction(bool on) { g_global_reduction = on; }
 
@@ -44,7 +63,10 @@ template <typename F> struct BlasArg {
   long n;        // chunks per segment
   int stride;    // site path: plane stride
   F f;
-  double *red;
+  double *red;       // device result
+  double *hred;      // pinned host result (nullptr: an all-reduce follows, the host reads the device word afterwards)
+  double *part;      // [block][nred] partial sums
+  unsigned *count;   // completion counter
 };
 
 template <typename real, int M> struct alignas(16) Chunk { real v[M]; };
@@ -210,10 +232,36 @@ __global__ void __launch_bounds__(256) blas_kernel(BlasArg<F> arg) {
       if (lane == 0) lds[wave][k] = v;
     }
     __syncthreads();
+    // block partial -> memory (agent-scope write-through stores: no L2 write-back needed before the counter is bumped)
     if (threadIdx.x < F::nred) {
       double v = 0;
       for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) v += lds[wv][threadIdx.x];
-      atomicAdd(&arg.red[threadIdx.x], v);
+      __hip_atomic_store(&arg.part[(size_t)blockIdx.x * F::nred + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __shared__ int isLast;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) isLast = __hip_atomic_fetch_add(arg.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+    __syncthreads();
+    if (isLast) {
+      // the last block adds the partials in a fixed order: thread t takes blocks t, t + blockDim, ...; then the block tree
+#pragma unroll
+      for (int k = 0; k < F::nred; k++) {
+        double v = 0;
+        for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) v += __hip_atomic_load(&arg.part[(size_t)b * F::nred + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        __syncthreads();
+        if (lane == 0) lds[wave][k] = v;
+      }
+      __syncthreads();
+      if (threadIdx.x < F::nred) {
+        double v = 0;
+        for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) v += lds[wv][threadIdx.x];
+        arg.red[threadIdx.x] = v;
+        if (arg.hred) __hip_atomic_store(&arg.hred[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      if (threadIdx.x == 0) __hip_atomic_store(arg.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -252,11 +300,18 @@ static void launch(const F &f, const ColorSpinorField &x, const ColorSpinorField
   arg.stride = x.Stride();
   arg.f = f;
   arg.red = d_red;
+  arg.part = d_part;
+  arg.count = d_count;
+  const bool allreduce = g_global_reduction && commReductionsNeeded();
+  arg.hred = allreduce ? nullptr : h_red_dev;
   hipStream_t s = computeStream();
-  if (F::nred > 0) HIP_CHECK(hipMemsetAsync(d_red, 0, F::nred * sizeof(double), s));
   const long nreal = (long)x.Stride() * x.Nspin() * x.Ncolor() * 2;
   const int bs = 256;
-  auto grid = [&](long n) { long b = (n * arg.nseg + bs - 1) / bs; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); };
+  // grid cap: 512 blocks (2 per CU) measured best on MI355X — 32x16x16x16 fp64 norm2 65 us at 4096 blocks (the completion
+  // counter / fp64 atomics of 3072 blocks serialise on one address) -> 34 us at 512; streaming axpy 5.5 -> 6.0 TB/s
+  static int cap = 0;
+  if (!cap) { const char *e = getenv("QUDA_AMD_BLAS_BLOCKS"); cap = e ? atoi(e) : 512; if (cap < 1 || cap > kMaxBlocks) cap = 512; }
+  auto grid = [&](long n) { long b = (n * arg.nseg + bs - 1) / bs; return (int)(b > cap ? cap : (b < 1 ? 1 : b)); };
   switch (x.Precision()) {
     case QUDA_DOUBLE_PRECISION:
       arg.n = nreal / 2;
@@ -276,8 +331,10 @@ static void launch(const F &f, const ColorSpinorField &x, const ColorSpinorField
   }
   HIP_CHECK(hipGetLastError());
   if (F::nred > 0) {
-    if (g_global_reduction) commAllreduceDevice(d_red, F::nred, s);  // RCCL all-reduce of the partial sums, in stream order
-    HIP_CHECK(hipMemcpyAsync(h_red, d_red, F::nred * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (allreduce) {
+      commAllreduceDevice(d_red, F::nred, s);  // RCCL all-reduce of the rank sums, in stream order
+      HIP_CHECK(hipMemcpyAsync(h_red, d_red, F::nred * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
     HIP_CHECK(hipStreamSynchronize(s));
     for (int k = 0; k < F::nred; k++) out[k] = h_red[k];
   }

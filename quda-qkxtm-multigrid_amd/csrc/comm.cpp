@@ -137,6 +137,8 @@ static void shmAllreduce(double *data, int n, bool is_max) {
   for (int k = 0; k < n; k++) data[k] = acc[k];
 }
 
+bool commReductionsNeeded() { return commGrid().size > 1 || g_rccl_self; }
+
 void commAllreduceDevice(double *d_data, int n, hipStream_t s) {
   if (commGrid().size == 1 && !g_rccl_self) return;
   if (g_shm) {
