@@ -67,6 +67,14 @@ def run_mg(qa, X=(16, 16, 16, 16)):
     res = float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b))
     out = dict(lattice="x".join(map(str, X)), kappa=kappa, mu=mu, levels=3, n_vec=24, setup_secs=round(mp.secs, 3), solve_secs=round(solve, 4),
                iters=ip.iter, true_res=res, plain_gcr=plain)
+    # the QKXTM production shape: the same hierarchy under an outer GCR on the even-odd preconditioned system
+    # (solve_type = QUDA_DIRECT_PC_SOLVE, reference lib/interface_quda.cpp:6041), full-field solution via prepare / reconstruct
+    ip.solve_type = qa.QUDA_DIRECT_PC_SOLVE
+    t0 = time.perf_counter()
+    x = qa.invert(b, ip)
+    solve_pc = time.perf_counter() - t0
+    ip.solve_type = qa.QUDA_DIRECT_SOLVE
+    out["outer_even_odd"] = dict(solve_secs=round(solve_pc, 4), iters=ip.iter, true_res=float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b)))
     mg.free()
     return out
 

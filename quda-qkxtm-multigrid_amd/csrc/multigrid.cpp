@@ -4,6 +4,8 @@
 #include <cmath>
 #include <sys/time.h>
 
+#include <cstdlib>
+
 #include "interface_internal.h"
 
 namespace quda {
@@ -221,8 +223,75 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
 }
 
 // reference :488-604 (outer and inner solution type QUDA_MAT_SOLUTION; smoother full or even-odd preconditioned)
+// QUDA_AMD_MG_PROFILE=1: synchronised wall-clock per cycle stage and level, printed when the hierarchy is destroyed
+// (the reference keeps a TimeProfile per level, lib/multigrid.cpp:16-17)
+static double g_mgProf[QUDA_MAX_MG_LEVEL][6];
+static long g_mgCalls[QUDA_MAX_MG_LEVEL];
+static int mgProfiling() {
+  static int on = -1;
+  if (on < 0) { const char *e = getenv("QUDA_AMD_MG_PROFILE"); on = e ? atoi(e) : 0; }
+  return on;
+}
+struct StageTimer {
+  int level, stage; double t0; bool on;
+  StageTimer(int l, int s) : level(l), stage(s), t0(0), on(mgProfiling() != 0) {
+    if (on) { HIP_CHECK(hipStreamSynchronize(computeStream())); t0 = now(); }
+  }
+  ~StageTimer() { if (on) { HIP_CHECK(hipStreamSynchronize(computeStream())); g_mgProf[level][stage] += now() - t0; } }
+};
+void mgProfilePrint() {
+  if (!mgProfiling()) return;
+  static const char *names[6] = {"pre-smooth", "residual", "restrict", "coarse solve", "prolong", "post-smooth"};
+  for (int l = 0; l < QUDA_MAX_MG_LEVEL; l++) {
+    if (!g_mgCalls[l]) continue;
+    printfQuda("MG profile level %d (%ld cycles):", l, g_mgCalls[l]);
+    for (int s = 0; s < 6; s++) printfQuda("  %s %.3f ms", names[s], 1e3 * g_mgProf[l][s]);
+    printfQuda("\n");
+    g_mgCalls[l] = 0;
+    for (int s = 0; s < 6; s++) g_mgProf[l][s] = 0;
+  }
+}
+
+// Outer even-odd preconditioned solve (the way the QKXTM drivers run: solve_type = QUDA_DIRECT_PC_SOLVE, reference
+// lib/interface_quda.cpp:6041, :6427-6445): b and x live on one parity and the cycle preconditions Mhat x = b.  As in the
+// reference (lib/multigrid.cpp:492-560, outer_solution_type = QUDA_MATPC_SOLUTION) this needs the even-odd preconditioned
+// smoother; the single-parity residual is injected into the coarse grid (Transfer::setSiteSubset), the coarse problem is
+// the usual full coarse operator, and only the solved parity of the prolongated correction is added.
+void MG::cycleParity(ColorSpinorField &x, ColorSpinorField &b) {
+  if (mgp.level != 0) errorQuda("a single-parity source can only enter the multigrid cycle on the finest level");
+  if (!pcSmooth) errorQuda("For this coarse grid solution type, a preconditioned smoother is required");
+  const Dirac &dirac = *mgp.matSmooth.Expose();
+  const bool odd = dirac.getMatPCType() == QUDA_MATPC_ODD_ODD || dirac.getMatPCType() == QUDA_MATPC_ODD_ODD_ASYMMETRIC;
+  x.twistFlavor = b.twistFlavor;
+  if (mgp.level == mgp.Nlevel - 1) { (*presmoother)(x, b); return; }
+  ColorSpinorField &rp = odd ? r->Odd() : r->Even();
+  r->twistFlavor = rp.twistFlavor = b.twistFlavor;
+  g_mgCalls[mgp.level]++;
+  { StageTimer t(mgp.level, 0); (*presmoother)(x, b); }
+  {
+    StageTimer t(mgp.level, 1);
+    mgp.matSmooth(rp, x);
+    blas::axpby(1.0, b, -1.0, rp);   // preconditioned residual rhat = b - Mhat x
+  }
+  {
+    StageTimer t(mgp.level, 2);
+    transfer->setSiteSubset(QUDA_PARITY_SITE_SUBSET, odd ? QUDA_ODD_PARITY : QUDA_EVEN_PARITY);
+    transfer->R(*r_coarse, rp);
+    blas::zero(*x_coarse);
+  }
+  { StageTimer t(mgp.level, 3); (*coarse_solver)(*x_coarse, *r_coarse); }
+  {
+    StageTimer t(mgp.level, 4);
+    transfer->P(rp, *x_coarse);
+    transfer->setSiteSubset(QUDA_FULL_SITE_SUBSET, QUDA_INVALID_PARITY);
+    blas::xpy(rp, x);
+  }
+  { StageTimer t(mgp.level, 5); (*postsmoother)(x, b); }
+  blas::setGlobalReduction(true);
+}
+
 void MG::operator()(ColorSpinorField &x, ColorSpinorField &b) {
-  if (b.SiteSubset() != QUDA_FULL_SITE_SUBSET) errorQuda("the multigrid cycle preconditions the full system (QUDA_DIRECT_SOLVE outer solve)");
+  if (b.SiteSubset() != QUDA_FULL_SITE_SUBSET) { cycleParity(x, b); return; }
   const Dirac &dirac = *mgp.matSmooth.Expose();
   ColorSpinorField *out = nullptr, *in = nullptr;
   r->twistFlavor = b.twistFlavor;
@@ -231,15 +300,32 @@ void MG::operator()(ColorSpinorField &x, ColorSpinorField &b) {
     blas::copy(*r, b);  // the source is copied: prepare() of a preconditioned smoother builds its source from it
     dirac.prepare(in, out, x, *r, QUDA_MAT_SOLUTION);
     if (pcSmooth) { b_tilde->twistFlavor = b.twistFlavor; blas::copy(*b_tilde, *in); }  // keep the prepared source for the post-smoother
-    (*presmoother)(*out, *in);
-    dirac.reconstruct(x, b, QUDA_MAT_SOLUTION);
-    mgp.matResidual(*r, x);
-    blas::axpby(1.0, b, -1.0, *r);  // r = b - A x   (full residual: coarse_grid_solution_type = MAT)
-    transfer->R(*r_coarse, *r);
-    blas::zero(*x_coarse);
-    (*coarse_solver)(*x_coarse, *r_coarse);
-    transfer->P(*r, *x_coarse);     // repurpose residual storage
-    blas::xpy(*r, x);
+    g_mgCalls[mgp.level]++;
+    {
+      StageTimer t(mgp.level, 0);
+      (*presmoother)(*out, *in);
+      dirac.reconstruct(x, b, QUDA_MAT_SOLUTION);
+    }
+    {
+      StageTimer t(mgp.level, 1);
+      mgp.matResidual(*r, x);
+      blas::axpby(1.0, b, -1.0, *r);  // r = b - A x   (full residual: coarse_grid_solution_type = MAT)
+    }
+    {
+      StageTimer t(mgp.level, 2);
+      transfer->R(*r_coarse, *r);
+      blas::zero(*x_coarse);
+    }
+    {
+      StageTimer t(mgp.level, 3);
+      (*coarse_solver)(*x_coarse, *r_coarse);
+    }
+    {
+      StageTimer t(mgp.level, 4);
+      transfer->P(*r, *x_coarse);     // repurpose residual storage
+      blas::xpy(*r, x);
+    }
+    StageTimer tpost(mgp.level, 5);
     if (pcSmooth) {
       in = b_tilde;
       out = dirac.getMatPCType() == QUDA_MATPC_ODD_ODD || dirac.getMatPCType() == QUDA_MATPC_ODD_ODD_ASYMMETRIC ? &x.Odd() : &x.Even();
@@ -252,6 +338,8 @@ void MG::operator()(ColorSpinorField &x, ColorSpinorField &b) {
     dirac.reconstruct(x, b, QUDA_MAT_SOLUTION);
   } else {
     // coarsest-grid solve
+    g_mgCalls[mgp.level]++;
+    StageTimer t(mgp.level, 0);
     blas::copy(*r, b);
     dirac.prepare(in, out, x, *r, QUDA_MAT_SOLUTION);
     (*presmoother)(*out, *in);
@@ -353,6 +441,7 @@ multigrid_solver::multigrid_solver(QudaMultigridParam &mg_param) : d(nullptr), m
 }
 
 multigrid_solver::~multigrid_solver() {
+  mgProfilePrint();
   delete mg;
   delete mgParam;
   for (ColorSpinorField *f : B) delete f;

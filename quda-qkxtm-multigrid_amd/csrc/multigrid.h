@@ -9,8 +9,9 @@
 // Smoother per level: the full operator (smoother_solve_type = QUDA_DIRECT_SOLVE) or — the reference's default — the
 // even-odd preconditioned one (QUDA_DIRECT_PC_SOLVE: DiracTwistedMassPC / DiracTwistedCloverPC / DiracWilsonPC on level 0,
 // DiracCoarsePC with Xinv / Yhat on coarse levels) wrapped in Dirac::prepare / reconstruct exactly as the reference's
-// cycle does.  Coarse-grid solution type is QUDA_MAT_SOLUTION (full residual restricted); the outer solver is GCR on the
-// full system, the only outer solve the reference's MG accepts (lib/interface_quda.cpp:2183-2184).
+// cycle does.  Outer solve on the full system (QUDA_DIRECT_SOLVE: full residual restricted, coarse-grid solution type
+// QUDA_MAT_SOLUTION) or — the way the QKXTM drivers run it (lib/interface_quda.cpp:6041) — on the even-odd preconditioned
+// system (QUDA_DIRECT_PC_SOLVE: single-parity residual injected, reference QUDA_MATPC_SOLUTION branch lib/multigrid.cpp:492-560).
 #pragma once
 
 #include <vector>
@@ -52,6 +53,7 @@ class MG : public Solver {
   bool pcSmooth;
   bool ownCoarseSolver;
   void generateNullVectors(std::vector<ColorSpinorField *> &B);
+  void cycleParity(ColorSpinorField &x, ColorSpinorField &b);
 
  public:
   explicit MG(MGParam &param);

@@ -48,7 +48,6 @@ void invertQuda(void *hp_x, void *hp_b, QudaInvertParam *param) {
   if (pc_solution && !pc_solve) errorQuda("Preconditioned (PC) solution_type requires a PC solve_type");
   if (!mat_solution && !pc_solution && pc_solve) errorQuda("Unpreconditioned MATDAG_MAT solution_type requires an unpreconditioned solve_type");
   if (param->inv_type_precondition == QUDA_MG_INVERTER && (!direct_solve || !mat_solution)) errorQuda("Multigrid preconditioning only supported for direct solves");
-  if (param->inv_type_precondition == QUDA_MG_INVERTER && pc_solve) errorQuda("Outer MG solver can only use QUDA_DIRECT_SOLVE at present");
   param->secs = 0; param->gflops = 0; param->iter = 0;
 
   // reference createDirac :1386-1410

@@ -28,6 +28,8 @@ class Transfer {
   int *block_to_fine;          // [A*blockVol + b] -> fine full index (parity*Vh + x_cb)
   int *fine_to_block;          // inverse
   mutable unsigned long long flops_;
+  QudaSiteSubset site_subset;
+  QudaParity subset_parity;
 
   // B: Nvec null vectors on the fine level (device, fp32, full fields).  geo_bs is adjusted in place with the reference's
   // fallback rule (lib/transfer.cpp:31-44) so callers can read back the block size actually used.
@@ -38,6 +40,9 @@ class Transfer {
   // outside the site's own aggregate contribute (used by the Galerkin coarse-operator construction).
   void R(ColorSpinorField &coarse, const ColorSpinorField &fine, int dir = -1, int boundary = 0) const;
   void P(ColorSpinorField &fine, const ColorSpinorField &coarse) const;
+  // single-parity fine fields (outer even-odd preconditioned solve: the residual of one parity is injected into the coarse
+  // grid, reference Transfer::setSiteSubset lib/transfer.cpp:276-290): the absent parity restricts as zero / is not prolongated
+  void setSiteSubset(QudaSiteSubset subset, QudaParity parity);
 
   ColorSpinorField *createCoarseField() const;   // reference ColorSpinorField::CreateCoarse, lib/color_spinor_field.cpp:737-763
   ColorSpinorField *createFineField() const;

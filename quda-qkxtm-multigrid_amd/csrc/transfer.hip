@@ -22,12 +22,19 @@ struct CoarseVec {
   int stride, Vh;
 };
 
-static FineVec fineVec(const ColorSpinorField &f) {
-  if (f.Location() != QUDA_CUDA_FIELD_LOCATION || f.Precision() != QUDA_SINGLE_PRECISION || f.SiteSubset() != QUDA_FULL_SITE_SUBSET)
-    errorQuda("transfer operators work on full fp32 device fields (precision %d subset %d)", f.Precision(), f.SiteSubset());
+// parity >= 0: `f` is a single-parity field holding that parity; the other parity is absent (nullptr): it restricts as zero
+// and is not written by the prolongator (reference Transfer::setSiteSubset, lib/transfer.cpp:276-290)
+static FineVec fineVec(const ColorSpinorField &f, int parity = -1) {
+  if (f.Location() != QUDA_CUDA_FIELD_LOCATION || f.Precision() != QUDA_SINGLE_PRECISION)
+    errorQuda("transfer operators work on fp32 device fields (precision %d)", f.Precision());
   ColorSpinorField &g = const_cast<ColorSpinorField &>(f);
   FineVec r;
-  r.v[0] = (float *)g.Even().V(); r.v[1] = (float *)g.Odd().V();
+  if (f.SiteSubset() == QUDA_FULL_SITE_SUBSET) {
+    r.v[0] = (float *)g.Even().V(); r.v[1] = (float *)g.Odd().V();
+  } else {
+    if (parity != 0 && parity != 1) errorQuda("single-parity field without Transfer::setSiteSubset(QUDA_PARITY_SITE_SUBSET, parity)");
+    r.v[parity] = (float *)g.V(); r.v[1 - parity] = nullptr;
+  }
   r.stride = f.Stride(); r.Vh = f.VolumeCB();
   return r;
 }
@@ -74,19 +81,23 @@ __global__ void restrict_kernel(CoarseVec out, FineVec in, const float4 *V, cons
   const int A = blockIdx.x, b = threadIdx.x;
   const bool active = b < blockVol && mask_keep(mask, b);
   float2 r[K];
+  bool have = false;
   if (active) {
     const int f = block_to_fine[(size_t)A * blockVol + b];
     const int parity = f >= in.Vh, x = f - parity * in.Vh;
     const float *base = in.v[parity];
+    if (base) {   // nullptr: this parity is absent from a single-parity field
+      have = true;
 #pragma unroll
-    for (int k = 0; k < K; k++) { const size_t i = fidx<NV>(in.stride, x, k); r[k] = make_float2(base[i], base[i + 1]); }
+      for (int k = 0; k < K; k++) { const size_t i = fidx<NV>(in.stride, x, k); r[k] = make_float2(base[i], base[i + 1]); }
+    }
   }
   const int cpar = A >= out.Vh, xc = A - cpar * out.Vh;
   float *ob = out.v[cpar];
   for (int chi = 0; chi < 2; chi++) {
     for (int vp = 0; vp < NVEC / 2; vp++) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (active) {
+      if (have) {
 #pragma unroll
         for (int k = 0; k < K; k++) {
           if ((k / NCF) / spin_bs != chi) continue;
@@ -122,6 +133,7 @@ __global__ void prolong_kernel(FineVec out, CoarseVec in, const float4 *V, const
   const int f = block_to_fine[(size_t)A * blockVol + b];
   const int parity = f >= out.Vh, x = f - parity * out.Vh;
   float *base = out.v[parity];
+  if (!base) return;   // this parity is absent from a single-parity output field
 #pragma unroll
   for (int k = 0; k < K; k++) {
     const int chi = (k / NCF) / spin_bs;
@@ -237,7 +249,8 @@ void spinorRandom(ColorSpinorField &f, unsigned long long seed) {
 
 // ================================================================================================
 Transfer::Transfer(const std::vector<ColorSpinorField *> &B, int Nvec_, int *gbs, int spin_bs_)
-    : Nvec(Nvec_), spin_bs(spin_bs_), V(nullptr), block_to_fine(nullptr), fine_to_block(nullptr), flops_(0) {
+    : Nvec(Nvec_), spin_bs(spin_bs_), V(nullptr), block_to_fine(nullptr), fine_to_block(nullptr), flops_(0),
+      site_subset(QUDA_FULL_SITE_SUBSET), subset_parity(QUDA_INVALID_PARITY) {
   if ((int)B.size() < Nvec) errorQuda("need %d null vectors, got %zu", Nvec, B.size());
   if (Nvec % 2 || Nvec > kMaxVec) errorQuda("Nvec = %d must be even and <= %d", Nvec, kMaxVec);
   const ColorSpinorField &b0 = *B[0];
@@ -358,10 +371,18 @@ static CoarseVec coarseVec(const ColorSpinorField &c) {
   } else if (fineSpin == 2 && fineColor == 32 && Nvec == 32) { CALL(2, 32, 32, 2);             \
   } else errorQuda("transfer %d x %d -> Nvec %d not instantiated", fineSpin, fineColor, Nvec);
 
+void Transfer::setSiteSubset(QudaSiteSubset subset, QudaParity parity) {
+  if (subset == QUDA_PARITY_SITE_SUBSET && parity != QUDA_EVEN_PARITY && parity != QUDA_ODD_PARITY) errorQuda("Undefined parity %d", parity);
+  site_subset = subset;
+  subset_parity = parity;
+}
+
 void Transfer::R(ColorSpinorField &coarse, const ColorSpinorField &fine, int dir, int boundary) const {
-  if (fine.Nspin() != fineSpin || fine.Ncolor() != fineColor || fine.Volume() != fineVol) errorQuda("fine field does not match the transfer operator");
+  const bool sub = fine.SiteSubset() == QUDA_PARITY_SITE_SUBSET;
+  if (sub && site_subset != QUDA_PARITY_SITE_SUBSET) errorQuda("single-parity fine field but the transfer is set to full fields");
+  if (fine.Nspin() != fineSpin || fine.Ncolor() != fineColor || (long)fine.VolumeCB() * 2 != fineVol) errorQuda("fine field does not match the transfer operator");
   if (coarse.Nspin() != 2 || coarse.Ncolor() != Nvec || coarse.Volume() != nAgg) errorQuda("coarse field does not match the transfer operator");
-  const FineVec in = fineVec(fine);
+  const FineVec in = fineVec(fine, sub ? (int)subset_parity : -1);
   const CoarseVec out = coarseVec(coarse);
   MaskArg m;
   m.dir = dir; m.boundary = boundary;
@@ -376,9 +397,11 @@ void Transfer::R(ColorSpinorField &coarse, const ColorSpinorField &fine, int dir
 }
 
 void Transfer::P(ColorSpinorField &fine, const ColorSpinorField &coarse) const {
-  if (fine.Nspin() != fineSpin || fine.Ncolor() != fineColor || fine.Volume() != fineVol) errorQuda("fine field does not match the transfer operator");
+  const bool sub = fine.SiteSubset() == QUDA_PARITY_SITE_SUBSET;
+  if (sub && site_subset != QUDA_PARITY_SITE_SUBSET) errorQuda("single-parity fine field but the transfer is set to full fields");
+  if (fine.Nspin() != fineSpin || fine.Ncolor() != fineColor || (long)fine.VolumeCB() * 2 != fineVol) errorQuda("fine field does not match the transfer operator");
   if (coarse.Nspin() != 2 || coarse.Ncolor() != Nvec || coarse.Volume() != nAgg) errorQuda("coarse field does not match the transfer operator");
-  const FineVec out = fineVec(fine);
+  const FineVec out = fineVec(fine, sub ? (int)subset_parity : -1);
   const CoarseVec in = coarseVec(coarse);
   const int threads = (blockVol + 63) / 64 * 64;
 #define QA_P(NSF, NCF, NVEC, NV) \

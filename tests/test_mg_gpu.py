@@ -168,3 +168,44 @@ def test_hierarchy_against_oracle_restatement(qa, oracle, mask):
     finally:
         mg.free()
         qa.lib().qudaAmdSetPartitionMask(0)
+
+
+def test_outer_even_odd_solve_with_up_and_down_hierarchies(qa, oracle):
+    """The QKXTM production shape (reference lib/interface_quda.cpp:6041, :6389-6520; qkxtm/CalcMG_2pt3pt_EvenOdd.cpp:649-747):
+    outer GCR on the even-odd preconditioned system (solve_type = QUDA_DIRECT_PC_SOLVE, full-field MAT solution through
+    prepare / reconstruct) preconditioned by a multigrid hierarchy, one hierarchy per twist flavour (preconditionerUP for
+    +mu, preconditionerDN for -mu), the flavour flipped between solves.  Residuals are recomputed with the oracle's tm_mat."""
+    X, kappa, mu = (8, 8, 8, 16), 0.124, 0.005
+    gauge, ip = _setup(qa, X, kappa, mu)
+    rng = np.random.default_rng(23)
+    b = rng.random(int(np.prod(X)) * 24)
+    ip.solve_type = qa.QUDA_DIRECT_PC_SOLVE
+    hier = {}
+    try:
+        for flavor in (+1, -1):
+            ipm = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, flavor, "ee", 0, cuda_prec=8, prec_sloppy=4, prec_precondition=4,
+                                  solution_type=qa.QUDA_MAT_SOLUTION)
+            ipm.solve_type = qa.QUDA_DIRECT_SOLVE   # the MG-internal parameter set (reference lib/interface_quda.cpp:2183)
+            ipm.inv_type, ipm.gcrNkrylov, ipm.tol, ipm.maxiter, ipm.reliable_delta, ipm.verbosity = qa.QUDA_GCR_INVERTER, 20, 1e-10, 2000, 1e-4, qa.QUDA_SILENT
+            mp = qa.multigrid_param(ipm, n_level=3, geo_block=[(4, 4, 4, 4), (1, 1, 1, 2), (2, 2, 2, 2)], n_vec=8, setup_maxiter=300, setup_tol=1e-5, smoother_pc=True)
+            hier[flavor] = (qa.Multigrid(mp), ipm, mp)
+        ip.preconditionerUP, ip.preconditionerDN = hier[+1][0].h, hier[-1][0].h
+        for flavor in (+1, -1, +1):
+            ip.twist_flavor = qa.QUDA_TWIST_PLUS if flavor > 0 else qa.QUDA_TWIST_MINUS
+            ip.inv_type_precondition = qa.QUDA_INVALID_ENUM
+            ip.preconditioner = None
+            qa.invert(b, ip)
+            plain = ip.iter
+            ip.inv_type_precondition = qa.QUDA_MG_INVERTER
+            ip.preconditioner = ip.preconditionerUP if flavor > 0 else ip.preconditionerDN
+            ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
+            x = qa.invert(b, ip)
+            oracle.set_threads(8)
+            res = float(np.linalg.norm(b - oracle.tm_mat(gauge, x, list(X), kappa, mu, flavor, 0)) / np.linalg.norm(b))
+            oracle.set_threads(1)
+            print("outer even-odd MG-GCR flavour %+d: %d iterations (plain even-odd GCR %d), true residual %.2e" % (flavor, ip.iter, plain, res))
+            assert res < 5e-10, (flavor, res)
+            assert ip.iter * 3 < plain, (flavor, ip.iter, plain)
+    finally:
+        for h, _, _ in hier.values():
+            h.free()
