@@ -30,6 +30,15 @@ MGParam::MGParam(QudaMultigridParam &g, std::vector<ColorSpinorField *> &B_, Dir
   iter = 0; gflops = 0; secs = 0;
 }
 
+// QUDA_AMD_MG_PROFILE=1: synchronised wall-clock per cycle stage and level, printed when the hierarchy is destroyed
+// (the reference keeps a TimeProfile per level, lib/multigrid.cpp:16-17)
+static double g_mgProf[QUDA_MAX_MG_LEVEL][6];
+static long g_mgCalls[QUDA_MAX_MG_LEVEL];
+static int mgProfiling() {
+  static int on = -1;
+  if (on < 0) { const char *e = getenv("QUDA_AMD_MG_PROFILE"); on = e ? atoi(e) : 0; }
+  return on;
+}
 static ColorSpinorField *likeField(const ColorSpinorField &x) {
   ColorSpinorParam p = x.param();
   p.create = QUDA_ZERO_FIELD_CREATE;
@@ -48,8 +57,12 @@ MG::MG(MGParam &p)
   if (pcSmooth != p.matSmooth.isPC()) errorQuda("smoother_solve_type[%d] and the smoother operator disagree about even-odd preconditioning", p.level);
 
   if (!coarsest) {
-    if (p.mg_global.compute_null_vector == QUDA_COMPUTE_NULL_VECTOR_YES && (p.mg_global.generate_all_levels == QUDA_BOOLEAN_YES || p.level == 0))
+    if (p.mg_global.compute_null_vector == QUDA_COMPUTE_NULL_VECTOR_YES && (p.mg_global.generate_all_levels == QUDA_BOOLEAN_YES || p.level == 0)) {
+      const double t0 = now();
       generateNullVectors(p.B);
+      HIP_CHECK(hipStreamSynchronize(computeStream()));
+      if (getVerbosity() >= QUDA_SUMMARIZE || mgProfiling()) printfQuda("MG level %d: %d null vectors generated in %.3f s\n", p.level + 1, p.Nvec, now() - t0);
+    }
   }
 
   // smoothers (reference :40-85)
@@ -91,7 +104,9 @@ MG::MG(MGParam &p)
     b_tilde->twistFlavor = p.fineFlavor;
   }
   if (!coarsest) {
+    const double tT = now();
     transfer = new Transfer(p.B, p.Nvec, p.geoBlockSize, p.spinBlockSize);
+    if (getVerbosity() >= QUDA_SUMMARIZE || mgProfiling()) printfQuda("MG level %d: transfer (fill + block Gram-Schmidt) in %.3f s\n", p.level + 1, now() - tT);
     for (int d = 0; d < 4; d++) p.mg_global.geo_block_size[p.level][d] = p.geoBlockSize[d];
     r_coarse = transfer->createCoarseField();
     x_coarse = transfer->createCoarseField();
@@ -108,7 +123,7 @@ MG::MG(MGParam &p)
     const double t0 = now();
     diracCoarse = new DiracCoarse(dp);
     matCoarse = new DiracM(*diracCoarse);
-    if (getVerbosity() >= QUDA_SUMMARIZE) printfQuda("MG level %d: coarse operator %d^2 x 9 per site on %d x %d x %d x %d built in %.3f s\n", p.level + 1, 2 * p.Nvec, transfer->Xc[0], transfer->Xc[1], transfer->Xc[2], transfer->Xc[3], now() - t0);
+    if (getVerbosity() >= QUDA_SUMMARIZE || mgProfiling()) printfQuda("MG level %d: coarse operator %d^2 x 9 per site on %d x %d x %d x %d built in %.3f s\n", p.level + 1, 2 * p.Nvec, transfer->Xc[0], transfer->Xc[1], transfer->Xc[2], transfer->Xc[3], now() - t0);
 
     // coarse null vectors: restricted fine ones unless every level generates its own (reference :196-208)
     const int nVecCoarse = std::max(p.Nvec, p.level + 1 < p.Nlevel ? p.mg_global.n_vec[p.level + 1] : p.Nvec);
@@ -223,21 +238,19 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
 }
 
 // reference :488-604 (outer and inner solution type QUDA_MAT_SOLUTION; smoother full or even-odd preconditioned)
-// QUDA_AMD_MG_PROFILE=1: synchronised wall-clock per cycle stage and level, printed when the hierarchy is destroyed
-// (the reference keeps a TimeProfile per level, lib/multigrid.cpp:16-17)
-static double g_mgProf[QUDA_MAX_MG_LEVEL][6];
-static long g_mgCalls[QUDA_MAX_MG_LEVEL];
-static int mgProfiling() {
-  static int on = -1;
-  if (on < 0) { const char *e = getenv("QUDA_AMD_MG_PROFILE"); on = e ? atoi(e) : 0; }
-  return on;
-}
 struct StageTimer {
   int level, stage; double t0; bool on;
   StageTimer(int l, int s) : level(l), stage(s), t0(0), on(mgProfiling() != 0) {
     if (on) { HIP_CHECK(hipStreamSynchronize(computeStream())); t0 = now(); }
   }
-  ~StageTimer() { if (on) { HIP_CHECK(hipStreamSynchronize(computeStream())); g_mgProf[level][stage] += now() - t0; } }
+  ~StageTimer() {
+    if (!on) return;
+    const double t1 = now();
+    HIP_CHECK(hipStreamSynchronize(computeStream()));
+    const double t2 = now();
+    g_mgProf[level][stage] += t2 - t0;
+    if (mgProfiling() == 2 && t2 - t0 > 2e-3) printfQuda("MG stage: level %d stage %d took %.3f ms (host %.3f ms + drain %.3f ms)\n", level, stage, 1e3 * (t2 - t0), 1e3 * (t1 - t0), 1e3 * (t2 - t1));
+  }
 };
 void mgProfilePrint() {
   if (!mgProfiling()) return;
