@@ -398,3 +398,90 @@ void qo_mg_coarse_apply(double *out_, const double *in_, const double *Y_, const
       }
     }
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Clover term from the gauge field (what loadCloverQuda(NULL, NULL, ...) computes on the device): restatement of
+ * computeFmunuCore (lib/field_strength_tensor.cu:30-192: F_mu_nu = (Q - Q^dagger)/8 from the four plaquette leaves, pairs
+ * mu > nu at index mu(mu-1)/2 + nu) and cloverComputeCore (lib/clover_quda.cu:41-139: the two chiral blocks
+ * [[1 - B1, B2^dag], [B2, 1 + B1]] with B1 = i c (F0 -/+ F5), B2 = c (F1 +/- F4 - i (F2 -/+ F3))).  Output: host packed order
+ * (6 diagonal reals + 15 lower-triangle complex per chiral block, tests/clover_reference.cpp:25-53) holding the TRUE
+ * clover matrix — the reference's native device order stores half of it (lib/clover_quda.cu:128-133).
+ * No golden vectors exist for this (nvcc-only sources): "parity unpinned"; tests check unit gauge -> identity,
+ * Hermiticity and the independent sigma_mu_nu construction (tests/test_oracle_mg.py).
+ * ------------------------------------------------------------------------------------------------------------------- */
+static void m3_mul(cplx *c, const cplx *a, const cplx *b) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) { cplx s = 0.0; for (int k = 0; k < 3; k++) s += a[i * 3 + k] * b[k * 3 + j]; c[i * 3 + j] = s; }
+}
+static void m3_dag(cplx *c, const cplx *a) {
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c[i * 3 + j] = conj(a[j * 3 + i]);
+}
+/* link U_mu at the site with (unwrapped) coordinates x */
+static const cplx *link_at(double *const gauge[4], int mu, const int xin[4], const int X[4]) {
+  int x[4];
+  for (int d = 0; d < 4; d++) x[d] = ((xin[d] % X[d]) + X[d]) % X[d];
+  const long Vh = vol(X) / 2;
+  return (const cplx *)gauge[mu] + ((size_t)site_parity(x) * Vh + cb_index(x, X)) * 9;
+}
+static void plaq4(cplx *out, const cplx *a, int da, const cplx *b, int db, const cplx *c, int dc, const cplx *d, int dd) {
+  cplx t[4][9], p[9], q[9];
+  const cplx *m[4] = {a, b, c, d};
+  const int dg[4] = {da, db, dc, dd};
+  for (int k = 0; k < 4; k++) { if (dg[k]) m3_dag(t[k], m[k]); else memcpy(t[k], m[k], sizeof(t[k])); }
+  m3_mul(p, t[0], t[1]); m3_mul(q, p, t[2]); m3_mul(out, q, t[3]);
+}
+
+void qo_clover_compute_d(double *clover, double *const gauge[4], double coeff, const int X[4]) {
+  const long Vh = vol(X) / 2;
+  static const int idtab[15] = {0, 1, 3, 6, 10, 2, 4, 7, 11, 5, 8, 12, 9, 13, 14};
+  for (int parity = 0; parity < 2; parity++)
+    for (long idx = 0; idx < Vh; idx++) {
+      int x[4];
+      cb_coords(x, (int)idx, parity, X);
+      cplx F[6][9];
+      for (int mu = 0; mu < 4; mu++)
+        for (int nu = 0; nu < mu; nu++) {
+          cplx Q[9], L[9];
+          int y[4], z[4], w[4];
+          /* U(x,mu) U(x+mu,nu) U^dag(x+nu,mu) U^dag(x,nu) */
+          memcpy(y, x, sizeof(y)); y[mu]++;
+          memcpy(z, x, sizeof(z)); z[nu]++;
+          plaq4(Q, link_at(gauge, mu, x, X), 0, link_at(gauge, nu, y, X), 0, link_at(gauge, mu, z, X), 1, link_at(gauge, nu, x, X), 1);
+          /* U(x,nu) U^dag(x+nu-mu,mu) U^dag(x-mu,nu) U(x-mu,mu) */
+          memcpy(y, x, sizeof(y)); y[nu]++; y[mu]--;
+          memcpy(z, x, sizeof(z)); z[mu]--;
+          plaq4(L, link_at(gauge, nu, x, X), 0, link_at(gauge, mu, y, X), 1, link_at(gauge, nu, z, X), 1, link_at(gauge, mu, z, X), 0);
+          for (int k = 0; k < 9; k++) Q[k] += L[k];
+          /* U^dag(x-nu,nu) U(x-nu,mu) U(x+mu-nu,nu) U^dag(x,mu) */
+          memcpy(y, x, sizeof(y)); y[nu]--;
+          memcpy(z, x, sizeof(z)); z[mu]++; z[nu]--;
+          plaq4(L, link_at(gauge, nu, y, X), 1, link_at(gauge, mu, y, X), 0, link_at(gauge, nu, z, X), 0, link_at(gauge, mu, x, X), 1);
+          for (int k = 0; k < 9; k++) Q[k] += L[k];
+          /* U^dag(x-mu,mu) U^dag(x-mu-nu,nu) U(x-mu-nu,mu) U(x-nu,nu) */
+          memcpy(y, x, sizeof(y)); y[mu]--;
+          memcpy(z, x, sizeof(z)); z[mu]--; z[nu]--;
+          memcpy(w, x, sizeof(w)); w[nu]--;
+          plaq4(L, link_at(gauge, mu, y, X), 1, link_at(gauge, nu, z, X), 1, link_at(gauge, mu, z, X), 0, link_at(gauge, nu, w, X), 0);
+          for (int k = 0; k < 9; k++) Q[k] += L[k];
+          cplx *Fm = F[mu * (mu - 1) / 2 + nu];
+          for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Fm[i * 3 + j] = 0.125 * (Q[i * 3 + j] - conj(Q[j * 3 + i]));
+        }
+      for (int ch = 0; ch < 2; ch++) {
+        cplx b1[9], b2[9], tri[15];
+        double diag[6];
+        for (int k = 0; k < 9; k++) {
+          b1[k] = (I * coeff) * (ch == 0 ? F[0][k] - F[5][k] : F[0][k] + F[5][k]);
+          b2[k] = coeff * (ch == 0 ? F[1][k] + F[4][k] - I * (F[2][k] - F[3][k]) : F[1][k] - F[4][k] - I * (F[2][k] + F[3][k]));
+        }
+        for (int i = 0; i < 3; i++) { diag[i] = 1.0 - creal(b1[i * 3 + i]); diag[i + 3] = 1.0 + creal(b1[i * 3 + i]); }
+        tri[0] = -b1[1 * 3 + 0];
+        tri[1] = -b1[2 * 3 + 0]; tri[2] = -b1[2 * 3 + 1];
+        tri[3] = b2[0]; tri[4] = b2[1]; tri[5] = b2[2];
+        tri[6] = b2[3]; tri[7] = b2[4]; tri[8] = b2[5]; tri[9] = b1[1 * 3 + 0];
+        tri[10] = b2[6]; tri[11] = b2[7]; tri[12] = b2[8]; tri[13] = b1[2 * 3 + 0]; tri[14] = b1[2 * 3 + 1];
+        double *A = clover + (((size_t)parity * Vh + idx) * 2 + ch) * 36;
+        for (int i = 0; i < 6; i++) A[i] = diag[i];
+        for (int i = 0; i < 15; i++) { A[6 + 2 * i] = creal(tri[idtab[i]]); A[6 + 2 * i + 1] = cimag(tri[idtab[i]]); }
+      }
+    }
+}

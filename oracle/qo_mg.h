@@ -14,6 +14,7 @@ void qo_mg_coarse_op_fine(double *Y, double *X_out, const double *V, double *con
 void qo_mg_coarse_op_coarse(double *Y, double *X_out, const double *V, const double *Yf, const double *Xf, double kappa, const int X[4],
                             const int geo_bs[4], int NcF, int Nvec);
 void qo_mg_coarse_apply(double *out, const double *in, const double *Y, const double *X, double kappa, const int Xc[4], int Nvec);
+void qo_clover_compute_d(double *clover, double *const gauge[4], double coeff, const int X[4]);
 #ifdef __cplusplus
 }
 #endif

@@ -276,7 +276,9 @@ def load_gauge(gauge, gp):
 
 
 def load_clover(clover, clover_inv, ip):
-    lib().loadCloverQuda(_vp(clover), _vp(clover_inv), C.byref(ip))
+    """loadCloverQuda; clover = clover_inv = None: the clover term is built on the device from the resident links with
+    ip.clover_coeff (reference lib/interface_quda.cpp:743-747)"""
+    lib().loadCloverQuda(_vp(clover) if clover is not None else None, _vp(clover_inv) if clover_inv is not None else None, C.byref(ip))
 
 
 def dslash(h_in, ip, parity):

@@ -163,6 +163,10 @@ class CloverField {
   CloverField(const LatticeGeom &g, QudaPrecision prec);
   ~CloverField();
   void loadPacked(const void *h_clover, const void *h_inv, QudaPrecision cpu_prec);
+  // A = 1 + i c sum_{mu>nu} sigma_mu_nu F_mu_nu from the resident links (reference createCloverQuda, lib/interface_quda.cpp:3950-4010:
+  // computeFmunu + computeClover with c = clover_coeff); fp64 arithmetic, stored in this field's precision
+  void computeFromGauge(const GaugeField &U, double coeff);
+  void savePacked(void *h_clover, QudaPrecision cpu_prec) const;
   // compute cloverInv = (A^2 + mu2)^-1 (mu2 = 0: plain inverse) on device; reference lib/clover_invert.cu:56-85
   void computeInverse(double mu2);
   void savePackedInverse(void *h_inv, QudaPrecision cpu_prec) const;

@@ -630,6 +630,162 @@ __global__ void clover_invert_kernel(char *inv, float *invNorm, const char *A, c
   if (trlog) atomicAdd(&trlog[parity], tl);
 }
 
+// ---- clover term from the gauge field (reference computeFmunu, lib/field_strength_tensor.cu:30-192, and computeClover,
+// lib/clover_quda.cu:41-139): one thread per site builds the six clover-leaf field strengths F_mu_nu = (Q - Q^dag)/8 and folds
+// them straight into the four 3x3 colour blocks of the two chiral blocks, B1[ch] = i c (F0 -/+ F5), B2[ch] = c (F1 +/- F4 -
+// i (F2 -/+ F3)); each chiral block is [[1 - B1, B2^dag], [B2, 1 + B1]].  Arithmetic in fp64 whatever the link precision;
+// output = the TRUE clover matrix in packed order (the reference's native order stores half of it). ----
+struct M3 { double re[9], im[9]; };
+__device__ __forceinline__ void m3_mul(M3 &c, const M3 &a, const M3 &b) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double r = 0, m = 0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { r += a.re[i * 3 + k] * b.re[k * 3 + j] - a.im[i * 3 + k] * b.im[k * 3 + j]; m += a.re[i * 3 + k] * b.im[k * 3 + j] + a.im[i * 3 + k] * b.re[k * 3 + j]; }
+      c.re[i * 3 + j] = r; c.im[i * 3 + j] = m;
+    }
+}
+__device__ __forceinline__ void m3_dag(M3 &c, const M3 &a) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) { c.re[i * 3 + j] = a.re[j * 3 + i]; c.im[i * 3 + j] = -a.im[j * 3 + i]; }
+}
+struct GaugeView { const char *data; size_t link_bytes; int stride; int X[4]; int tsign; };
+// U_mu at the (possibly out-of-range, wrapped) coordinates x: the forward link stored at its own site
+template <typename T, int R> __device__ __forceinline__ void load_link(M3 &U, const GaugeView &g, int mu, const int *xin) {
+  using real = typename Store<T>::real;
+  int x[4];
+#pragma unroll
+  for (int d = 0; d < 4; d++) { x[d] = xin[d]; if (x[d] < 0) x[d] += g.X[d]; if (x[d] >= g.X[d]) x[d] -= g.X[d]; }
+  const int par = (x[0] + x[1] + x[2] + x[3]) & 1;
+  const int idx = (((x[3] * g.X[2] + x[2]) * g.X[1] + x[1]) * g.X[0] + x[0]) >> 1;
+  real u[18];
+  // the host links carry the anti-periodic sign on the last time slice; recon-12 stores rows 0,1 as given and has to put the
+  // sign back on the reconstructed third row (in the plaquette the two boundary links of a leaf then cancel their signs)
+  const real sign = (R == 12 && mu == 3 && x[3] == g.X[3] - 1) ? (real)g.tsign : (real)1;
+  Link<T, R>::load(u, g.data + ((size_t)par * 8 + 2 * mu) * g.link_bytes, g.stride, idx, sign);
+#pragma unroll
+  for (int k = 0; k < 9; k++) { U.re[k] = u[2 * k]; U.im[k] = u[2 * k + 1]; }
+}
+// leaf = A^(dag) B^(dag) C^(dag) D^(dag) of the links (mu_k at x_k), accumulated into Q
+template <typename T, int R>
+__device__ __forceinline__ void add_leaf(M3 &Q, const GaugeView &g, int m0, const int *x0, bool d0, int m1, const int *x1, bool d1, int m2, const int *x2, bool d2,
+                                         int m3, const int *x3, bool d3) {
+  M3 a, b, t;
+  load_link<T, R>(a, g, m0, x0); if (d0) { m3_dag(t, a); a = t; }
+  load_link<T, R>(b, g, m1, x1); if (d1) { m3_dag(t, b); b = t; }
+  m3_mul(t, a, b);
+  load_link<T, R>(b, g, m2, x2); if (d2) { m3_dag(a, b); b = a; }
+  m3_mul(a, t, b);
+  load_link<T, R>(b, g, m3, x3); if (d3) { m3_dag(t, b); b = t; }
+  m3_mul(t, a, b);
+#pragma unroll
+  for (int k = 0; k < 9; k++) { Q.re[k] += t.re[k]; Q.im[k] += t.im[k]; }
+}
+
+template <typename T, int R>
+__global__ void __launch_bounds__(128) clover_from_gauge_kernel(double *packed, GaugeView g, double coeff, int Vh) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= 2 * Vh) return;
+  const int parity = gid >= Vh, idx = gid - parity * Vh;
+  int x[4];
+  {
+    const int Xh = g.X[0] >> 1;
+    int l = idx;
+    const int xh = l % Xh; l /= Xh;
+    x[1] = l % g.X[1]; l /= g.X[1];
+    x[2] = l % g.X[2]; x[3] = l / g.X[2];
+    x[0] = 2 * xh + ((x[1] + x[2] + x[3] + parity) & 1);
+  }
+  M3 b1[2], b2[2];
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int k = 0; k < 9; k++) { b1[c].re[k] = b1[c].im[k] = b2[c].re[k] = b2[c].im[k] = 0; }
+  for (int mu = 1; mu < 4; mu++)
+    for (int nu = 0; nu < mu; nu++) {
+      M3 Q;
+#pragma unroll
+      for (int k = 0; k < 9; k++) Q.re[k] = Q.im[k] = 0;
+      int xpm[4], xpn[4], xmm[4], xmn[4], xpn_mm[4], xpm_mn[4], xmm_mn[4];
+#pragma unroll
+      for (int d = 0; d < 4; d++) xpm[d] = xpn[d] = xmm[d] = xmn[d] = xpn_mm[d] = xpm_mn[d] = xmm_mn[d] = x[d];
+      xpm[mu]++; xpn[nu]++; xmm[mu]--; xmn[nu]--; xpn_mm[nu]++; xpn_mm[mu]--; xpm_mn[mu]++; xpm_mn[nu]--; xmm_mn[mu]--; xmm_mn[nu]--;
+      add_leaf<T, R>(Q, g, mu, x, false, nu, xpm, false, mu, xpn, true, nu, x, true);            // U(x,mu) U(x+mu,nu) U^(x+nu,mu) U^(x,nu)
+      add_leaf<T, R>(Q, g, nu, x, false, mu, xpn_mm, true, nu, xmm, true, mu, xmm, false);       // U(x,nu) U^(x+nu-mu,mu) U^(x-mu,nu) U(x-mu,mu)
+      add_leaf<T, R>(Q, g, nu, xmn, true, mu, xmn, false, nu, xpm_mn, false, mu, x, true);       // U^(x-nu,nu) U(x-nu,mu) U(x+mu-nu,nu) U^(x,mu)
+      add_leaf<T, R>(Q, g, mu, xmm, true, nu, xmm_mn, true, mu, xmm_mn, false, nu, xmn, false);  // U^(x-mu,mu) U^(x-mu-nu,nu) U(x-mu-nu,mu) U(x-nu,nu)
+      // F = (Q - Q^dag) / 8, scattered into the blocks (F index = mu(mu-1)/2 + nu)
+      const int fi = mu * (mu - 1) / 2 + nu;
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const double fr = 0.125 * (Q.re[i * 3 + j] - Q.re[j * 3 + i]), fm = 0.125 * (Q.im[i * 3 + j] + Q.im[j * 3 + i]);
+          const int k = i * 3 + j;
+          // i c F = c (-fm + i fr);   c F = c (fr + i fm);   -i c F = c (fm - i fr)
+          switch (fi) {
+            case 0: b1[0].re[k] += -coeff * fm; b1[0].im[k] += coeff * fr; b1[1].re[k] += -coeff * fm; b1[1].im[k] += coeff * fr; break;
+            case 5: b1[0].re[k] -= -coeff * fm; b1[0].im[k] -= coeff * fr; b1[1].re[k] += -coeff * fm; b1[1].im[k] += coeff * fr; break;
+            case 1: b2[0].re[k] += coeff * fr; b2[0].im[k] += coeff * fm; b2[1].re[k] += coeff * fr; b2[1].im[k] += coeff * fm; break;
+            case 4: b2[0].re[k] += coeff * fr; b2[0].im[k] += coeff * fm; b2[1].re[k] -= coeff * fr; b2[1].im[k] -= coeff * fm; break;
+            case 2: b2[0].re[k] += coeff * fm; b2[0].im[k] -= coeff * fr; b2[1].re[k] += coeff * fm; b2[1].im[k] -= coeff * fr; break;
+            default: b2[0].re[k] -= coeff * fm; b2[0].im[k] += coeff * fr; b2[1].re[k] += coeff * fm; b2[1].im[k] -= coeff * fr; break;  // fi == 3
+          }
+        }
+    }
+  // packed order: 6 diagonal reals, then the 15 strictly-lower entries column by column (tests/clover_reference.cpp:45-53)
+  for (int ch = 0; ch < 2; ch++) {
+    double *A = packed + (((size_t)parity * Vh + idx) * 2 + ch) * 36;
+    for (int i = 0; i < 3; i++) { A[i] = 1.0 - b1[ch].re[i * 3 + i]; A[i + 3] = 1.0 + b1[ch].re[i * 3 + i]; }
+    int k = 0;
+    for (int col = 0; col < 6; col++)
+      for (int row = col + 1; row < 6; row++, k++) {
+        double re, im;
+        const int rs = row / 3, rc = row % 3, cs = col / 3, cc = col % 3;
+        if (rs == 0) { re = -b1[ch].re[rc * 3 + cc]; im = -b1[ch].im[rc * 3 + cc]; }          // spin 0 x spin 0: -B1
+        else if (cs == 1) { re = b1[ch].re[rc * 3 + cc]; im = b1[ch].im[rc * 3 + cc]; }       // spin 1 x spin 1: +B1
+        else { re = b2[ch].re[rc * 3 + cc]; im = b2[ch].im[rc * 3 + cc]; }                    // spin 1 x spin 0: B2
+        A[6 + 2 * k] = re; A[6 + 2 * k + 1] = im;
+      }
+  }
+}
+
+void CloverField::computeFromGauge(const GaugeField &U, double coeff) {
+  if (!(U.geom == geom)) errorQuda("gauge and clover geometry differ");
+  for (int d = 0; d < 4; d++)
+    if (commGrid().partitioned(d)) errorQuda("device clover construction on a grid-decomposed lattice needs the extended gauge halo (not built): upload the clover field instead");
+  if (U.anisotropy != 1.0) errorQuda("cannot compute anisotropic clover field");
+  const size_t n = (size_t)geom.V * 72 * sizeof(double);
+  double *stage = (double *)stagingBuffer(n);
+  GaugeView g;
+  g.data = (const char *)U.data; g.link_bytes = U.link_bytes; g.stride = U.stride;
+  for (int d = 0; d < 4; d++) g.X[d] = geom.X[d];
+  g.tsign = U.t_boundary == QUDA_ANTI_PERIODIC_T ? -1 : 1;
+  const int bs = 128, nb = (2 * geom.Vh + bs - 1) / bs;
+  const bool r12 = U.reconstruct == QUDA_RECONSTRUCT_12;
+#define QA_CG(T) \
+  if (r12) hipLaunchKernelGGL((clover_from_gauge_kernel<T, 12>), dim3(nb), dim3(bs), 0, computeStream(), stage, g, coeff, geom.Vh); \
+  else hipLaunchKernelGGL((clover_from_gauge_kernel<T, 18>), dim3(nb), dim3(bs), 0, computeStream(), stage, g, coeff, geom.Vh);
+  switch (U.precision) {
+    case QUDA_DOUBLE_PRECISION: QA_CG(double) break;
+    case QUDA_SINGLE_PRECISION: QA_CG(float) break;
+    case QUDA_HALF_PRECISION: QA_CG(short) break;
+    default: errorQuda("bad gauge precision %d", U.precision);
+  }
+#undef QA_CG
+  HIP_CHECK(hipGetLastError());
+  const int bl = 256, nl = (2 * geom.Vh + bl - 1) / bl;
+#define QA_CL2(TD) hipLaunchKernelGGL((clover_load_kernel<TD, double>), dim3(nl), dim3(bl), 0, computeStream(), (char *)clover, norm, parity_bytes, stride, (const double *)stage, geom.Vh)
+  QA_DISPATCH_DEV(precision, QA_CL2(TD));
+#undef QA_CL2
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(computeStream()));
+}
+
 template <typename TDev, typename THost> static void cloverLoad(CloverField &c, void *dev, float *nrm, const void *host) {
   const size_t n = (size_t)c.geom.V * 72 * sizeof(THost);
   void *stage = stagingBuffer(n);
@@ -679,6 +835,24 @@ void CloverField::savePackedInverse(void *h_inv, QudaPrecision cpu_prec) const {
                        parity_bytes, stride, geom.Vh);                                                                         \
   else                                                                                                                         \
     hipLaunchKernelGGL((clover_save_kernel<TD, float>), dim3(nb), dim3(bs), 0, computeStream(), (float *)stage, (const char *)cloverInv, invNorm,  \
+                       parity_bytes, stride, geom.Vh);
+  QA_DISPATCH_DEV(precision, QA_CS(TD));
+#undef QA_CS
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(h_inv, stage, n, hipMemcpyDeviceToHost, computeStream()));
+  HIP_CHECK(hipStreamSynchronize(computeStream()));
+}
+
+void CloverField::savePacked(void *h_inv, QudaPrecision cpu_prec) const {
+  const size_t n = (size_t)geom.V * 72 * (int)cpu_prec;
+  void *stage = stagingBuffer(n);
+  const int bs = 256, nb = (2 * geom.Vh + bs - 1) / bs;
+#define QA_CS(TD)                                                                                                              \
+  if (cpu_prec == QUDA_DOUBLE_PRECISION)                                                                                       \
+    hipLaunchKernelGGL((clover_save_kernel<TD, double>), dim3(nb), dim3(bs), 0, computeStream(), (double *)stage, (const char *)clover, norm, \
+                       parity_bytes, stride, geom.Vh);                                                                         \
+  else                                                                                                                         \
+    hipLaunchKernelGGL((clover_save_kernel<TD, float>), dim3(nb), dim3(bs), 0, computeStream(), (float *)stage, (const char *)clover, norm,  \
                        parity_bytes, stride, geom.Vh);
   QA_DISPATCH_DEV(precision, QA_CS(TD));
 #undef QA_CS

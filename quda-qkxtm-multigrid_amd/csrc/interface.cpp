@@ -307,14 +307,19 @@ void loadCloverQuda(void *h_clover, void *h_clovinv, QudaInvertParam *inv) {
   if (!gaugePrecise) errorQuda("Cannot call loadCloverQuda with no resident gauge field");
   if (inv->clover_order != QUDA_PACKED_CLOVER_ORDER) errorQuda("clover_order %d: only QUDA_PACKED_CLOVER_ORDER host fields are supported", inv->clover_order);
   if (inv->clover_cpu_prec != QUDA_DOUBLE_PRECISION && inv->clover_cpu_prec != QUDA_SINGLE_PRECISION) errorQuda("Parameter clover_cpu_prec undefined");
-  if (!h_clover) errorQuda("loadCloverQuda(NULL, ...): device construction of the clover term from the gauge field is a 'next' row (SURVEY 8f-2) and not built yet");
+  // reference :743-747: with neither field given (or compute_clover set) the clover term is built on the device from the
+  // resident links, A = 1 + i clover_coeff sum sigma F (createCloverQuda :3950-4010); what the QKXTM drivers do
+  const bool device_calc = (!h_clover && !h_clovinv) || inv->compute_clover;
+  if (device_calc && (inv->clover_coeff == 0.0 || inv->clover_coeff != inv->clover_coeff)) errorQuda("called with neither clover term nor inverse and clover coefficient not set");
+  if (!device_calc && !h_clover) errorQuda("loadCloverQuda: an inverse without the clover term is not supported (the operators need A itself)");
   freeCloverQuda();
   const bool twisted = inv->dslash_type == QUDA_TWISTED_CLOVER_DSLASH;
   const double mu2 = twisted ? 4.0 * inv->kappa * inv->kappa * inv->mu * inv->mu : 0.0;
-  const bool compute_inv = !h_clovinv || inv->compute_clover_inverse || inv->return_clover_inverse;
+  const bool compute_inv = device_calc || !h_clovinv || inv->compute_clover_inverse || inv->return_clover_inverse;
   auto make = [&](QudaPrecision prec) {
     CloverField *c = new CloverField(g_geom, prec);
-    c->loadPacked(h_clover, compute_inv ? nullptr : h_clovinv, inv->clover_cpu_prec);
+    if (device_calc) c->computeFromGauge(*gaugePrecise, inv->clover_coeff);
+    else c->loadPacked(h_clover, compute_inv ? nullptr : h_clovinv, inv->clover_cpu_prec);
     if (compute_inv) c->computeInverse(mu2);
     else { c->twisted = twisted; c->mu2 = mu2; }
     return c;
@@ -328,6 +333,7 @@ void loadCloverQuda(void *h_clover, void *h_clovinv, QudaInvertParam *inv) {
   inv->cloverGiB = gib;
   inv->trlogA[0] = cloverPrecise->trlog[0];
   inv->trlogA[1] = cloverPrecise->trlog[1];
+  if (h_clover && device_calc && inv->return_clover) cloverPrecise->savePacked(h_clover, inv->clover_cpu_prec);
   if (h_clovinv && compute_inv && inv->return_clover_inverse) {
     // hand the inverse back in double if the device field is 16-bit? no: from the most precise resident copy
     cloverPrecise->savePackedInverse(h_clovinv, inv->clover_cpu_prec);

@@ -150,6 +150,12 @@ class Oracle:
     def norm2(self, a):
         return self.lib.qo_norm2_d(_p(a), C.c_long(a.size))
 
+    def clover_compute(self, gauge, coeff, X):
+        """clover term from the gauge field, host packed order (oracle/qo_mg.c: computeFmunu + computeClover)"""
+        out = np.zeros(int(np.prod(X)) * 72)
+        self.lib.qo_clover_compute_d(_p(out), _g(gauge), C.c_double(coeff), _x(X))
+        return out
+
     # -- multigrid pieces (oracle/qo_mg.c); complex128 arrays in the reference CPU orders
     @staticmethod
     def _c(a):

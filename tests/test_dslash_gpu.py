@@ -231,3 +231,35 @@ def test_two_process_decomposition_on_one_gpu():
         text = open(log).read()
     assert "rank 0: all checks passed" in text and "rank 1: all checks passed" in text, text[-3000:]
     assert text.count("MG-GCR") >= 6
+
+
+@pytest.mark.parametrize("prec,recon,tol", [(8, 18, 1e-12), (8, 12, 1e-12), (4, 18, 2e-6)])
+def test_device_clover_construction(qa, oracle, prec, recon, tol):
+    """loadCloverQuda(NULL, NULL): the clover term built on the device from the resident links (reference createCloverQuda,
+    lib/interface_quda.cpp:3950-4010) against the oracle's restatement of computeFmunu + computeClover, then the
+    twisted-clover operator on top of it against the oracle's tmc_mat / tmc_matpc fed with the oracle-built clover.
+    Anti-periodic links: the boundary sign must cancel in every plaquette (folded for recon-18, reconstructed for 12)."""
+    X, kappa, mu, coeff = [8, 4, 6, 8], 0.12, 0.3, 0.17
+    gauge, spinor, _ = oracle.make_fields(X, seed=77, antiperiodic_t=True, clover=False)
+    want_clover = oracle.clover_compute(gauge, coeff, X)
+    qa.load_gauge(gauge, qa.gauge_param(X, cuda_prec=prec, recon=recon))
+    ip = qa.invert_param(qa.QUDA_TWISTED_CLOVER_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=prec, solution_type=qa.QUDA_MAT_SOLUTION)
+    ip.clover_coeff = coeff
+    ip.compute_clover, ip.return_clover, ip.return_clover_inverse = 1, 1, 1
+    got_clover, got_inv = np.zeros_like(want_clover), np.zeros_like(want_clover)
+    qa.load_clover(got_clover, got_inv, ip)
+    assert np.max(np.abs(got_clover - want_clover)) < tol * 10
+    want_inv = oracle.clover_twisted_inverse(want_clover, 4 * kappa * kappa * mu * mu)
+    assert np.max(np.abs(got_inv - want_inv)) < tol * 100
+    # and with nothing handed over at all, as the QKXTM drivers call it
+    ip.compute_clover, ip.return_clover, ip.return_clover_inverse = 0, 0, 0
+    qa.load_clover(None, None, ip)
+    got = qa.mat(spinor.copy(), ip)
+    want = oracle.tmc_mat(gauge, want_clover, spinor, X, kappa, mu, +1, 0)
+    assert qc.rel_err(got, want) < tol * 10
+    ipc = qa.invert_param(qa.QUDA_TWISTED_CLOVER_DSLASH, kappa, mu, -1, "oo", 1, cuda_prec=prec)
+    nh = spinor.size // 2
+    got = qa.mat(spinor[nh:].copy(), ipc)
+    want = oracle.tmc_matpc(gauge, spinor[nh:].copy(), want_clover, oracle.clover_twisted_inverse(want_clover, 4 * kappa * kappa * mu * mu), X, kappa, mu, -1, "oo", 1)
+    assert qc.rel_err(got, want) < tol * 100
+    qa.lib().freeCloverQuda()

@@ -80,3 +80,62 @@ def test_galerkin_coarse(env):
     want = o.mg_restrict(mid, V2, Xc, bs2, 2, NVEC, nv2, 1)
     got = o.mg_coarse_apply(eta, Y2, X2, KAPPA, Xcc, nv2)
     assert np.max(np.abs(got - want)) < 1e-11 * np.max(np.abs(want))
+
+
+def test_clover_from_gauge_restatement(env):
+    """oracle.clover_compute (restated computeFmunu + computeClover): unit links give the identity; on a random field the
+    two chiral blocks equal 1 + i c sum_{mu>nu} sigma_mu_nu (x) F_mu_nu with sigma = (i/2)[gamma_mu, gamma_nu] in the
+    DeGrand-Rossi matrices of include/gamma.cuh and F built independently in numpy."""
+    o, gauge, _, _, _ = env
+    V, Vh, c = int(np.prod(X)), int(np.prod(X)) // 2, 0.3
+    unit = np.zeros((4, V, 9), dtype=complex)
+    unit[:, :, [0, 4, 8]] = 1
+    expect = np.zeros(36)
+    expect[:6] = 1
+    assert np.max(np.abs(o.clover_compute(np.ascontiguousarray(unit).view(float).reshape(4, -1), c, X).reshape(-1, 36) - expect)) == 0.0
+    A = o.clover_compute(gauge, c, X).reshape(-1, 2, 36)
+
+    def expand(blk):
+        M = np.diag(blk[:6]).astype(complex)
+        L = blk[6:].reshape(15, 2)
+        for a in range(6):
+            for b in range(a + 1, 6):
+                k = 15 - (6 - a) * (5 - a) // 2 + b - a - 1
+                M[b, a] = L[k, 0] + 1j * L[k, 1]
+                M[a, b] = np.conj(M[b, a])
+        return M
+
+    coup = [[3, 2, 1, 0], [3, 2, 1, 0], [2, 3, 0, 1], [2, 3, 0, 1]]
+    elem = [[1j, 1j, -1j, -1j], [-1, 1, 1, -1], [1j, -1j, -1j, 1j], [1, 1, 1, 1]]
+    g = [np.zeros((4, 4), dtype=complex) for _ in range(4)]
+    for d in range(4):
+        for s in range(4):
+            g[d][s, coup[d][s]] = elem[d][s]
+
+    def link(mu, x):
+        x = [x[d] % X[d] for d in range(4)]
+        cb = (((x[3] * X[2] + x[2]) * X[1] + x[1]) * X[0] + x[0]) >> 1
+        return (gauge[mu].reshape(-1, 9, 2)[(sum(x) & 1) * Vh + cb] @ np.array([1, 1j])).reshape(3, 3)
+
+    def sh(x, mu, s):
+        y = list(x)
+        y[mu] += s
+        return y
+
+    def dag(m):
+        return m.conj().T
+
+    for site in ([0, 0, 0, 0], [1, 2, 3, 4], [3, 3, 0, 7]):
+        S = np.zeros((12, 12), dtype=complex)
+        for mu in range(4):
+            for nu in range(mu):
+                U = link
+                Q = U(mu, site) @ U(nu, sh(site, mu, 1)) @ dag(U(mu, sh(site, nu, 1))) @ dag(U(nu, site))
+                Q += U(nu, site) @ dag(U(mu, sh(sh(site, nu, 1), mu, -1))) @ dag(U(nu, sh(site, mu, -1))) @ U(mu, sh(site, mu, -1))
+                Q += dag(U(nu, sh(site, nu, -1))) @ U(mu, sh(site, nu, -1)) @ U(nu, sh(sh(site, mu, 1), nu, -1)) @ dag(U(mu, site))
+                Q += dag(U(mu, sh(site, mu, -1))) @ dag(U(nu, sh(sh(site, mu, -1), nu, -1))) @ U(mu, sh(sh(site, mu, -1), nu, -1)) @ U(nu, sh(site, nu, -1))
+                S += np.kron(0.5j * (g[mu] @ g[nu] - g[nu] @ g[mu]), (Q - dag(Q)) / 8)
+        i = (sum(site) & 1) * Vh + ((((site[3] * X[2] + site[2]) * X[1] + site[1]) * X[0] + site[0]) >> 1)
+        full = np.zeros((12, 12), dtype=complex)
+        full[:6, :6], full[6:, 6:] = expand(A[i, 0]), expand(A[i, 1])
+        assert np.max(np.abs(full - (np.eye(12) + 1j * c * S))) < 1e-13
