@@ -259,7 +259,7 @@ void DiracCoarse::build() {
   const int n = 2 * T.Nvec;
   links = new CoarseGauge(T.Xc, n);
   ownLinks = true;
-  ColorSpinorField *E = T.createCoarseField(), *c = T.createCoarseField();
+  ColorSpinorField *E = T.createCoarseField(), *c = T.createCoarseField(), *c2 = T.createCoarseField();
   ColorSpinorField *phi = T.createFineField(), *w = T.createFineField();
   phi->twistFlavor = w->twistFlavor = fineFlavor;
   const int bs = 256;
@@ -268,10 +268,9 @@ void DiracCoarse::build() {
     T.P(*phi, *E);
     for (int d = 0; d < 8; d++) {
       parent->hopDir(*w, *phi, d);
-      T.R(*c, *w, d, 1);
+      T.RSplit(*c, *c2, *w, d);   // one pass over V: the part of the hop that leaves the aggregate -> link d, the rest -> local term
       hipLaunchKernelGGL(insert_column_kernel, dim3(((long)links->nSites * n + bs - 1) / bs), dim3(bs), 0, computeStream(), links->data, cvecFull(*c), n, d, j, 0, links->nSites);
-      T.R(*c, *w, d, 0);
-      hipLaunchKernelGGL(insert_column_kernel, dim3(((long)links->nSites * n + bs - 1) / bs), dim3(bs), 0, computeStream(), links->data, cvecFull(*c), n, 8, j, 1, links->nSites);
+      hipLaunchKernelGGL(insert_column_kernel, dim3(((long)links->nSites * n + bs - 1) / bs), dim3(bs), 0, computeStream(), links->data, cvecFull(*c2), n, 8, j, 1, links->nSites);
     }
     parent->localTerm(*w, *phi);
     T.R(*c, *w);
@@ -279,7 +278,7 @@ void DiracCoarse::build() {
   }
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(computeStream()));
-  delete E; delete c; delete phi; delete w;
+  delete E; delete c; delete c2; delete phi; delete w;
 }
 
 // ---- preconditioned links: batched dense inverse and products ----

@@ -40,6 +40,9 @@ class Transfer {
   // outside the site's own aggregate contribute (used by the Galerkin coarse-operator construction).
   void R(ColorSpinorField &coarse, const ColorSpinorField &fine, int dir = -1, int boundary = 0) const;
   void P(ColorSpinorField &fine, const ColorSpinorField &coarse) const;
+  // both halves of the Galerkin split in one pass over V: `leaving` = R over the fine sites whose dir-neighbour lies outside
+  // their aggregate, `staying` = R over the others (equal to R(.., dir, 1) and R(.., dir, 0))
+  void RSplit(ColorSpinorField &leaving, ColorSpinorField &staying, const ColorSpinorField &fine, int dir) const;
   // single-parity fine fields (outer even-odd preconditioned solve: the residual of one parity is injected into the coarse
   // grid, reference Transfer::setSiteSubset lib/transfer.cpp:276-290): the absent parity restricts as zero / is not prolongated
   void setSiteSubset(QudaSiteSubset subset, QudaParity parity);

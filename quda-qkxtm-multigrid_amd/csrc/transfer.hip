@@ -73,13 +73,24 @@ __device__ __forceinline__ float4 block_sum4(float4 v, float4 *lds) {
   return r;
 }
 
-// ---- restrictor: one work-group per aggregate, one thread per fine site of it ----
-template <int NSF, int NCF, int NVEC, int NV>
-__global__ void restrict_kernel(CoarseVec out, FineVec in, const float4 *V, const int *block_to_fine, int blockVol, int spin_bs, MaskArg mask) {
+// ---- restrictor: one work-group per aggregate, one thread per fine site of it.  DUAL (Galerkin construction): the sites whose
+// mask.dir neighbour leaves the aggregate go into `out`, the others into `out2`, in ONE pass over V (V is the whole cost) ----
+__device__ __forceinline__ bool mask_outside(const MaskArg &m, int b) {
+  const int mu = m.dir >> 1, fwd = !(m.dir & 1);
+  int y[4], l = b;
+  y[0] = l % m.bs[0]; l /= m.bs[0];
+  y[1] = l % m.bs[1]; l /= m.bs[1];
+  y[2] = l % m.bs[2]; y[3] = l / m.bs[2];
+  return !m.single[mu] && (fwd ? y[mu] == m.bs[mu] - 1 : y[mu] == 0);
+}
+
+template <int NSF, int NCF, int NVEC, int NV, bool DUAL>
+__global__ void restrict_kernel(CoarseVec out, CoarseVec out2, FineVec in, const float4 *V, const int *block_to_fine, int blockVol, int spin_bs, MaskArg mask) {
   constexpr int K = NSF * NCF;
   __shared__ float4 lds[16];
   const int A = blockIdx.x, b = threadIdx.x;
-  const bool active = b < blockVol && mask_keep(mask, b);
+  const bool active = b < blockVol && (DUAL || mask_keep(mask, b));
+  const bool outside = DUAL && b < blockVol && mask_outside(mask, b);
   float2 r[K];
   bool have = false;
   if (active) {
@@ -93,7 +104,7 @@ __global__ void restrict_kernel(CoarseVec out, FineVec in, const float4 *V, cons
     }
   }
   const int cpar = A >= out.Vh, xc = A - cpar * out.Vh;
-  float *ob = out.v[cpar];
+  float *ob = out.v[cpar], *ob2 = DUAL ? out2.v[cpar] : nullptr;
   for (int chi = 0; chi < 2; chi++) {
     for (int vp = 0; vp < NVEC / 2; vp++) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -107,11 +118,23 @@ __global__ void restrict_kernel(CoarseVec out, FineVec in, const float4 *V, cons
           acc.z += w.z * r[k].x + w.w * r[k].y; acc.w += w.z * r[k].y - w.w * r[k].x;
         }
       }
-      const float4 s = block_sum4(acc, lds);
-      if (threadIdx.x == 0) {
-        const int c0 = chi * NVEC + 2 * vp;
-        ob[((size_t)c0 * out.stride + xc) * 2] = s.x; ob[((size_t)c0 * out.stride + xc) * 2 + 1] = s.y;
-        ob[((size_t)(c0 + 1) * out.stride + xc) * 2] = s.z; ob[((size_t)(c0 + 1) * out.stride + xc) * 2 + 1] = s.w;
+      const int c0 = chi * NVEC + 2 * vp;
+      if (DUAL) {
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 so = block_sum4(outside ? acc : zero4, lds);
+        const float4 si = block_sum4(outside ? zero4 : acc, lds);
+        if (threadIdx.x == 0) {
+          ob[((size_t)c0 * out.stride + xc) * 2] = so.x; ob[((size_t)c0 * out.stride + xc) * 2 + 1] = so.y;
+          ob[((size_t)(c0 + 1) * out.stride + xc) * 2] = so.z; ob[((size_t)(c0 + 1) * out.stride + xc) * 2 + 1] = so.w;
+          ob2[((size_t)c0 * out2.stride + xc) * 2] = si.x; ob2[((size_t)c0 * out2.stride + xc) * 2 + 1] = si.y;
+          ob2[((size_t)(c0 + 1) * out2.stride + xc) * 2] = si.z; ob2[((size_t)(c0 + 1) * out2.stride + xc) * 2 + 1] = si.w;
+        }
+      } else {
+        const float4 s = block_sum4(acc, lds);
+        if (threadIdx.x == 0) {
+          ob[((size_t)c0 * out.stride + xc) * 2] = s.x; ob[((size_t)c0 * out.stride + xc) * 2 + 1] = s.y;
+          ob[((size_t)(c0 + 1) * out.stride + xc) * 2] = s.z; ob[((size_t)(c0 + 1) * out.stride + xc) * 2 + 1] = s.w;
+        }
       }
     }
   }
@@ -389,11 +412,30 @@ void Transfer::R(ColorSpinorField &coarse, const ColorSpinorField &fine, int dir
   for (int d = 0; d < 4; d++) { m.bs[d] = geo_bs[d]; m.single[d] = Xc[d] == 1; }
   const int threads = (blockVol + 63) / 64 * 64;
 #define QA_R(NSF, NCF, NVEC, NV) \
-  hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV>), dim3(nAgg), dim3(threads), 0, computeStream(), out, in, (const float4 *)V, block_to_fine, blockVol, spin_bs, m)
+  hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out, in, (const float4 *)V, block_to_fine, blockVol, spin_bs, m)
   QA_TRANSFER_DISPATCH(QA_R)
 #undef QA_R
   HIP_CHECK(hipGetLastError());
   flops_ += 8ull * fineSpin * fineColor * Nvec * fineVol;  // reference lib/restrictor.cu:405
+}
+
+void Transfer::RSplit(ColorSpinorField &leaving, ColorSpinorField &staying, const ColorSpinorField &fine, int dir) const {
+  if (fine.SiteSubset() != QUDA_FULL_SITE_SUBSET) errorQuda("the split restriction works on full fields");
+  if (fine.Nspin() != fineSpin || fine.Ncolor() != fineColor || fine.Volume() != fineVol) errorQuda("fine field does not match the transfer operator");
+  if (leaving.Nspin() != 2 || leaving.Ncolor() != Nvec || leaving.Volume() != nAgg || staying.Volume() != nAgg || staying.Ncolor() != Nvec) errorQuda("coarse field does not match the transfer operator");
+  if (dir < 0 || dir > 7) errorQuda("direction %d", dir);
+  const FineVec in = fineVec(fine);
+  const CoarseVec out = coarseVec(leaving), out2 = coarseVec(staying);
+  MaskArg m;
+  m.dir = dir; m.boundary = 1;
+  for (int d = 0; d < 4; d++) { m.bs[d] = geo_bs[d]; m.single[d] = Xc[d] == 1; }
+  const int threads = (blockVol + 63) / 64 * 64;
+#define QA_R2(NSF, NCF, NVEC, NV) \
+  hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, true>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out2, in, (const float4 *)V, block_to_fine, blockVol, spin_bs, m)
+  QA_TRANSFER_DISPATCH(QA_R2)
+#undef QA_R2
+  HIP_CHECK(hipGetLastError());
+  flops_ += 8ull * fineSpin * fineColor * Nvec * fineVol;
 }
 
 void Transfer::P(ColorSpinorField &fine, const ColorSpinorField &coarse) const {
