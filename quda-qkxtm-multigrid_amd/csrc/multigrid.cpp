@@ -4,7 +4,10 @@
 #include <cmath>
 #include <sys/time.h>
 
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 
 #include "interface_internal.h"
 
@@ -62,6 +65,9 @@ MG::MG(MGParam &p)
       generateNullVectors(p.B);
       HIP_CHECK(hipStreamSynchronize(computeStream()));
       if (getVerbosity() >= QUDA_SUMMARIZE || mgProfiling()) printfQuda("MG level %d: %d null vectors generated in %.3f s\n", p.level + 1, p.Nvec, now() - t0);
+      saveVectors(p.B);
+    } else if (p.mg_global.compute_null_vector == QUDA_COMPUTE_NULL_VECTOR_NO && (p.mg_global.generate_all_levels == QUDA_BOOLEAN_YES || p.level == 0)) {
+      loadVectors(p.B);   // reference :25-32: a previously saved null space instead of a fresh setup
     }
   }
 
@@ -235,6 +241,68 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
   }
   (void)v0;
   delete b;
+}
+
+// ---- null-vector persistence (reference MG::saveVectors / loadVectors, lib/multigrid.cpp:607-691: "<file>_level_<l>", all
+// Nvec vectors of a level in one file).  The reference hands the vectors to QIO/LIME (lib/qio_field.cpp), which this image does
+// not have; the container here is a 64-byte header (magic, lattice, nSpin, nColor, Nvec, process grid) followed by the
+// vectors in the order the reference gives QIO — site-major (parity*Vh + x_cb, spin, colour, re/im), fp32 — one file per
+// rank ("….rank<r>" when there is more than one). ----
+struct NullVecHeader { char magic[8]; int X[4]; int nSpin, nColor, Nvec, precision; int grid[4]; int rank, pad; };
+static std::string nullVecFile(const char *base, int level) {
+  std::string f(base);
+  f += "_level_" + std::to_string(level);
+  if (commGrid().size > 1) f += ".rank" + std::to_string(commGrid().rank);
+  return f;
+}
+static ColorSpinorParam hostParamLike(const ColorSpinorField &dev, void *ptr) {
+  ColorSpinorParam p = dev.param();
+  p.location = QUDA_CPU_FIELD_LOCATION; p.precision = QUDA_SINGLE_PRECISION; p.fieldOrder = QUDA_SPACE_SPIN_COLOR_FIELD_ORDER;
+  p.gammaBasis = QUDA_DEGRAND_ROSSI_GAMMA_BASIS; p.create = QUDA_REFERENCE_FIELD_CREATE; p.pad = 0; p.v = ptr;
+  return p;
+}
+void MG::saveVectors(std::vector<ColorSpinorField *> &B) {
+  if (!mgp.mg_global.vec_outfile[0]) return;
+  const std::string f = nullVecFile(mgp.mg_global.vec_outfile, mgp.level);
+  if (getVerbosity() >= QUDA_SUMMARIZE) printfQuda("Start saving %zu vectors to %s\n", B.size(), f.c_str());
+  FILE *fp = fopen(f.c_str(), "wb");
+  if (!fp) errorQuda("cannot open %s for writing", f.c_str());
+  NullVecHeader h;
+  memset(&h, 0, sizeof(h));
+  memcpy(h.magic, "QAMDNV01", 8);
+  for (int d = 0; d < 4; d++) { h.X[d] = B[0]->X(d); h.grid[d] = commGrid().dims[d]; }
+  h.nSpin = B[0]->Nspin(); h.nColor = B[0]->Ncolor(); h.Nvec = (int)B.size(); h.precision = 4; h.rank = commGrid().rank;
+  const size_t n = (size_t)B[0]->Volume() * h.nSpin * h.nColor * 2;
+  std::vector<float> buf(n);
+  bool ok = fwrite(&h, sizeof(h), 1, fp) == 1;
+  for (size_t i = 0; i < B.size() && ok; i++) {
+    ColorSpinorField host(hostParamLike(*B[i], buf.data()));
+    host = *B[i];
+    ok = fwrite(buf.data(), sizeof(float), n, fp) == n;
+  }
+  fclose(fp);
+  if (!ok) errorQuda("short write on %s", f.c_str());
+}
+void MG::loadVectors(std::vector<ColorSpinorField *> &B) {
+  if (!mgp.mg_global.vec_infile[0]) errorQuda("compute_null_vector = NO needs vec_infile (no null-space file defined)");
+  const std::string f = nullVecFile(mgp.mg_global.vec_infile, mgp.level);
+  if (getVerbosity() >= QUDA_SUMMARIZE) printfQuda("Start loading %zu vectors from %s\n", B.size(), f.c_str());
+  FILE *fp = fopen(f.c_str(), "rb");
+  if (!fp) errorQuda("cannot open %s", f.c_str());
+  NullVecHeader h;
+  if (fread(&h, sizeof(h), 1, fp) != 1 || memcmp(h.magic, "QAMDNV01", 8)) errorQuda("%s is not a null-vector file of this library", f.c_str());
+  for (int d = 0; d < 4; d++)
+    if (h.X[d] != B[0]->X(d) || h.grid[d] != commGrid().dims[d]) errorQuda("%s was written for lattice %d %d %d %d on grid %d %d %d %d", f.c_str(), h.X[0], h.X[1], h.X[2], h.X[3], h.grid[0], h.grid[1], h.grid[2], h.grid[3]);
+  if (h.nSpin != B[0]->Nspin() || h.nColor != B[0]->Ncolor() || h.Nvec < (int)B.size() || h.rank != commGrid().rank) errorQuda("%s does not match this level (nSpin %d nColor %d Nvec %d rank %d)", f.c_str(), h.nSpin, h.nColor, h.Nvec, h.rank);
+  const size_t n = (size_t)B[0]->Volume() * h.nSpin * h.nColor * 2;
+  std::vector<float> buf(n);
+  for (size_t i = 0; i < B.size(); i++) {
+    if (fread(buf.data(), sizeof(float), n, fp) != n) errorQuda("short read on %s", f.c_str());
+    ColorSpinorField host(hostParamLike(*B[i], buf.data()));
+    *B[i] = host;
+    B[i]->twistFlavor = mgp.fineFlavor;
+  }
+  fclose(fp);
 }
 
 // reference :488-604 (outer and inner solution type QUDA_MAT_SOLUTION; smoother full or even-odd preconditioned)

@@ -54,6 +54,8 @@ class MG : public Solver {
   bool ownCoarseSolver;
   void generateNullVectors(std::vector<ColorSpinorField *> &B);
   void cycleParity(ColorSpinorField &x, ColorSpinorField &b);
+  void saveVectors(std::vector<ColorSpinorField *> &B);
+  void loadVectors(std::vector<ColorSpinorField *> &B);
 
  public:
   explicit MG(MGParam &param);

@@ -209,3 +209,32 @@ def test_outer_even_odd_solve_with_up_and_down_hierarchies(qa, oracle):
     finally:
         for h, _, _ in hier.values():
             h.free()
+
+
+def test_null_vector_persistence(qa, tmp_path):
+    """vec_outfile / vec_infile (reference MG::saveVectors / loadVectors, lib/multigrid.cpp:607-691): a hierarchy rebuilt from the
+    saved null vectors with compute_null_vector = NO has bit-identical transfer operators and coarse links on every level."""
+    X, kappa, mu = (8, 8, 8, 16), 0.124, 0.005
+    _, ip = _setup(qa, X, kappa, mu)
+    base = str(tmp_path / "nullvec").encode()
+    mp = qa.multigrid_param(ip, n_level=3, geo_block=[(4, 4, 4, 4), (1, 1, 1, 2), (2, 2, 2, 2)], n_vec=8, setup_maxiter=100, setup_tol=1e-4)
+    mp.vec_outfile = base
+    mg = qa.Multigrid(mp)
+    V0, V1 = mg.V(0), mg.V(1)
+    Y0, X0 = mg.coarse_links(0)
+    Y1, X1 = mg.coarse_links(1)
+    mg.free()
+    assert (tmp_path / "nullvec_level_0").exists() and (tmp_path / "nullvec_level_1").exists()
+    mp2 = qa.multigrid_param(ip, n_level=3, geo_block=[(4, 4, 4, 4), (1, 1, 1, 2), (2, 2, 2, 2)], n_vec=8)
+    mp2.compute_null_vector = qa.QUDA_COMPUTE_NULL_VECTOR_NO
+    mp2.vec_infile = base
+    mg2 = qa.Multigrid(mp2)
+    try:
+        assert np.array_equal(mg2.V(0), V0) and np.array_equal(mg2.V(1), V1)
+        Yb, Xb = mg2.coarse_links(0)
+        assert np.array_equal(Yb, Y0) and np.array_equal(Xb, X0)
+        Yb, Xb = mg2.coarse_links(1)
+        assert np.array_equal(Yb, Y1) and np.array_equal(Xb, X1)
+        assert mp2.secs < mp.secs
+    finally:
+        mg2.free()
