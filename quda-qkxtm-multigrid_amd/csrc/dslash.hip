@@ -1022,6 +1022,63 @@ void applyHopDir(ColorSpinorField &out, const ColorSpinorField &in, const GaugeF
   }
 }
 
+// ---- neighbour shift of a 24-real fp64 planar site field: out(x) = in(x + dhat(dir)), ghost-aware like the single-direction
+// hop (full faces exchanged through commExchange).  Used by the grid-decomposed clover construction, which moves 3x3 matrix
+// fields (18 of the 24 reals) between neighbouring sites; setup-time only. ----
+__global__ void __launch_bounds__(256) shift_kernel(double *out, const double *in, int stride, int Vh, int Xh, int Y, int Z, int T, int parity, int dir,
+                                                    const void *ghost, int ghostFaceCB) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Vh) return;
+  int l = idx;
+  const int xh = l % Xh; l /= Xh;
+  const int y = l % Y; l /= Y;
+  const int z = l % Z, t = l / Z;
+  const int xodd = (y + z + t + parity) & 1, xf = 2 * xh + xodd, X0 = 2 * Xh;
+  const int sy = Xh, sz = Xh * Y, st = Xh * Y * Z;
+  int nbr, f;
+  bool cross;
+  switch (dir) {
+    case 0: nbr = xodd ? (xh == Xh - 1 ? idx - (Xh - 1) : idx + 1) : idx; cross = xf == X0 - 1; f = (y + Y * (z + Z * t)) >> 1; break;
+    case 1: nbr = xodd ? idx : (xh == 0 ? idx + (Xh - 1) : idx - 1); cross = xf == 0; f = (y + Y * (z + Z * t)) >> 1; break;
+    case 2: nbr = y == Y - 1 ? idx - (Y - 1) * sy : idx + sy; cross = y == Y - 1; f = (xf + X0 * (z + Z * t)) >> 1; break;
+    case 3: nbr = y == 0 ? idx + (Y - 1) * sy : idx - sy; cross = y == 0; f = (xf + X0 * (z + Z * t)) >> 1; break;
+    case 4: nbr = z == Z - 1 ? idx - (Z - 1) * sz : idx + sz; cross = z == Z - 1; f = (xf + X0 * (y + Y * t)) >> 1; break;
+    case 5: nbr = z == 0 ? idx + (Z - 1) * sz : idx - sz; cross = z == 0; f = (xf + X0 * (y + Y * t)) >> 1; break;
+    case 6: nbr = t == T - 1 ? idx - (T - 1) * st : idx + st; cross = t == T - 1; f = (xf + X0 * (y + Y * z)) >> 1; break;
+    default: nbr = t == 0 ? idx + (T - 1) * st : idx - st; cross = t == 0; f = (xf + X0 * (y + Y * z)) >> 1; break;
+  }
+  double v[24];
+  if (ghost && cross) Planar<double, 24>::load(v, ghost, ghostFaceCB, f, nullptr, f);
+  else Planar<double, 24>::load(v, in, stride, nbr, nullptr, nbr);
+  Planar<double, 24>::store(v, out, stride, idx, nullptr, idx);
+}
+
+// out: parity `parity` block, in: the other parity's block (both [12 double2 planes][stride])
+void applyShift(double *out, const double *in, const LatticeGeom &g, int stride, int parity, int dir) {
+  const int mu = dir >> 1;
+  const void *ghost = nullptr;
+  if (commGrid().partitioned(mu)) {
+    const size_t bytes = (size_t)g.faceCB[mu] * 24 * sizeof(double);
+    if (bytes > g_ffBytes) {
+      freeFullFaceBuffers();
+      HIP_CHECK(hipMalloc((void **)&g_ffSend, bytes));
+      HIP_CHECK(hipMalloc((void **)&g_ffGhost, bytes));
+      g_ffBytes = bytes;
+    }
+    const bool fwd = !(dir & 1);
+    hipLaunchKernelGGL((face_full_pack_kernel<double>), dim3((g.faceCB[mu] + 255) / 256), dim3(256), 0, computeStream(), (void *)g_ffSend, (const void *)in,
+                       (const float *)nullptr, stride, g.X[0], g.X[1], g.X[2], g.X[3], mu, fwd ? 0 : g.X[mu] - 1, 1 - parity, g.faceCB[mu]);
+    HIP_CHECK(hipGetLastError());
+    std::vector<HaloMsg> msgs;
+    msgs.push_back({mu, fwd ? -1 : +1, g_ffSend, g_ffGhost, bytes});
+    commExchange(msgs, computeStream());
+    ghost = g_ffGhost;
+  }
+  hipLaunchKernelGGL(shift_kernel, dim3((g.Vh + 255) / 256), dim3(256), 0, computeStream(), out, in, stride, g.Vh, g.Xh, g.X[1], g.X[2], g.X[3], parity, dir, ghost,
+                     g.faceCB[mu]);
+  HIP_CHECK(hipGetLastError());
+}
+
 template <typename T> static void launchSite(ColorSpinorField &out, const ColorSpinorField &in, SiteOp op, double a, double b,
                                              const CloverField *cl, int parity, bool inverse) {
   using real = typename Store<T>::real;

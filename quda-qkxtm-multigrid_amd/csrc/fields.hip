@@ -653,7 +653,7 @@ __device__ __forceinline__ void m3_dag(M3 &c, const M3 &a) {
 #pragma unroll
     for (int j = 0; j < 3; j++) { c.re[i * 3 + j] = a.re[j * 3 + i]; c.im[i * 3 + j] = -a.im[j * 3 + i]; }
 }
-struct GaugeView { const char *data; size_t link_bytes; int stride; int X[4]; int tsign; };
+struct GaugeView { const char *data; size_t link_bytes; int stride; int X[4]; int tsign, tsign_bwd; };
 // U_mu at the (possibly out-of-range, wrapped) coordinates x: the forward link stored at its own site
 template <typename T, int R> __device__ __forceinline__ void load_link(M3 &U, const GaugeView &g, int mu, const int *xin) {
   using real = typename Store<T>::real;
@@ -754,19 +754,207 @@ __global__ void __launch_bounds__(128) clover_from_gauge_kernel(double *packed, 
   }
 }
 
+// ---- the same construction on a grid-decomposed lattice.  A leaf that starts at x - mu, x - nu or x - mu - nu is the plaquette
+// P_mu_nu of that site carried to x along the links in between (U^dag P U), so instead of gathering links from up to three
+// neighbouring ranks (corners included) the field P is built once from forward-shifted links and then transported with
+// ghost-aware nearest-neighbour shifts (dslash.h applyShift): Q = P + T_mu P + T_nu P + T_nu T_mu P,
+// (T_mu F)(x) = U_mu(x - mu)^dag F(x - mu) U_mu(x - mu) — and U_mu(x - mu)^dag is stored at x (bidirectional links). ----
+struct MatField { double *p; int Vh; __host__ __device__ double *par(int q) const { return p + (size_t)q * 24 * Vh; } };
+__device__ __forceinline__ void mf_load(M3 &m, const MatField &f, int par, int idx) {
+  double v[24];
+  Planar<double, 24>::load(v, f.par(par), f.Vh, idx, nullptr, idx);
+#pragma unroll
+  for (int k = 0; k < 9; k++) { m.re[k] = v[2 * k]; m.im[k] = v[2 * k + 1]; }
+}
+__device__ __forceinline__ void mf_store(const M3 &m, const MatField &f, int par, int idx) {
+  double v[24];
+#pragma unroll
+  for (int k = 0; k < 9; k++) { v[2 * k] = m.re[k]; v[2 * k + 1] = m.im[k]; }
+#pragma unroll
+  for (int k = 18; k < 24; k++) v[k] = 0;
+  Planar<double, 24>::store(v, f.par(par), f.Vh, idx, nullptr, idx);
+}
+// stored matrix `slot` (2 mu: U_mu(x); 2 mu + 1: U_mu(x - mu)^dag) of site (par, idx) at time coordinate t
+template <typename T, int R> __device__ __forceinline__ void load_w(M3 &U, const GaugeView &g, int par, int idx, int slot, int t) {
+  using real = typename Store<T>::real;
+  real sign = 1;
+  if (R == 12 && (slot >> 1) == 3) sign = (slot & 1) ? (t == 0 ? (real)g.tsign_bwd : (real)1) : (t == g.X[3] - 1 ? (real)g.tsign : (real)1);
+  real u[18];
+  Link<T, R>::load(u, g.data + ((size_t)par * 8 + slot) * g.link_bytes, g.stride, idx, sign);
+#pragma unroll
+  for (int k = 0; k < 9; k++) { U.re[k] = u[2 * k]; U.im[k] = u[2 * k + 1]; }
+}
+__device__ __forceinline__ int time_coord(const GaugeView &g, int idx) { return idx / ((g.X[0] >> 1) * g.X[1] * g.X[2]); }
+
+template <typename T, int R> __global__ void cl_extract_kernel(MatField out, GaugeView g, int mu, int Vh) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= 2 * Vh) return;
+  const int par = gid >= Vh, idx = gid - par * Vh;
+  M3 u;
+  load_w<T, R>(u, g, par, idx, 2 * mu, time_coord(g, idx));
+  mf_store(u, out, par, idx);
+}
+// P = U_mu(x) Gnu(x) Gmu(x)^dag U_nu(x)^dag with Gnu = U_nu(x + mu), Gmu = U_mu(x + nu)
+template <typename T, int R> __global__ void cl_plaq_kernel(MatField P, MatField Gnu, MatField Gmu, GaugeView g, int mu, int nu, int Vh) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= 2 * Vh) return;
+  const int par = gid >= Vh, idx = gid - par * Vh, t = time_coord(g, idx);
+  M3 a, b, c, d;
+  load_w<T, R>(a, g, par, idx, 2 * mu, t);
+  mf_load(b, Gnu, par, idx);
+  m3_mul(c, a, b);
+  mf_load(b, Gmu, par, idx); m3_dag(a, b);
+  m3_mul(d, c, a);
+  load_w<T, R>(b, g, par, idx, 2 * nu, t); m3_dag(a, b);
+  m3_mul(c, d, a);
+  mf_store(c, P, par, idx);
+}
+// out = W S W^dag with W = U_mu(x - mu)^dag (slot 2 mu + 1) and S = F(x - mu) already shifted to x
+template <typename T, int R> __global__ void cl_transport_kernel(MatField out, MatField S, GaugeView g, int mu, int Vh) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= 2 * Vh) return;
+  const int par = gid >= Vh, idx = gid - par * Vh;
+  M3 w, s, a, b;
+  load_w<T, R>(w, g, par, idx, 2 * mu + 1, time_coord(g, idx));
+  mf_load(s, S, par, idx);
+  m3_mul(a, w, s);
+  m3_dag(b, w);
+  m3_mul(s, a, b);
+  mf_store(s, out, par, idx);
+}
+// F = (Q - Q^dag)/8 with Q = P + A + B + C, scattered into the four colour blocks (same table as clover_from_gauge_kernel)
+__global__ void cl_accum_kernel(MatField b1_0, MatField b1_1, MatField b2_0, MatField b2_1, MatField P, MatField A, MatField B, MatField C, int fi, double coeff,
+                                int first, int Vh) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= 2 * Vh) return;
+  const int par = gid >= Vh, idx = gid - par * Vh;
+  M3 Q, m, b1[2], b2[2];
+  mf_load(Q, P, par, idx);
+  mf_load(m, A, par, idx);
+#pragma unroll
+  for (int k = 0; k < 9; k++) { Q.re[k] += m.re[k]; Q.im[k] += m.im[k]; }
+  mf_load(m, B, par, idx);
+#pragma unroll
+  for (int k = 0; k < 9; k++) { Q.re[k] += m.re[k]; Q.im[k] += m.im[k]; }
+  mf_load(m, C, par, idx);
+#pragma unroll
+  for (int k = 0; k < 9; k++) { Q.re[k] += m.re[k]; Q.im[k] += m.im[k]; }
+  if (first) {
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int k = 0; k < 9; k++) { b1[c].re[k] = b1[c].im[k] = b2[c].re[k] = b2[c].im[k] = 0; }
+  } else {
+    mf_load(b1[0], b1_0, par, idx); mf_load(b1[1], b1_1, par, idx); mf_load(b2[0], b2_0, par, idx); mf_load(b2[1], b2_1, par, idx);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const double fr = 0.125 * (Q.re[i * 3 + j] - Q.re[j * 3 + i]), fm = 0.125 * (Q.im[i * 3 + j] + Q.im[j * 3 + i]);
+      const int k = i * 3 + j;
+      switch (fi) {
+        case 0: b1[0].re[k] += -coeff * fm; b1[0].im[k] += coeff * fr; b1[1].re[k] += -coeff * fm; b1[1].im[k] += coeff * fr; break;
+        case 5: b1[0].re[k] -= -coeff * fm; b1[0].im[k] -= coeff * fr; b1[1].re[k] += -coeff * fm; b1[1].im[k] += coeff * fr; break;
+        case 1: b2[0].re[k] += coeff * fr; b2[0].im[k] += coeff * fm; b2[1].re[k] += coeff * fr; b2[1].im[k] += coeff * fm; break;
+        case 4: b2[0].re[k] += coeff * fr; b2[0].im[k] += coeff * fm; b2[1].re[k] -= coeff * fr; b2[1].im[k] -= coeff * fm; break;
+        case 2: b2[0].re[k] += coeff * fm; b2[0].im[k] -= coeff * fr; b2[1].re[k] += coeff * fm; b2[1].im[k] -= coeff * fr; break;
+        default: b2[0].re[k] -= coeff * fm; b2[0].im[k] += coeff * fr; b2[1].re[k] += coeff * fm; b2[1].im[k] -= coeff * fr; break;
+      }
+    }
+  mf_store(b1[0], b1_0, par, idx); mf_store(b1[1], b1_1, par, idx); mf_store(b2[0], b2_0, par, idx); mf_store(b2[1], b2_1, par, idx);
+}
+__global__ void cl_pack_kernel(double *packed, MatField b1_0, MatField b1_1, MatField b2_0, MatField b2_1, int Vh) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= 2 * Vh) return;
+  const int par = gid >= Vh, idx = gid - par * Vh;
+  for (int ch = 0; ch < 2; ch++) {
+    M3 b1, b2;
+    mf_load(b1, ch ? b1_1 : b1_0, par, idx);
+    mf_load(b2, ch ? b2_1 : b2_0, par, idx);
+    double *A = packed + (((size_t)par * Vh + idx) * 2 + ch) * 36;
+    for (int i = 0; i < 3; i++) { A[i] = 1.0 - b1.re[i * 3 + i]; A[i + 3] = 1.0 + b1.re[i * 3 + i]; }
+    int k = 0;
+    for (int col = 0; col < 6; col++)
+      for (int row = col + 1; row < 6; row++, k++) {
+        const int rs = row / 3, rc = row % 3, cs = col / 3, cc = col % 3;
+        double re, im;
+        if (rs == 0) { re = -b1.re[rc * 3 + cc]; im = -b1.im[rc * 3 + cc]; }
+        else if (cs == 1) { re = b1.re[rc * 3 + cc]; im = b1.im[rc * 3 + cc]; }
+        else { re = b2.re[rc * 3 + cc]; im = b2.im[rc * 3 + cc]; }
+        A[6 + 2 * k] = re; A[6 + 2 * k + 1] = im;
+      }
+  }
+}
+
+void applyShift(double *out, const double *in, const LatticeGeom &g, int stride, int parity, int dir);  // dslash.hip
+
+template <typename T, int R> static void cloverFromGaugeDecomposed(double *stage, const GaugeField &U, const GaugeView &g, double coeff) {
+  const LatticeGeom &geom = U.geom;
+  const int Vh = geom.Vh, bs = 128, nb = (2 * Vh + bs - 1) / bs;
+  const size_t fieldDoubles = (size_t)2 * 24 * Vh;
+  double *pool = nullptr;
+  HIP_CHECK(hipMalloc((void **)&pool, 9 * fieldDoubles * sizeof(double)));
+  MatField W[5], b1[2], b2[2];
+  for (int i = 0; i < 5; i++) W[i] = {pool + i * fieldDoubles, Vh};
+  b1[0] = {pool + 5 * fieldDoubles, Vh}; b1[1] = {pool + 6 * fieldDoubles, Vh};
+  b2[0] = {pool + 7 * fieldDoubles, Vh}; b2[1] = {pool + 8 * fieldDoubles, Vh};
+  hipStream_t s = computeStream();
+  auto shift = [&](MatField out, MatField in, int dir) {   // out(x) = in(x + dhat(dir)), both parities
+    for (int par = 0; par < 2; par++) applyShift(out.par(par), in.par(1 - par), geom, Vh, par, dir);
+  };
+  bool first = true;
+  for (int mu = 1; mu < 4; mu++)
+    for (int nu = 0; nu < mu; nu++) {
+      hipLaunchKernelGGL((cl_extract_kernel<T, R>), dim3(nb), dim3(bs), 0, s, W[0], g, nu, Vh);
+      hipLaunchKernelGGL((cl_extract_kernel<T, R>), dim3(nb), dim3(bs), 0, s, W[1], g, mu, Vh);
+      shift(W[2], W[0], 2 * mu);   // U_nu(x + mu)
+      shift(W[3], W[1], 2 * nu);   // U_mu(x + nu)
+      hipLaunchKernelGGL((cl_plaq_kernel<T, R>), dim3(nb), dim3(bs), 0, s, W[4], W[2], W[3], g, mu, nu, Vh);            // P
+      shift(W[0], W[4], 2 * mu + 1);
+      hipLaunchKernelGGL((cl_transport_kernel<T, R>), dim3(nb), dim3(bs), 0, s, W[1], W[0], g, mu, Vh);                  // A = T_mu P
+      shift(W[0], W[4], 2 * nu + 1);
+      hipLaunchKernelGGL((cl_transport_kernel<T, R>), dim3(nb), dim3(bs), 0, s, W[2], W[0], g, nu, Vh);                  // B = T_nu P
+      shift(W[0], W[1], 2 * nu + 1);
+      hipLaunchKernelGGL((cl_transport_kernel<T, R>), dim3(nb), dim3(bs), 0, s, W[3], W[0], g, nu, Vh);                  // C = T_nu T_mu P
+      hipLaunchKernelGGL(cl_accum_kernel, dim3(nb), dim3(bs), 0, s, b1[0], b1[1], b2[0], b2[1], W[4], W[1], W[2], W[3], mu * (mu - 1) / 2 + nu, coeff,
+                         first ? 1 : 0, Vh);
+      HIP_CHECK(hipGetLastError());
+      first = false;
+    }
+  hipLaunchKernelGGL(cl_pack_kernel, dim3(nb), dim3(bs), 0, s, stage, b1[0], b1[1], b2[0], b2[1], Vh);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(s));
+  HIP_CHECK(hipFree(pool));
+}
+
 void CloverField::computeFromGauge(const GaugeField &U, double coeff) {
   if (!(U.geom == geom)) errorQuda("gauge and clover geometry differ");
-  for (int d = 0; d < 4; d++)
-    if (commGrid().partitioned(d)) errorQuda("device clover construction on a grid-decomposed lattice needs the extended gauge halo (not built): upload the clover field instead");
   if (U.anisotropy != 1.0) errorQuda("cannot compute anisotropic clover field");
+  bool decomposed = false;
+  for (int d = 0; d < 4; d++) decomposed = decomposed || commGrid().partitioned(d);
+  { const char *e = getenv("QUDA_AMD_CLOVER_TRANSPORT"); if (e && atoi(e)) decomposed = true; }  // force the transport formulation (tests)
   const size_t n = (size_t)geom.V * 72 * sizeof(double);
   double *stage = (double *)stagingBuffer(n);
   GaugeView g;
   g.data = (const char *)U.data; g.link_bytes = U.link_bytes; g.stride = U.stride;
   for (int d = 0; d < 4; d++) g.X[d] = geom.X[d];
-  g.tsign = U.t_boundary == QUDA_ANTI_PERIODIC_T ? -1 : 1;
+  // anti-periodic sign of the reconstructed third row (recon-12): on the last / first rank in t only
+  const bool first_t = commGrid().coords[3] == 0, last_t = commGrid().coords[3] == commGrid().dims[3] - 1;
+  g.tsign = (U.t_boundary == QUDA_ANTI_PERIODIC_T && last_t) ? -1 : 1;
+  g.tsign_bwd = (U.t_boundary == QUDA_ANTI_PERIODIC_T && first_t) ? -1 : 1;
   const int bs = 128, nb = (2 * geom.Vh + bs - 1) / bs;
   const bool r12 = U.reconstruct == QUDA_RECONSTRUCT_12;
+  if (decomposed) {
+#define QA_CD(T) { if (r12) cloverFromGaugeDecomposed<T, 12>(stage, U, g, coeff); else cloverFromGaugeDecomposed<T, 18>(stage, U, g, coeff); }
+    switch (U.precision) {
+      case QUDA_DOUBLE_PRECISION: QA_CD(double) break;
+      case QUDA_SINGLE_PRECISION: QA_CD(float) break;
+      case QUDA_HALF_PRECISION: QA_CD(short) break;
+      default: errorQuda("bad gauge precision %d", U.precision);
+    }
+#undef QA_CD
+  } else {
 #define QA_CG(T) \
   if (r12) hipLaunchKernelGGL((clover_from_gauge_kernel<T, 12>), dim3(nb), dim3(bs), 0, computeStream(), stage, g, coeff, geom.Vh); \
   else hipLaunchKernelGGL((clover_from_gauge_kernel<T, 18>), dim3(nb), dim3(bs), 0, computeStream(), stage, g, coeff, geom.Vh);
@@ -777,6 +965,7 @@ void CloverField::computeFromGauge(const GaugeField &U, double coeff) {
     default: errorQuda("bad gauge precision %d", U.precision);
   }
 #undef QA_CG
+  }
   HIP_CHECK(hipGetLastError());
   const int bl = 256, nl = (2 * geom.Vh + bl - 1) / bl;
 #define QA_CL2(TD) hipLaunchKernelGGL((clover_load_kernel<TD, double>), dim3(nl), dim3(bl), 0, computeStream(), (char *)clover, norm, parity_bytes, stride, (const double *)stage, geom.Vh)

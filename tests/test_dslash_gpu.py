@@ -263,3 +263,28 @@ def test_device_clover_construction(qa, oracle, prec, recon, tol):
     want = oracle.tmc_matpc(gauge, spinor[nh:].copy(), want_clover, oracle.clover_twisted_inverse(want_clover, 4 * kappa * kappa * mu * mu), X, kappa, mu, -1, "oo", 1)
     assert qc.rel_err(got, want) < tol * 100
     qa.lib().freeCloverQuda()
+
+
+@pytest.mark.parametrize("mask", [0, 15, 6], ids=["forced", "self-neighbour-xyzt", "self-neighbour-yz"])
+@pytest.mark.parametrize("prec,recon,tol", [(8, 18, 1e-11), (8, 12, 1e-11), (4, 18, 2e-5)])
+def test_device_clover_construction_by_transport(qa, oracle, mask, prec, recon, tol):
+    """The grid-decomposed formulation of the clover construction (plaquette field built from forward-shifted links, the
+    other three leaves obtained by transporting it with ghost-aware shifts) must reproduce the oracle — unpartitioned
+    (forced with QUDA_AMD_CLOVER_TRANSPORT) and with self-neighbour partitioning, where every shift crosses a 'rank' boundary."""
+    X, kappa, mu, coeff = [8, 4, 6, 8], 0.12, 0.3, 0.17
+    gauge, _, _ = oracle.make_fields(X, seed=78, antiperiodic_t=True, clover=False)
+    want = oracle.clover_compute(gauge, coeff, X)
+    os.environ["QUDA_AMD_CLOVER_TRANSPORT"] = "1"
+    try:
+        qa.lib().qudaAmdSetPartitionMask(mask)
+        qa.load_gauge(gauge, qa.gauge_param(X, cuda_prec=prec, recon=recon))
+        ip = qa.invert_param(qa.QUDA_TWISTED_CLOVER_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=prec, solution_type=qa.QUDA_MAT_SOLUTION)
+        ip.clover_coeff = coeff
+        ip.compute_clover, ip.return_clover = 1, 1
+        got = np.zeros_like(want)
+        qa.load_clover(got, None, ip)
+        assert np.max(np.abs(got - want)) < tol * 10
+    finally:
+        del os.environ["QUDA_AMD_CLOVER_TRANSPORT"]
+        qa.lib().qudaAmdSetPartitionMask(0)
+        qa.lib().freeCloverQuda()

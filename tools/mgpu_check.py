@@ -74,6 +74,18 @@ def main():
             want_g = oracle.tmc_matpc(gauge, spinor[nh_g:].copy(), clover, cinv, X, kappa, mu, +1, "oo", 1)
             err = np.max(np.abs(got - local_part(want_g, 1))) / np.max(np.abs(want_g))
             assert err < 4 * tol, ("tmc_matpc", X, grid, prec, err)
+        # clover term built on the device from the decomposed links (transport formulation) against the oracle's global field
+        coeff = 0.17
+        c_built = mg.scatter_field(oracle.clover_compute(gauge, coeff, X), X, grid, dist.coords, 72)
+        for prec, tol in ((8, 1e-11), (4, 2e-5)):
+            qa.load_gauge(g_loc, qa.gauge_param(Xl, cuda_prec=prec))
+            ipb = qa.invert_param(qa.QUDA_TWISTED_CLOVER_DSLASH, kappa, mu, cuda_prec=prec)
+            ipb.clover_coeff = coeff
+            ipb.compute_clover, ipb.return_clover = 1, 1
+            got_c = np.zeros_like(c_built)
+            qa.load_clover(got_c, None, ipb)
+            errc = float(np.max(np.abs(got_c - c_built)))
+            assert errc < 10 * tol, ("device clover", X, grid, prec, errc)
         # a mixed-precision even-odd GCR solve across ranks (halo + global reductions), residual checked with MatQuda
         qa.load_gauge(g_loc, qa.gauge_param(Xl, cuda_prec=8, prec_sloppy=4))
         ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, 0.05, +1, "ee", 0, cuda_prec=8, prec_sloppy=4, solution_type=qa.QUDA_MAT_SOLUTION)
