@@ -55,7 +55,7 @@ def run_mg(qa, X=(16, 16, 16, 16)):
     qa.invert(b, ip)
     t0 = time.perf_counter()
     qa.invert(b, ip)
-    plain = dict(iters=ip.iter, secs=round(time.perf_counter() - t0, 4))
+    plain = dict(iters=ip.iter, secs=round(time.perf_counter() - t0, 4), solver_secs=round(ip.secs, 4))
     mp = qa.multigrid_param(ip, n_level=3, geo_block=[(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)], n_vec=24, setup_maxiter=500, setup_tol=5e-6,
                             smoother_pc=True)
     mg = qa.Multigrid(mp)
@@ -67,8 +67,10 @@ def run_mg(qa, X=(16, 16, 16, 16)):
     x = qa.invert(b, ip)
     solve = time.perf_counter() - t0
     res = float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b))
+    # solve_secs: wall clock of invertQuda (host source in, host solution out, as SURVEY 8d defines it: includes the two
+    # 200 MB PCIe transfers and the operator / field set-up); solver_secs: the GCR loop alone (QudaInvertParam.secs)
     out = dict(lattice="x".join(map(str, X)), kappa=kappa, mu=mu, levels=3, n_vec=24, setup_secs=round(mp.secs, 3), solve_secs=round(solve, 4),
-               iters=ip.iter, true_res=res, plain_gcr=plain)
+               solver_secs=round(ip.secs, 4), iters=ip.iter, true_res=res, plain_gcr=plain)
     # the QKXTM production shape: the same hierarchy under an outer GCR on the even-odd preconditioned system
     # (solve_type = QUDA_DIRECT_PC_SOLVE, reference lib/interface_quda.cpp:6041), full-field solution via prepare / reconstruct
     ip.solve_type = qa.QUDA_DIRECT_PC_SOLVE
@@ -77,7 +79,17 @@ def run_mg(qa, X=(16, 16, 16, 16)):
     x = qa.invert(b, ip)
     solve_pc = time.perf_counter() - t0
     ip.solve_type = qa.QUDA_DIRECT_SOLVE
-    out["outer_even_odd"] = dict(solve_secs=round(solve_pc, 4), iters=ip.iter, true_res=float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b)))
+    oeo = dict(solve_secs=round(solve_pc, 4), solver_secs=round(ip.secs, 4), iters=ip.iter, true_res=float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b)))
+    out["outer_even_odd"] = oeo
+    # opt-in fp16 storage of V and the coarse links in the cycle (not in the reference; the outer solve is unchanged)
+    mg.set_half_storage(True)
+    qa.invert(b, ip)
+    t0 = time.perf_counter()
+    x = qa.invert(b, ip)
+    solve_h = time.perf_counter() - t0
+    out["fp16_coarse_storage"] = dict(solve_secs=round(solve_h, 4), solver_secs=round(ip.secs, 4), iters=ip.iter,
+                                      true_res=float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b)))
+    mg.set_half_storage(False)
     mg.free()
     return out
 

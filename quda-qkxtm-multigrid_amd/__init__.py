@@ -117,7 +117,7 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
                  "qudaAmdSetPartitionMask", "qudaAmdComputeStream", "qudaAmdDeviceSynchronize", "qudaAmdHaloTransport", "qudaAmdCommGetUniqueId",
                  "qudaAmdCommInit", "qudaAmdCommRank", "qudaAmdCommSize", "qudaAmdCommCoords", "qudaAmdCommBarrier", "qudaAmdCommAllreduce", "qudaAmdCommAllreduceMax",
                  "qudaAmdMultigridVerify", "qudaAmdMultigridCycle", "qudaAmdTimeAxpy", "qudaAmdMultigridLevels", "qudaAmdMultigridLevelInfo",
-                 "qudaAmdMultigridGetNullVector", "qudaAmdMultigridGetV", "qudaAmdMultigridGetCoarseLinks", "qudaAmdMultigridApply"]
+                 "qudaAmdMultigridSetHalfStorage", "qudaAmdMultigridGetNullVector", "qudaAmdMultigridGetV", "qudaAmdMultigridGetCoarseLinks", "qudaAmdMultigridApply"]
 
 _lib = None
 
@@ -179,6 +179,7 @@ def lib():
         L.qudaAmdMultigridCycle.argtypes = [_p, _p, _p, C.POINTER(QudaInvertParam)]
         L.qudaAmdTimeAxpy.argtypes = [_d, _p, _p, _i]
         L.qudaAmdTimeAxpy.restype = _d
+        L.qudaAmdMultigridSetHalfStorage.argtypes = [_p, _i]
         L.qudaAmdMultigridLevels.argtypes = [_p]
         L.qudaAmdMultigridLevelInfo.argtypes = [_p, _i, C.POINTER(_i)]
         L.qudaAmdMultigridGetNullVector.argtypes = [_p, _i, _i, _p]
@@ -411,6 +412,9 @@ class Multigrid:
         x = np.zeros_like(h_b)
         lib().qudaAmdMultigridCycle(self.h, _vp(x), _vp(h_b), C.byref(ip))
         return x
+
+    def set_half_storage(self, on=True):
+        lib().qudaAmdMultigridSetHalfStorage(self.h, int(bool(on)))
 
     # ---- introspection (include/quda_amd_ext.h): reference CPU orders, fp32 complex ----
     def levels(self):

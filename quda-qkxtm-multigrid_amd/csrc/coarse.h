@@ -25,6 +25,11 @@ struct CoarseGauge {
   int nSites;      // full coarse volume
   int n;           // 2 * Ncolor
   float *data;     // [site][9][n/2][n] float4
+  // optional fp16 mirror (same index structure, 8 bytes per column pair) the apply kernel streams instead of `data` when the
+  // hierarchy runs with half-precision storage (QUDA_AMD_MG_HALF=1 / qudaAmdMultigridSetHalfStorage): the operator is
+  // HBM-bound on exactly these bytes; construction, inversion and introspection stay fp32
+  mutable void *data_h;
+  void makeHalf() const;
   size_t bytes;
   CoarseGauge(const int Xc[4], int n);
   ~CoarseGauge();

@@ -11,14 +11,35 @@
 
 namespace quda {
 
-CoarseGauge::CoarseGauge(const int xc[4], int n_) : n(n_), data(nullptr) {
+CoarseGauge::CoarseGauge(const int xc[4], int n_) : n(n_), data(nullptr), data_h(nullptr) {
   nSites = 1;
   for (int d = 0; d < 4; d++) { Xc[d] = xc[d]; nSites *= xc[d]; }
   bytes = (size_t)nSites * 9 * n * n * 2 * sizeof(float);
   HIP_CHECK(hipMalloc((void **)&data, bytes));
   HIP_CHECK(hipMemsetAsync(data, 0, bytes, computeStream()));
 }
-CoarseGauge::~CoarseGauge() { if (data) (void)hipFree(data); }
+CoarseGauge::~CoarseGauge() { if (data) (void)hipFree(data); if (data_h) (void)hipFree(data_h); }
+
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+__global__ void to_half_kernel(half4_t *out, const float4 *in, size_t n) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 v = in[i];
+  half4_t h;
+  h.x = (_Float16)v.x; h.y = (_Float16)v.y; h.z = (_Float16)v.z; h.w = (_Float16)v.w;
+  out[i] = h;
+}
+void CoarseGauge::makeHalf() const {
+  if (data_h) return;
+  const size_t n4 = bytes / sizeof(float4);
+  HIP_CHECK(hipMalloc(&data_h, n4 * sizeof(half4_t)));
+  hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, computeStream(), (half4_t *)data_h, (const float4 *)data, n4);
+  HIP_CHECK(hipGetLastError());
+}
+
+static bool g_mgHalf = false;
+void setCoarseHalfStorage(bool on) { g_mgHalf = on; }
+bool coarseHalfStorage() { return g_mgHalf; }
 
 struct CVec { float *v[2]; int stride, Vh; };
 
@@ -30,7 +51,7 @@ static CVec cvecFull(ColorSpinorField &f) {
 
 struct CoarseArg {
   CVec out, in;
-  const float4 *G;
+  const void *G;     // float4 (fp32) or half4 (fp16 mirror) per (row, column pair)
   int Xc[4];
   int n, mmask, parity, nwork;
   // grid-decomposed lattice: ghost[m] = the neighbour rank's face needed by hop m (full coarse spinors, both or one
@@ -40,7 +61,7 @@ struct CoarseArg {
   int commMask, ghostSingle;
 };
 
-template <int NMAX>
+template <int NMAX, bool HALF>
 __global__ void __launch_bounds__(256) coarse_apply_kernel(const CoarseArg arg) {
   __shared__ float2 xin[9][NMAX];
   __shared__ float2 part[4][NMAX];
@@ -93,9 +114,15 @@ __global__ void __launch_bounds__(256) coarse_apply_kernel(const CoarseArg arg) 
   if (lane < n) {
     for (int m = wave; m < 9; m += 4) {
       if (!((arg.mmask >> m) & 1)) continue;
-      const float4 *M = arg.G + ((size_t)A * 9 + m) * (n / 2) * n + lane;
+      const size_t mbase = ((size_t)A * 9 + m) * (n / 2) * n + lane;
       for (int jp = 0; jp < n / 2; jp++) {
-        const float4 w = M[(size_t)jp * n];
+        float4 w;
+        if (HALF) {
+          const half4_t h = reinterpret_cast<const half4_t *>(arg.G)[mbase + (size_t)jp * n];
+          w = make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+        } else {
+          w = reinterpret_cast<const float4 *>(arg.G)[mbase + (size_t)jp * n];
+        }
         const float2 a = xin[m][2 * jp], b = xin[m][2 * jp + 1];
         re += w.x * a.x - w.y * a.y + w.z * b.x - w.w * b.y;
         im += w.x * a.y + w.y * a.x + w.z * b.y + w.w * b.x;
@@ -223,11 +250,13 @@ void applyCoarse(ColorSpinorField &out, const ColorSpinorField &in, const Coarse
     if (!local_only && (mmask & (1 << 8))) errorQuda("hop + local on parity fields needs both parities of the input");
     arg.nwork = G.nSites / 2;
   }
-  arg.G = (const float4 *)G.data;
+  const bool half = g_mgHalf && G.data_h != nullptr;
+  arg.G = half ? (const void *)G.data_h : (const void *)G.data;
   for (int d = 0; d < 4; d++) arg.Xc[d] = G.Xc[d];
   arg.n = G.n; arg.mmask = mmask; arg.parity = parity;
   exchangeCoarseGhost(arg, G, parity < 0 ? -1 : 1 - parity);
-  hipLaunchKernelGGL((coarse_apply_kernel<64>), dim3(arg.nwork), dim3(256), 0, computeStream(), arg);
+  if (half) hipLaunchKernelGGL((coarse_apply_kernel<64, true>), dim3(arg.nwork), dim3(256), 0, computeStream(), arg);
+  else hipLaunchKernelGGL((coarse_apply_kernel<64, false>), dim3(arg.nwork), dim3(256), 0, computeStream(), arg);
   HIP_CHECK(hipGetLastError());
 }
 

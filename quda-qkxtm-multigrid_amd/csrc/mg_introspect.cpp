@@ -37,6 +37,8 @@ static ColorSpinorField hostView(const ColorSpinorField &dev, void *ptr) {
 
 extern "C" {
 
+void qudaAmdMultigridSetHalfStorage(void *mg_instance, int on) { multigridSetHalfStorage(*static_cast<multigrid_solver *>(mg_instance), on != 0); }
+
 int qudaAmdMultigridLevels(void *mg_instance) {
   int n = 0;
   for (MG *m = static_cast<multigrid_solver *>(mg_instance)->mg; m; m = m->getCoarse()) n++;

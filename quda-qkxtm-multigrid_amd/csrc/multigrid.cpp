@@ -42,6 +42,8 @@ static int mgProfiling() {
   if (on < 0) { const char *e = getenv("QUDA_AMD_MG_PROFILE"); on = e ? atoi(e) : 0; }
   return on;
 }
+void multigridSetHalfStorage(multigrid_solver &mgs, bool on);
+
 static ColorSpinorField *likeField(const ColorSpinorField &x) {
   ColorSpinorParam p = x.param();
   p.create = QUDA_ZERO_FIELD_CREATE;
@@ -429,6 +431,13 @@ void MG::operator()(ColorSpinorField &x, ColorSpinorField &b) {
   blas::setGlobalReduction(true);
 }
 
+void MG::makeHalfMirrors() {
+  if (transfer) transfer->makeHalf();
+  if (diracCoarse) diracCoarse->Links().makeHalf();
+  if (diracCoarseSmoother) diracCoarseSmoother->HatLinks().makeHalf();
+  if (coarse) coarse->makeHalfMirrors();
+}
+
 void MG::verify(double dev[3]) {
   dev[0] = dev[1] = dev[2] = 0.0;
   if (mgp.level >= mgp.Nlevel - 1) return;
@@ -516,9 +525,18 @@ multigrid_solver::multigrid_solver(QudaMultigridParam &mg_param) : d(nullptr), m
   mgParam = new MGParam(mg_param, B, *m, mSmooth ? *mSmooth : *m, 0, param->twist_flavor);
   mg = new MG(*mgParam);
   if (mg_param.run_verify == QUDA_BOOLEAN_YES) { double dev[3]; mg->verify(dev); }
+  { const char *e = getenv("QUDA_AMD_MG_HALF"); if (e && atoi(e)) multigridSetHalfStorage(*this, true); }
   mg_param.secs = now() - t0;
   mg_param_copy = mg_param;
   inv_param_copy = *param;
+}
+
+void multigridSetHalfStorage(multigrid_solver &mgs, bool on) {
+  if (on) {
+    mgs.mg->makeHalfMirrors();
+    HIP_CHECK(hipStreamSynchronize(computeStream()));
+  }
+  setCoarseHalfStorage(on);
 }
 
 multigrid_solver::~multigrid_solver() {

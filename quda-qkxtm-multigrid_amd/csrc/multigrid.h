@@ -69,6 +69,8 @@ class MG : public Solver {
   const Transfer *getTransfer() const { return transfer; }
   const DiracCoarse *getCoarseDirac() const { return diracCoarse; }
   MG *getCoarse() const { return coarse; }
+  // fp16 mirrors of V and of the coarse links (plain and preconditioned) on every level below this one
+  void makeHalfMirrors();
   const std::vector<ColorSpinorField *> &nullVectors() const { return mgp.B; }
   DiracMatrix &residualMatrix() const { return mgp.matResidual; }
 };
@@ -87,5 +89,10 @@ struct multigrid_solver {
   explicit multigrid_solver(QudaMultigridParam &mg_param);
   ~multigrid_solver();
 };
+
+// R, P and the coarse operators of every level stream fp16 mirrors of V and of the coarse links instead of the fp32 masters
+// (those kernels are HBM-bound on exactly these bytes); setup, verify and introspection keep using fp32.  Not in the
+// reference (its MG is fp32 throughout): opt-in, QUDA_AMD_MG_HALF=1 or qudaAmdMultigridSetHalfStorage.
+void multigridSetHalfStorage(multigrid_solver &mgs, bool on);
 
 }  // namespace quda

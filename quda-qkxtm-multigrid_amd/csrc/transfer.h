@@ -25,6 +25,8 @@ class Transfer {
   int nAgg;                    // aggregates = coarse volume
   long fineVol;
   float *V;                    // device, aggregate-major (see above)
+  mutable void *V_h;           // optional fp16 mirror of V streamed by R and P in the solve phase (coarse.h setCoarseHalfStorage)
+  void makeHalf() const;
   int *block_to_fine;          // [A*blockVol + b] -> fine full index (parity*Vh + x_cb)
   int *fine_to_block;          // inverse
   mutable unsigned long long flops_;
@@ -60,5 +62,9 @@ class Transfer {
 // uniform(0,1) random spinor from a counter-based generator keyed by (seed, global site, component): the same field for
 // any process grid (reference uses a private rand48 clone, lib/color_spinor_util.cu:12-22)
 void spinorRandom(ColorSpinorField &f, unsigned long long seed);
+
+// half-precision storage switch of the hierarchy (coarse.hip): R, P and the coarse operators stream fp16 mirrors of V / Y when set
+void setCoarseHalfStorage(bool on);
+bool coarseHalfStorage();
 
 }  // namespace quda

@@ -84,8 +84,17 @@ __device__ __forceinline__ bool mask_outside(const MaskArg &m, int b) {
   return !m.single[mu] && (fwd ? y[mu] == m.bs[mu] - 1 : y[mu] == 0);
 }
 
-template <int NSF, int NCF, int NVEC, int NV, bool DUAL>
-__global__ void restrict_kernel(CoarseVec out, CoarseVec out2, FineVec in, const float4 *V, const int *block_to_fine, int blockVol, int spin_bs, MaskArg mask) {
+typedef _Float16 vhalf4_t __attribute__((ext_vector_type(4)));
+template <bool HALF> __device__ __forceinline__ float4 load_v(const void *V, size_t i) {
+  if (HALF) {
+    const vhalf4_t h = reinterpret_cast<const vhalf4_t *>(V)[i];
+    return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w);
+  }
+  return reinterpret_cast<const float4 *>(V)[i];
+}
+
+template <int NSF, int NCF, int NVEC, int NV, bool DUAL, bool HALF = false>
+__global__ void restrict_kernel(CoarseVec out, CoarseVec out2, FineVec in, const void *V, const int *block_to_fine, int blockVol, int spin_bs, MaskArg mask) {
   constexpr int K = NSF * NCF;
   __shared__ float4 lds[16];
   const int A = blockIdx.x, b = threadIdx.x;
@@ -112,7 +121,7 @@ __global__ void restrict_kernel(CoarseVec out, CoarseVec out2, FineVec in, const
 #pragma unroll
         for (int k = 0; k < K; k++) {
           if ((k / NCF) / spin_bs != chi) continue;
-          const float4 w = V[(((size_t)A * K + k) * (NVEC / 2) + vp) * blockVol + b];
+          const float4 w = load_v<HALF>(V, (((size_t)A * K + k) * (NVEC / 2) + vp) * blockVol + b);
           // conj(V) * r
           acc.x += w.x * r[k].x + w.y * r[k].y; acc.y += w.x * r[k].y - w.y * r[k].x;
           acc.z += w.z * r[k].x + w.w * r[k].y; acc.w += w.z * r[k].y - w.w * r[k].x;
@@ -141,8 +150,8 @@ __global__ void restrict_kernel(CoarseVec out, CoarseVec out2, FineVec in, const
 }
 
 // ---- prolongator ----
-template <int NSF, int NCF, int NVEC, int NV>
-__global__ void prolong_kernel(FineVec out, CoarseVec in, const float4 *V, const int *block_to_fine, int blockVol, int spin_bs) {
+template <int NSF, int NCF, int NVEC, int NV, bool HALF = false>
+__global__ void prolong_kernel(FineVec out, CoarseVec in, const void *V, const int *block_to_fine, int blockVol, int spin_bs) {
   constexpr int K = NSF * NCF;
   __shared__ float2 xc_s[2 * NVEC];
   const int A = blockIdx.x, b = threadIdx.x;
@@ -162,7 +171,7 @@ __global__ void prolong_kernel(FineVec out, CoarseVec in, const float4 *V, const
     const int chi = (k / NCF) / spin_bs;
     float re = 0.f, im = 0.f;
     for (int vp = 0; vp < NVEC / 2; vp++) {
-      const float4 w = V[(((size_t)A * K + k) * (NVEC / 2) + vp) * blockVol + b];
+      const float4 w = load_v<HALF>(V, (((size_t)A * K + k) * (NVEC / 2) + vp) * blockVol + b);
       const float2 c0 = xc_s[chi * NVEC + 2 * vp], c1 = xc_s[chi * NVEC + 2 * vp + 1];
       re += w.x * c0.x - w.y * c0.y + w.z * c1.x - w.w * c1.y;
       im += w.x * c0.y + w.y * c0.x + w.z * c1.y + w.w * c1.x;
@@ -272,7 +281,7 @@ void spinorRandom(ColorSpinorField &f, unsigned long long seed) {
 
 // ================================================================================================
 Transfer::Transfer(const std::vector<ColorSpinorField *> &B, int Nvec_, int *gbs, int spin_bs_)
-    : Nvec(Nvec_), spin_bs(spin_bs_), V(nullptr), block_to_fine(nullptr), fine_to_block(nullptr), flops_(0),
+    : Nvec(Nvec_), spin_bs(spin_bs_), V(nullptr), V_h(nullptr), block_to_fine(nullptr), fine_to_block(nullptr), flops_(0),
       site_subset(QUDA_FULL_SITE_SUBSET), subset_parity(QUDA_INVALID_PARITY) {
   if ((int)B.size() < Nvec) errorQuda("need %d null vectors, got %zu", Nvec, B.size());
   if (Nvec % 2 || Nvec > kMaxVec) errorQuda("Nvec = %d must be even and <= %d", Nvec, kMaxVec);
@@ -302,7 +311,24 @@ Transfer::Transfer(const std::vector<ColorSpinorField *> &B, int Nvec_, int *gbs
   fillAndOrthonormalise(B);
 }
 
+__global__ void v_to_half_kernel(vhalf4_t *out, const float4 *in, size_t n) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 v = in[i];
+  vhalf4_t h;
+  h.x = (_Float16)v.x; h.y = (_Float16)v.y; h.z = (_Float16)v.z; h.w = (_Float16)v.w;
+  out[i] = h;
+}
+void Transfer::makeHalf() const {
+  if (V_h) return;
+  const size_t n4 = vBytes() / sizeof(float4);
+  HIP_CHECK(hipMalloc(&V_h, n4 * sizeof(vhalf4_t)));
+  hipLaunchKernelGGL(v_to_half_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, computeStream(), (vhalf4_t *)V_h, (const float4 *)V, n4);
+  HIP_CHECK(hipGetLastError());
+}
+
 Transfer::~Transfer() {
+  if (V_h) (void)hipFree(V_h);
   if (V) (void)hipFree(V);
   if (block_to_fine) (void)hipFree(block_to_fine);
   if (fine_to_block) (void)hipFree(fine_to_block);
@@ -411,8 +437,10 @@ void Transfer::R(ColorSpinorField &coarse, const ColorSpinorField &fine, int dir
   m.dir = dir; m.boundary = boundary;
   for (int d = 0; d < 4; d++) { m.bs[d] = geo_bs[d]; m.single[d] = Xc[d] == 1; }
   const int threads = (blockVol + 63) / 64 * 64;
+  const bool half = coarseHalfStorage() && V_h != nullptr && dir < 0;   // the Galerkin-split variants always use the fp32 master
 #define QA_R(NSF, NCF, NVEC, NV) \
-  hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out, in, (const float4 *)V, block_to_fine, blockVol, spin_bs, m)
+  if (half) hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, false, true>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out, in, (const void *)V_h, block_to_fine, blockVol, spin_bs, m); \
+  else hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, false, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out, in, (const void *)V, block_to_fine, blockVol, spin_bs, m)
   QA_TRANSFER_DISPATCH(QA_R)
 #undef QA_R
   HIP_CHECK(hipGetLastError());
@@ -431,7 +459,7 @@ void Transfer::RSplit(ColorSpinorField &leaving, ColorSpinorField &staying, cons
   for (int d = 0; d < 4; d++) { m.bs[d] = geo_bs[d]; m.single[d] = Xc[d] == 1; }
   const int threads = (blockVol + 63) / 64 * 64;
 #define QA_R2(NSF, NCF, NVEC, NV) \
-  hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, true>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out2, in, (const float4 *)V, block_to_fine, blockVol, spin_bs, m)
+  hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, true, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out2, in, (const void *)V, block_to_fine, blockVol, spin_bs, m)
   QA_TRANSFER_DISPATCH(QA_R2)
 #undef QA_R2
   HIP_CHECK(hipGetLastError());
@@ -446,8 +474,10 @@ void Transfer::P(ColorSpinorField &fine, const ColorSpinorField &coarse) const {
   const FineVec out = fineVec(fine, sub ? (int)subset_parity : -1);
   const CoarseVec in = coarseVec(coarse);
   const int threads = (blockVol + 63) / 64 * 64;
+  const bool half = coarseHalfStorage() && V_h != nullptr;
 #define QA_P(NSF, NCF, NVEC, NV) \
-  hipLaunchKernelGGL((prolong_kernel<NSF, NCF, NVEC, NV>), dim3(nAgg), dim3(threads), 0, computeStream(), out, in, (const float4 *)V, block_to_fine, blockVol, spin_bs)
+  if (half) hipLaunchKernelGGL((prolong_kernel<NSF, NCF, NVEC, NV, true>), dim3(nAgg), dim3(threads), 0, computeStream(), out, in, (const void *)V_h, block_to_fine, blockVol, spin_bs); \
+  else hipLaunchKernelGGL((prolong_kernel<NSF, NCF, NVEC, NV, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, in, (const void *)V, block_to_fine, blockVol, spin_bs)
   QA_TRANSFER_DISPATCH(QA_P)
 #undef QA_P
   HIP_CHECK(hipGetLastError());

@@ -238,3 +238,31 @@ def test_null_vector_persistence(qa, tmp_path):
         assert mp2.secs < mp.secs
     finally:
         mg2.free()
+
+
+def test_half_precision_storage_of_the_hierarchy(qa, oracle):
+    """Opt-in fp16 mirrors of V and of the coarse links (qudaAmdMultigridSetHalfStorage): the cycle streams half the bytes, the
+    outer fp64 GCR still reaches 1e-10 with the oracle-verified residual, and switching back restores the fp32 behaviour."""
+    X, kappa, mu = (16, 8, 8, 16), 0.124, 0.005
+    gauge, ip = _setup(qa, X, kappa, mu)
+    b = np.random.default_rng(29).random(int(np.prod(X)) * 24)
+    mp = qa.multigrid_param(ip, n_level=3, geo_block=[(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)], n_vec=8, setup_maxiter=300, setup_tol=1e-5, smoother_pc=True)
+    mg = qa.Multigrid(mp)
+    try:
+        ip.inv_type_precondition, ip.preconditioner = qa.QUDA_MG_INVERTER, mg.h
+        ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
+        x32 = qa.invert(b, ip)
+        it32 = ip.iter
+        mg.set_half_storage(True)
+        x16 = qa.invert(b, ip)
+        it16 = ip.iter
+        assert _true_residual(oracle, gauge, X, kappa, mu, x16, b) < 5e-10
+        assert it16 <= it32 + 2, (it16, it32)
+        mg.set_half_storage(False)
+        x32b = qa.invert(b, ip)
+        assert ip.iter == it32 and np.array_equal(x32b, x32)
+        dev = mg.verify()
+        assert max(dev) < 1e-4
+    finally:
+        mg.set_half_storage(False)
+        mg.free()
