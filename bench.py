@@ -36,7 +36,8 @@ from synth import make_clover, make_gauge, smooth_gauge  # noqa: E402
 def run_mg(qa, X=(16, 16, 16, 16)):
     """MG-preconditioned GCR to |r|/|b| <= 1e-10 (the second half of the metric) on one GPU: 3-level K-cycle, 24 null
     vectors, 4^4 then 2^4 aggregates, even-odd preconditioned MR smoother — the reference harness' default shape
-    (tests/multigrid_invert_test.cpp:224-286) on a 16^4 warm-start gauge field at kappa close to critical.  Setup (null
+    (tests/multigrid_invert_test.cpp:224-286) on a smooth synthetic gauge field (synth.smooth_gauge: far easier than a production
+    configuration — plain GCR needs only 76 iterations — so the MG / plain ratio here understates what MG buys at the physical point).  Setup (null
     vectors + Galerkin operators) and solve are timed separately; the residual is re-computed with MatQuda."""
     kappa, mu = 0.124, 0.005
     qa.lib().freeCloverQuda()
@@ -51,43 +52,47 @@ def run_mg(qa, X=(16, 16, 16, 16)):
     ip.tol = 1e-10
     ip.maxiter = 5000
     b = np.random.default_rng(5).random(int(np.prod(X)) * 24)
+
+    def timed_solve():
+        """best of three after one warm-up: (wall seconds of invertQuda, GCR-loop seconds, iterations, solution).  The first solve
+        through a new path pays one-off lazy initialisation, and single calls on the shared test boxes occasionally stall
+        for 50-100 ms on the host side (seen inside otherwise 0.1 ms stages), hence the minimum."""
+        qa.invert(b, ip)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            x = qa.invert(b, ip)
+            wall = time.perf_counter() - t0
+            if best is None or wall < best[0]:
+                best = (wall, ip.secs, ip.iter, x)
+        return best
+
     ip.inv_type_precondition = qa.QUDA_INVALID_ENUM
-    qa.invert(b, ip)
-    t0 = time.perf_counter()
-    qa.invert(b, ip)
-    plain = dict(iters=ip.iter, secs=round(time.perf_counter() - t0, 4), solver_secs=round(ip.secs, 4))
+    wall, inner, iters, _ = timed_solve()
+    plain = dict(iters=iters, secs=round(wall, 4), solver_secs=round(inner, 4))
     mp = qa.multigrid_param(ip, n_level=3, geo_block=[(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)], n_vec=24, setup_maxiter=500, setup_tol=5e-6,
                             smoother_pc=True)
     mg = qa.Multigrid(mp)
     ip.inv_type_precondition = qa.QUDA_MG_INVERTER
     ip.preconditioner = mg.h
     ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
-    qa.invert(b, ip)   # first solve through a new hierarchy pays one-off lazy initialisation; the timed one is the second
-    t0 = time.perf_counter()
-    x = qa.invert(b, ip)
-    solve = time.perf_counter() - t0
+    wall, inner, iters, x = timed_solve()
     res = float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b))
     # solve_secs: wall clock of invertQuda (host source in, host solution out, as SURVEY 8d defines it: includes the two
-    # 200 MB PCIe transfers and the operator / field set-up); solver_secs: the GCR loop alone (QudaInvertParam.secs)
-    out = dict(lattice="x".join(map(str, X)), kappa=kappa, mu=mu, levels=3, n_vec=24, setup_secs=round(mp.secs, 3), solve_secs=round(solve, 4),
-               solver_secs=round(ip.secs, 4), iters=ip.iter, true_res=res, plain_gcr=plain)
+    # PCIe transfers and the operator / field set-up); solver_secs: the GCR loop alone (QudaInvertParam.secs)
+    out = dict(lattice="x".join(map(str, X)), kappa=kappa, mu=mu, levels=3, n_vec=24, setup_secs=round(mp.secs, 3), solve_secs=round(wall, 4),
+               solver_secs=round(inner, 4), iters=iters, true_res=res, plain_gcr=plain, timing="best of 3 after 1 warm-up solve")
     # the QKXTM production shape: the same hierarchy under an outer GCR on the even-odd preconditioned system
     # (solve_type = QUDA_DIRECT_PC_SOLVE, reference lib/interface_quda.cpp:6041), full-field solution via prepare / reconstruct
     ip.solve_type = qa.QUDA_DIRECT_PC_SOLVE
-    qa.invert(b, ip)
-    t0 = time.perf_counter()
-    x = qa.invert(b, ip)
-    solve_pc = time.perf_counter() - t0
+    wall, inner, iters, x = timed_solve()
     ip.solve_type = qa.QUDA_DIRECT_SOLVE
-    oeo = dict(solve_secs=round(solve_pc, 4), solver_secs=round(ip.secs, 4), iters=ip.iter, true_res=float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b)))
-    out["outer_even_odd"] = oeo
+    out["outer_even_odd"] = dict(solve_secs=round(wall, 4), solver_secs=round(inner, 4), iters=iters,
+                                 true_res=float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b)))
     # opt-in fp16 storage of V and the coarse links in the cycle (not in the reference; the outer solve is unchanged)
     mg.set_half_storage(True)
-    qa.invert(b, ip)
-    t0 = time.perf_counter()
-    x = qa.invert(b, ip)
-    solve_h = time.perf_counter() - t0
-    out["fp16_coarse_storage"] = dict(solve_secs=round(solve_h, 4), solver_secs=round(ip.secs, 4), iters=ip.iter,
+    wall, inner, iters, x = timed_solve()
+    out["fp16_coarse_storage"] = dict(solve_secs=round(wall, 4), solver_secs=round(inner, 4), iters=iters,
                                       true_res=float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b)))
     mg.set_half_storage(False)
     mg.free()
@@ -190,7 +195,7 @@ def main():
         sx.free(); sy.free()
 
     if not args.no_extra and rank == 0 and world == 1:
-        extra["mg_gcr"] = run_mg(qa)
+        extra["mg_gcr"] = run_mg(qa, (32, 32, 32, 32))
 
     cpu = None
     if rank == 0 and not args.no_cpu:

@@ -68,8 +68,8 @@ ColorSpinorField::ColorSpinorField(const ColorSpinorParam &p)
   } else {
     owns = true;
     if (location == QUDA_CUDA_FIELD_LOCATION) {
-      HIP_CHECK(hipMalloc(&v_, bytes));
-      if (norm_bytes) HIP_CHECK(hipMalloc(&norm_, norm_bytes));
+      v_ = poolDeviceMalloc(bytes);
+      if (norm_bytes) norm_ = poolDeviceMalloc(norm_bytes);
     } else {
       v_ = malloc(bytes);
       if (!v_) errorQuda("host allocation of %zu bytes failed", bytes);
@@ -96,8 +96,8 @@ ColorSpinorField::~ColorSpinorField() {
   delete odd_;
   if (owns) {
     if (location == QUDA_CUDA_FIELD_LOCATION) {
-      if (v_) (void)hipFree(v_);
-      if (norm_) (void)hipFree(norm_);
+      poolDeviceFree(v_, bytes);
+      poolDeviceFree(norm_, norm_bytes);
     } else {
       free(v_);
     }

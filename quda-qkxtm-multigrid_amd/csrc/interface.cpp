@@ -145,6 +145,7 @@ void endQuda(void) {
   freeGaugeQuda();
   freeCloverQuda();
   freeStagingBuffer();
+  poolDeviceFlush();
   blas::end();
   commFinalize();
   destroyStreams();

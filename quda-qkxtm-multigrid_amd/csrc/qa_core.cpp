@@ -3,6 +3,9 @@
 // lib/comm_common.cpp (topology), include/quda_internal.h:314-319 (streams).
 #include "qa_core.h"
 
+#include <map>
+#include <vector>
+
 #include <cstring>
 
 namespace quda {
@@ -70,5 +73,27 @@ void destroyStreams() {
 }
 hipStream_t computeStream() { return g_compute; }
 hipStream_t commStream() { return g_comm; }
+
+static std::map<size_t, std::vector<void *>> g_pool;
+
+void *poolDeviceMalloc(size_t bytes) {
+  auto it = g_pool.find(bytes);
+  if (it != g_pool.end() && !it->second.empty()) {
+    void *p = it->second.back();
+    it->second.pop_back();
+    return p;
+  }
+  void *p = nullptr;
+  HIP_CHECK(hipMalloc(&p, bytes));
+  return p;
+}
+void poolDeviceFree(void *ptr, size_t bytes) {
+  if (ptr) g_pool[bytes].push_back(ptr);
+}
+void poolDeviceFlush() {
+  for (auto &kv : g_pool)
+    for (void *p : kv.second) (void)hipFree(p);
+  g_pool.clear();
+}
 
 }  // namespace quda

@@ -86,6 +86,15 @@ struct CommGrid {
 };
 CommGrid &commGrid();
 
+// Size-bucketed cache of device allocations for the short-lived work fields (Krylov spaces, solver temporaries, API staging
+// spinors): hipMalloc / hipFree synchronise the device and occasionally stall for ~100 ms when the runtime has to grow or
+// trim its memory pool (measured inside invertQuda); the reference has the same kind of pool (lib/malloc.cpp pool_device_malloc).
+// Blocks return to the cache on free and are handed out again to the next request of the same size — safe because every user
+// works in compute-stream order.  Emptied by endQuda.
+void *poolDeviceMalloc(size_t bytes);
+void poolDeviceFree(void *ptr, size_t bytes);
+void poolDeviceFlush();
+
 hipStream_t computeStream();
 hipStream_t commStream();
 

@@ -2,6 +2,8 @@
 // createDirac / massRescale, :2161-2275 multigrid, :2276-2540 invertQuda).
 #include <cmath>
 
+#include <sys/time.h>
+#include <cstdlib>
 #include "blas.h"
 #include "interface_internal.h"
 #include "multigrid.h"
@@ -49,6 +51,17 @@ void invertQuda(void *hp_x, void *hp_b, QudaInvertParam *param) {
   if (!mat_solution && !pc_solution && pc_solve) errorQuda("Unpreconditioned MATDAG_MAT solution_type requires an unpreconditioned solve_type");
   if (param->inv_type_precondition == QUDA_MG_INVERTER && (!direct_solve || !mat_solution)) errorQuda("Multigrid preconditioning only supported for direct solves");
   param->secs = 0; param->gflops = 0; param->iter = 0;
+  const bool prof = getenv("QUDA_AMD_INVERT_PROFILE") != nullptr;
+  auto stamp = [&](const char *what) {
+    static double last = 0;
+    if (!prof) return;
+    HIP_CHECK(hipDeviceSynchronize());
+    timeval tv; gettimeofday(&tv, nullptr);
+    const double t = tv.tv_sec + 1e-6 * tv.tv_usec;
+    if (what) printfQuda("invertQuda: %-12s %.3f ms\n", what, 1e3 * (t - last));
+    last = t;
+  };
+  stamp(nullptr);
 
   // reference createDirac :1386-1410
   DiracParam dp, dpSloppy, dpPre;
@@ -57,6 +70,7 @@ void invertQuda(void *hp_x, void *hp_b, QudaInvertParam *param) {
   setDiracPreParam(dpPre, param, pc_solve);
   Dirac *d = Dirac::create(dp), *dSloppy = Dirac::create(dpSloppy), *dPre = Dirac::create(dpPre);
   Dirac &dirac = *d;
+  stamp("operators");
 
   const LatticeGeom &geom = residentGeom();
   ColorSpinorParam cpuParam(hp_b, *param, geom.X, pc_solution);
@@ -72,9 +86,11 @@ void invertQuda(void *hp_x, void *hp_b, QudaInvertParam *param) {
   if (nb == 0.0) errorQuda("Source has zero norm");
   if (param->solver_normalization == QUDA_SOURCE_NORMALIZATION) { blas::ax(1.0 / sqrt(nb), *b); blas::ax(1.0 / sqrt(nb), *x); }
   massRescale(*b, *param);
+  stamp("upload");
 
   ColorSpinorField *in = nullptr, *out = nullptr;
   dirac.prepare(in, out, *x, *b, param->solution_type);
+  stamp("prepare");
 
   if (mat_solution && !direct_solve) {  // prepare source: b' = A^dag b
     ColorSpinorField tmp(*in);
@@ -103,11 +119,15 @@ void invertQuda(void *hp_x, void *hp_b, QudaInvertParam *param) {
     sp.updateInvertParam(*param);
     delete solve;
   }
+  stamp("solve");
   dirac.reconstruct(*x, *b, param->solution_type);
   if (param->solver_normalization == QUDA_SOURCE_NORMALIZATION) blas::ax(sqrt(nb), *x);
+  stamp("reconstruct");
   h_x = *x;
+  stamp("download");
   delete b; delete x;
   delete d; delete dSloppy; delete dPre;
+  stamp("free");
 }
 
 void *newMultigridQuda(QudaMultigridParam *mg_param) { return new multigrid_solver(*mg_param); }
