@@ -149,6 +149,101 @@ __global__ void restrict_kernel(CoarseVec out, CoarseVec out2, FineVec in, const
   }
 }
 
+// ---- small aggregates (blockVol <= 32, the coarse levels: 2^4 = 16 sites).  One thread per site leaves most of a wave idle and
+// runs the (chirality, vector pair) iterations one after the other behind block-wide reductions — 0.28 ms for a 37 MB
+// transfer.  Here a wave holds 64 / GS groups of GS lanes (GS = blockVol rounded up to a power of two), every group takes its
+// own (chi, vp) iteration for the whole aggregate and reduces with GS-wide shuffles: no LDS, no barriers, all iterations
+// of an aggregate in flight at once across the 8 waves of its work-group. ----
+template <int NSF, int NCF, int NVEC, int NV, bool DUAL, bool HALF>
+__global__ void __launch_bounds__(512) restrict_small_kernel(CoarseVec out, CoarseVec out2, FineVec in, const void *V, const int *block_to_fine, int blockVol, int GS,
+                                                             int spin_bs, MaskArg mask) {
+  constexpr int K = NSF * NCF, NIT = NVEC;   // iterations = 2 chiralities x NVEC/2 vector pairs
+  const int A = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int groupsPerWave = 64 / GS, b = lane % GS, grp = lane / GS;
+  const int slot = wave * groupsPerWave + grp, nslots = (blockDim.x >> 6) * groupsPerWave;
+  const bool site = b < blockVol;
+  const bool active = site && (DUAL || mask_keep(mask, b));
+  const bool outside = DUAL && site && mask_outside(mask, b);
+  float2 r[K];
+  bool have = false;
+  if (active) {
+    const int f = block_to_fine[(size_t)A * blockVol + b];
+    const int parity = f >= in.Vh, x = f - parity * in.Vh;
+    const float *base = in.v[parity];
+    if (base) {
+      have = true;
+#pragma unroll
+      for (int k = 0; k < K; k++) { const size_t i = fidx<NV>(in.stride, x, k); r[k] = make_float2(base[i], base[i + 1]); }
+    }
+  }
+  const int cpar = A >= out.Vh, xc = A - cpar * out.Vh;
+  float *ob = out.v[cpar], *ob2 = DUAL ? out2.v[cpar] : nullptr;
+  for (int it = slot; it < NIT; it += nslots) {
+    const int chi = it / (NVEC / 2), vp = it - chi * (NVEC / 2);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (have) {
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        if ((k / NCF) / spin_bs != chi) continue;
+        const float4 w = load_v<HALF>(V, (((size_t)A * K + k) * (NVEC / 2) + vp) * blockVol + b);
+        acc.x += w.x * r[k].x + w.y * r[k].y; acc.y += w.x * r[k].y - w.y * r[k].x;
+        acc.z += w.z * r[k].x + w.w * r[k].y; acc.w += w.z * r[k].y - w.w * r[k].x;
+      }
+    }
+    float4 so = acc, si = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (DUAL) { if (!outside) { si = acc; so = make_float4(0.f, 0.f, 0.f, 0.f); } }
+    for (int off = GS >> 1; off > 0; off >>= 1) {
+      so.x += __shfl_down(so.x, off, GS); so.y += __shfl_down(so.y, off, GS); so.z += __shfl_down(so.z, off, GS); so.w += __shfl_down(so.w, off, GS);
+      if (DUAL) { si.x += __shfl_down(si.x, off, GS); si.y += __shfl_down(si.y, off, GS); si.z += __shfl_down(si.z, off, GS); si.w += __shfl_down(si.w, off, GS); }
+    }
+    if (b == 0) {
+      const int c0 = chi * NVEC + 2 * vp;
+      ob[((size_t)c0 * out.stride + xc) * 2] = so.x; ob[((size_t)c0 * out.stride + xc) * 2 + 1] = so.y;
+      ob[((size_t)(c0 + 1) * out.stride + xc) * 2] = so.z; ob[((size_t)(c0 + 1) * out.stride + xc) * 2 + 1] = so.w;
+      if (DUAL) {
+        ob2[((size_t)c0 * out2.stride + xc) * 2] = si.x; ob2[((size_t)c0 * out2.stride + xc) * 2 + 1] = si.y;
+        ob2[((size_t)(c0 + 1) * out2.stride + xc) * 2] = si.z; ob2[((size_t)(c0 + 1) * out2.stride + xc) * 2 + 1] = si.w;
+      }
+    }
+  }
+}
+
+// prolongator for small aggregates: the K fine components of a site are spread over the groups / waves the same way
+template <int NSF, int NCF, int NVEC, int NV, bool HALF>
+__global__ void __launch_bounds__(512) prolong_small_kernel(FineVec out, CoarseVec in, const void *V, const int *block_to_fine, int blockVol, int GS, int spin_bs) {
+  constexpr int K = NSF * NCF;
+  __shared__ float2 xc_s[2 * NVEC];
+  const int A = blockIdx.x;
+  const int cpar = A >= in.Vh, xc = A - cpar * in.Vh;
+  for (int j = threadIdx.x; j < 2 * NVEC; j += blockDim.x) {
+    const float *p = in.v[cpar] + ((size_t)j * in.stride + xc) * 2;
+    xc_s[j] = make_float2(p[0], p[1]);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int groupsPerWave = 64 / GS, b = lane % GS, grp = lane / GS;
+  const int slot = wave * groupsPerWave + grp, nslots = (blockDim.x >> 6) * groupsPerWave;
+  if (b >= blockVol) return;
+  const int f = block_to_fine[(size_t)A * blockVol + b];
+  const int parity = f >= out.Vh, x = f - parity * out.Vh;
+  float *base = out.v[parity];
+  if (!base) return;
+  for (int k = slot; k < K; k += nslots) {
+    const int chi = (k / NCF) / spin_bs;
+    float re = 0.f, im = 0.f;
+#pragma unroll 4
+    for (int vp = 0; vp < NVEC / 2; vp++) {
+      const float4 w = load_v<HALF>(V, (((size_t)A * K + k) * (NVEC / 2) + vp) * blockVol + b);
+      const float2 c0 = xc_s[chi * NVEC + 2 * vp], c1 = xc_s[chi * NVEC + 2 * vp + 1];
+      re += w.x * c0.x - w.y * c0.y + w.z * c1.x - w.w * c1.y;
+      im += w.x * c0.y + w.y * c0.x + w.z * c1.y + w.w * c1.x;
+    }
+    const size_t i = fidx<NV>(out.stride, x, k);
+    base[i] = re; base[i + 1] = im;
+  }
+}
+
 // ---- prolongator ----
 template <int NSF, int NCF, int NVEC, int NV, bool HALF = false>
 __global__ void prolong_kernel(FineVec out, CoarseVec in, const void *V, const int *block_to_fine, int blockVol, int spin_bs) {
@@ -437,9 +532,13 @@ void Transfer::R(ColorSpinorField &coarse, const ColorSpinorField &fine, int dir
   m.dir = dir; m.boundary = boundary;
   for (int d = 0; d < 4; d++) { m.bs[d] = geo_bs[d]; m.single[d] = Xc[d] == 1; }
   const int threads = (blockVol + 63) / 64 * 64;
+  int gs = 1; while (gs < blockVol) gs <<= 1;
+  const bool small = blockVol <= 32;
   const bool half = coarseHalfStorage() && V_h != nullptr && dir < 0;   // the Galerkin-split variants always use the fp32 master
 #define QA_R(NSF, NCF, NVEC, NV) \
-  if (half) hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, false, true>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out, in, (const void *)V_h, block_to_fine, blockVol, spin_bs, m); \
+  if (small && half) hipLaunchKernelGGL((restrict_small_kernel<NSF, NCF, NVEC, NV, false, true>), dim3(nAgg), dim3(512), 0, computeStream(), out, out, in, (const void *)V_h, block_to_fine, blockVol, gs, spin_bs, m); \
+  else if (small) hipLaunchKernelGGL((restrict_small_kernel<NSF, NCF, NVEC, NV, false, false>), dim3(nAgg), dim3(512), 0, computeStream(), out, out, in, (const void *)V, block_to_fine, blockVol, gs, spin_bs, m); \
+  else if (half) hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, false, true>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out, in, (const void *)V_h, block_to_fine, blockVol, spin_bs, m); \
   else hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, false, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out, in, (const void *)V, block_to_fine, blockVol, spin_bs, m)
   QA_TRANSFER_DISPATCH(QA_R)
 #undef QA_R
@@ -458,8 +557,11 @@ void Transfer::RSplit(ColorSpinorField &leaving, ColorSpinorField &staying, cons
   m.dir = dir; m.boundary = 1;
   for (int d = 0; d < 4; d++) { m.bs[d] = geo_bs[d]; m.single[d] = Xc[d] == 1; }
   const int threads = (blockVol + 63) / 64 * 64;
+  int gs = 1; while (gs < blockVol) gs <<= 1;
+  const bool small = blockVol <= 32;
 #define QA_R2(NSF, NCF, NVEC, NV) \
-  hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, true, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out2, in, (const void *)V, block_to_fine, blockVol, spin_bs, m)
+  if (small) hipLaunchKernelGGL((restrict_small_kernel<NSF, NCF, NVEC, NV, true, false>), dim3(nAgg), dim3(512), 0, computeStream(), out, out2, in, (const void *)V, block_to_fine, blockVol, gs, spin_bs, m); \
+  else hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, true, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out2, in, (const void *)V, block_to_fine, blockVol, spin_bs, m)
   QA_TRANSFER_DISPATCH(QA_R2)
 #undef QA_R2
   HIP_CHECK(hipGetLastError());
@@ -474,9 +576,13 @@ void Transfer::P(ColorSpinorField &fine, const ColorSpinorField &coarse) const {
   const FineVec out = fineVec(fine, sub ? (int)subset_parity : -1);
   const CoarseVec in = coarseVec(coarse);
   const int threads = (blockVol + 63) / 64 * 64;
+  int gs = 1; while (gs < blockVol) gs <<= 1;
+  const bool small = blockVol <= 32;
   const bool half = coarseHalfStorage() && V_h != nullptr;
 #define QA_P(NSF, NCF, NVEC, NV) \
-  if (half) hipLaunchKernelGGL((prolong_kernel<NSF, NCF, NVEC, NV, true>), dim3(nAgg), dim3(threads), 0, computeStream(), out, in, (const void *)V_h, block_to_fine, blockVol, spin_bs); \
+  if (small && half) hipLaunchKernelGGL((prolong_small_kernel<NSF, NCF, NVEC, NV, true>), dim3(nAgg), dim3(512), 0, computeStream(), out, in, (const void *)V_h, block_to_fine, blockVol, gs, spin_bs); \
+  else if (small) hipLaunchKernelGGL((prolong_small_kernel<NSF, NCF, NVEC, NV, false>), dim3(nAgg), dim3(512), 0, computeStream(), out, in, (const void *)V, block_to_fine, blockVol, gs, spin_bs); \
+  else if (half) hipLaunchKernelGGL((prolong_kernel<NSF, NCF, NVEC, NV, true>), dim3(nAgg), dim3(threads), 0, computeStream(), out, in, (const void *)V_h, block_to_fine, blockVol, spin_bs); \
   else hipLaunchKernelGGL((prolong_kernel<NSF, NCF, NVEC, NV, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, in, (const void *)V, block_to_fine, blockVol, spin_bs)
   QA_TRANSFER_DISPATCH(QA_P)
 #undef QA_P
