@@ -288,3 +288,25 @@ def test_device_clover_construction_by_transport(qa, oracle, mask, prec, recon, 
         del os.environ["QUDA_AMD_CLOVER_TRANSPORT"]
         qa.lib().qudaAmdSetPartitionMask(0)
         qa.lib().freeCloverQuda()
+
+
+@pytest.mark.parametrize("case,message", [
+    ("not_initialized", "QUDA not initialized"),
+    ("sentinel_gauge_param", "Parameter"),
+    ("dslash_without_gauge", "Gauge field not allocated"),
+    ("unsupported_dslash_type", "Unsupported dslash_type"),
+    ("clover_without_coefficient", "clover coefficient not set"),
+    ("mg_outer_pc_with_full_smoother", "a preconditioned smoother is required"),
+])
+def test_error_convention(case, message):
+    """No return codes and no exceptions, as the reference (include/util_quda.h:51-61): `ERROR: <text> (rank, file:line in
+    func())` on stdout and exit status 1; parameter structs are validated against their "invalid" sentinels
+    (lib/check_params.h).  Each case runs in a child process (tools/error_cases.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "error_cases.py"), case], capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert r.returncode == 1, (r.returncode, out[-1500:])
+    assert "ERROR:" in out and message in out and "NOT REACHED" not in out, out[-1500:]
+    assert "csrc/" in out and " in " in out   # file:line in func()
