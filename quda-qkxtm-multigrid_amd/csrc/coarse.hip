@@ -261,16 +261,6 @@ void applyCoarse(ColorSpinorField &out, const ColorSpinorField &in, const Coarse
 }
 
 // ---- construction helpers ----
-__global__ void unit_vector_kernel(CVec v, int j, int ncomp) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  if (x >= v.Vh) return;
-  for (int p = 0; p < 2; p++)
-    for (int k = 0; k < ncomp; k++) {
-      float *q = v.v[p] + ((size_t)k * v.stride + x) * 2;
-      q[0] = k == j ? 1.f : 0.f; q[1] = 0.f;
-    }
-}
-
 // column j of matrix m at every site (+)= coarse vector c
 __global__ void insert_column_kernel(float *G, CVec c, int n, int m, int j, int accumulate, int nSites) {
   const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -288,26 +278,48 @@ void DiracCoarse::build() {
   const int n = 2 * T.Nvec;
   links = new CoarseGauge(T.Xc, n);
   ownLinks = true;
-  ColorSpinorField *E = T.createCoarseField(), *c = T.createCoarseField(), *c2 = T.createCoarseField();
+  ColorSpinorField *c = T.createCoarseField(), *c2 = T.createCoarseField();
   ColorSpinorField *phi = T.createFineField(), *w = T.createFineField();
   phi->twistFlavor = w->twistFlavor = fineFlavor;
   const int bs = 256;
+  const unsigned nins = (unsigned)(((long)links->nSites * n + bs - 1) / bs);
+  // first coarse level: the 8 hop outputs of a probe are restricted four at a time (V streamed 3 instead of 9 times per probe)
+  const bool four = T.canSplit4();
+  ColorSpinorField *w8[8] = {}, *cl[4] = {}, *cs[4] = {};
+  if (four) {
+    for (int d = 0; d < 8; d++) { w8[d] = T.createFineField(); w8[d]->twistFlavor = fineFlavor; }
+    for (int q = 0; q < 4; q++) { cl[q] = T.createCoarseField(); cs[q] = T.createCoarseField(); }
+  }
   for (int j = 0; j < n; j++) {
-    hipLaunchKernelGGL(unit_vector_kernel, dim3((E->VolumeCB() + bs - 1) / bs), dim3(bs), 0, computeStream(), cvecFull(*E), j, n);
-    T.P(*phi, *E);
-    for (int d = 0; d < 8; d++) {
-      parent->hopDir(*w, *phi, d);
-      T.RSplit(*c, *c2, *w, d);   // one pass over V: the part of the hop that leaves the aggregate -> link d, the rest -> local term
-      hipLaunchKernelGGL(insert_column_kernel, dim3(((long)links->nSites * n + bs - 1) / bs), dim3(bs), 0, computeStream(), links->data, cvecFull(*c), n, d, j, 0, links->nSites);
-      hipLaunchKernelGGL(insert_column_kernel, dim3(((long)links->nSites * n + bs - 1) / bs), dim3(bs), 0, computeStream(), links->data, cvecFull(*c2), n, 8, j, 1, links->nSites);
+    T.column(*phi, j);   // = P e_j for the unit vector j at every coarse site
+    if (four) {
+      for (int d = 0; d < 8; d++) parent->hopDir(*w8[d], *phi, d);
+      for (int half = 0; half < 2; half++) {
+        const int dirs[4] = {4 * half, 4 * half + 1, 4 * half + 2, 4 * half + 3};
+        ColorSpinorField *in4[4] = {w8[dirs[0]], w8[dirs[1]], w8[dirs[2]], w8[dirs[3]]};
+        T.RSplit4(cl, cs, in4, dirs);
+        for (int q = 0; q < 4; q++) {
+          hipLaunchKernelGGL(insert_column_kernel, dim3(nins), dim3(bs), 0, computeStream(), links->data, cvecFull(*cl[q]), n, dirs[q], j, 0, links->nSites);
+          hipLaunchKernelGGL(insert_column_kernel, dim3(nins), dim3(bs), 0, computeStream(), links->data, cvecFull(*cs[q]), n, 8, j, 1, links->nSites);
+        }
+      }
+    } else {
+      for (int d = 0; d < 8; d++) {
+        parent->hopDir(*w, *phi, d);
+        T.RSplit(*c, *c2, *w, d);   // one pass over V: the part of the hop that leaves the aggregate -> link d, the rest -> local term
+        hipLaunchKernelGGL(insert_column_kernel, dim3(nins), dim3(bs), 0, computeStream(), links->data, cvecFull(*c), n, d, j, 0, links->nSites);
+        hipLaunchKernelGGL(insert_column_kernel, dim3(nins), dim3(bs), 0, computeStream(), links->data, cvecFull(*c2), n, 8, j, 1, links->nSites);
+      }
     }
     parent->localTerm(*w, *phi);
     T.R(*c, *w);
-    hipLaunchKernelGGL(insert_column_kernel, dim3(((long)links->nSites * n + bs - 1) / bs), dim3(bs), 0, computeStream(), links->data, cvecFull(*c), n, 8, j, 1, links->nSites);
+    hipLaunchKernelGGL(insert_column_kernel, dim3(nins), dim3(bs), 0, computeStream(), links->data, cvecFull(*c), n, 8, j, 1, links->nSites);
   }
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(computeStream()));
-  delete E; delete c; delete c2; delete phi; delete w;
+  for (int d = 0; d < 8; d++) delete w8[d];
+  for (int q = 0; q < 4; q++) { delete cl[q]; delete cs[q]; }
+  delete c; delete c2; delete phi; delete w;
 }
 
 // ---- preconditioned links: batched dense inverse and products ----

@@ -45,6 +45,11 @@ class Transfer {
   // both halves of the Galerkin split in one pass over V: `leaving` = R over the fine sites whose dir-neighbour lies outside
   // their aggregate, `staying` = R over the others (equal to R(.., dir, 1) and R(.., dir, 0))
   void RSplit(ColorSpinorField &leaving, ColorSpinorField &staying, const ColorSpinorField &fine, int dir) const;
+  // the same for four fine vectors (each with its own direction) in ONE pass over V; fine level only (canSplit4)
+  bool canSplit4() const;
+  void RSplit4(ColorSpinorField *const leaving[4], ColorSpinorField *const staying[4], ColorSpinorField *const fine[4], const int dir[4]) const;
+  // fine = P e_j for the coarse unit vector j (same component at every coarse site): column j of V, without streaming all of V
+  void column(ColorSpinorField &fine, int j) const;
   // single-parity fine fields (outer even-odd preconditioned solve: the residual of one parity is injected into the coarse
   // grid, reference Transfer::setSiteSubset lib/transfer.cpp:276-290): the absent parity restricts as zero / is not prolongated
   void setSiteSubset(QudaSiteSubset subset, QudaParity parity);

@@ -149,6 +149,111 @@ __global__ void restrict_kernel(CoarseVec out, CoarseVec out2, FineVec in, const
   }
 }
 
+// ---- four right-hand sides per pass over V (Galerkin construction of the first coarse level: the 8 single-direction hops of
+// one probe are restricted in two launches instead of eight; V is the whole cost of a restriction) ----
+struct Multi4 {
+  CoarseVec out[4], out2[4];
+  FineVec in[4];
+  int dir[4];
+};
+__device__ __forceinline__ bool mask_outside_dir(const MaskArg &m, int dir, int b) {
+  const int mu = dir >> 1, fwd = !(dir & 1);
+  int y[4], l = b;
+  y[0] = l % m.bs[0]; l /= m.bs[0];
+  y[1] = l % m.bs[1]; l /= m.bs[1];
+  y[2] = l % m.bs[2]; y[3] = l / m.bs[2];
+  return !m.single[mu] && (fwd ? y[mu] == m.bs[mu] - 1 : y[mu] == 0);
+}
+// wave partial sums go to this wave's own LDS row (no barrier per reduction); one barrier at the end of the (chi, vp) step
+template <int NSF, int NCF, int NVEC, int NV>
+__global__ void __launch_bounds__(256) restrict4_kernel(Multi4 a, const float4 *V, const int *block_to_fine, int blockVol, int spin_bs, MaskArg mask) {
+  constexpr int K = NSF * NCF;
+  __shared__ float4 part[4][8];   // [wave][rhs*2 + (0 leaving, 1 staying)]
+  const int A = blockIdx.x, b = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const bool site = b < blockVol;
+  float2 r[4][K];
+  bool outside[4];
+  if (site) {
+    const int f = block_to_fine[(size_t)A * blockVol + b];
+    const int parity = f >= a.in[0].Vh, x = f - parity * a.in[0].Vh;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float *base = a.in[q].v[parity];
+      outside[q] = mask_outside_dir(mask, a.dir[q], b);
+#pragma unroll
+      for (int k = 0; k < K; k++) { const size_t i = fidx<NV>(a.in[q].stride, x, k); r[q][k] = make_float2(base[i], base[i + 1]); }
+    }
+  }
+  const int cpar = A >= a.out[0].Vh, xc = A - cpar * a.out[0].Vh;
+  for (int chi = 0; chi < 2; chi++) {
+    for (int vp = 0; vp < NVEC / 2; vp++) {
+      float4 acc[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (site) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+          if ((k / NCF) / spin_bs != chi) continue;
+          const float4 w = V[(((size_t)A * K + k) * (NVEC / 2) + vp) * blockVol + b];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            acc[q].x += w.x * r[q][k].x + w.y * r[q][k].y; acc[q].y += w.x * r[q][k].y - w.y * r[q][k].x;
+            acc[q].z += w.z * r[q][k].x + w.w * r[q][k].y; acc[q].w += w.z * r[q][k].y - w.w * r[q][k].x;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 so = (site && outside[q]) ? acc[q] : z, si = (site && !outside[q]) ? acc[q] : z;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+          so.x += __shfl_down(so.x, off, 64); so.y += __shfl_down(so.y, off, 64); so.z += __shfl_down(so.z, off, 64); so.w += __shfl_down(so.w, off, 64);
+          si.x += __shfl_down(si.x, off, 64); si.y += __shfl_down(si.y, off, 64); si.z += __shfl_down(si.z, off, 64); si.w += __shfl_down(si.w, off, 64);
+        }
+        if (lane == 0) { part[wave][2 * q] = so; part[wave][2 * q + 1] = si; }
+      }
+      __syncthreads();
+      if (threadIdx.x < 8) {
+        float4 s = part[0][threadIdx.x];
+        for (int w2 = 1; w2 < nw; w2++) { const float4 t = part[w2][threadIdx.x]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+        const int q = threadIdx.x >> 1;
+        const CoarseVec &o = (threadIdx.x & 1) ? a.out2[q] : a.out[q];
+        float *ob = o.v[cpar];
+        const int c0 = chi * NVEC + 2 * vp;
+        ob[((size_t)c0 * o.stride + xc) * 2] = s.x; ob[((size_t)c0 * o.stride + xc) * 2 + 1] = s.y;
+        ob[((size_t)(c0 + 1) * o.stride + xc) * 2] = s.z; ob[((size_t)(c0 + 1) * o.stride + xc) * 2 + 1] = s.w;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// phi = P e_j for the coarse unit vector j = (chirality, vector) at every coarse site: column j of V, copied out of the
+// aggregate-major layout (1/12 of V is touched instead of the whole of it by a prolongation)
+template <int NSF, int NCF, int NV>
+__global__ void column_kernel(FineVec out, const float4 *V, const int *block_to_fine, int blockVol, int spin_bs, int NVEC, int j, long total) {
+  constexpr int K = NSF * NCF;
+  const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const long A = t / blockVol;
+  const int b = (int)(t - A * blockVol);
+  const int f = block_to_fine[t];
+  const int parity = f >= out.Vh, x = f - parity * out.Vh;
+  float *base = out.v[parity];
+  const int chi = j / NVEC, v = j - chi * NVEC;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    float re = 0.f, im = 0.f;
+    if ((k / NCF) / spin_bs == chi) {
+      const float4 w = V[(((size_t)A * K + k) * (NVEC / 2) + (v >> 1)) * blockVol + b];
+      re = (v & 1) ? w.z : w.x; im = (v & 1) ? w.w : w.y;
+    }
+    const size_t i = fidx<NV>(out.stride, x, k);
+    base[i] = re; base[i + 1] = im;
+  }
+}
+
 // ---- small aggregates (blockVol <= 32, the coarse levels: 2^4 = 16 sites).  One thread per site leaves most of a wave idle and
 // runs the (chirality, vector pair) iterations one after the other behind block-wide reductions — 0.28 ms for a 37 MB
 // transfer.  Here a wave holds 64 / GS groups of GS lanes (GS = blockVol rounded up to a power of two), every group takes its
@@ -588,6 +693,49 @@ void Transfer::P(ColorSpinorField &fine, const ColorSpinorField &coarse) const {
 #undef QA_P
   HIP_CHECK(hipGetLastError());
   flops_ += 8ull * fineSpin * fineColor * Nvec * fineVol;  // reference lib/prolongator.cu:228
+}
+
+void Transfer::column(ColorSpinorField &fine, int j) const {
+  if (fine.SiteSubset() != QUDA_FULL_SITE_SUBSET || fine.Nspin() != fineSpin || fine.Ncolor() != fineColor || fine.Volume() != fineVol) errorQuda("fine field does not match the transfer operator");
+  if (j < 0 || j >= 2 * Nvec) errorQuda("coarse component %d of %d", j, 2 * Nvec);
+  const FineVec out = fineVec(fine);
+  const int bs = 256;
+  const long total = fineVol;
+  if (fineSpin == 4) hipLaunchKernelGGL((column_kernel<4, 3, 4>), dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, computeStream(), out, (const float4 *)V, block_to_fine, blockVol, spin_bs, Nvec, j, total);
+  else {
+    switch (fineColor) {
+      case 4: hipLaunchKernelGGL((column_kernel<2, 4, 2>), dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, computeStream(), out, (const float4 *)V, block_to_fine, blockVol, spin_bs, Nvec, j, total); break;
+      case 8: hipLaunchKernelGGL((column_kernel<2, 8, 2>), dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, computeStream(), out, (const float4 *)V, block_to_fine, blockVol, spin_bs, Nvec, j, total); break;
+      case 24: hipLaunchKernelGGL((column_kernel<2, 24, 2>), dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, computeStream(), out, (const float4 *)V, block_to_fine, blockVol, spin_bs, Nvec, j, total); break;
+      case 32: hipLaunchKernelGGL((column_kernel<2, 32, 2>), dim3((unsigned)((total + bs - 1) / bs)), dim3(bs), 0, computeStream(), out, (const float4 *)V, block_to_fine, blockVol, spin_bs, Nvec, j, total); break;
+      default: errorQuda("column extraction for %d fine colours not instantiated", fineColor);
+    }
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+bool Transfer::canSplit4() const { return fineSpin == 4 && fineColor == 3 && blockVol > 32 && blockVol <= 256; }
+
+void Transfer::RSplit4(ColorSpinorField *const leaving[4], ColorSpinorField *const staying[4], ColorSpinorField *const fine[4], const int dir[4]) const {
+  if (!canSplit4()) errorQuda("the four-way split restriction is built for the fine level");
+  Multi4 a;
+  for (int q = 0; q < 4; q++) {
+    if (fine[q]->SiteSubset() != QUDA_FULL_SITE_SUBSET || fine[q]->Volume() != fineVol) errorQuda("fine field does not match the transfer operator");
+    a.in[q] = fineVec(*fine[q]); a.out[q] = coarseVec(*leaving[q]); a.out2[q] = coarseVec(*staying[q]); a.dir[q] = dir[q];
+  }
+  MaskArg m;
+  m.dir = 0; m.boundary = 1;
+  for (int d = 0; d < 4; d++) { m.bs[d] = geo_bs[d]; m.single[d] = Xc[d] == 1; }
+  const int threads = (blockVol + 63) / 64 * 64;
+  switch (Nvec) {
+    case 4: hipLaunchKernelGGL((restrict4_kernel<4, 3, 4, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const float4 *)V, block_to_fine, blockVol, spin_bs, m); break;
+    case 8: hipLaunchKernelGGL((restrict4_kernel<4, 3, 8, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const float4 *)V, block_to_fine, blockVol, spin_bs, m); break;
+    case 24: hipLaunchKernelGGL((restrict4_kernel<4, 3, 24, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const float4 *)V, block_to_fine, blockVol, spin_bs, m); break;
+    case 32: hipLaunchKernelGGL((restrict4_kernel<4, 3, 32, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const float4 *)V, block_to_fine, blockVol, spin_bs, m); break;
+    default: errorQuda("Nvec = %d not instantiated", Nvec);
+  }
+  HIP_CHECK(hipGetLastError());
+  flops_ += 4 * 8ull * fineSpin * fineColor * Nvec * fineVol;
 }
 
 }  // namespace quda
