@@ -9,6 +9,8 @@
 
 #include "blas.h"
 
+#include <cstring>
+
 namespace quda {
 
 CoarseGauge::CoarseGauge(const int xc[4], int n_) : n(n_), data(nullptr), data_h(nullptr) {
@@ -59,6 +61,11 @@ struct CoarseArg {
   const float2 *ghost[8];
   int faceCB[4];
   int commMask, ghostSingle;
+  // peer-store transport: counter each crossing hop's face must have reached (0 pointers: data arrived in stream order)
+  const unsigned *waitFlag[8];
+  unsigned waitCount[8];
+  unsigned long long waitTicks;
+  int *errWord;
 };
 
 template <int NMAX, bool HALF>
@@ -77,6 +84,22 @@ __global__ void __launch_bounds__(256) coarse_apply_kernel(const CoarseArg arg) 
   const int y = l % arg.Xc[1]; l /= arg.Xc[1];
   const int z = l % arg.Xc[2]; const int t = l / arg.Xc[2];
   const int c[4] = {2 * xh + ((y + z + t + par) & 1), y, z, t};
+  // peer-store transport: a site with a hop across a partitioned face waits for that face (threads 0-7 poll one counter each)
+  if (arg.commMask) {
+    bool need = false;
+    if (threadIdx.x < 8 && ((arg.mmask >> threadIdx.x) & 1) && ((arg.commMask >> (threadIdx.x >> 1)) & 1) && arg.waitFlag[threadIdx.x]) {
+      const int mu = threadIdx.x >> 1;
+      need = (threadIdx.x & 1) ? c[mu] == 0 : c[mu] == arg.Xc[mu] - 1;
+    }
+    if (need && !__hip_atomic_load(arg.errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      const unsigned long long t0 = wall_clock64();
+      while ((int)(__hip_atomic_load(arg.waitFlag[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - arg.waitCount[threadIdx.x]) < 0) {
+        if (wall_clock64() - t0 > arg.waitTicks) { __hip_atomic_store(arg.errWord, 17 + (int)threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+  }
   // stage the 9 input vectors (8 neighbours + self)
   for (int m = 0; m < 9; m++) {
     if (!((arg.mmask >> m) & 1)) continue;
@@ -98,7 +121,9 @@ __global__ void __launch_bounds__(256) coarse_apply_kernel(const CoarseArg arg) 
       for (int k = 0; k < 4; k++) if (k != mu) { l += cn[k] * mul; mul *= arg.Xc[k]; }
       const int f = l >> 1, q = arg.ghostSingle ? 0 : npar;
       const float2 *src = arg.ghost[m] + (size_t)q * n * arg.faceCB[mu] + f;
-      for (int j = threadIdx.x; j < n; j += blockDim.x) xin[m][j] = src[(size_t)j * arg.faceCB[mu]];
+      // system-scope loads: the zone may have been written by another GPU while this kernel was running
+      for (int j = threadIdx.x; j < n; j += blockDim.x)
+        xin[m][j] = __builtin_bit_cast(float2, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(src + (size_t)j * arg.faceCB[mu]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
     } else {
       const int nx = (((cn[3] * arg.Xc[2] + cn[2]) * arg.Xc[1] + cn[1]) * arg.Xc[0] + cn[0]) >> 1;
       const float *src = arg.in.v[npar];
@@ -145,10 +170,28 @@ struct CoarseGhost {
   int faceCB[4];
   float2 *pool;
   float2 *send[4][2], *ghost[4][2];   // [mu][0: x_mu = 0 face / from the -mu neighbour, 1: x_mu = L-1 face / from the +mu neighbour]
+  // peer-store transport (p2p.h, same protocol as the fine stencil's halo): fine-grained window with double-buffered ghost
+  // blocks [mu][k][buf] + one cumulative thread counter per block, mapped into the neighbours
+  bool p2p;
+  char *window;
+  float2 *ghostBuf[4][2][2], *peerGhost[4][2][2];   // peerGhost[mu][face 0/1][buf]: where my x_mu = 0 / L-1 face lands
+  unsigned *flag[4][2], *peerFlag[4][2];             // + buf
+  unsigned seq, uses[4][2][2];
+  PeerMap *map;
 };
 static std::vector<CoarseGhost> g_cghosts;
 void freeCoarseGhosts() {
-  for (CoarseGhost &c : g_cghosts) if (c.pool) (void)hipFree(c.pool);
+  bool any = false;
+  for (CoarseGhost &c : g_cghosts) any = any || c.window;
+  if (any) { HIP_CHECK(hipDeviceSynchronize()); commBarrier(); }
+  for (CoarseGhost &c : g_cghosts) {
+    if (c.window) { commUnmapPeers(*c.map); delete c.map; }
+  }
+  if (any) commBarrier();
+  for (CoarseGhost &c : g_cghosts) {
+    if (c.window) p2pFree(c.window);
+    if (c.pool) (void)hipFree(c.pool);
+  }
   g_cghosts.clear();
 }
 static CoarseGhost &coarseGhost(const int Xc[4], int n) {
@@ -164,6 +207,33 @@ static CoarseGhost &coarseGhost(const int Xc[4], int n) {
   float2 *p = c.pool;
   for (int d = 0; d < 4; d++)
     for (int k = 0; k < 2; k++) { c.send[d][k] = p; p += (size_t)2 * n * c.faceCB[d]; c.ghost[d][k] = p; p += (size_t)2 * n * c.faceCB[d]; }
+  c.p2p = p2pHaloEnabled();
+  c.window = nullptr; c.map = nullptr; c.seq = 0;
+  memset(c.uses, 0, sizeof(c.uses));
+  if (c.p2p) {
+    size_t wbytes = 0;
+    for (int d = 0; d < 4; d++) wbytes += (size_t)4 * 2 * n * c.faceCB[d] * sizeof(float2);   // [k][buf] blocks of both parities
+    const size_t flags_off = (wbytes + 255) / 256 * 256;
+    c.window = (char *)p2pAlloc(flags_off + 256);
+    c.map = new PeerMap;
+    if (!commMapPeers(c.window, *c.map)) errorQuda("peer mapping of a coarse halo window failed after the transport probe succeeded");
+    size_t off = 0;
+    for (int d = 0; d < 4; d++)
+      for (int k = 0; k < 2; k++) {
+        // zone k = 0: filled by the -d neighbour with its x_d = L-1 face (needed by my backward hops);
+        // zone k = 1: filled by the +d neighbour with its x_d = 0 face (needed by my forward hops)
+        const int face = k == 0 ? 1 : 0;          // which of MY faces goes into the neighbour's zone k
+        const int slot = 2 * d + (face ? 1 : 0);  // face L-1 travels to the +d neighbour, face 0 to the -d neighbour
+        for (int buf = 0; buf < 2; buf++) {
+          c.ghostBuf[d][k][buf] = (float2 *)(c.window + off);
+          c.peerGhost[d][face][buf] = (float2 *)((char *)c.map->peer[slot] + off);
+          off += (size_t)2 * n * c.faceCB[d] * sizeof(float2);
+        }
+        c.flag[d][k] = (unsigned *)(c.window + flags_off) + (2 * d + k) * 2;
+        c.peerFlag[d][face] = (unsigned *)((char *)c.map->peer[slot] + flags_off) + (2 * d + k) * 2;
+      }
+    commBarrier();
+  }
   g_cghosts.push_back(c);
   return g_cghosts.back();
 }
@@ -174,10 +244,12 @@ struct CoarsePackArg {
   int start[9];
   int Xc[4], faceCB[4];
   int n, single;     // single >= 0: only that parity of `in` exists
+  unsigned *peerFlag[8];   // peer-store transport: thread counters of the faces in the neighbours' windows (send[] then point there too)
+  int p2p;
 };
 __global__ void __launch_bounds__(256) coarse_pack_kernel(const CoarsePackArg arg) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= arg.start[8]) return;
+  if (tid < arg.start[8]) {
   int slot = 0;
   for (int k = 1; k < 8; k++) slot += tid >= arg.start[k];
   const int mu = slot >> 1, nf = arg.faceCB[mu];
@@ -195,37 +267,77 @@ __global__ void __launch_bounds__(256) coarse_pack_kernel(const CoarsePackArg ar
   const int idx = (((c[3] * arg.Xc[2] + c[2]) * arg.Xc[1] + c[1]) * arg.Xc[0] + c[0]) >> 1;
   const float2 *src = reinterpret_cast<const float2 *>(arg.in.v[par]) + idx;
   float2 *dst = arg.send[slot] + (size_t)q * arg.n * nf + f;
-  for (int j = 0; j < arg.n; j++) dst[(size_t)j * nf] = src[(size_t)j * arg.in.stride];
+  if (arg.p2p) {
+    // system-scope write-through stores into the neighbour's window (8-byte granules)
+    for (int j = 0; j < arg.n; j++) {
+      const float2 v = src[(size_t)j * arg.in.stride];
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + (size_t)j * nf), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  } else {
+    for (int j = 0; j < arg.n; j++) dst[(size_t)j * nf] = src[(size_t)j * arg.in.stride];
+  }
+  }
+  if (arg.p2p) {
+    // as pack_body of the fine stencil: wait for this block's stores, then add the threads it contributed to each face counter
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x < 8 && arg.peerFlag[threadIdx.x]) {
+      const int beg = blockIdx.x * (int)blockDim.x, end = beg + (int)blockDim.x;
+      const int lo = beg > arg.start[threadIdx.x] ? beg : arg.start[threadIdx.x];
+      const int hi = end < arg.start[threadIdx.x + 1] ? end : arg.start[threadIdx.x + 1];
+      if (hi > lo) (void)__hip_atomic_fetch_add(arg.peerFlag[threadIdx.x], (unsigned)(hi - lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // exchange the faces of `in` the masked hops need; fills arg.ghost / commMask
 static void exchangeCoarseGhost(CoarseArg &arg, const CoarseGauge &G, int single) {
   arg.commMask = 0; arg.ghostSingle = single >= 0;
-  for (int m = 0; m < 8; m++) arg.ghost[m] = nullptr;
+  arg.waitTicks = 0; arg.errWord = nullptr;
+  for (int m = 0; m < 8; m++) { arg.ghost[m] = nullptr; arg.waitFlag[m] = nullptr; arg.waitCount[m] = 0; }
   int mask = 0;
   for (int d = 0; d < 4; d++) if (commGrid().partitioned(d) && ((arg.mmask >> (2 * d)) & 3)) mask |= 1 << d;
   for (int d = 0; d < 4; d++) arg.faceCB[d] = G.nSites / 2 / G.Xc[d];
   if (!mask) return;
   CoarseGhost &cg = coarseGhost(G.Xc, G.n);
   CoarsePackArg pa;
-  pa.in = arg.in; pa.n = G.n; pa.single = single;
+  pa.in = arg.in; pa.n = G.n; pa.single = single; pa.p2p = cg.p2p ? 1 : 0;
+  for (int k = 0; k < 8; k++) pa.peerFlag[k] = nullptr;
   const int nq = single >= 0 ? 1 : 2;
   int nt = 0;
   std::vector<HaloMsg> msgs;
+  const int buf = cg.p2p ? (int)(++cg.seq & 1) : 0;
   for (int d = 0; d < 4; d++) {
     pa.Xc[d] = G.Xc[d]; pa.faceCB[d] = cg.faceCB[d];
     const size_t bytes = (size_t)nq * G.n * cg.faceCB[d] * sizeof(float2);
     // hop 2d (forward) reads the +d neighbour's x_d = 0 face: every rank sends that face backward
     const bool needFwd = ((mask >> d) & 1) && ((arg.mmask >> (2 * d)) & 1), needBwd = ((mask >> d) & 1) && ((arg.mmask >> (2 * d + 1)) & 1);
-    pa.send[2 * d] = cg.send[d][0]; pa.start[2 * d] = nt; if (needFwd) nt += nq * cg.faceCB[d];
-    pa.send[2 * d + 1] = cg.send[d][1]; pa.start[2 * d + 1] = nt; if (needBwd) nt += nq * cg.faceCB[d];
-    if (needBwd) { msgs.push_back({d, +1, cg.send[d][1], cg.ghost[d][0], bytes}); arg.ghost[2 * d + 1] = cg.ghost[d][0]; }
-    if (needFwd) { msgs.push_back({d, -1, cg.send[d][0], cg.ghost[d][1], bytes}); arg.ghost[2 * d] = cg.ghost[d][1]; }
+    pa.send[2 * d] = cg.p2p ? cg.peerGhost[d][0][buf] : cg.send[d][0]; pa.start[2 * d] = nt; if (needFwd) nt += nq * cg.faceCB[d];
+    pa.send[2 * d + 1] = cg.p2p ? cg.peerGhost[d][1][buf] : cg.send[d][1]; pa.start[2 * d + 1] = nt; if (needBwd) nt += nq * cg.faceCB[d];
+    if (cg.p2p) {
+      // my x_d = 0 face (needed by the -d neighbour's forward hops) lands in its zone 1, my x_d = L-1 face in the +d neighbour's zone 0
+      if (needFwd) {
+        pa.peerFlag[2 * d] = cg.peerFlag[d][0] + buf;
+        arg.ghost[2 * d] = cg.ghostBuf[d][1][buf];
+        arg.waitFlag[2 * d] = cg.flag[d][1] + buf;
+        arg.waitCount[2 * d] = (cg.uses[d][1][buf] += (unsigned)(nq * cg.faceCB[d]));
+      }
+      if (needBwd) {
+        pa.peerFlag[2 * d + 1] = cg.peerFlag[d][1] + buf;
+        arg.ghost[2 * d + 1] = cg.ghostBuf[d][0][buf];
+        arg.waitFlag[2 * d + 1] = cg.flag[d][0] + buf;
+        arg.waitCount[2 * d + 1] = (cg.uses[d][0][buf] += (unsigned)(nq * cg.faceCB[d]));
+      }
+    } else {
+      if (needBwd) { msgs.push_back({d, +1, cg.send[d][1], cg.ghost[d][0], bytes}); arg.ghost[2 * d + 1] = cg.ghost[d][0]; }
+      if (needFwd) { msgs.push_back({d, -1, cg.send[d][0], cg.ghost[d][1], bytes}); arg.ghost[2 * d] = cg.ghost[d][1]; }
+    }
   }
   pa.start[8] = nt;
   hipLaunchKernelGGL(coarse_pack_kernel, dim3((nt + 255) / 256), dim3(256), 0, computeStream(), pa);
   HIP_CHECK(hipGetLastError());
-  commExchange(msgs, computeStream());
+  if (cg.p2p) { arg.waitTicks = p2pTimeoutTicks(); arg.errWord = p2pErrorWord(); }
+  else commExchange(msgs, computeStream());
   arg.commMask = mask;
 }
 
