@@ -365,7 +365,7 @@ class Dirac:
 
 
 def multigrid_param(ip, n_level=2, geo_block=(4, 4, 4, 4), n_vec=24, nu_pre=2, nu_post=2, cycle=QUDA_MG_CYCLE_RECURSIVE, smoother_tol=0.25,
-                    setup_maxiter=500, setup_tol=5e-6, generate_all_levels=True, omega=0.85, smoother_pc=False):
+                    setup_maxiter=500, setup_tol=5e-6, generate_all_levels=True, omega=0.85, smoother_pc=False, coarse_matpc=False):
     """QudaMultigridParam filled the way the reference harness does (tests/multigrid_invert_test.cpp:195-290), with the
     smoother on the full operator (QUDA_DIRECT_SOLVE) or, smoother_pc=True, the reference default QUDA_DIRECT_PC_SOLVE."""
     mp = lib().newQudaMultigridParam()
@@ -386,7 +386,8 @@ def multigrid_param(ip, n_level=2, geo_block=(4, 4, 4, 4), n_vec=24, nu_pre=2, n
         mp.smoother_tol[i] = smoother_tol
         mp.global_reduction[i] = QUDA_BOOLEAN_YES
         mp.smoother_solve_type[i] = QUDA_DIRECT_PC_SOLVE if smoother_pc else QUDA_DIRECT_SOLVE
-        mp.coarse_grid_solution_type[i] = QUDA_MAT_SOLUTION
+        # QUDA_MATPC_SOLUTION: single-parity injection, what the harness pairs with an outer even-odd solve (multigrid_invert_test.cpp:246-252)
+        mp.coarse_grid_solution_type[i] = QUDA_MATPC_SOLUTION if coarse_matpc else QUDA_MAT_SOLUTION
         mp.omega[i] = omega
         mp.location[i] = QUDA_CUDA_FIELD_LOCATION
     mp.setup_maxiter, mp.setup_tol = setup_maxiter, setup_tol

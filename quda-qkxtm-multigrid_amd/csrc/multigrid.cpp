@@ -376,6 +376,19 @@ void MG::cycleParity(ColorSpinorField &x, ColorSpinorField &b) {
 void MG::operator()(ColorSpinorField &x, ColorSpinorField &b) {
   if (b.SiteSubset() != QUDA_FULL_SITE_SUBSET) { cycleParity(x, b); return; }
   const Dirac &dirac = *mgp.matSmooth.Expose();
+  if (mgp.level == 0 && mgp.level < mgp.Nlevel - 1 && pcSmooth && mgp.mg_global.coarse_grid_solution_type[0] == QUDA_MATPC_SOLUTION) {
+    // full-system outer solve with single-parity injection (reference outer QUDA_MAT_SOLUTION / inner QUDA_MATPC_SOLUTION,
+    // lib/multigrid.cpp:513-560): Schur-prepare the source, run the parity cycle, reconstruct the other parity
+    ColorSpinorField *out = nullptr, *in = nullptr;
+    r->twistFlavor = x.twistFlavor = b.twistFlavor;
+    blas::copy(*r, b);
+    dirac.prepare(in, out, x, *r, QUDA_MAT_SOLUTION);
+    b_tilde->twistFlavor = b.twistFlavor;
+    blas::copy(*b_tilde, *in);     // cycleParity overwrites r's parity halves
+    cycleParity(*out, *b_tilde);
+    dirac.reconstruct(x, b, QUDA_MAT_SOLUTION);
+    return;
+  }
   ColorSpinorField *out = nullptr, *in = nullptr;
   r->twistFlavor = b.twistFlavor;
   x.twistFlavor = b.twistFlavor;
@@ -490,8 +503,13 @@ multigrid_solver::multigrid_solver(QudaMultigridParam &mg_param) : d(nullptr), m
   for (int i = 0; i < mg_param.n_level; i++) {
     if (mg_param.smoother_solve_type[i] != QUDA_DIRECT_SOLVE && mg_param.smoother_solve_type[i] != QUDA_DIRECT_PC_SOLVE)
       errorQuda("Unsupported smoother solve type %d on level %d", mg_param.smoother_solve_type[i], i);
-    if (mg_param.coarse_grid_solution_type[i] != QUDA_MAT_SOLUTION)
-      errorQuda("coarse_grid_solution_type[%d] = %d: this build restricts the full residual (QUDA_MAT_SOLUTION)", i, mg_param.coarse_grid_solution_type[i]);
+    // QUDA_MAT_SOLUTION: the full residual is restricted; QUDA_MATPC_SOLUTION (what the harness sets for an outer even-odd
+    // solve, tests/multigrid_invert_test.cpp:246-252): single-parity injection, needs the even-odd smoother (reference
+    // lib/multigrid.cpp:503-504).  Honoured on the finest level; the coarse levels always restrict their full residual.
+    if (mg_param.coarse_grid_solution_type[i] != QUDA_MAT_SOLUTION && mg_param.coarse_grid_solution_type[i] != QUDA_MATPC_SOLUTION)
+      errorQuda("coarse_grid_solution_type[%d] = %d not supported (QUDA_MAT_SOLUTION, QUDA_MATPC_SOLUTION)", i, mg_param.coarse_grid_solution_type[i]);
+    if (mg_param.coarse_grid_solution_type[i] == QUDA_MATPC_SOLUTION && mg_param.smoother_solve_type[i] != QUDA_DIRECT_PC_SOLVE)
+      errorQuda("For this coarse grid solution type, a preconditioned smoother is required");
   }
   if (param->solve_type != QUDA_DIRECT_SOLVE) errorQuda("Outer MG solver can only use QUDA_DIRECT_SOLVE at present");
   GaugeField *g = gaugePrecondition ? gaugePrecondition : (gaugeSloppy ? gaugeSloppy : gaugePrecise);

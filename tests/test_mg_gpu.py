@@ -187,7 +187,8 @@ def test_outer_even_odd_solve_with_up_and_down_hierarchies(qa, oracle):
                                   solution_type=qa.QUDA_MAT_SOLUTION)
             ipm.solve_type = qa.QUDA_DIRECT_SOLVE   # the MG-internal parameter set (reference lib/interface_quda.cpp:2183)
             ipm.inv_type, ipm.gcrNkrylov, ipm.tol, ipm.maxiter, ipm.reliable_delta, ipm.verbosity = qa.QUDA_GCR_INVERTER, 20, 1e-10, 2000, 1e-4, qa.QUDA_SILENT
-            mp = qa.multigrid_param(ipm, n_level=3, geo_block=[(4, 4, 4, 4), (1, 1, 1, 2), (2, 2, 2, 2)], n_vec=8, setup_maxiter=300, setup_tol=1e-5, smoother_pc=True)
+            mp = qa.multigrid_param(ipm, n_level=3, geo_block=[(4, 4, 4, 4), (1, 1, 1, 2), (2, 2, 2, 2)], n_vec=8, setup_maxiter=300, setup_tol=1e-5, smoother_pc=True,
+                                    coarse_matpc=True)   # single-parity injection, as the harness configures an outer even-odd solve
             hier[flavor] = (qa.Multigrid(mp), ipm, mp)
         ip.preconditionerUP, ip.preconditionerDN = hier[+1][0].h, hier[-1][0].h
         for flavor in (+1, -1, +1):
@@ -206,6 +207,15 @@ def test_outer_even_odd_solve_with_up_and_down_hierarchies(qa, oracle):
             print("outer even-odd MG-GCR flavour %+d: %d iterations (plain even-odd GCR %d), true residual %.2e" % (flavor, ip.iter, plain, res))
             assert res < 5e-10, (flavor, res)
             assert ip.iter * 3 < plain, (flavor, ip.iter, plain)
+        # the same hierarchies under a full-system outer solve (outer QUDA_MAT_SOLUTION / inner QUDA_MATPC_SOLUTION, lib/multigrid.cpp:513-560)
+        ip.solve_type = qa.QUDA_DIRECT_SOLVE
+        ip.twist_flavor = qa.QUDA_TWIST_PLUS
+        ip.preconditioner = ip.preconditionerUP
+        x = qa.invert(b, ip)
+        oracle.set_threads(8)
+        res = float(np.linalg.norm(b - oracle.tm_mat(gauge, x, list(X), kappa, mu, +1, 0)) / np.linalg.norm(b))
+        oracle.set_threads(1)
+        assert res < 5e-10 and ip.iter < 30, (res, ip.iter)
     finally:
         for h, _, _ in hier.values():
             h.free()
