@@ -68,9 +68,11 @@ void qudaAmdMultigridCycle(void *mg_instance, void *h_x, void *h_b, QudaInvertPa
  * (site, spin, colour, vector) (lib/transfer_util.cu:15-36); coarse links as QDP-ordered
  * Y[dim 0-3 backward | 4-7 forward][site][row][col] and X[site][row][col] (lib/dslash_coarse.cu:50-64) with the
  * operator's -kappa already multiplied into Y.  `level` names the finer of the two levels a transfer connects. */
-/* opt-in (not in the reference, whose MG is fp32 throughout): R, P and the coarse operators stream fp16 mirrors of the null
- * vector matrix V and of the coarse links; setup, verify and the accessors below keep the fp32 masters.  The switch is
- * process-wide; `on` also creates the mirrors of this hierarchy.  Env QUDA_AMD_MG_HALF=1 does the same at newMultigridQuda. */
+/* opt-in half-precision cycle: R, P and the coarse operators stream fp16 mirrors of the null-vector matrix V and of the
+ * coarse links, and the level-0 even-odd smoother iterates in 16-bit storage (work fields + a 16-bit copy of the links made
+ * on the device; twisted-mass / Wilson only).  Setup, verify, residuals, the accessors below and the outer solve keep their
+ * precision.  The V / link switch is process-wide; `on` also creates the mirrors of this hierarchy.  Env QUDA_AMD_MG_HALF=1
+ * does the same at newMultigridQuda. */
 void qudaAmdMultigridSetHalfStorage(void *mg_instance, int on);
 int qudaAmdMultigridLevels(void *mg_instance);
 void qudaAmdMultigridLevelInfo(void *mg_instance, int level, int info[18]); /* Xf[4] Xc[4] fineSpin fineColor Nvec geo_bs[4] spin_bs 0 0 */

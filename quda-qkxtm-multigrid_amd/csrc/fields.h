@@ -136,6 +136,7 @@ class GaugeField {
   ~GaugeField();
   // host QDP-order links (array of 4 pointers, even then odd, row-major 3x3; reference SURVEY section 9)
   void loadQDP(void *const h_gauge[4], QudaPrecision cpu_prec);
+  void copyFrom(const GaugeField &src);   // device copy with precision change (fp32 -> 16-bit), same reconstruct
   const void *block(int parity, int dir) const { return (const char *)data + ((size_t)parity * 8 + dir) * link_bytes; }
   const void *parityBase(int parity) const { return block(parity, 0); }
   double GiB() const { return bytes / (double)(1 << 30); }

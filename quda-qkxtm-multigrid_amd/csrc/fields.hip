@@ -501,6 +501,31 @@ void GaugeField::loadQDP(void *const h_gauge[4], QudaPrecision cpu_prec) {
 #undef QA_GL
 }
 
+// device-to-device copy of all 16 link blocks with precision change (same reconstruct): the 16-bit links of the multigrid's
+// half-precision smoother are made from the resident fp32 field, the host copy is not kept
+template <typename TOut, typename TIn, int R>
+__global__ void gauge_convert_kernel(char *out, size_t out_link_bytes, const char *in, size_t in_link_bytes, int stride, int Vh) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= 16 * Vh) return;
+  const int blk = gid / Vh, idx = gid - blk * Vh;
+  typename Store<TIn>::real u[R];
+  Planar<TIn, R>::load(u, in + (size_t)blk * in_link_bytes, stride, idx, nullptr, 0);
+  typename Store<TOut>::real v[R];
+#pragma unroll
+  for (int k = 0; k < R; k++) v[k] = (typename Store<TOut>::real)u[k];
+  Planar<TOut, R>::store(v, out + (size_t)blk * out_link_bytes, stride, idx, nullptr, 0);
+}
+void GaugeField::copyFrom(const GaugeField &src) {
+  if (!(src.geom == geom) || src.reconstruct != reconstruct) errorQuda("gauge copy: geometry / reconstruct mismatch");
+  if (src.precision != QUDA_SINGLE_PRECISION || precision != QUDA_HALF_PRECISION) errorQuda("gauge copy: fp32 -> 16-bit only");
+  const int bs = 256, nb = (16 * geom.Vh + bs - 1) / bs;
+  if (reconstruct == QUDA_RECONSTRUCT_12)
+    hipLaunchKernelGGL((gauge_convert_kernel<short, float, 12>), dim3(nb), dim3(bs), 0, computeStream(), (char *)data, link_bytes, (const char *)src.data, src.link_bytes, stride, geom.Vh);
+  else
+    hipLaunchKernelGGL((gauge_convert_kernel<short, float, 18>), dim3(nb), dim3(bs), 0, computeStream(), (char *)data, link_bytes, (const char *)src.data, src.link_bytes, stride, geom.Vh);
+  HIP_CHECK(hipGetLastError());
+}
+
 // ================================================================================================
 // CloverField
 // ================================================================================================

@@ -444,6 +444,16 @@ void MG::operator()(ColorSpinorField &x, ColorSpinorField &b) {
   blas::setGlobalReduction(true);
 }
 
+void MG::setSmootherSloppy(DiracMatrix *sloppy) {
+  if (mgp.level != 0 || mgp.level == mgp.Nlevel - 1) return;
+  delete presmoother; delete postsmoother;
+  const QudaPrecision sp = sloppy ? QUDA_HALF_PRECISION : QUDA_SINGLE_PRECISION;
+  param_presmooth->precision_sloppy = param_postsmooth->precision_sloppy = sp;
+  DiracMatrix &ms = sloppy ? *sloppy : mgp.matSmooth;
+  presmoother = Solver::create(*param_presmooth, mgp.matSmooth, ms, ms);
+  postsmoother = Solver::create(*param_postsmooth, mgp.matSmooth, ms, ms);
+}
+
 void MG::makeHalfMirrors() {
   if (transfer) transfer->makeHalf();
   if (diracCoarse) diracCoarse->Links().makeHalf();
@@ -496,7 +506,8 @@ void MG::verify(double dev[3]) {
 
 // ================================================================================================
 // reference multigrid_solver ctor, lib/interface_quda.cpp:2161-2255
-multigrid_solver::multigrid_solver(QudaMultigridParam &mg_param) : d(nullptr), m(nullptr), dSmooth(nullptr), mSmooth(nullptr), mgParam(nullptr), mg(nullptr) {
+multigrid_solver::multigrid_solver(QudaMultigridParam &mg_param)
+    : d(nullptr), m(nullptr), dSmooth(nullptr), mSmooth(nullptr), gaugeHalf(nullptr), dSmoothHalf(nullptr), mSmoothHalf(nullptr), mgParam(nullptr), mg(nullptr) {
   QudaInvertParam *param = mg_param.invert_param;
   if (!param) errorQuda("QudaMultigridParam.invert_param is NULL");
   if (mg_param.n_level < 2 || mg_param.n_level > QUDA_MAX_MG_LEVEL) errorQuda("Requested MG levels %d outside 2..%d", mg_param.n_level, QUDA_MAX_MG_LEVEL);
@@ -543,16 +554,37 @@ multigrid_solver::multigrid_solver(QudaMultigridParam &mg_param) : d(nullptr), m
   mgParam = new MGParam(mg_param, B, *m, mSmooth ? *mSmooth : *m, 0, param->twist_flavor);
   mg = new MG(*mgParam);
   if (mg_param.run_verify == QUDA_BOOLEAN_YES) { double dev[3]; mg->verify(dev); }
-  { const char *e = getenv("QUDA_AMD_MG_HALF"); if (e && atoi(e)) multigridSetHalfStorage(*this, true); }
-  mg_param.secs = now() - t0;
   mg_param_copy = mg_param;
   inv_param_copy = *param;
+  { const char *e = getenv("QUDA_AMD_MG_HALF"); if (e && atoi(e)) multigridSetHalfStorage(*this, true); }
+  mg_param.secs = now() - t0;
 }
 
 void multigridSetHalfStorage(multigrid_solver &mgs, bool on) {
   if (on) {
     mgs.mg->makeHalfMirrors();
+    // 16-bit level-0 smoother (the work fields and the operator of the MR iterations; source and result stay fp32): only
+    // with the even-odd smoother of the twisted-mass / Wilson operators (a 16-bit clover copy is not made)
+    QudaInvertParam *param = &mgs.inv_param_copy;
+    if (mgs.mSmooth && !mgs.mSmoothHalf && param->dslash_type != QUDA_TWISTED_CLOVER_DSLASH) {
+      GaugeField *g = gaugePrecondition ? gaugePrecondition : (gaugeSloppy ? gaugeSloppy : gaugePrecise);
+      mgs.gaugeHalf = new GaugeField(g->geom, QUDA_HALF_PRECISION, g->reconstruct, g->t_boundary, g->anisotropy);
+      mgs.gaugeHalf->copyFrom(*g);
+      const double orig_mu = param->mu, orig_kappa = param->kappa, orig_mass = param->mass;
+      param->kappa *= mgs.mg_param_copy.delta_kappaPR;
+      param->mu *= mgs.mg_param_copy.delta_muPR;
+      param->mass = 0.5 / param->kappa - 4.0;
+      DiracParam dps;
+      setDiracPreParam(dps, param, true);
+      dps.gauge = mgs.gaugeHalf;
+      mgs.dSmoothHalf = Dirac::create(dps);
+      mgs.mSmoothHalf = new DiracM(*mgs.dSmoothHalf);
+      param->kappa = orig_kappa; param->mu = orig_mu; param->mass = orig_mass;
+    }
+    if (mgs.mSmoothHalf) mgs.mg->setSmootherSloppy(mgs.mSmoothHalf);
     HIP_CHECK(hipStreamSynchronize(computeStream()));
+  } else {
+    mgs.mg->setSmootherSloppy(nullptr);
   }
   setCoarseHalfStorage(on);
 }
@@ -562,6 +594,9 @@ multigrid_solver::~multigrid_solver() {
   delete mg;
   delete mgParam;
   for (ColorSpinorField *f : B) delete f;
+  delete mSmoothHalf;
+  delete dSmoothHalf;
+  delete gaugeHalf;
   delete mSmooth;
   delete dSmooth;
   delete m;

@@ -71,6 +71,8 @@ class MG : public Solver {
   MG *getCoarse() const { return coarse; }
   // fp16 mirrors of V and of the coarse links (plain and preconditioned) on every level below this one
   void makeHalfMirrors();
+  // level-0 smoothers re-created with `sloppy` as their inner (MR work-field) operator in its precision; nullptr: back to fp32
+  void setSmootherSloppy(DiracMatrix *sloppy);
   const std::vector<ColorSpinorField *> &nullVectors() const { return mgp.B; }
   DiracMatrix &residualMatrix() const { return mgp.matResidual; }
 };
@@ -81,6 +83,9 @@ struct multigrid_solver {
   DiracM *m;
   Dirac *dSmooth; // level-0 smoother operator (== d, or its even-odd preconditioned form)
   DiracM *mSmooth;
+  GaugeField *gaugeHalf;   // 16-bit copy of the links for the half-precision smoother (multigridSetHalfStorage), owned
+  Dirac *dSmoothHalf;
+  DiracM *mSmoothHalf;
   std::vector<ColorSpinorField *> B;
   MGParam *mgParam;
   MG *mg;
