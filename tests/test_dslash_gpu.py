@@ -310,3 +310,20 @@ def test_error_convention(case, message):
     assert r.returncode == 1, (r.returncode, out[-1500:])
     assert "ERROR:" in out and message in out and "NOT REACHED" not in out, out[-1500:]
     assert "csrc/" in out and " in " in out   # file:line in func()
+
+
+def test_missing_neighbour_face_is_an_error_not_a_hang():
+    """Peer-store transport: the in-kernel wait for a neighbour's face has a wall-clock timeout.  Two processes on this GPU;
+    rank 1 leaves after the first exchange, rank 0 applies the operator again and must abort with the time-out message."""
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory(dir="/dev/shm") as shm:
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29811", WORLD_SIZE="2", QUDA_AMD_FORCE_DEVICE="0", QUDA_AMD_TRANSPORT="shm",
+                   QUDA_AMD_SHM_DIR=shm, QUDA_AMD_P2P_TIMEOUT_S="1")
+        procs = [subprocess.Popen([sys.executable, os.path.join(root, "tools", "p2p_timeout_check.py")], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+        outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert "transport 1" in outs[0], outs[0][-1500:]
+    assert procs[0].returncode == 1 and "a halo wait timed out" in outs[0] and "NOT REACHED" not in outs[0], outs[0][-1500:]
