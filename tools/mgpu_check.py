@@ -23,6 +23,10 @@ def main():
     qa = importlib.import_module("quda-qkxtm-multigrid_amd")
     oracle = oracle_api.load()
     cases = [([8, 8, 8, 16], None)]
+    if world == 3:   # three ranks along t: the +t and -t neighbours are DIFFERENT ranks (never the case with two per dimension)
+        cases = [([8, 8, 8, 24], [1, 1, 1, 3]), ([8, 12, 8, 8], [1, 3, 1, 1])]
+    if world == 6:
+        cases = [([8, 8, 8, 24], [1, 1, 2, 3])]
     if world == 2:
         cases += [([8, 4, 8, 8], [1, 1, 2, 1]), ([4, 8, 8, 8], [2, 1, 1, 1])]
     for X, grid in cases:
