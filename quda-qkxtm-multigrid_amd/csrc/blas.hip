@@ -10,9 +10,12 @@
 // stream synchronisation (the memset/copy pair cost ~7 us per reduction and 35 ms of the 16^4 MG setup+solve profile).
 // fp64/fp32 fields of any spin/colour are treated as flat arrays (complex pairs stay adjacent in the
 // FLOAT2/FLOAT4 planar orders); 16-bit fields go site by site because of their per-site scale.
+#include <cstring>
 #include "blas.h"
 
 #include "device_io.h"
+#include "halo.h"
+#include "p2p.h"
 
 namespace quda {
 namespace blas {
@@ -26,6 +29,129 @@ static double *h_red_dev = nullptr;  // device address of h_red
 static double *d_part = nullptr;  // per-block partial sums
 static unsigned *d_count = nullptr;  // completion counter (zero between launches)
 constexpr int kMaxBlocks = 4096;
+constexpr int kSlotDoubles = 8;   // doubles per (buffer, rank) slot of the all-reduce window
+
+// Block-level all-reduce over ranks through the peer windows (called by ONE block per rank, all threads of it).  Thread r
+// delivers this rank's nred sums to rank r with system-scope write-through stores followed by a fire-and-forget counter
+// bump; thread 0 then waits until every rank's contribution has arrived in the own window (bounded by waitTicks: a
+// missing rank sets *errWord = 33 instead of hanging), and thread k < nred returns sum_r slot[r][k], added in rank order
+// on every rank, so all ranks hold bit-identical results.
+template <int NRED>
+__device__ __forceinline__ double peer_allreduce(const double *mine, double *const *peerSlots, unsigned *const *peerCount, int nranks, int rank, int buf,
+                                                 unsigned expect, unsigned long long waitTicks, int *errWord) {
+  if ((int)threadIdx.x < nranks) {
+    double *slot = peerSlots[threadIdx.x] + ((size_t)buf * nranks + rank) * kSlotDoubles;
+    for (int k = 0; k < NRED; k++)
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot + k), __builtin_bit_cast(unsigned long long, mine[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    (void)__hip_atomic_fetch_add(peerCount[threadIdx.x] + buf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (threadIdx.x == 0 && !__hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+    const unsigned long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(peerCount[rank] + buf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - expect) < 0) {
+      if (wall_clock64() - t0 > waitTicks) { __hip_atomic_store(errWord, 33, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  double v = 0;
+  if (threadIdx.x < NRED) {
+    const double *slots = peerSlots[rank] + (size_t)buf * nranks * kSlotDoubles;
+    for (int r = 0; r < nranks; r++)
+      v += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(slots + (size_t)r * kSlotDoubles + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+  }
+  return v;
+}
+
+// start-up probe: one all-reduce of known values per round; result[0] = 1 if every sum came out right and in time
+__global__ void allreduce_probe_kernel(double *const *peerSlots, unsigned *const *peerCount, int nranks, int rank, int buf, unsigned expect,
+                                       unsigned long long waitTicks, int round, int *result) {
+  __shared__ double mine[kSlotDoubles];
+  __shared__ int err;
+  if (threadIdx.x == 0) err = 0;
+  if (threadIdx.x < kSlotDoubles) mine[threadIdx.x] = (double)((rank + 1) * (round + 1) + 1000 * (int)threadIdx.x);
+  __syncthreads();
+  const double v = peer_allreduce<kSlotDoubles>(mine, peerSlots, peerCount, nranks, rank, buf, expect, waitTicks, &err);
+  bool ok = true;
+  if (threadIdx.x < kSlotDoubles) ok = v == (double)((round + 1) * (nranks * (nranks + 1) / 2) + 1000 * (int)threadIdx.x * nranks);
+  const int allOk = __syncthreads_and(ok);
+  if (threadIdx.x == 0) result[0] = allOk && !err;
+}
+
+// ---- all-reduce window: [2 buffers][ranks][kSlotDoubles] doubles + 2 counters, fine-grained, mapped into every rank ----
+struct ReduceWindow {
+  char *window = nullptr;
+  double **d_slots = nullptr;      // device tables [rank]
+  unsigned **d_counts = nullptr;
+  std::vector<void *> opened;
+  unsigned long seq = 0;
+  unsigned uses[2] = {0, 0};
+  int state = -1;                  // -1 not decided, 0 unavailable (RCCL all-reduce), 1 active
+};
+static ReduceWindow g_rw;
+
+static void releaseReduceWindow() {
+  if (g_rw.window) {
+    HIP_CHECK(hipDeviceSynchronize());
+    commBarrier();
+    for (void *p : g_rw.opened) (void)hipIpcCloseMemHandle(p);
+    commBarrier();
+    p2pFree(g_rw.window);
+    (void)hipFree(g_rw.d_slots);
+    (void)hipFree(g_rw.d_counts);
+  }
+  g_rw = ReduceWindow();
+}
+
+// collective (first global reduction of a multi-rank run)
+static bool reduceWindowActive() {
+  if (g_rw.state >= 0) return g_rw.state == 1;
+  const CommGrid &g = commGrid();
+  g_rw.state = 0;
+  // QUDA_AMD_ALLREDUCE=rccl keeps global sums on the collective library; default: peer stores wherever the halo uses them
+  const char *e = getenv("QUDA_AMD_ALLREDUCE");
+  if (e && !strcmp(e, "rccl")) return false;
+  if (e && strcmp(e, "p2p")) errorQuda("QUDA_AMD_ALLREDUCE=%s: expected rccl or p2p", e);
+  if (g.size < 2 || g.size > 64 || !p2pHaloEnabled()) return false;
+  const size_t slotBytes = (size_t)2 * g.size * kSlotDoubles * sizeof(double);
+  g_rw.window = (char *)p2pAlloc(slotBytes + 256);
+  std::vector<void *> byRank;
+  if (!commMapAllRanks(g_rw.window, byRank, g_rw.opened)) { p2pFree(g_rw.window); g_rw.window = nullptr; return false; }
+  std::vector<double *> hs(g.size);
+  std::vector<unsigned *> hc(g.size);
+  for (int r = 0; r < g.size; r++) { hs[r] = (double *)byRank[r]; hc[r] = (unsigned *)((char *)byRank[r] + slotBytes); }
+  HIP_CHECK(hipMalloc((void **)&g_rw.d_slots, g.size * sizeof(double *)));
+  HIP_CHECK(hipMalloc((void **)&g_rw.d_counts, g.size * sizeof(unsigned *)));
+  HIP_CHECK(hipMemcpy(g_rw.d_slots, hs.data(), g.size * sizeof(double *), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(g_rw.d_counts, hc.data(), g.size * sizeof(unsigned *), hipMemcpyHostToDevice));
+  HIP_CHECK(hipDeviceSynchronize());
+  commBarrier();
+  // probe: three all-reduces of known values with the production kernel code; any rank that sees a wrong sum or a
+  // timeout vetoes, and then every rank drops back to the RCCL all-reduce
+  int *d_res = nullptr;
+  HIP_CHECK(hipMalloc((void **)&d_res, sizeof(int)));
+  double fail = 0;
+  for (int round = 0; round < 3; round++) {
+    const int buf = (int)(++g_rw.seq & 1);
+    const unsigned expect = (g_rw.uses[buf] += (unsigned)g.size);
+    hipLaunchKernelGGL(allreduce_probe_kernel, dim3(1), dim3(64), 0, computeStream(), (double *const *)g_rw.d_slots, (unsigned *const *)g_rw.d_counts, g.size, g.rank,
+                       buf, expect, (unsigned long long)3e8, round, d_res);
+    int res = 0;
+    HIP_CHECK(hipMemcpyAsync(&res, d_res, sizeof(int), hipMemcpyDeviceToHost, computeStream()));
+    HIP_CHECK(hipStreamSynchronize(computeStream()));
+    if (!res) fail = 1;
+  }
+  (void)hipFree(d_res);
+  comm_allreduce(&fail, 1);
+  if (fail != 0) {
+    if (g.rank == 0) warningQuda("peer-store all-reduce probe failed on some rank: global sums use the collective library");
+    releaseReduceWindow();
+    g_rw.state = 0;
+    return false;
+  }
+  g_rw.state = 1;
+  return true;
+}
 static bool g_global_reduction = true;
 constexpr int kMaxRed = 64;
 
@@ -43,6 +169,7 @@ void init() {
   }
 }
 void end() {
+  releaseReduceWindow();
   if (d_red) (void)hipFree(d_red);
   if (h_red) (void)hipHostFree(h_red);
   if (d_part) (void)hipFree(d_part);
@@ -67,6 +194,15 @@ template <typename F> struct BlasArg {
   double *hred;      // pinned host result (nullptr: an all-reduce follows, the host reads the device word afterwards)
   double *part;      // [block][nred] partial sums
   unsigned *count;   // completion counter
+  // all-reduce through peer-mapped windows (p2p.h), done by the last block: every rank stores its sums into slot [buf][rank]
+  // of every rank's window, bumps that rank's counter, waits for its own counter and adds the slots in rank order —
+  // bit-identical on all ranks, no collective-library launch, no device-to-host copy
+  double *const *peerSlots;     // [rank] -> that rank's window (nullptr table: no peer all-reduce)
+  unsigned *const *peerCount;   // [rank] -> that rank's counters
+  int nranks, rank, buf;
+  unsigned expect;
+  unsigned long long waitTicks;
+  int *errWord;
 };
 
 template <typename real, int M> struct alignas(16) Chunk { real v[M]; };
@@ -255,7 +391,21 @@ __global__ void __launch_bounds__(256) blas_kernel(BlasArg<F> arg) {
         if (lane == 0) lds[wave][k] = v;
       }
       __syncthreads();
-      if (threadIdx.x < F::nred) {
+      if (arg.peerSlots) {
+        constexpr int NR = F::nred > 0 ? F::nred : 1;
+        __shared__ double mine[NR];
+        if (threadIdx.x < F::nred) {
+          double v = 0;
+          for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) v += lds[wv][threadIdx.x];
+          mine[threadIdx.x] = v;
+        }
+        __syncthreads();
+        const double v = peer_allreduce<F::nred>(mine, arg.peerSlots, arg.peerCount, arg.nranks, arg.rank, arg.buf, arg.expect, arg.waitTicks, arg.errWord);
+        if (threadIdx.x < F::nred) {
+          arg.red[threadIdx.x] = v;
+          __hip_atomic_store(&arg.hred[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      } else if (threadIdx.x < F::nred) {
         double v = 0;
         for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) v += lds[wv][threadIdx.x];
         arg.red[threadIdx.x] = v;
@@ -302,8 +452,20 @@ static void launch(const F &f, const ColorSpinorField &x, const ColorSpinorField
   arg.red = d_red;
   arg.part = d_part;
   arg.count = d_count;
-  const bool allreduce = g_global_reduction && commReductionsNeeded();
+  bool allreduce = g_global_reduction && commReductionsNeeded();
   arg.hred = allreduce ? nullptr : h_red_dev;
+  arg.peerSlots = nullptr; arg.peerCount = nullptr; arg.nranks = 1; arg.rank = 0; arg.buf = 0; arg.expect = 0; arg.waitTicks = 0; arg.errWord = nullptr;
+  if (allreduce && F::nred > 0 && F::nred <= kSlotDoubles && reduceWindowActive()) {
+    // the last block of the kernel does the all-reduce itself through the peer windows and writes the global sums to the host
+    const CommGrid &cg = commGrid();
+    arg.peerSlots = g_rw.d_slots; arg.peerCount = g_rw.d_counts;
+    arg.nranks = cg.size; arg.rank = cg.rank;
+    arg.buf = (int)(++g_rw.seq & 1);
+    arg.expect = (g_rw.uses[arg.buf] += (unsigned)cg.size);
+    arg.waitTicks = p2pTimeoutTicks(); arg.errWord = p2pErrorWord();
+    arg.hred = h_red_dev;
+    allreduce = false;
+  }
   hipStream_t s = computeStream();
   const long nreal = (long)x.Stride() * x.Nspin() * x.Ncolor() * 2;
   const int bs = 256;

@@ -25,6 +25,8 @@ struct PeerMap {
 bool commMapPeers(void *local, PeerMap &m);
 void commUnmapPeers(PeerMap &m);
 void commAllgatherBytes(const void *mine, void *all, size_t n);
+// the same for EVERY rank (all-reduce windows): byRank[r] = rank r's allocation mapped here (own pointer for r = rank)
+bool commMapAllRanks(void *local, std::vector<void *> &byRank, std::vector<void *> &opened);
 
 // Decided once, collectively, at the first halo exchange: QUDA_AMD_HALO=rccl forces the staged transport; otherwise the
 // windows are mapped and a token round trip through them must succeed on every rank.

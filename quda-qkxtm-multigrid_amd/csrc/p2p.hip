@@ -47,6 +47,36 @@ bool commMapPeers(void *local, PeerMap &m) {
   if (fail > 0) { commUnmapPeers(m); return false; }
   return true;
 }
+bool commMapAllRanks(void *local, std::vector<void *> &byRank, std::vector<void *> &opened) {
+  const CommGrid &g = commGrid();
+  byRank.assign(g.size, nullptr);
+  opened.clear();
+  byRank[g.rank] = local;
+  if (g.size == 1) return true;
+  double fail = 0;
+  hipIpcMemHandle_t mine;
+  memset(&mine, 0, sizeof(mine));
+  if (hipIpcGetMemHandle(&mine, local) != hipSuccess) { (void)hipGetLastError(); fail = 1; }
+  std::vector<hipIpcMemHandle_t> all(g.size);
+  commAllgatherBytes(&mine, all.data(), sizeof(mine));
+  comm_allreduce(&fail, 1);
+  if (fail > 0) return false;
+  for (int r = 0; r < g.size && fail == 0; r++) {
+    if (r == g.rank) continue;
+    void *p = nullptr;
+    if (hipIpcOpenMemHandle(&p, all[r], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); fail = 1; break; }
+    byRank[r] = p;
+    opened.push_back(p);
+  }
+  comm_allreduce(&fail, 1);
+  if (fail > 0) {
+    for (void *p : opened) (void)hipIpcCloseMemHandle(p);
+    opened.clear();
+    return false;
+  }
+  return true;
+}
+
 void commUnmapPeers(PeerMap &m) {
   for (void *p : m.opened) (void)hipIpcCloseMemHandle(p);
   m.opened.clear();

@@ -4,6 +4,7 @@ Started once per rank by tools/mgpu_rehearsal.sh (env RANK/WORLD_SIZE/...); ever
 fields, cuts out its sub-lattice (multi_gpu.py), runs the library on it and compares with the oracle's GLOBAL result
 restricted to its sub-lattice."""
 import ctypes as C
+import faulthandler
 import importlib
 import os
 import sys
@@ -18,6 +19,7 @@ import oracle_api  # noqa: E402
 
 
 def main():
+    faulthandler.enable()   # a crash in one rank otherwise leaves an empty log and a timeout in the others
     world = int(sys.argv[1])
     rank = int(os.environ["RANK"])
     qa = importlib.import_module("quda-qkxtm-multigrid_amd")

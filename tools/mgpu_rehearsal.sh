@@ -7,12 +7,12 @@ export MASTER_ADDR=127.0.0.1 MASTER_PORT=29611 WORLD_SIZE=$N QUDA_AMD_FORCE_DEVI
 export QUDA_AMD_TRANSPORT=shm QUDA_AMD_SHM_DIR=$(mktemp -d /dev/shm/quda_amd_XXXXXX)
 pids=()
 for r in $(seq 0 $((N-1))); do
-  RANK=$r LOCAL_RANK=$r timeout -k 5 120 python3 tools/mgpu_check.py $N > ${LOG}.rank$r 2>&1 &
+  RANK=$r LOCAL_RANK=$r timeout -k 5 150 python3 -u tools/mgpu_check.py $N > ${LOG}.rank$r 2>&1 &
   pids+=($!)
 done
 rc=0
 for p in "${pids[@]}"; do wait $p || rc=$?; done
-cat ${LOG}.rank* > $LOG
+for r in $(seq 0 $((N-1))); do echo "--- rank $r ---"; cat ${LOG}.rank$r; done > $LOG
 echo "rehearsal rc=$rc" >> $LOG
 rm -rf $QUDA_AMD_SHM_DIR
 exit 0
