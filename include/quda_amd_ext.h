@@ -82,6 +82,30 @@ void qudaAmdMultigridGetCoarseLinks(void *mg_instance, int level, float *h_Y, fl
 /* op 0: R (level -> level+1; lib/restrictor.cu), 1: P (level+1 -> level; lib/prolongator.cu), 2: M of `level` */
 void qudaAmdMultigridApply(void *mg_instance, int level, int op, float *h_out, const float *h_in);
 
+/* ---- the solve loop of the QKXTM correlator drivers ----
+ * calcMG_threepTwop_EvenOdd / calcMG_loop_wOneD_TSM_* (lib/interface_quda.cpp:6018-6531, :7093, :8535) open with the same
+ * loop: for every spin-colour component of a point source, Gaussian-smear it with the APE-smeared links, solve for the up
+ * quark (twist +, inv_param->preconditionerUP) and the down quark (twist -, preconditionerDN) with even-odd preconditioned
+ * GCR, reconstruct, rescale by 2 kappa under mass normalisation.  The reference then contracts and writes HDF5 (out of
+ * scope); these entry points hand the propagators back instead.
+ * Host layouts are the QKXTM ones: sites lexicographic x fastest (LOCAL lattice of the calling rank), vectors
+ * iv*24 + (spin*3 + colour)*2 + re/im in the UKQCD basis (lib/qudaQKXTM_Vector_Kepler.cpp:72-81), smearing links
+ * gauge_APE[dir][iv*18 + (row*3 + col)*2 + re/im] (lib/qudaQKXTM_Gauge_Kepler.cpp:73-89, what mapEvenOddToNormalGauge
+ * leaves in the driver, qkxtm/CalcMG_2pt3pt_EvenOdd.cpp:684-686); fp64. */
+typedef struct QudaAmdSourceParam_s {
+  int sourcePosition[4];   /* GLOBAL (x, y, z, t): qudaQKXTMinfo_Kepler::sourcePosition[i] (include/qudaQKXTM_Kepler_utils.h:51) */
+  int nsmearGauss;         /* qudaQKXTMinfo_Kepler::nsmearGauss (:46); 0: point source, gauge_APE may be NULL */
+  double alphaGauss;       /* qudaQKXTMinfo_Kepler::alphaGauss (:48) */
+} QudaAmdSourceParam;
+/* h_out = smear^nsmear(h_in) (QKXTM_Vector_Kepler::gaussianSmearing, lib/qudaQKXTM_Vector_Kepler.cpp:386-421); the lattice is
+ * that of the resident gauge field */
+void qudaAmdGaussianSmear(void *h_out, const void *h_in, void **gauge_APE, int nsmear, double alpha);
+/* h_prop_up / h_prop_dn: 12 vectors each (index isc = spin*3 + colour of the source, as the reference's loop), V*24 doubles per
+ * vector.  inv_param as the reference requires it (:6041-6054): QUDA_DIRECT_PC_SOLVE, QUDA_GCR_INVERTER, UKQCD basis,
+ * QUDA_DIRAC_ORDER, symmetric even-even / odd-odd preconditioning, QUDA_MAT_SOLUTION; iter / secs / gflops are summed over
+ * the 24 solves; twist_flavor and preconditioner are left at their last values (minus / DN), as in the reference. */
+void qudaAmdCalcMGPropagators(void *h_prop_up, void *h_prop_dn, void **gauge_APE, QudaInvertParam *inv_param, const QudaAmdSourceParam *source);
+
 /* RCCL bootstrap (the transport that replaces the reference's MPI layer, lib/comm_mpi.cpp:50-155): rank 0 obtains a
  * 128-byte id, the launcher broadcasts it out of band, every rank calls qudaAmdCommInit BEFORE initCommsGridQuda / initQuda. */
 void qudaAmdCommGetUniqueId(void *out128);

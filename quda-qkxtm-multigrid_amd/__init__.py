@@ -122,6 +122,11 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
 _lib = None
 
 
+class QudaAmdSourceParam(C.Structure):
+    """include/quda_amd_ext.h: the source description of the QKXTM solve loop"""
+    _fields_ = [("sourcePosition", C.c_int * 4), ("nsmearGauss", C.c_int), ("alphaGauss", C.c_double)]
+
+
 def lib():
     """The loaded libquda.so; raises if the HIP extension has not been built (no fallback)."""
     global _lib
@@ -186,6 +191,8 @@ def lib():
         L.qudaAmdMultigridGetV.argtypes = [_p, _i, _p]
         L.qudaAmdMultigridGetCoarseLinks.argtypes = [_p, _i, _p, _p]
         L.qudaAmdMultigridApply.argtypes = [_p, _i, _i, _p, _p]
+        L.qudaAmdGaussianSmear.argtypes = [_p, _p, C.POINTER(_p), _i, _d]
+        L.qudaAmdCalcMGPropagators.argtypes = [_p, _p, C.POINTER(_p), C.POINTER(QudaInvertParam), C.POINTER(QudaAmdSourceParam)]
         _lib = L
     return _lib
 
@@ -304,6 +311,35 @@ def invert(h_b, ip):
     x = np.zeros_like(h_b)
     lib().invertQuda(_vp(x), _vp(h_b), C.byref(ip))
     return x
+
+
+def _lex_links(gauge_lex):
+    if gauge_lex is None:
+        return None, None
+    keep = [np.ascontiguousarray(gauge_lex[d], dtype=np.float64) for d in range(4)]
+    return keep, (_p * 4)(*[_vp(a) for a in keep])
+
+
+def gaussian_smear(vec_lex, gauge_lex, nsmear, alpha):
+    """QKXTM_Vector_Kepler::gaussianSmearing on a lexicographic UKQCD host vector (local lattice of the resident gauge field)"""
+    vec_lex = np.ascontiguousarray(vec_lex, dtype=np.float64)
+    out = np.empty_like(vec_lex)
+    keep, links = _lex_links(gauge_lex)
+    lib().qudaAmdGaussianSmear(_vp(out), _vp(vec_lex), links, int(nsmear), float(alpha))
+    return out
+
+
+def calc_mg_propagators(gauge_lex, ip, source_position, nsmear, alpha, local_volume):
+    """the solve loop of calcMG_threepTwop_EvenOdd: returns (prop_up, prop_dn), each (12, V*24) lexicographic UKQCD vectors"""
+    sp = QudaAmdSourceParam()
+    for k in range(4):
+        sp.sourcePosition[k] = int(source_position[k])
+    sp.nsmearGauss, sp.alphaGauss = int(nsmear), float(alpha)
+    up = np.zeros((12, int(local_volume) * 24))
+    dn = np.zeros((12, int(local_volume) * 24))
+    keep, links = _lex_links(gauge_lex)
+    lib().qudaAmdCalcMGPropagators(_vp(up), _vp(dn), links, C.byref(ip), C.byref(sp))
+    return up, dn
 
 
 class Spinor:

@@ -36,6 +36,10 @@ void applyDslash(ColorSpinorField &out, const ColorSpinorField &in, const GaugeF
 // one direction of the stencil only: out(parity) = coef * U P psi(x + dhat(dir)), dir = 2 mu + (0 fwd, 1 bwd), no dagger
 // (building block of the Galerkin coarse-operator construction)
 void applyHopDir(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, int parity, int dir, double coef);
+// the same hop WITHOUT spin projection, optionally accumulated: out(parity) = xcoef x + coef U psi(x + dhat(dir)); x may be
+// nullptr or the output field itself (building block of the Gaussian source smearing, qkxtm.hip)
+void applyCovariantShift(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, int parity, int dir, double coef,
+                         const ColorSpinorField *x, double xcoef);
 // out(x) = in(x + dhat(dir)) for a 24-real fp64 planar site field (out: parity block `parity`, in: the other parity's block), ghost-aware
 void applyShift(double *out, const double *in, const LatticeGeom &g, int stride, int parity, int dir);
 

@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
 // ---- single-direction hop (setup-time helper for the multigrid coarse-operator construction) ----
 template <typename T, int R>
 __global__ void __launch_bounds__(256) hop_dir_kernel(const DslashArg<typename Store<T>::real> arg, int dir, typename Store<T>::real coef,
-                                                      const void *ghost, int ghostFaceCB) {
+                                                      const void *ghost, int ghostFaceCB, int plain) {
   using real = typename Store<T>::real;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= arg.Vh) return;
@@ -532,6 +532,12 @@ __global__ void __launch_bounds__(256) hop_dir_kernel(const DslashArg<typename S
   if (cross) Planar<T, 24>::load(psi, ghost, ghostFaceCB, f, nullptr, f);
   else Planar<T, 24>::load(psi, arg.in, arg.sp_stride, nbr, arg.inNorm, nbr);
   Link<T, R>::load(U, arg.gauge + (size_t)dir * arg.link_bytes, arg.g_stride, idx, sign);
+  if (plain) {
+    // covariant shift without spin projection: acc = U psi on all four spins (the links of the backward directions are
+    // stored daggered, so this is U_mu(x - mu)^dagger psi(x - mu) there)
+#pragma unroll
+    for (int sp = 0; sp < 4; sp++) su3_mv(acc + 6 * sp, U, psi + 6 * sp);
+  } else
   switch (dir) {
     case 0: hop_compute<T, 0, false, 0>(acc, psi, U, arg); break;
     case 1: hop_compute<T, 1, false, 0>(acc, psi, U, arg); break;
@@ -542,8 +548,15 @@ __global__ void __launch_bounds__(256) hop_dir_kernel(const DslashArg<typename S
     case 6: hop_compute<T, 6, false, 0>(acc, psi, U, arg); break;
     default: hop_compute<T, 7, false, 0>(acc, psi, U, arg); break;
   }
+  if (arg.xpay) {   // out = k x + coef hop (x may be the output field itself: every thread reads its site before it writes it)
+    real xs[24];
+    Planar<T, 24>::load(xs, arg.x, arg.sp_stride, idx, arg.xNorm, idx);
 #pragma unroll
-  for (int k = 0; k < 24; k++) acc[k] *= coef;
+    for (int k = 0; k < 24; k++) acc[k] = arg.k * xs[k] + coef * acc[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 24; k++) acc[k] *= coef;
+  }
   Planar<T, 24>::store(acc, arg.out, arg.sp_stride, idx, arg.outNorm, idx);
 }
 
@@ -970,7 +983,8 @@ void freeFullFaceBuffers() {
   g_ffSend = g_ffGhost = nullptr; g_ffBytes = 0;
 }
 
-template <typename T, int R> static void launchHopDir(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, int parity, int dir, double coef) {
+template <typename T, int R> static void launchHopDir(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, int parity, int dir, double coef,
+                                                      bool plain = false, const ColorSpinorField *x = nullptr, double xcoef = 0) {
   using real = typename Store<T>::real;
   DslashArg<real> arg;
   memset(&arg, 0, sizeof(arg));
@@ -983,6 +997,7 @@ template <typename T, int R> static void launchHopDir(ColorSpinorField &out, con
   arg.Vh = g.Vh; arg.Xh = g.Xh; arg.Y = g.X[1]; arg.Z = g.X[2]; arg.T = g.X[3];
   arg.dXh = g.dXh; arg.dY = g.dY; arg.dZ = g.dZ;
   arg.parity = parity; arg.sfwd = 1;
+  if (x) { arg.x = x->V(); arg.xNorm = (const float *)x->Norm(); arg.xpay = 1; arg.k = (real)xcoef; }
   const bool first_t = commGrid().coords[3] == 0, last_t = commGrid().coords[3] == commGrid().dims[3] - 1;
   arg.tsign_fwd = (R == 12 && U.t_boundary == QUDA_ANTI_PERIODIC_T && last_t) ? -1 : 1;
   arg.tsign_bwd = (R == 12 && U.t_boundary == QUDA_ANTI_PERIODIC_T && first_t) ? -1 : 1;
@@ -1007,8 +1022,23 @@ template <typename T, int R> static void launchHopDir(ColorSpinorField &out, con
     commExchange(msgs, computeStream());
     ghost = g_ffGhost;
   }
-  hipLaunchKernelGGL((hop_dir_kernel<T, R>), dim3((g.Vh + 255) / 256), dim3(256), 0, computeStream(), arg, dir, (real)coef, ghost, g.faceCB[mu]);
+  hipLaunchKernelGGL((hop_dir_kernel<T, R>), dim3((g.Vh + 255) / 256), dim3(256), 0, computeStream(), arg, dir, (real)coef, ghost, g.faceCB[mu], plain ? 1 : 0);
   HIP_CHECK(hipGetLastError());
+}
+
+// out(parity) = xcoef x + coef U_dir psi(x + dhat(dir)) with NO spin projection (x may be nullptr or alias out); ghost-aware
+void applyCovariantShift(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, int parity, int dir, double coef,
+                         const ColorSpinorField *x, double xcoef) {
+  if (in.Precision() != out.Precision() || in.Precision() != U.precision) errorQuda("precision mismatch");
+  if (in.VolumeCB() != U.geom.Vh || out.VolumeCB() != U.geom.Vh) errorQuda("volume mismatch");
+  if (x && (x->Precision() != out.Precision() || x->Stride() != out.Stride())) errorQuda("accumulation field does not match the output");
+  if (in.Stride() != out.Stride()) errorQuda("stride mismatch");
+  const bool r12 = U.reconstruct == QUDA_RECONSTRUCT_12;
+  switch (in.Precision()) {
+    case QUDA_DOUBLE_PRECISION: r12 ? launchHopDir<double, 12>(out, in, U, parity, dir, coef, true, x, xcoef) : launchHopDir<double, 18>(out, in, U, parity, dir, coef, true, x, xcoef); break;
+    case QUDA_SINGLE_PRECISION: r12 ? launchHopDir<float, 12>(out, in, U, parity, dir, coef, true, x, xcoef) : launchHopDir<float, 18>(out, in, U, parity, dir, coef, true, x, xcoef); break;
+    default: errorQuda("covariant shift: fp64/fp32 only");
+  }
 }
 
 void applyHopDir(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, int parity, int dir, double coef) {

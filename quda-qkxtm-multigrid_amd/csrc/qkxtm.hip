@@ -1,0 +1,281 @@
+// qkxtm.hip — the solve loop of the QKXTM correlator drivers behind the library: source preparation
+// (point source, Gaussian smearing with the APE-smeared links), even-odd preconditioned GCR with the resident multigrid
+// hierarchies of the two twist flavours, reconstruction, and the propagators handed back in the drivers' own layout.
+//
+// Reference: calcMG_threepTwop_EvenOdd (lib/interface_quda.cpp:6018-6531; the same loop opens calcMG_loop_wOneD_TSM_*,
+// :7093, :8535), QKXTM_Vector_Kepler::gaussianSmearing (lib/qudaQKXTM_Vector_Kepler.cpp:386-421),
+// lib/code_pieces_Kepler/Gauss_core_Kepler.h, uploadToCuda / downloadFromCuda (lib/qudaQKXTM_Kepler_kernels.cu:972-1056).
+// Contractions, momentum projection and the HDF5 / ASCII writers that follow the loop in the reference are out of scope
+// (SURVEY 2 row 20): the caller gets the propagators instead.
+//
+// Everything stays on the device between the point source and the finished propagator:
+//  * smearing acts on colour only, so ONE smearing pass per source position serves all twelve spin-colour sources: the
+//    point sources of the three colours sit in spin slots 0..2 of a single vector (the reference smears 24 times);
+//  * a smearing step is six covariant shifts accumulated in place (applyCovariantShift: the ghost-aware single-direction
+//    hop of the multigrid setup without the spin projector), so it runs unchanged on a grid-decomposed lattice;
+//  * the QKXTM host layouts are lexicographic in the sites and UKQCD in spin; site reordering and the spin rotation to the
+//    device basis happen in the copy kernels.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "basis.h"
+#include "blas.h"
+#include "device_io.h"
+#include "dslash.h"
+#include "interface_internal.h"
+#include "p2p.h"
+#include "quda_amd_ext.h"
+#include "solver.h"
+
+namespace quda {
+
+void *stagingBuffer(size_t bytes);   // fields.hip
+
+// ---- site order / basis: QKXTM host vector (lexicographic sites, UKQCD spin) <-> device full field (even-odd, DeGrand-Rossi) ----
+__device__ __forceinline__ long lex_of(int idx, int parity, int Xh, int Y, int Z) {
+  int l = idx / Xh;
+  const int y = l % Y; l /= Y;
+  const int z = l % Z, t = l / Z;
+  return 2l * idx + ((y + z + t + parity) & 1);   // checkerboard index = lexicographic index / 2
+}
+
+__global__ void __launch_bounds__(256) lex_to_dev_kernel(double *dev, int stride, size_t parityDoubles, const double *lex, int Vh, int Xh, int Y, int Z, int change) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x, parity = blockIdx.y;
+  if (idx >= Vh) return;
+  const double *h = lex + lex_of(idx, parity, Xh, Y, Z) * 24;
+  double r[24], q[24];
+#pragma unroll
+  for (int k = 0; k < 24; k++) r[k] = h[k];
+  if (change) rotate_basis(q, r, change);
+  Planar<double, 24>::store(change ? q : r, dev + parity * parityDoubles, stride, idx, nullptr, idx);
+}
+
+__global__ void __launch_bounds__(256) dev_to_lex_kernel(double *lex, const double *dev, int stride, size_t parityDoubles, int Vh, int Xh, int Y, int Z, int change,
+                                                         double scale) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x, parity = blockIdx.y;
+  if (idx >= Vh) return;
+  double r[24], q[24];
+  Planar<double, 24>::load(r, dev + parity * parityDoubles, stride, idx, nullptr, idx);
+  if (change) rotate_basis(q, r, change);
+  double *h = lex + lex_of(idx, parity, Xh, Y, Z) * 24;
+#pragma unroll
+  for (int k = 0; k < 24; k++) h[k] = scale * (change ? q[k] : r[k]);
+}
+
+// colour point sources in spin slots: psi(site)[slot c][colour c] = 1 for c = 0, 1, 2 (host-basis slots, rotated like any host vector)
+__global__ void point_slots_kernel(double *dev, int stride, int idx) {
+  double r[24], q[24];
+  for (int k = 0; k < 24; k++) r[k] = 0;
+  for (int c = 0; c < 3; c++) r[6 * c + 2 * c] = 1.0;
+  rotate_basis(q, r, BASIS_UKQCD_TO_DR);
+  Planar<double, 24>::store(q, dev, stride, idx, nullptr, idx);
+}
+
+// out = e_{spin s0} (x) [colour vector held in spin slot `slot` of in], both in the device basis of host-basis slots
+__global__ void __launch_bounds__(256) spread_slot_kernel(double *out, const double *in, int stride, size_t parityDoubles, int Vh, int s0, int slot) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x, parity = blockIdx.y;
+  if (idx >= Vh) return;
+  double r[24], q[24];
+  Planar<double, 24>::load(r, in + parity * parityDoubles, stride, idx, nullptr, idx);
+  rotate_basis(q, r, BASIS_DR_TO_UKQCD);
+#pragma unroll
+  for (int k = 0; k < 24; k++) r[k] = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) r[6 * s0 + k] = q[6 * slot + k];
+  rotate_basis(q, r, BASIS_UKQCD_TO_DR);
+  Planar<double, 24>::store(q, out + parity * parityDoubles, stride, idx, nullptr, idx);
+}
+
+static size_t parityDoubles(const ColorSpinorField &f) { return (size_t)((const char *)f.Odd().V() - (const char *)f.Even().V()) / sizeof(double); }
+
+static void checkFullDouble(const ColorSpinorField &f) {
+  if (f.Location() != QUDA_CUDA_FIELD_LOCATION || f.Precision() != QUDA_DOUBLE_PRECISION || f.SiteSubset() != QUDA_FULL_SITE_SUBSET || f.Nspin() != 4 || f.Ncolor() != 3)
+    errorQuda("expected a full fp64 device spinor");
+}
+
+static void lexToDevice(ColorSpinorField &dst, const double *h_lex, const LatticeGeom &g, bool ukqcd) {
+  checkFullDouble(dst);
+  const size_t bytes = (size_t)g.V * 24 * sizeof(double);
+  double *stage = (double *)stagingBuffer(bytes);
+  HIP_CHECK(hipMemcpyAsync(stage, h_lex, bytes, hipMemcpyHostToDevice, computeStream()));
+  hipLaunchKernelGGL(lex_to_dev_kernel, dim3((g.Vh + 255) / 256, 2), dim3(256), 0, computeStream(), (double *)dst.V(), dst.Stride(), parityDoubles(dst), stage, g.Vh, g.Xh,
+                     g.X[1], g.X[2], ukqcd ? BASIS_UKQCD_TO_DR : BASIS_NONE);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(computeStream()));
+}
+
+static void deviceToLex(double *h_lex, const ColorSpinorField &src, const LatticeGeom &g, bool ukqcd, double scale) {
+  checkFullDouble(src);
+  const size_t bytes = (size_t)g.V * 24 * sizeof(double);
+  double *stage = (double *)stagingBuffer(bytes);
+  hipLaunchKernelGGL(dev_to_lex_kernel, dim3((g.Vh + 255) / 256, 2), dim3(256), 0, computeStream(), stage, (const double *)src.V(), src.Stride(), parityDoubles(src), g.Vh, g.Xh,
+                     g.X[1], g.X[2], ukqcd ? BASIS_DR_TO_UKQCD : BASIS_NONE, scale);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(h_lex, stage, bytes, hipMemcpyDeviceToHost, computeStream()));
+  HIP_CHECK(hipStreamSynchronize(computeStream()));
+  p2pCheck("deviceToLex");
+}
+
+// ---- the smearing links: QKXTM host layout gauge[dir][lexicographic site][3][3][2] (lib/qudaQKXTM_Gauge_Kepler.cpp:73-89) ----
+static GaugeField *loadLexGauge(void **gauge_lex, const LatticeGeom &g) {
+  // reorder to the QDP host order (even sites then odd) the loader takes; host loop, once per call
+  std::vector<std::vector<double>> eo(4, std::vector<double>((size_t)g.V * 18));
+  void *ptr[4];
+  for (int d = 0; d < 4; d++) {
+    const double *src = (const double *)gauge_lex[d];
+    if (!src) errorQuda("gauge_APE[%d] is NULL", d);
+    for (long iv = 0; iv < g.V; iv++) {
+      long l = iv / g.X[0];
+      const int x = (int)(iv % g.X[0]), y = (int)(l % g.X[1]); l /= g.X[1];
+      const int z = (int)(l % g.X[2]), t = (int)(l / g.X[2]);
+      const int parity = (x + y + z + t) & 1;
+      memcpy(&eo[d][((size_t)parity * g.Vh + iv / 2) * 18], src + iv * 18, 18 * sizeof(double));
+    }
+    ptr[d] = eo[d].data();
+  }
+  GaugeField *U = new GaugeField(g, QUDA_DOUBLE_PRECISION, QUDA_RECONSTRUCT_NO, QUDA_PERIODIC_T, 1.0);
+  loadGaugeWithHalo(*U, ptr, QUDA_DOUBLE_PRECISION);
+  return U;
+}
+
+// v <- smear^n(v):  psi' = (psi + alpha sum_{i<3} [U_i(x) psi(x+i) + U_i(x-i)^dag psi(x-i)]) / (1 + 6 alpha)   (Gauss_core_Kepler.h)
+static void gaussianSmear(ColorSpinorField &v, const GaugeField &U, double alpha, int nsmear) {
+  checkFullDouble(v);
+  ColorSpinorField tmp(v);
+  ColorSpinorField *src = &v, *dst = &tmp;
+  const double normalize = 1.0 / (1.0 + 6.0 * alpha);
+  for (int it = 0; it < nsmear; it++) {
+    for (int parity = 0; parity < 2; parity++) {
+      ColorSpinorField &o = parity ? dst->Odd() : dst->Even();
+      const ColorSpinorField &same = parity ? src->Odd() : src->Even();
+      const ColorSpinorField &other = parity ? src->Even() : src->Odd();
+      for (int dir = 0; dir < 6; dir++)
+        applyCovariantShift(o, other, U, parity, dir, alpha * normalize, dir == 0 ? &same : &o, dir == 0 ? normalize : 1.0);
+    }
+    std::swap(src, dst);
+  }
+  if (src != &v) blas::copy(v, *src);
+}
+
+static void checkCalcParam(const QudaInvertParam *param, const char *fname) {
+  // reference :6041-6054
+  if (param->solve_type != QUDA_DIRECT_PC_SOLVE) errorQuda("%s: This function works only with Direct solve and even odd preconditioning", fname);
+  if (param->inv_type != QUDA_GCR_INVERTER) errorQuda("%s: This function works only with GCR method", fname);
+  if (param->gamma_basis != QUDA_UKQCD_GAMMA_BASIS) errorQuda("%s: This function works only with ukqcd gamma basis", fname);
+  if (param->dirac_order != QUDA_DIRAC_ORDER) errorQuda("%s: This function works only with colors inside the spins", fname);
+  if (param->matpc_type != QUDA_MATPC_EVEN_EVEN && param->matpc_type != QUDA_MATPC_ODD_ODD) errorQuda("%s: matpc_type %d not supported (symmetric even-even / odd-odd only)", fname, param->matpc_type);
+  if (param->solution_type != QUDA_MAT_SOLUTION) errorQuda("%s: solution_type %d not supported (the drivers ask for QUDA_MAT_SOLUTION)", fname, param->solution_type);
+  if (param->dslash_type != QUDA_TWISTED_MASS_DSLASH && param->dslash_type != QUDA_TWISTED_CLOVER_DSLASH) errorQuda("%s: twisted-mass / twisted-clover operators only", fname);
+  if (param->inv_type_precondition == QUDA_MG_INVERTER && (!param->preconditionerUP || !param->preconditionerDN))
+    errorQuda("%s: preconditionerUP / preconditionerDN not set (one multigrid hierarchy per twist flavour)", fname);
+}
+
+}  // namespace quda
+
+using namespace quda;
+
+extern "C" {
+
+void qudaAmdGaussianSmear(void *h_out, const void *h_in, void **gauge_APE, int nsmear, double alpha) {
+  if (!gaugePrecise) errorQuda("Gauge field not allocated");   // the lattice geometry comes from the resident field, as in the reference
+  if (nsmear < 0) errorQuda("nsmear = %d", nsmear);
+  const LatticeGeom &g = residentGeom();
+  GaugeField *U = loadLexGauge(gauge_APE, g);
+  ColorSpinorParam cp = deviceSpinorParam(QUDA_DOUBLE_PRECISION, QUDA_FULL_SITE_SUBSET, QUDA_TWIST_NO);
+  cp.create = QUDA_ZERO_FIELD_CREATE;
+  ColorSpinorField v(cp);
+  lexToDevice(v, (const double *)h_in, g, true);
+  gaussianSmear(v, *U, alpha, nsmear);
+  deviceToLex((double *)h_out, v, g, true, 1.0);
+  delete U;
+}
+
+void qudaAmdCalcMGPropagators(void *h_prop_up, void *h_prop_dn, void **gauge_APE, QudaInvertParam *param, const QudaAmdSourceParam *src) {
+  const char *fname = "qudaAmdCalcMGPropagators";
+  if (!gaugePrecise) errorQuda("%s: Gauge field not allocated", fname);
+  if (!cloverPrecise && param->dslash_type == QUDA_TWISTED_CLOVER_DSLASH) errorQuda("%s: Clover field not allocated", fname);
+  if (!src) errorQuda("%s: source description is NULL", fname);
+  if (!h_prop_up || !h_prop_dn) errorQuda("%s: propagator buffers are NULL", fname);
+  checkCalcParam(param, fname);
+  const bool flag_eo = param->matpc_type == QUDA_MATPC_EVEN_EVEN;
+  const LatticeGeom &g = residentGeom();
+  const CommGrid &cg = commGrid();
+  for (int d = 0; d < 4; d++)
+    if (src->sourcePosition[d] < 0 || src->sourcePosition[d] >= g.X[d] * cg.dims[d]) errorQuda("%s: source position %d out of range in dimension %d", fname, src->sourcePosition[d], d);
+  if (src->nsmearGauss < 0) errorQuda("%s: nsmearGauss = %d", fname, src->nsmearGauss);
+  param->secs = 0; param->gflops = 0; param->iter = 0;
+
+  GaugeField *Uape = (src->nsmearGauss > 0) ? loadLexGauge(gauge_APE, g) : nullptr;
+
+  // reference createDirac :6291-6300, once, before the loop: the twist flavour travels with the fields
+  const bool pc_solve = true;
+  DiracParam dp, dpSloppy, dpPre;
+  setDiracParam(dp, param, pc_solve);
+  setDiracSloppyParam(dpSloppy, param, pc_solve);
+  setDiracPreParam(dpPre, param, pc_solve);
+  Dirac *d = Dirac::create(dp), *dSloppy = Dirac::create(dpSloppy), *dPre = Dirac::create(dpPre);
+  Dirac &dirac = *d;
+  DiracM m(dirac), mSloppy(*dSloppy), mPre(*dPre);
+
+  ColorSpinorParam cp64 = deviceSpinorParam(QUDA_DOUBLE_PRECISION, QUDA_FULL_SITE_SUBSET, QUDA_TWIST_PLUS);
+  cp64.create = QUDA_ZERO_FIELD_CREATE;
+  ColorSpinorField phi(cp64), source(cp64), result(cp64);
+  ColorSpinorParam cp = deviceSpinorParam(param->cuda_prec, QUDA_FULL_SITE_SUBSET, QUDA_TWIST_PLUS);
+  cp.create = QUDA_ZERO_FIELD_CREATE;
+  ColorSpinorField *b = new ColorSpinorField(cp), *x = new ColorSpinorField(cp);
+
+  // the three colour point sources in spin slots 0..2, on the rank that owns the site (reference :6404-6421), smeared once
+  int my_src[4];
+  bool mine = true;
+  for (int k = 0; k < 4; k++) { my_src[k] = src->sourcePosition[k] - cg.coords[k] * g.X[k]; mine = mine && my_src[k] >= 0 && my_src[k] < g.X[k]; }
+  if (mine) {
+    const long iv = (((long)my_src[3] * g.X[2] + my_src[2]) * g.X[1] + my_src[1]) * g.X[0] + my_src[0];
+    const int parity = (my_src[0] + my_src[1] + my_src[2] + my_src[3]) & 1;
+    ColorSpinorField &half = parity ? phi.Odd() : phi.Even();
+    hipLaunchKernelGGL(point_slots_kernel, dim3(1), dim3(1), 0, computeStream(), (double *)half.V(), half.Stride(), (int)(iv / 2));
+    HIP_CHECK(hipGetLastError());
+  }
+  if (Uape) gaussianSmear(phi, *Uape, src->alphaGauss, src->nsmearGauss);
+
+  const size_t vec = (size_t)g.V * 24;
+  double secs = 0, gflops = 0;
+  int iters = 0;
+  const bool rescale = param->mass_normalization == QUDA_MASS_NORMALIZATION || param->mass_normalization == QUDA_ASYMMETRIC_MASS_NORMALIZATION;
+  for (int isc = 0; isc < 12; isc++) {
+    hipLaunchKernelGGL(spread_slot_kernel, dim3((g.Vh + 255) / 256, 2), dim3(256), 0, computeStream(), (double *)source.V(), (const double *)phi.V(), source.Stride(),
+                       parityDoubles(source), g.Vh, isc / 3, isc % 3);
+    HIP_CHECK(hipGetLastError());
+    for (int fl = 0; fl < 2; fl++) {
+      const QudaTwistFlavorType flavor = fl == 0 ? QUDA_TWIST_PLUS : QUDA_TWIST_MINUS;   // up, then down (:6401, :6470)
+      param->twist_flavor = flavor;
+      b->changeTwist(flavor); x->changeTwist(flavor);
+      *b = source;
+      ColorSpinorField *in = nullptr, *out = nullptr;
+      dirac.prepare(in, out, *x, *b, param->solution_type);
+      param->preconditioner = fl == 0 ? param->preconditionerUP : param->preconditionerDN;
+      // counters: SolverParam starts from the values in *param and updateInvertParam adds them back (reference
+      // include/invert_quda.h:262-300), which in the reference's loop doubles the running totals at every solve; summed
+      // properly here
+      param->secs = 0; param->gflops = 0; param->iter = 0;
+      SolverParam sp(*param);
+      Solver *solve = Solver::create(sp, m, mSloppy, mPre);
+      // the smeared source on the solve parity is the initial guess (:6442-6445; used when use_init_guess says so)
+      *out = flag_eo ? source.Even() : source.Odd();
+      out->changeTwist(flavor);
+      (*solve)(*out, *in);
+      sp.updateInvertParam(*param);
+      secs += param->secs; gflops += param->gflops; iters += param->iter;
+      dirac.reconstruct(*x, *b, param->solution_type);
+      delete solve;
+      result = *x;
+      deviceToLex((double *)(fl == 0 ? h_prop_up : h_prop_dn) + isc * vec, result, g, true, rescale ? 2.0 * param->kappa : 1.0);
+    }
+  }
+  param->secs = secs; param->gflops = gflops; param->iter = iters;
+  delete b; delete x;
+  delete d; delete dSloppy; delete dPre;
+  delete Uape;
+}
+
+}

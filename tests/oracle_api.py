@@ -156,6 +156,43 @@ class Oracle:
         self.lib.qo_clover_compute_d(_p(out), _g(gauge), C.c_double(coeff), _x(X))
         return out
 
+    # -- QKXTM source preparation (oracle/qo_qkxtm.c); lexicographic QKXTM host layouts
+    def gauss_smear(self, vec_lex, gauge_lex, X, alpha, nsmear):
+        """vec_lex: (V*24,) lexicographic spin-colour vector, gauge_lex: (4, V*18) lexicographic links"""
+        out = np.zeros_like(vec_lex)
+        self.lib.qo_gauss_smear(_p(out), _p(np.ascontiguousarray(vec_lex)), _g(gauge_lex), _x(X), C.c_double(alpha), C.c_int(nsmear))
+        return out
+
+    def eo_to_lex(self, eo, X, n):
+        out = np.zeros_like(eo)
+        self.lib.qo_eo_to_lex(_p(out), _p(np.ascontiguousarray(eo)), _x(X), C.c_int(n))
+        return out
+
+    def lex_to_eo(self, lex, X, n):
+        out = np.zeros_like(lex)
+        self.lib.qo_lex_to_eo(_p(out), _p(np.ascontiguousarray(lex)), _x(X), C.c_int(n))
+        return out
+
+    @staticmethod
+    def ukqcd_to_dr(v):
+        """host spinor(s) (..., 24) UKQCD -> DeGrand-Rossi: the reference's RelBasis (lib/copy_color_spinor.cuh:73-91)"""
+        k = 1.0 / np.sqrt(2.0)
+        a = np.asarray(v).reshape(-1, 4, 6)
+        o = np.empty_like(a)
+        o[:, 0] = -k * (a[:, 1] + a[:, 3]); o[:, 1] = k * (a[:, 0] + a[:, 2])
+        o[:, 2] = k * (a[:, 3] - a[:, 1]); o[:, 3] = k * (a[:, 0] - a[:, 2])
+        return o.reshape(np.asarray(v).shape)
+
+    @staticmethod
+    def dr_to_ukqcd(v):
+        """DeGrand-Rossi -> UKQCD: the reference's NonRelBasis (lib/copy_color_spinor.cuh:49-70)"""
+        k = 1.0 / np.sqrt(2.0)
+        a = np.asarray(v).reshape(-1, 4, 6)
+        o = np.empty_like(a)
+        o[:, 0] = k * (a[:, 1] + a[:, 3]); o[:, 1] = -k * (a[:, 0] + a[:, 2])
+        o[:, 2] = k * (a[:, 1] - a[:, 3]); o[:, 3] = k * (a[:, 2] - a[:, 0])
+        return o.reshape(np.asarray(v).shape)
+
     # -- multigrid pieces (oracle/qo_mg.c); complex128 arrays in the reference CPU orders
     @staticmethod
     def _c(a):

@@ -1,0 +1,132 @@
+"""The solve loop of the QKXTM drivers through the C ABI (reference lib/interface_quda.cpp:6018-6531):
+Gaussian smearing against oracle/qo_qkxtm.c, and the up / down propagators of a smeared point source, each checked the way
+the reference checks a solve (tests/multigrid_invert_test.cpp:529-577): the oracle's host tm_mat applied to the returned
+solution must reproduce the source to the solver tolerance."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from synth import smooth_gauge  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def qa():
+    mod = importlib.import_module("quda-qkxtm-multigrid_amd")
+    mod.init(0)
+    yield mod
+    mod.end()
+
+
+def _lex_gauge(oracle, gauge, X):
+    return np.stack([oracle.eo_to_lex(np.ascontiguousarray(gauge[d]), list(X), 18) for d in range(4)])
+
+
+@pytest.mark.parametrize("X", [(4, 4, 4, 4), (6, 4, 2, 8)])
+@pytest.mark.parametrize("mask", [0, 0b0110])
+def test_gaussian_smearing_matches_oracle(qa, oracle, X, mask):
+    """fp64, same operation order up to the summation order of the six hops: 1e-12 relative per site"""
+    gauge, _, _ = oracle.make_fields(list(X), seed=7, antiperiodic_t=False, clover=False)
+    gp = qa.gauge_param(X, t_boundary=qa.QUDA_PERIODIC_T)
+    qa.load_gauge(gauge, gp)
+    g_lex = _lex_gauge(oracle, gauge, X)
+    rng = np.random.default_rng(2)
+    v = rng.standard_normal(int(np.prod(X)) * 24)
+    qa.lib().qudaAmdSetPartitionMask(mask)
+    try:
+        got = qa.gaussian_smear(v, g_lex, 5, 0.8)
+    finally:
+        qa.lib().qudaAmdSetPartitionMask(0)
+    want = oracle.gauss_smear(v, g_lex, list(X), 0.8, 5)
+    assert np.max(np.abs(got - want)) < 1e-12 * np.max(np.abs(want))
+    # zero steps: the identity (through the site reordering and both spin rotations)
+    assert np.max(np.abs(qa.gaussian_smear(v, g_lex, 0, 0.8) - v)) < 1e-14 * np.max(np.abs(v))
+
+
+def _check_propagators(qa, oracle, gauge, g_lex, X, kappa, mu, ip, pos, nsmear, alpha, normalized):
+    V = int(np.prod(X))
+    up, dn = qa.calc_mg_propagators(g_lex, ip, pos, nsmear, alpha, V)
+    worst = 0.0
+    oracle.set_threads(8)
+    try:
+        for isc in range(12):
+            src = np.zeros(V * 24)
+            iv = ((pos[3] * X[2] + pos[2]) * X[1] + pos[1]) * X[0] + pos[0]
+            src[iv * 24 + isc * 2] = 1.0
+            b_lex = oracle.gauss_smear(src, g_lex, list(X), alpha, nsmear) if nsmear else src
+            b = oracle.lex_to_eo(oracle.ukqcd_to_dr(b_lex.reshape(-1, 24)).reshape(-1), list(X), 24)
+            for flavor, prop in ((+1, up), (-1, dn)):
+                x = oracle.lex_to_eo(oracle.ukqcd_to_dr(prop[isc].reshape(-1, 24)).reshape(-1), list(X), 24)
+                if normalized:
+                    x = x / (2 * kappa)
+                res = float(np.linalg.norm(b - oracle.tm_mat(gauge, x, list(X), kappa, mu, flavor, 0)) / np.linalg.norm(b))
+                worst = max(worst, res)
+    finally:
+        oracle.set_threads(1)
+    return worst
+
+
+def test_propagators_plain_gcr(qa, oracle):
+    """no multigrid: the loop itself (source, smearing, flavour flip, prepare / reconstruct, 2 kappa rescaling, layouts)"""
+    X, kappa, mu = (4, 4, 4, 8), 0.12, 0.05
+    gauge, _, _ = oracle.make_fields(list(X), seed=11, antiperiodic_t=False, clover=False)
+    gp = qa.gauge_param(X, t_boundary=qa.QUDA_PERIODIC_T)
+    qa.load_gauge(gauge, gp)
+    g_lex = _lex_gauge(oracle, gauge, X)
+    for matpc, norm in (("ee", qa.QUDA_KAPPA_NORMALIZATION), ("oo", qa.QUDA_MASS_NORMALIZATION)):
+        ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, matpc, 0, cuda_prec=8, solution_type=qa.QUDA_MAT_SOLUTION,
+                             gamma_basis=qa.QUDA_UKQCD_GAMMA_BASIS)
+        ip.solve_type, ip.inv_type, ip.gcrNkrylov, ip.tol, ip.maxiter = qa.QUDA_DIRECT_PC_SOLVE, qa.QUDA_GCR_INVERTER, 20, 1e-10, 4000
+        ip.inv_type_precondition = qa.QUDA_INVALID_ENUM
+        ip.mass_normalization = norm
+        ip.verbosity = qa.QUDA_SILENT
+        worst = _check_propagators(qa, oracle, gauge, g_lex, X, kappa, mu, ip, (1, 2, 3, 5), 4, 0.6, norm == qa.QUDA_MASS_NORMALIZATION)
+        assert worst < 5e-10, (matpc, worst)
+        assert ip.twist_flavor == qa.QUDA_TWIST_MINUS and 24 < ip.iter < 24 * 4000   # last solve was the down quark; iterations are summed
+
+
+def test_propagators_with_up_and_down_hierarchies(qa, oracle):
+    """the production shape: one multigrid hierarchy per flavour in preconditionerUP / preconditionerDN"""
+    X, kappa, mu = (8, 8, 8, 16), 0.124, 0.005
+    gauge = smooth_gauge(X, 0.35)
+    gp = qa.gauge_param(X, cuda_prec=8, prec_sloppy=4, prec_precondition=4, t_boundary=qa.QUDA_PERIODIC_T)
+    qa.load_gauge(gauge, gp)
+    g_lex = _lex_gauge(oracle, gauge, X)
+    hier = {}
+    try:
+        for flavor in (+1, -1):
+            ipm = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, flavor, "ee", 0, cuda_prec=8, prec_sloppy=4, prec_precondition=4,
+                                  solution_type=qa.QUDA_MAT_SOLUTION)
+            ipm.solve_type = qa.QUDA_DIRECT_SOLVE
+            ipm.inv_type, ipm.gcrNkrylov, ipm.tol, ipm.maxiter, ipm.reliable_delta, ipm.verbosity = qa.QUDA_GCR_INVERTER, 20, 1e-10, 2000, 1e-4, qa.QUDA_SILENT
+            mp = qa.multigrid_param(ipm, n_level=3, geo_block=[(4, 4, 4, 4), (1, 1, 1, 2), (2, 2, 2, 2)], n_vec=8, setup_maxiter=300, setup_tol=1e-5, smoother_pc=True,
+                                    coarse_matpc=True)
+            hier[flavor] = (qa.Multigrid(mp), ipm, mp)
+        ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=8, prec_sloppy=4, prec_precondition=4,
+                             solution_type=qa.QUDA_MAT_SOLUTION, gamma_basis=qa.QUDA_UKQCD_GAMMA_BASIS)
+        ip.solve_type, ip.inv_type, ip.gcrNkrylov, ip.tol, ip.maxiter, ip.reliable_delta = qa.QUDA_DIRECT_PC_SOLVE, qa.QUDA_GCR_INVERTER, 20, 1e-10, 2000, 1e-4
+        ip.verbosity = qa.QUDA_SILENT
+        ip.inv_type_precondition = qa.QUDA_MG_INVERTER
+        ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
+        ip.preconditionerUP, ip.preconditionerDN = hier[+1][0].h, hier[-1][0].h
+        worst = _check_propagators(qa, oracle, gauge, g_lex, X, kappa, mu, ip, (3, 0, 7, 9), 6, 1.0, False)
+        print("24 MG-GCR solves: %d outer iterations in total, %.3f s in the solvers, worst true residual %.2e" % (ip.iter, ip.secs, worst))
+        assert worst < 5e-10, worst
+        assert ip.iter < 24 * 30, ip.iter
+    finally:
+        for h, _, _ in hier.values():
+            h.free()
+
+
+@pytest.mark.parametrize("case", ["calcmg_not_pc", "calcmg_not_ukqcd"])
+def test_parameter_checks(case):
+    """the reference's guards (lib/interface_quda.cpp:6041-6054) through the usual error convention; child process (tools/error_cases.py)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "error_cases.py"), case], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1, (case, r.returncode, r.stdout[-300:], r.stderr[-300:])
+    assert "ERROR" in r.stdout + r.stderr and "works only with" in r.stdout + r.stderr

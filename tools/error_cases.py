@@ -50,4 +50,13 @@ elif case == "mg_outer_pc_with_full_smoother":
     ip.inv_type_precondition, ip.preconditioner = qa.QUDA_MG_INVERTER, mg.h
     ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
     qa.invert(np.ones(int(np.prod(Xm)) * 24), ip)
+elif case in ("calcmg_not_pc", "calcmg_not_ukqcd"):
+    unit = np.zeros((4, V, 9, 2))
+    unit[:, :, [0, 4, 8], 0] = 1
+    qa.load_gauge(unit.reshape(4, -1), qa.gauge_param(X, t_boundary=qa.QUDA_PERIODIC_T))
+    ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, 0.1, 0.01, solution_type=qa.QUDA_MAT_SOLUTION,
+                         gamma_basis=qa.QUDA_DEGRAND_ROSSI_GAMMA_BASIS if case == "calcmg_not_ukqcd" else qa.QUDA_UKQCD_GAMMA_BASIS)
+    ip.solve_type = qa.QUDA_DIRECT_SOLVE if case == "calcmg_not_pc" else qa.QUDA_DIRECT_PC_SOLVE
+    ip.inv_type, ip.gcrNkrylov, ip.tol, ip.maxiter = qa.QUDA_GCR_INVERTER, 10, 1e-6, 100
+    qa.calc_mg_propagators(unit.reshape(4, -1), ip, (0, 0, 0, 0), 1, 0.5, V)
 print("NOT REACHED: %s did not abort" % case)
