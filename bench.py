@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 from synth import make_clover, make_gauge, smooth_gauge  # noqa: E402
 
 
-def run_mg(qa, X=(16, 16, 16, 16)):
+def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)), gauge=None, extras=True):
     """MG-preconditioned GCR to |r|/|b| <= 1e-10 (the second half of the metric) on one GPU: 3-level K-cycle, 24 null
     vectors, 4^4 then 2^4 aggregates, even-odd preconditioned MR smoother — the reference harness' default shape
     (tests/multigrid_invert_test.cpp:224-286) on a smooth synthetic gauge field (synth.smooth_gauge: far easier than a production
@@ -41,9 +41,11 @@ def run_mg(qa, X=(16, 16, 16, 16)):
     vectors + Galerkin operators) and solve are timed separately; the residual is re-computed with MatQuda."""
     kappa, mu = 0.124, 0.005
     qa.lib().freeCloverQuda()
-    gauge = smooth_gauge(X, 0.35)
+    if gauge is None:
+        gauge = smooth_gauge(X, 0.35)
     gp = qa.gauge_param(X, cuda_prec=8, prec_sloppy=4, prec_precondition=4, t_boundary=qa.QUDA_PERIODIC_T)
     qa.load_gauge(gauge, gp)
+    del gauge
     ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=8, prec_sloppy=4, prec_precondition=4,
                          solution_type=qa.QUDA_MAT_SOLUTION)
     ip.solve_type = qa.QUDA_DIRECT_SOLVE
@@ -70,8 +72,7 @@ def run_mg(qa, X=(16, 16, 16, 16)):
     ip.inv_type_precondition = qa.QUDA_INVALID_ENUM
     wall, inner, iters, _ = timed_solve()
     plain = dict(iters=iters, secs=round(wall, 4), solver_secs=round(inner, 4))
-    mp = qa.multigrid_param(ip, n_level=3, geo_block=[(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)], n_vec=24, setup_maxiter=500, setup_tol=5e-6,
-                            smoother_pc=True)
+    mp = qa.multigrid_param(ip, n_level=3, geo_block=[tuple(bk) for bk in blocks], n_vec=24, setup_maxiter=500, setup_tol=5e-6, smoother_pc=True)
     mg = qa.Multigrid(mp)
     ip.inv_type_precondition = qa.QUDA_MG_INVERTER
     ip.preconditioner = mg.h
@@ -80,8 +81,11 @@ def run_mg(qa, X=(16, 16, 16, 16)):
     res = float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b))
     # solve_secs: wall clock of invertQuda (host source in, host solution out, as SURVEY 8d defines it: includes the two
     # PCIe transfers and the operator / field set-up); solver_secs: the GCR loop alone (QudaInvertParam.secs)
-    out = dict(lattice="x".join(map(str, X)), kappa=kappa, mu=mu, levels=3, n_vec=24, setup_secs=round(mp.secs, 3), solve_secs=round(wall, 4),
+    out = dict(lattice="x".join(map(str, X)), kappa=kappa, mu=mu, levels=3, n_vec=24, blocks=[list(bk) for bk in blocks[:2]], setup_secs=round(mp.secs, 3), solve_secs=round(wall, 4),
                solver_secs=round(inner, 4), iters=iters, true_res=res, plain_gcr=plain, timing="best of 3 after 1 warm-up solve")
+    if not extras:
+        mg.free()
+        return out
     # the QKXTM production shape: the same hierarchy under an outer GCR on the even-odd preconditioned system
     # (solve_type = QUDA_DIRECT_PC_SOLVE, reference lib/interface_quda.cpp:6041), full-field solution via prepare / reconstruct
     ip.solve_type = qa.QUDA_DIRECT_PC_SOLVE
@@ -196,6 +200,11 @@ def main():
 
     if not args.no_extra and rank == 0 and world == 1:
         extra["mg_gcr"] = run_mg(qa, (32, 32, 32, 32))
+        # BASELINE.json configs[4] (48^3 x 96, quoted by the reference on 8 GPUs) resident on this one GPU: 288 GB holds the whole
+        # hierarchy; levels by the reference's blocking rule 48^3 x 96 -> 12^3 x 24 -> 6^4 (lib/transfer.cpp:31-44)
+        from synth import smooth_gauge_cayley
+        extra["mg_gcr_c5_one_gpu"] = run_mg(qa, (48, 48, 48, 96), blocks=((4, 4, 4, 4), (2, 2, 2, 4), (2, 2, 2, 2)),
+                                            gauge=smooth_gauge_cayley((48, 48, 48, 96), 0.35, workers=min(16, os.cpu_count() or 8)))
 
     cpu = None
     if rank == 0 and not args.no_cpu:
