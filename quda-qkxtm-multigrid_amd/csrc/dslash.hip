@@ -158,7 +158,9 @@ template <typename real> __device__ __forceinline__ void twist_inplace(real *p, 
 template <typename T, int R, int DIR, int GAUX, int GH = 0, typename real>
 __device__ __forceinline__ void hop_load(real *psi, real *U, const DslashArg<real> &arg, int idx, int nbr, real sign, bool off_node = false, int face = 0) {
   constexpr int MU = DIR / 2;
-  if (GH == 2 && off_node) return;
+  // GH == 2: the load is issued for every lane (the periodic wrap makes the index valid) and the contribution of an off-node
+  // lane is zeroed in hop_compute: a per-lane branch here splits the 8-hop pipeline into many basic blocks and costs the
+  // fp64 kernel its second wave per SIMD (256 + 8 registers against 231 for the branch-free loop)
   if (GH == 1 && off_node) {
     // the neighbour lives on another rank: its (pre-twisted,) spin-projected half spinor was packed there with the same
     // projector sign; it goes into the first 12 slots of the buffer.  Issued here, with the other loads of the hop, so it
@@ -174,7 +176,6 @@ __device__ __forceinline__ void hop_load(real *psi, real *U, const DslashArg<rea
 template <typename T, int DIR, bool PRETWIST, int GH, typename real>
 __device__ __forceinline__ void hop_compute(real *acc, real *psi, const real *U, const DslashArg<real> &arg, bool off_node = false, int face = 0) {
   constexpr int MU = DIR / 2;
-  if (GH == 2 && off_node) return;
   real h[12], g[12];
   const real s = (DIR & 1) ? -arg.sfwd : arg.sfwd;
   if (GH == 1 && off_node) {
@@ -183,6 +184,10 @@ __device__ __forceinline__ void hop_compute(real *acc, real *psi, const real *U,
   } else {
     if (PRETWIST) twist_inplace(psi, arg.a);  // QUDA_DEG_TWIST_INV_DSLASH: A^-1 applied to the neighbour before the hop
     spin_project<MU>(h, psi, s);
+    if (GH == 2) {   // off-node hop: added later from the ghost zone (ghost_hop); select, not branch
+#pragma unroll
+      for (int k = 0; k < 12; k++) h[k] = off_node ? (real)0 : h[k];
+    }
   }
   su3_mv(g, U, h);
   su3_mv(g + 6, U, h + 6);
