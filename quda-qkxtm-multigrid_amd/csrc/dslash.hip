@@ -41,7 +41,7 @@ template <typename real> struct PackArg {
   int normOff[4];
   int start[9];     // prefix offsets of the 8 (dim, dir) thread ranges
   // peer-store transport: send[][] point into the NEIGHBOURS' ghost zones; the last block to finish raises the flags there
-  unsigned *peerFlag[8];   // the neighbours' site counters of the faces this rank sends
+  unsigned llFlag[4];      // flag-in-data value of this exchange per dimension (use count of the (dimension, buffer) zone)
   unsigned long long *timeline;
 };
 
@@ -72,11 +72,9 @@ template <typename real> struct DslashArg {
   const char *ghost[4][2];    // [dim][0: from the -dim neighbour, 1: from the +dim neighbour] spin-projected half spinors
   int faceCB[4];
   int ghostNormOff[4];        // byte offset of the fp32 scales inside a ghost block (16-bit storage)
-  // peer-store transport (p2p.h): the exterior pass polls these flags (one per incoming face, raised by the neighbour's pack
-  // kernel) until they reach waitSeq before it touches the ghost zone; waitSeq = 0: the data arrived in stream order
-  const unsigned *waitFlag[8];
-  unsigned waitCount[8];      // value each incoming-face site counter must have reached (cumulative, compared modulo 2^32)
-  unsigned waitSeq;
+  // peer-store transport (p2p.h): every ghost word carries the flag of its exchange (GhostLL); waitCount[dir] is the value the
+  // off-node hop in direction dir expects, waitTicks bounds the polling, a time-out lands in *errWord
+  unsigned waitCount[8];
   unsigned long long waitTicks;
   int *errWord;
   // peer-store transport: the first packBlocks blocks of the interior launch pack the faces (pack_body) while the rest of
@@ -147,6 +145,96 @@ template <typename real> __device__ __forceinline__ void twist_inplace(real *p, 
   }
 }
 
+// ---- flag-in-data ghost transport (peer stores) ----
+// A face site travels as NV 16-byte vectors {w0, flag, w1, flag}: two 4-byte payload words, each next to the exchange's flag
+// (the cumulative use count of the (dimension, buffer) zone, never 0), plane-major [vector][faceCB].  Every 8-byte half is
+// self-validating, so the receiver needs neither a counter nor any ordering between stores: it polls the very words it is
+// about to use, and the sender just stores and leaves — no acknowledgement wait, no barrier, no atomic (those put the
+// slowest pack block, 18 us under a saturated memory system, on the critical path of a 10-20 us kernel; the same idea as the
+// LL protocol of the collective libraries).  Costs 2x the face bytes, which are a few hundred KB.
+template <typename T> struct GhostLL;
+template <> struct GhostLL<double> {
+  static constexpr int NV = 12;
+  static __device__ __forceinline__ void encode(unsigned *w, const double *h) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) { const unsigned long long b = __builtin_bit_cast(unsigned long long, h[k]); w[2 * k] = (unsigned)b; w[2 * k + 1] = (unsigned)(b >> 32); }
+  }
+  static __device__ __forceinline__ void decode(double *h, const unsigned *w) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) h[k] = __builtin_bit_cast(double, (unsigned long long)w[2 * k] | ((unsigned long long)w[2 * k + 1] << 32));
+  }
+};
+template <> struct GhostLL<float> {
+  static constexpr int NV = 6;
+  static __device__ __forceinline__ void encode(unsigned *w, const float *h) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) w[k] = __builtin_bit_cast(unsigned, h[k]);
+  }
+  static __device__ __forceinline__ void decode(float *h, const unsigned *w) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) h[k] = __builtin_bit_cast(float, w[k]);
+  }
+};
+template <> struct GhostLL<short> {   // 12 int16 + the fp32 scale of the site (same quantisation as Planar<short>::store)
+  static constexpr int NV = 4;
+  static __device__ __forceinline__ void encode(unsigned *w, const float *h) {
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < 12; k++) m = fmaxf(m, fabsf(h[k]));
+    const float sc = m > 0.f ? kShortMax / m : 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      w[k] = (unsigned)(unsigned short)Planar<short, 12>::q16(h[2 * k] * sc) | ((unsigned)(unsigned short)Planar<short, 12>::q16(h[2 * k + 1] * sc) << 16);
+    w[6] = __builtin_bit_cast(unsigned, m);
+    w[7] = 0u;
+  }
+  static __device__ __forceinline__ void decode(float *h, const unsigned *w) {
+    const float sc = __builtin_bit_cast(float, w[6]) * kShortInv;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { h[2 * k] = (float)(short)(w[k] & 0xffffu) * sc; h[2 * k + 1] = (float)(short)(w[k] >> 16) * sc; }
+  }
+};
+template <typename T> __device__ __forceinline__ __amdgpu_buffer_rsrc_t ghost_ll_rsrc(const void *base, int faceCB) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)((unsigned)faceCB * (unsigned)(GhostLL<T>::NV * 16)), 0x00020000);
+}
+// sender: system-scope write-through stores into the neighbour's zone
+template <typename T, typename real> __device__ __forceinline__ void ghost_ll_store(const real *h, void *zone, int faceCB, int f, unsigned flag) {
+  constexpr int NV = GhostLL<T>::NV;
+  unsigned w[2 * NV];
+  GhostLL<T>::encode(w, h);
+  const __amdgpu_buffer_rsrc_t rs = ghost_ll_rsrc<T>(zone, faceCB);
+#pragma unroll
+  for (int v = 0; v < NV; v++) {
+    u32x4_t q; q.x = w[2 * v]; q.y = flag; q.z = w[2 * v + 1]; q.w = flag;
+    __builtin_amdgcn_raw_buffer_store_b128(q, rs, f * 16, v * faceCB * 16, 17);
+  }
+}
+// receiver: poll the site's own vectors (system-scope loads) until every half carries this exchange's flag; bounded by `ticks`
+template <typename T, typename real>
+__device__ __forceinline__ void ghost_ll_load(real *h, const void *zone, int faceCB, int f, unsigned flag, unsigned long long ticks, int *errWord, int code) {
+  constexpr int NV = GhostLL<T>::NV;
+  unsigned w[2 * NV];
+  const __amdgpu_buffer_rsrc_t rs = ghost_ll_rsrc<T>(zone, faceCB);
+  unsigned long long t0 = 0;
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rs, f * 16, v * faceCB * 16, 17);
+      w[2 * v] = q.x; w[2 * v + 1] = q.z;
+      ok = ok && q.y == flag && q.w == flag;
+    }
+    if (ok) break;
+    if (!t0) t0 = wall_clock64();
+    else if (wall_clock64() - t0 > ticks || __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      __hip_atomic_store(errWord, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // give up: the host reports it (p2pCheck)
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  GhostLL<T>::decode(h, w);
+}
+
 // One hop = load (neighbour spinor + this site's pre-daggered link) then project / multiply / reconstruct.
 // The two phases are separate so the kernel can software-pipeline them: loads of direction d+1 are issued
 // before the arithmetic of direction d (register double-buffering), fenced with sched_barrier so hipcc neither
@@ -200,42 +288,12 @@ __device__ __forceinline__ void ghost_hop(real *acc, const DslashArg<real> &arg,
   constexpr int MU = DIR / 2;
   if (!off_node) return;
   real h[12], g[12], U[18];
-  const char *gb = arg.ghost[MU][(DIR & 1) ? 0 : 1];
-  Planar<T, 12>::template load<17>(h, gb, arg.faceCB[MU], face, reinterpret_cast<const float *>(gb + arg.ghostNormOff[MU]), face);
   Link<T, R>::template load<GAUX>(U, arg.gauge + (size_t)DIR * arg.link_bytes, arg.g_stride, idx, sign);
+  ghost_ll_load<T>(h, arg.ghost[MU][(DIR & 1) ? 0 : 1], arg.faceCB[MU], face, arg.waitCount[DIR], arg.waitTicks, arg.errWord, 1 + DIR);
   const real s = (DIR & 1) ? -arg.sfwd : arg.sfwd;
   su3_mv(g, U, h);
   su3_mv(g + 6, U, h + 6);
   spin_reconstruct<MU>(acc, g, s);
-}
-
-// wave-level variant of wait_for_faces (no block barrier: only the waves that own boundary sites wait)
-template <typename real> __device__ __forceinline__ void wait_for_faces_wave(const DslashArg<real> &arg) {
-  if (!arg.waitSeq) return;
-  const int lane = threadIdx.x & 63;
-  if (lane < 8 && arg.waitFlag[lane] && !__hip_atomic_load(arg.errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-    const unsigned long long t0 = wall_clock64();
-    while ((int)(__hip_atomic_load(arg.waitFlag[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - arg.waitCount[lane]) < 0) {
-      if (wall_clock64() - t0 > arg.waitTicks) { __hip_atomic_store(arg.errWord, 1 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
-}
-
-// Peer-store transport: threads 0-7 of the block poll one incoming-face flag each (relaxed system-scope loads: an acquire
-// load would invalidate the caches on EVERY poll, and 2700 waves doing that made this pass 4x slower); the rest of the block
-// waits at the barrier.  No cache maintenance is needed afterwards: the ghost zone is fine-grained (uncached) memory and is
-// read with system-scope loads, and it cannot have been read earlier in this kernel.
-template <typename real> __device__ __forceinline__ void wait_for_faces(const DslashArg<real> &arg) {
-  if (!arg.waitSeq) return;
-  if (threadIdx.x < 8 && arg.waitFlag[threadIdx.x] && !__hip_atomic_load(arg.errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-    const unsigned long long t0 = wall_clock64();
-    while ((int)(__hip_atomic_load(arg.waitFlag[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - arg.waitCount[threadIdx.x]) < 0) {
-      if (wall_clock64() - t0 > arg.waitTicks) { __hip_atomic_store(arg.errWord, 1 + (int)threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
-  __syncthreads();
 }
 
 // fused epilogue of the stencil: twist / inverse twist / xpay / clover-twist (+ inverse), then the store of the site
@@ -343,26 +401,10 @@ template <typename T, bool PRETWIST, bool P2P, typename real> __device__ __force
       default: spin_project<3>(h, psi, s); break;
     }
     char *sb = arg.send[d][to_fwd];
-    // peer-mapped target: sc0 sc1 stores (system scope, write-through) — an IPC mapping need not be fine-grained on the writer's side
-    Planar<T, 12>::template store<P2P ? 17 : 0>(h, sb, arg.faceCB[d], f, reinterpret_cast<float *>(sb + arg.normOff[d]), f);
+    if (P2P) ghost_ll_store<T>(h, sb, arg.faceCB[d], f, arg.llFlag[d]);   // straight into the neighbour's zone, flag in the data
+    else Planar<T, 12>::store(h, sb, arg.faceCB[d], f, reinterpret_cast<float *>(sb + arg.normOff[d]), f);
   }
-  if (P2P) {
-    // Signalling: every incoming face has a cumulative SITE COUNTER in the receiver's window.  A block waits until its own
-    // stores are acknowledged (the zones are fine-grained memory and the stores write-through at system scope, so nothing
-    // lingers in this GPU's L2: s_waitcnt vmcnt(0), i.e. a work-group-scope release, is all it takes — a system-scope fence
-    // would also write back the whole dirty L2, 10 us per launch when every wave did it), then adds the number of sites it
-    // packed for each face to that face's counter with a fire-and-forget remote atomic.  No completion counter, no last
-    // block, no returning atomic: under a saturated memory system every dependent round trip costs microseconds.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (threadIdx.x < 8 && arg.peerFlag[threadIdx.x]) {
-      const int beg = bid * (int)blockDim.x, end = beg + (int)blockDim.x;
-      const int lo = beg > arg.start[threadIdx.x] ? beg : arg.start[threadIdx.x];
-      const int hi = end < arg.start[threadIdx.x + 1] ? end : arg.start[threadIdx.x + 1];
-      if (hi > lo) (void)__hip_atomic_fetch_add(arg.peerFlag[threadIdx.x], (unsigned)(hi - lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    if (arg.timeline && threadIdx.x == 0) arg.timeline[1024 + bid] = wall_clock64();
-  }
+  if (P2P && arg.timeline && threadIdx.x == 0) arg.timeline[1024 + bid] = wall_clock64();
 }
 
 // VARIANT: 0 = Wilson / twist epilogues, 1 = twist applied to the neighbours first (TWIST_INV_DSLASH), 2 = clover epilogues.
@@ -442,8 +484,6 @@ __device__ __forceinline__ void stencil_site(const DslashArg<real> &arg, const i
     const bool anyoff = o_xp || o_xm || o_yp || o_ym || o_zp || o_zm || o_tp || o_tm;
     if (__builtin_amdgcn_ballot_w64(anyoff) != 0) {
       if (arg.timeline && (threadIdx.x & 63) == 0) arg.timeline[4096 + (blockIdx.x * 4 + (threadIdx.x >> 6))] = wall_clock64();
-      wait_for_faces_wave(arg);
-      if (arg.timeline && (threadIdx.x & 63) == 0) arg.timeline[8192 + (blockIdx.x * 4 + (threadIdx.x >> 6))] = wall_clock64();
       ghost_hop<T, R, 0, GAUX>(acc, arg, idx, o_xp, f_x, one);
       ghost_hop<T, R, 1, GAUX>(acc, arg, idx, o_xm, f_x, one);
       ghost_hop<T, R, 2, GAUX>(acc, arg, idx, o_yp, f_y, one);
@@ -452,6 +492,7 @@ __device__ __forceinline__ void stencil_site(const DslashArg<real> &arg, const i
       ghost_hop<T, R, 5, GAUX>(acc, arg, idx, o_zm, f_z, one);
       ghost_hop<T, R, 6, GAUX>(acc, arg, idx, o_tp, f_t, sg_tp);
       ghost_hop<T, R, 7, GAUX>(acc, arg, idx, o_tm, f_t, sg_tm);
+      if (arg.timeline && (threadIdx.x & 63) == 0) arg.timeline[8192 + (blockIdx.x * 4 + (threadIdx.x >> 6))] = wall_clock64();
     }
   }
   dslash_epilogue<T, VARIANT, GAUX, SAUX>(acc, arg, idx);
@@ -460,7 +501,6 @@ __device__ __forceinline__ void stencil_site(const DslashArg<real> &arg, const i
 template <typename T, int R, int VARIANT, int GAUX, int KT, int SAUX = 0>
 __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename Store<T>::real> arg) {
   if (KT == 2) {
-    wait_for_faces(arg);
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= arg.nboundary) return;
     stencil_site<T, R, VARIANT, GAUX, 2, SAUX>(arg, arg.blist[tid]);
@@ -477,6 +517,7 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
   // contiguous range of logical blocks (a slab of time slices) so t/z neighbours hit its own L2.
   const int xcd = b & 7, within = b >> 3;
   int lb = (xcd < arg.xcd_r ? xcd * (arg.xcd_q + 1) : arg.xcd_r * (arg.xcd_q + 1) + (xcd - arg.xcd_r) * arg.xcd_q) + within;
+  if (arg.xcd_q < 0) lb = b;   // remap off: consecutive blocks dealt round-robin over the XCDs (even spread of the boundary work)
   if (arg.ts > 0) {
     // inside an XCD's slab of ts time slices walk t fastest: consecutive blocks are the same (y,z) chunk on ts successive
     // slices, so the +-t neighbours of a chunk are touched within a few blocks of each other (L2-resident) instead of a
@@ -676,8 +717,13 @@ HaloBuffers &haloBuffers(const LatticeGeom &g, QudaPrecision prec) {
   // ---- peer-store transport: same offsets on every rank (same local lattice), so a neighbour address = its base + my offset
   h.p2p = p2pHaloEnabled();
   if (h.p2p) {
-    const size_t flags_off = total;               // 4 ghost blocks per dim (k x buf), then 16 flags
-    h.window = (char *)p2pAlloc(total + 256);
+    // window = double-buffered flag-in-data zones [dim][k][buf], each NV 16-byte vectors per face site (GhostLL); zero-filled,
+    // and the flag of an exchange is never 0
+    const int nv = prec == QUDA_DOUBLE_PRECISION ? GhostLL<double>::NV : (prec == QUDA_SINGLE_PRECISION ? GhostLL<float>::NV : GhostLL<short>::NV);
+    size_t wtotal = 0;
+    size_t zone[4];
+    for (int d = 0; d < 4; d++) { zone[d] = ((size_t)g.faceCB[d] * nv * 16 + 255) / 256 * 256; wtotal += 4 * zone[d]; }
+    h.window = (char *)p2pAlloc(wtotal + 256);
     if (!commMapPeers(h.window, h.map)) errorQuda("peer mapping of a halo window failed after the transport probe succeeded");
     HIP_CHECK(hipDeviceSynchronize());
     size_t off = 0;
@@ -689,12 +735,11 @@ HaloBuffers &haloBuffers(const LatticeGeom &g, QudaPrecision prec) {
         for (int buf = 0; buf < 2; buf++) {
           h.ghostBuf[d][k][buf] = h.window + off;
           h.peerGhost[d][to_fwd][buf] = (char *)h.map.peer[slot] + off;
-          off += h.face_bytes[d];
+          off += zone[d];
         }
-        h.flag[d][k] = (unsigned *)(h.window + flags_off) + (2 * d + k) * 2;
-        h.peerFlag[d][to_fwd] = (unsigned *)((char *)h.map.peer[slot] + flags_off) + (2 * d + k) * 2;
       }
     h.seq = 0;
+    for (int d = 0; d < 4; d++) h.uses[d][0] = h.uses[d][1] = 0;
     commBarrier();
   }
   return h;
@@ -779,6 +824,11 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
   const int nb = (g.Vh + bs - 1) / bs;
   arg.nblocks = nb; arg.xcd_q = nb / 8; arg.xcd_r = nb % 8;
   {
+    static int remap = -1;
+    if (remap < 0) { const char *e = getenv("QUDA_AMD_XCD_REMAP"); remap = e ? atoi(e) : 1; }
+    if (!remap) arg.xcd_q = -1;
+  }
+  {
     static int order = -1;
     if (order < 0) { const char *e = getenv("QUDA_AMD_DSLASH_ORDER"); order = e ? atoi(e) : 1; }
     const int slice = g.Vh / g.X[3];
@@ -788,10 +838,11 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
       arg.ts = order == 1 ? g.X[3] / 8 : order;   // order > 1: explicit slab thickness (must divide T/8)
       if ((g.X[3] / 8) % arg.ts != 0) arg.ts = g.X[3] / 8;
     }
+    if (arg.xcd_q < 0) arg.ts = 0;
   }
   arg.commMask = 0; arg.blist = nullptr; arg.nboundary = 0;
-  arg.waitSeq = 0; arg.waitTicks = 0; arg.errWord = nullptr; arg.packBlocks = 0;
-  for (int k = 0; k < 8; k++) { arg.waitFlag[k] = nullptr; arg.waitCount[k] = 0; }
+  arg.waitTicks = 0; arg.errWord = nullptr; arg.packBlocks = 0;
+  for (int k = 0; k < 8; k++) arg.waitCount[k] = 0;
   for (int d = 0; d < 4; d++) { arg.ghost[d][0] = arg.ghost[d][1] = nullptr; arg.faceCB[d] = g.faceCB[d]; arg.ghostNormOff[d] = 0; }
   // link/clover stream cache policy: nt for the 16-byte-per-lane formats (measured on 32^4: fp64 4.67 -> 5.2 TB/s, fp32
   // 4.68 -> 5.16 TB/s algorithmic; the read-once links no longer evict the re-used spinors), default for the 8-byte 16-bit format
@@ -817,75 +868,72 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
   for (int d = 0; d < 4; d++) pa.X[d] = g.X[d];
   pa.parity_in = 1 - p.parity; pa.sfwd = arg.sfwd; pa.a = arg.a;
   pa.timeline = nullptr; arg.timeline = nullptr;
-  for (int k = 0; k < 8; k++) { pa.peerFlag[k] = nullptr; arg.waitFlag[k] = nullptr; arg.waitCount[k] = 0; }
-  arg.waitSeq = 0; arg.waitTicks = 0; arg.errWord = nullptr;
+  for (int k = 0; k < 8; k++) arg.waitCount[k] = 0;
+  for (int d = 0; d < 4; d++) pa.llFlag[d] = 0;
+  arg.waitTicks = 0; arg.errWord = nullptr;
   arg.commMask = mask;
   arg.blist = bl.d_idx[p.parity]; arg.nboundary = bl.count[p.parity];
 
   if (hb.p2p) {
-    // peer-store transport, ONE stream: the pack kernel stores every face straight into the neighbours' ghost zones and
-    // raises their flags; the interior pass runs while the faces travel; the exterior pass polls this rank's flags.
-    // Ghost zones are double-buffered by the parity of the exchange counter: a neighbour can be at most one exchange ahead
-    // (it needs OUR face of exchange k+1, packed after our exterior pass k, before it can finish k+1 and pack k+2).
+    // peer-store transport: ONE launch on ONE stream, [pack blocks | every site].  The pack blocks store the faces straight into
+    // the neighbours' ghost zones with the exchange's flag inside every word pair; a boundary site does its local hops first
+    // and then polls exactly the ghost words it needs (ghost_hop).  Zones are double-buffered by the parity of the exchange
+    // counter: a neighbour can be at most one exchange ahead (to finish exchange k+1 it needs OUR face k+1, which is packed
+    // after our kernel k), and the flag — the use count of the (dimension, buffer) zone — tells this exchange's words from
+    // the ones two exchanges old.
     const unsigned seq = ++hb.seq;
     const int buf = seq & 1;
     int nt = 0;
     for (int d = 0; d < 4; d++) {
-      pa.faceCB[d] = g.faceCB[d]; pa.normOff[d] = (int)hb.norm_offset[d];
+      pa.faceCB[d] = g.faceCB[d]; pa.normOff[d] = 0;
       for (int dir = 0; dir < 2; dir++) {
         pa.send[d][dir] = hb.peerGhost[d][dir][buf];
         pa.start[2 * d + dir] = nt;
-        if ((mask >> d) & 1) { nt += g.faceCB[d]; pa.peerFlag[2 * d + dir] = hb.peerFlag[d][dir] + buf; }
+        if ((mask >> d) & 1) nt += g.faceCB[d];
       }
       if ((mask >> d) & 1) {
         arg.ghost[d][0] = hb.ghostBuf[d][0][buf]; arg.ghost[d][1] = hb.ghostBuf[d][1][buf];
-        arg.ghostNormOff[d] = (int)hb.norm_offset[d];
-        arg.waitFlag[2 * d] = hb.flag[d][0] + buf; arg.waitFlag[2 * d + 1] = hb.flag[d][1] + buf;
-        // the counters are cumulative per (dimension, buffer): expected value = times this buffer has been used x face sites
-        arg.waitCount[2 * d] = arg.waitCount[2 * d + 1] = ++hb.uses[d][buf] * (unsigned)g.faceCB[d];
+        unsigned flag = ++hb.uses[d][buf];
+        if (flag == 0) flag = ++hb.uses[d][buf];   // 0 is the value of a never-written word
+        pa.llFlag[d] = flag;
+        arg.waitCount[2 * d] = arg.waitCount[2 * d + 1] = flag;
       }
     }
     pa.start[8] = nt;
-    arg.waitSeq = seq; arg.waitTicks = p2pTimeoutTicks(); arg.errWord = p2pErrorWord();
-    static int fuse = -1;
-    if (fuse < 0) { const char *e = getenv("QUDA_AMD_FUSE"); fuse = e ? atoi(e) : 1; }
-    if (fuse) {
-      // ONE launch: [pack blocks | every site]; boundary sites add their off-node hops after polling the face counters
-      arg.packBlocks = (nt + bs - 1) / bs;
-      static unsigned long long *tl = nullptr;
-      static int tlmode = -1;
-      if (tlmode < 0) { const char *e = getenv("QUDA_AMD_TIMELINE"); tlmode = e ? atoi(e) : 0; if (tlmode) HIP_CHECK(hipHostMalloc((void **)&tl, 16384 * sizeof(unsigned long long), hipHostMallocMapped)); }
-      if (tlmode) {
-        static int calls = 0;
-        if (++calls == 60 && arg.packBlocks + nb <= 1024) {
-          HIP_CHECK(hipStreamSynchronize(cs));
-          memset(tl, 0, 16384 * sizeof(unsigned long long));
-          pa.timeline = tl; arg.timeline = tl; arg.pack = pa;
-          hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 3>), dim3(arg.packBlocks + nb), dim3(bs), 0, cs, arg);
-          HIP_CHECK(hipStreamSynchronize(cs));
-          unsigned long long t0 = ~0ull;
-          for (int i = 0; i < 16384; i++) if (tl[i] && tl[i] < t0) t0 = tl[i];
-          auto stat = [&](int off, int n, const char *name) {
-            double mn = 1e30, mx = 0, sum = 0; int c = 0;
-            for (int i = 0; i < n; i++) if (tl[off + i]) { const double v = (tl[off + i] - t0) * 0.01; mn = v < mn ? v : mn; mx = v > mx ? v : mx; sum += v; c++; }
-            if (c) printfQuda("timeline %-22s n=%4d  min %6.2f  mean %6.2f  max %6.2f us\n", name, c, mn, sum / c, mx);
-          };
-          stat(0, 1024, "pack block start"); stat(1024, 1024, "pack block end"); stat(2048, 1024, "stencil block start");
-          stat(4096, 4096, "boundary wave wait beg"); stat(8192, 4096, "boundary wave wait end"); stat(12288, 1024, "stencil block end");
-          return;
+    arg.waitTicks = p2pTimeoutTicks(); arg.errWord = p2pErrorWord();
+    arg.packBlocks = (nt + bs - 1) / bs;
+    static unsigned long long *tl = nullptr;
+    static int tlmode = -1;
+    if (tlmode < 0) { const char *e = getenv("QUDA_AMD_TIMELINE"); tlmode = e ? atoi(e) : 0; if (tlmode) HIP_CHECK(hipHostMalloc((void **)&tl, 16384 * sizeof(unsigned long long), hipHostMallocMapped)); }
+    if (tlmode) {
+      static int calls = 0;
+      if (++calls == 60 && arg.packBlocks + nb <= 1024) {
+        HIP_CHECK(hipStreamSynchronize(cs));
+        memset(tl, 0, 16384 * sizeof(unsigned long long));
+        pa.timeline = tl; arg.timeline = tl; arg.pack = pa;
+        hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 3>), dim3(arg.packBlocks + nb), dim3(bs), 0, cs, arg);
+        HIP_CHECK(hipStreamSynchronize(cs));
+        unsigned long long t0 = ~0ull;
+        for (int i = 0; i < 16384; i++) if (tl[i] && tl[i] < t0) t0 = tl[i];
+        auto stat = [&](int off, int n, const char *name) {
+          double mn = 1e30, mx = 0, sum = 0; int c = 0;
+          for (int i = 0; i < n; i++) if (tl[off + i]) { const double v = (tl[off + i] - t0) * 0.01; mn = v < mn ? v : mn; mx = v > mx ? v : mx; sum += v; c++; }
+          if (c) printfQuda("timeline %-22s n=%4d  min %6.2f  mean %6.2f  max %6.2f us\n", name, c, mn, sum / c, mx);
+        };
+        stat(0, 1024, "pack block start"); stat(1024, 1024, "pack block end"); stat(2048, 1024, "stencil block start");
+        stat(4096, 4096, "boundary wave ghost beg"); stat(8192, 4096, "boundary wave ghost end"); stat(12288, 1024, "stencil block end");
+        for (int x = 0; x < 8; x++) {   // per XCD (blocks are dealt round-robin): start / end of its stencil blocks
+          double sb = 0, se = 0, mx = 0; int c = 0;
+          for (int i = x; i < 1024; i += 8) if (tl[12288 + i]) { sb += (tl[2048 + i] - t0) * 0.01; const double e = (tl[12288 + i] - t0) * 0.01; se += e; mx = e > mx ? e : mx; c++; }
+          if (c) printfQuda("timeline xcd %d: %3d stencil blocks, mean start %6.2f, mean end %6.2f, max end %6.2f us\n", x, c, sb / c, se / c, mx);
         }
+        return;
       }
-      pa.timeline = nullptr; arg.timeline = nullptr;
-      arg.pack = pa;
-      hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 3>), dim3(arg.packBlocks + nb), dim3(bs), 0, cs, arg);
-      HIP_CHECK(hipGetLastError());
-      return;
     }
-    // QUDA_AMD_FUSE=0 (A/B measurements): pack, interior and exterior passes as three launches on the one stream
-    hipLaunchKernelGGL((pack_kernel<T, VARIANT == 1, true>), dim3((nt + 255) / 256), dim3(256), 0, cs, pa);
-    hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 1>), dim3(nb), dim3(bs), 0, cs, arg);   // interior
+    pa.timeline = nullptr; arg.timeline = nullptr;
+    arg.pack = pa;
+    hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 3>), dim3(arg.packBlocks + nb), dim3(bs), 0, cs, arg);
     HIP_CHECK(hipGetLastError());
-    launchExterior<T, R, VARIANT, GAUX>(arg, cs);
     return;
   }
 

@@ -36,17 +36,14 @@ struct HaloBuffers {
   char *ghost[4][2] = {};                // [dim][0: from -dim neighbour, 1: from +dim neighbour]
   char *pool = nullptr;
   size_t pool_bytes = 0;
-  // peer-store transport (p2p.h): a fine-grained window holding double-buffered ghost blocks [dim][k][buf] and one site counter per
-  // (dim, k, buf), mapped into the neighbours; peerGhost / peerFlag are the addresses inside THEIR windows where this rank's
-  // (dim, to_fwd) face and its flag land
+  // peer-store transport (p2p.h): a fine-grained window holding double-buffered flag-in-data ghost zones [dim][k][buf], mapped
+  // into the neighbours; peerGhost are the addresses inside THEIR windows where this rank's (dim, to_fwd) face lands
   bool p2p = false;
   char *window = nullptr;
   char *ghostBuf[4][2][2] = {};
-  unsigned *flag[4][2] = {};       // + buf
   char *peerGhost[4][2][2] = {};   // [dim][to_fwd][buf]
-  unsigned *peerFlag[4][2] = {};   // + buf
   unsigned seq = 0;
-  unsigned uses[4][2] = {};        // exchanges that used (dim, buf) so far
+  unsigned uses[4][2] = {};        // exchanges that used (dim, buf) so far = the flag carried by the words of the current one
   PeerMap map;
 };
 
