@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libquda.so")
+LIB_PATH = os.environ.get("QUDA_AMD_LIBRARY") or os.path.join(_HERE, "lib", "libquda.so")   # override: A/B timing of two builds
 INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 
 # ---- enum values (include/quda.h) ----

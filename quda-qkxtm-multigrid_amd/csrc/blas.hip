@@ -11,6 +11,8 @@
 // fp64/fp32 fields of any spin/colour are treated as flat arrays (complex pairs stay adjacent in the
 // FLOAT2/FLOAT4 planar orders); 16-bit fields go site by site because of their per-site scale.
 #include <cstring>
+#include <sys/time.h>
+#include <unistd.h>
 #include "blas.h"
 
 #include "device_io.h"
@@ -29,16 +31,19 @@ static double *h_red_dev = nullptr;  // device address of h_red
 static double *d_part = nullptr;  // per-block partial sums
 static unsigned *d_count = nullptr;  // completion counter (zero between launches)
 constexpr int kMaxBlocks = 4096;
+constexpr int kMaxRed = 64;
 constexpr int kSlotDoubles = 8;   // doubles per (buffer, rank) slot of the all-reduce window
 
 // Block-level all-reduce over ranks through the peer windows (called by ONE block per rank, all threads of it).  Thread r
 // delivers this rank's nred sums to rank r with system-scope write-through stores followed by a fire-and-forget counter
-// bump; thread 0 then waits until every rank's contribution has arrived in the own window (bounded by waitTicks: a
-// missing rank sets *errWord = 33 instead of hanging), and thread k < nred returns sum_r slot[r][k], added in rank order
-// on every rank, so all ranks hold bit-identical results.
+// bump; thread 0 then waits — for at most waitTicks — until every rank's contribution has arrived in the own window, and
+// thread k < nred returns sum_r slot[r][k], added in rank order on every rank, so all ranks hold bit-identical results.
+// *done = 0 if the wait ran out: ranks may be arbitrarily far apart when they reach a collective (one of them still busy on
+// its host), which is not an error — the caller then finishes the reduction from the host side (finishAllreduceOnHost);
+// this rank's own contribution has been delivered either way.
 template <int NRED>
 __device__ __forceinline__ double peer_allreduce(const double *mine, double *const *peerSlots, unsigned *const *peerCount, int nranks, int rank, int buf,
-                                                 unsigned expect, unsigned long long waitTicks, int *errWord) {
+                                                 unsigned expect, unsigned long long waitTicks, int *done) {
   if ((int)threadIdx.x < nranks) {
     double *slot = peerSlots[threadIdx.x] + ((size_t)buf * nranks + rank) * kSlotDoubles;
     for (int k = 0; k < NRED; k++)
@@ -46,16 +51,18 @@ __device__ __forceinline__ double peer_allreduce(const double *mine, double *con
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     (void)__hip_atomic_fetch_add(peerCount[threadIdx.x] + buf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  if (threadIdx.x == 0 && !__hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+  if (threadIdx.x == 0) {
     const unsigned long long t0 = wall_clock64();
+    int ok = 1;
     while ((int)(__hip_atomic_load(peerCount[rank] + buf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - expect) < 0) {
-      if (wall_clock64() - t0 > waitTicks) { __hip_atomic_store(errWord, 33, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (wall_clock64() - t0 > waitTicks) { ok = 0; break; }
       __builtin_amdgcn_s_sleep(1);
     }
+    *done = ok;
   }
   __syncthreads();
   double v = 0;
-  if (threadIdx.x < NRED) {
+  if (threadIdx.x < NRED && *done) {
     const double *slots = peerSlots[rank] + (size_t)buf * nranks * kSlotDoubles;
     for (int r = 0; r < nranks; r++)
       v += __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long *>(slots + (size_t)r * kSlotDoubles + threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
@@ -67,15 +74,14 @@ __device__ __forceinline__ double peer_allreduce(const double *mine, double *con
 __global__ void allreduce_probe_kernel(double *const *peerSlots, unsigned *const *peerCount, int nranks, int rank, int buf, unsigned expect,
                                        unsigned long long waitTicks, int round, int *result) {
   __shared__ double mine[kSlotDoubles];
-  __shared__ int err;
-  if (threadIdx.x == 0) err = 0;
+  __shared__ int done;
   if (threadIdx.x < kSlotDoubles) mine[threadIdx.x] = (double)((rank + 1) * (round + 1) + 1000 * (int)threadIdx.x);
   __syncthreads();
-  const double v = peer_allreduce<kSlotDoubles>(mine, peerSlots, peerCount, nranks, rank, buf, expect, waitTicks, &err);
+  const double v = peer_allreduce<kSlotDoubles>(mine, peerSlots, peerCount, nranks, rank, buf, expect, waitTicks, &done);
   bool ok = true;
   if (threadIdx.x < kSlotDoubles) ok = v == (double)((round + 1) * (nranks * (nranks + 1) / 2) + 1000 * (int)threadIdx.x * nranks);
   const int allOk = __syncthreads_and(ok);
-  if (threadIdx.x == 0) result[0] = allOk && !err;
+  if (threadIdx.x == 0) result[0] = allOk && done;
 }
 
 // ---- all-reduce window: [2 buffers][ranks][kSlotDoubles] doubles + 2 counters, fine-grained, mapped into every rank ----
@@ -152,8 +158,34 @@ static bool reduceWindowActive() {
   g_rw.state = 1;
   return true;
 }
+// The in-kernel wait of a peer all-reduce ran out (another rank has not reached this reduction yet — it may be busy on its
+// host for as long as it likes): wait for the missing contributions from the host side, with the patience of a blocking
+// collective (QUDA_AMD_COLLECTIVE_TIMEOUT_S, default 600 s), then add the slots in rank order exactly as the kernel would.
+static void finishAllreduceOnHost(int buf, unsigned expect, int nred, double *out) {
+  const CommGrid &g = commGrid();
+  const size_t slotBytes = (size_t)2 * g.size * kSlotDoubles * sizeof(double);
+  const unsigned *d_count = (const unsigned *)(g_rw.window + slotBytes) + buf;
+  static double limit = -1;
+  if (limit < 0) { const char *e = getenv("QUDA_AMD_COLLECTIVE_TIMEOUT_S"); limit = e ? atof(e) : 600.0; }
+  timeval t0; gettimeofday(&t0, nullptr);
+  for (long it = 0;; it++) {
+    unsigned cnt = 0;
+    HIP_CHECK(hipMemcpy(&cnt, d_count, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if ((int)(cnt - expect) >= 0) break;
+    timeval t1; gettimeofday(&t1, nullptr);
+    if ((t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec) > limit)
+      errorQuda("all-reduce: %u of %u contributions after %.0f s (a rank never reached this reduction)", cnt - (expect - (unsigned)g.size), (unsigned)g.size, limit);
+    usleep(it < 1000 ? 20 : 500);
+  }
+  std::vector<double> slots((size_t)g.size * kSlotDoubles);
+  HIP_CHECK(hipMemcpy(slots.data(), g_rw.window + (size_t)buf * g.size * kSlotDoubles * sizeof(double), slots.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int k = 0; k < nred; k++) {
+    double v = 0;
+    for (int r = 0; r < g.size; r++) v += slots[(size_t)r * kSlotDoubles + k];
+    out[k] = v;
+  }
+}
 static bool g_global_reduction = true;
-constexpr int kMaxRed = 64;
 
 void init() {
   if (!d_red) HIP_CHECK(hipMalloc((void **)&d_red, kMaxRed * sizeof(double)));
@@ -202,7 +234,6 @@ template <typename F> struct BlasArg {
   int nranks, rank, buf;
   unsigned expect;
   unsigned long long waitTicks;
-  int *errWord;
 };
 
 template <typename real, int M> struct alignas(16) Chunk { real v[M]; };
@@ -400,11 +431,14 @@ __global__ void __launch_bounds__(256) blas_kernel(BlasArg<F> arg) {
           mine[threadIdx.x] = v;
         }
         __syncthreads();
-        const double v = peer_allreduce<F::nred>(mine, arg.peerSlots, arg.peerCount, arg.nranks, arg.rank, arg.buf, arg.expect, arg.waitTicks, arg.errWord);
+        __shared__ int done;
+        const double v = peer_allreduce<F::nred>(mine, arg.peerSlots, arg.peerCount, arg.nranks, arg.rank, arg.buf, arg.expect, arg.waitTicks, &done);
         if (threadIdx.x < F::nred) {
           arg.red[threadIdx.x] = v;
           __hip_atomic_store(&arg.hred[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        // last word of the host buffer: 1 = the sums above are the global ones, 0 = the host has to finish the reduction
+        if (threadIdx.x == 0) __hip_atomic_store(&arg.hred[kMaxRed - 1], done ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       } else if (threadIdx.x < F::nred) {
         double v = 0;
         for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) v += lds[wv][threadIdx.x];
@@ -452,9 +486,9 @@ static void launch(const F &f, const ColorSpinorField &x, const ColorSpinorField
   arg.red = d_red;
   arg.part = d_part;
   arg.count = d_count;
-  bool allreduce = g_global_reduction && commReductionsNeeded();
+  bool allreduce = g_global_reduction && commReductionsNeeded(), peer = false;
   arg.hred = allreduce ? nullptr : h_red_dev;
-  arg.peerSlots = nullptr; arg.peerCount = nullptr; arg.nranks = 1; arg.rank = 0; arg.buf = 0; arg.expect = 0; arg.waitTicks = 0; arg.errWord = nullptr;
+  arg.peerSlots = nullptr; arg.peerCount = nullptr; arg.nranks = 1; arg.rank = 0; arg.buf = 0; arg.expect = 0; arg.waitTicks = 0;
   if (allreduce && F::nred > 0 && F::nred <= kSlotDoubles && reduceWindowActive()) {
     // the last block of the kernel does the all-reduce itself through the peer windows and writes the global sums to the host
     const CommGrid &cg = commGrid();
@@ -462,9 +496,10 @@ static void launch(const F &f, const ColorSpinorField &x, const ColorSpinorField
     arg.nranks = cg.size; arg.rank = cg.rank;
     arg.buf = (int)(++g_rw.seq & 1);
     arg.expect = (g_rw.uses[arg.buf] += (unsigned)cg.size);
-    arg.waitTicks = p2pTimeoutTicks(); arg.errWord = p2pErrorWord();
+    arg.waitTicks = 2000000ull;   // 20 ms of in-kernel waiting (ranks in step arrive within microseconds), then the host takes over
     arg.hred = h_red_dev;
     allreduce = false;
+    peer = true;
   }
   hipStream_t s = computeStream();
   const long nreal = (long)x.Stride() * x.Nspin() * x.Ncolor() * 2;
@@ -498,6 +533,7 @@ static void launch(const F &f, const ColorSpinorField &x, const ColorSpinorField
       HIP_CHECK(hipMemcpyAsync(h_red, d_red, F::nred * sizeof(double), hipMemcpyDeviceToHost, s));
     }
     HIP_CHECK(hipStreamSynchronize(s));
+    if (peer && h_red[kMaxRed - 1] == 0.0) finishAllreduceOnHost(arg.buf, arg.expect, F::nred, h_red);
     for (int k = 0; k < F::nred; k++) out[k] = h_red[k];
   }
   const int nrd = F::rx + F::ry + F::rz + F::rw, nwr = F::wx + F::wy + F::wz + F::ww;

@@ -105,11 +105,13 @@ void p2pCheck(const char *where) {
   if (h) errorQuda("%s: a halo wait timed out (a neighbour rank never delivered its face; error word %d)", where, h);
 }
 
-// ---- token round trips through the mapped windows, with the same access types as the halo protocol: system-scope
-// write-through stores for the payload, a fire-and-forget remote atomic add for the counter, system-scope polling and loads.
+// ---- token round trips through the mapped windows, with the same access types as the production protocols: system-scope
+// write-through stores for the payload + a fire-and-forget remote atomic add for the counter + system-scope polling and loads
+// (coarse-grid halo, all-reduce), and 16-byte flag-in-data buffer stores / polling buffer loads (fine-grid halo).
 // Several rounds over the SAME addresses, so a receiver that could serve a later round from a stale cache line fails here
 // and not in production. ----
-struct ProbeWindow { unsigned data[8][16]; unsigned flag[8]; };
+struct ProbeWindow { unsigned data[8][16]; unsigned flag[8]; unsigned pad[8]; unsigned ll[8][32][4]; };   // ll: 16-byte aligned
+typedef unsigned int probe_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned probe_token(int rank, int s, int k, int round) { return 0x5eed0000u + (unsigned)round * 4096u + (unsigned)rank * 128u + s * 16u + k; }
 
@@ -121,6 +123,12 @@ __global__ void p2p_probe_send(ProbeWindow *const *peer, int rank, int round) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   if (k == 0) (void)__hip_atomic_fetch_add(&w->flag[s], 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // the fine-grid halo's flag-in-data vectors {word, flag, word, flag}: 16-byte buffer stores, sc0 sc1, no ordering, no signal
+  for (int v = k; v < 32; v += 16) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)w->ll[s], 0, (int)sizeof(w->ll[s]), 0x00020000);
+    probe_u32x4 q; q.x = probe_token(rank, s, v, round); q.y = 0xf1a60000u + round; q.z = ~probe_token(rank, s, v, round); q.w = 0xf1a60000u + round;
+    __builtin_amdgcn_raw_buffer_store_b128(q, rs, v * 16, 0, 17);
+  }
 }
 __global__ void p2p_probe_recv(ProbeWindow *mine, const int *fromRank, unsigned long long ticks, int *result, int round) {
   const int s = threadIdx.x;
@@ -133,6 +141,17 @@ __global__ void p2p_probe_recv(ProbeWindow *mine, const int *fromRank, unsigned 
   }
   if (ok)
     for (int k = 0; k < 16; k++) ok = ok && __hip_atomic_load(&mine->data[s][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == probe_token(fromRank[s], s, k, round);
+  // flag-in-data vectors: poll each one until both halves carry this round's flag, then check the words
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)mine->ll[s], 0, (int)sizeof(mine->ll[s]), 0x00020000);
+  for (int v = 0; v < 32 && ok; v++) {
+    const unsigned flag = 0xf1a60000u + round;
+    for (;;) {
+      const probe_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, v * 16, 0, 17);
+      if (q.y == flag && q.w == flag) { ok = q.x == probe_token(fromRank[s], s, v, round) && q.z == ~probe_token(fromRank[s], s, v, round); break; }
+      if (wall_clock64() - t0 > ticks) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
   if (!ok) atomicAdd(result, 1);
 }
 

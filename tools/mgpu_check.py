@@ -112,6 +112,22 @@ def main():
         # (xg holds only this rank's piece; the oracle result is exact on sites whose 8 neighbours are local)
         if rank == 0:
             print("OK lattice %s grid %s: dslash/mat/matpc parity in 3 precisions; GCR %d iterations, global |r|/|b| = %.2e" % (X, grid, ip.iter, rel))
+        # a global sum that the ranks reach 0.3 s apart — longer than the in-kernel wait of the peer all-reduce, so the early ranks
+        # finish it from the host side: every rank must still get the same bits, and the value of the global field
+        import time
+        ipn = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=8)
+        spn = qa.Spinor(8)
+        spn.load(s_loc[:nh_l].copy(), ipn)
+        for late in (world - 1, 0):
+            if rank == late:
+                time.sleep(0.3)
+            n2v = spn.norm2()
+            mm = np.array([n2v, -n2v])
+            qa.lib().qudaAmdCommAllreduceMax(mm.ctypes.data_as(C.POINTER(C.c_double)), 2)
+            assert mm[0] == -mm[1] == n2v, ("skewed all-reduce differs between ranks", rank, n2v, mm)
+            want_n2 = float(np.dot(spinor[:nh_g], spinor[:nh_g]))
+            assert abs(n2v - want_n2) < 1e-12 * want_n2, ("skewed all-reduce value", n2v, want_n2)
+        spn.free()
         # ---- QKXTM solve loop on the decomposed lattice: smearing through ghost-aware covariant shifts, the point source on the
         # rank that owns it, up / down propagators in the drivers' lexicographic UKQCD layout ----
         g_lex_glob = np.stack([oracle.eo_to_lex(np.ascontiguousarray(gauge[d]), X, 18) for d in range(4)])

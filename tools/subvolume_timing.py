@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Dslash time on the 8-GPU strong-scaling sub-lattice (32x16x16x16 of the 32^4 bench lattice) on one GPU: unpartitioned and
 with y,z,t partitioned through the self-neighbour emulation (qudaAmdSetPartitionMask).  Launch geometry is read from the
-environment (QUDA_AMD_DSLASH_BLOCK, ...), so run once per setting.  usage: subvolume_timing.py [prec] [lattice]"""
+environment (QUDA_AMD_DSLASH_BLOCK, ...), so run once per setting.  usage: subvolume_timing.py [prec] [lattice] [mask]"""
 import importlib
 import os
 import sys
@@ -20,7 +20,8 @@ gauge = make_gauge(X)
 Vh = int(np.prod(X)) // 2
 src_h = np.random.default_rng(1).random(Vh * 24)
 out = []
-for mask in (0, 0b1110):
+pmask = int(sys.argv[3]) if len(sys.argv) > 3 else 0b1110
+for mask in (0, pmask):
     qa.lib().qudaAmdSetPartitionMask(mask)
     qa.load_gauge(gauge, qa.gauge_param(X, cuda_prec=prec))
     ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, 0.1, 0.01, +1, "ee", 0, cuda_prec=prec)
@@ -31,6 +32,6 @@ for mask in (0, 0b1110):
     best = min(d.time_dslash(dst, src, 0, 500) for _ in range(3))
     out.append("mask %2d: %.2f us" % (mask, 1e6 * best))
     src.free(); dst.free(); d.free()
-print("prec %d lattice %s block %s spt %s: %s" % (prec, X, os.environ.get("QUDA_AMD_DSLASH_BLOCK", "256"), os.environ.get("QUDA_AMD_DSLASH_SPT", "-"), "; ".join(out)))
+print("prec %d lattice %s remap %s: %s" % (prec, X, os.environ.get("QUDA_AMD_XCD_REMAP", "1"), "; ".join(out)))
 qa.lib().qudaAmdSetPartitionMask(0)
 qa.end()
