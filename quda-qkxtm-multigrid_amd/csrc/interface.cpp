@@ -9,6 +9,7 @@
 #include "blas.h"
 #include "dirac.h"
 #include "interface_internal.h"
+#include "halo.h"
 #include "p2p.h"
 #include "quda_amd_ext.h"
 
@@ -347,6 +348,14 @@ void freeCloverQuda(void) {
 }
 
 // reference :1496-1570
+// The device-side halo waits are bounded (QUDA_AMD_P2P_TIMEOUT_S: a neighbour that never delivers is an error, not a hang), so
+// ranks must not ENTER an operator application further apart than that bound.  Inside a solver the global sums keep them in
+// step; a stand-alone operator call through the C ABI can follow arbitrary host work (I/O, source construction), hence a
+// blocking host-level rendezvous first — tens of microseconds next to the two PCIe transfers of such a call.
+static void meetRanksBeforeOperator() {
+  if (commGrid().size > 1) commBarrier();
+}
+
 void dslashQuda(void *h_out, void *h_in, QudaInvertParam *inv, QudaParity parity) {
   checkResident(inv);
   ColorSpinorParam cpuParam(h_in, *inv, g_geom.X, true);
@@ -354,6 +363,7 @@ void dslashQuda(void *h_out, void *h_in, QudaInvertParam *inv, QudaParity parity
   ColorSpinorParam dp = deviceSpinorParam(inv->cuda_prec, QUDA_PARITY_SITE_SUBSET, inv->twist_flavor);
   ColorSpinorField in(dp), out(dp);
   in = in_h;
+  meetRanksBeforeOperator();
   DiracParam diracParam;
   setDiracParam(diracParam, inv, true);
   Dirac *dirac = Dirac::create(diracParam);
@@ -391,6 +401,7 @@ static void applyMat(void *h_out, void *h_in, QudaInvertParam *inv, bool dagmat)
   ColorSpinorParam dp = deviceSpinorParam(inv->cuda_prec, pc ? QUDA_PARITY_SITE_SUBSET : QUDA_FULL_SITE_SUBSET, inv->twist_flavor);
   ColorSpinorField in(dp), out(dp);
   in = in_h;
+  meetRanksBeforeOperator();
   DiracParam diracParam;
   setDiracParam(diracParam, inv, pc);
   Dirac *dirac = Dirac::create(diracParam);
