@@ -329,6 +329,9 @@ void printQudaMultigridParam(QudaMultigridParam *param); /* ref quda.h:573 */
 
 void loadGaugeQuda(void *h_gauge, QudaGaugeParam *param);  /* ref quda.h:586; lib/interface_quda.cpp:521 */
 void freeGaugeQuda(void);                                  /* ref quda.h:591 */
+void saveGaugeQuda(void *h_gauge, QudaGaugeParam *param);  /* ref quda.h:598; lib/interface_quda.cpp:694: resident links back in host QDP order */
+void plaqQuda(double plaq[3]);                             /* ref quda.h:964; lib/interface_quda.cpp:5510: total, spatial, temporal plaquette of the resident links */
+void performAPEnStep(unsigned int nSteps, double alpha);   /* ref quda.h:971; lib/interface_quda.cpp:5565: APE-smear the resident spatial links into the library's smeared field */
 void loadCloverQuda(void *h_clover, void *h_clovinv, QudaInvertParam *inv_param); /* ref quda.h:607; interface_quda.cpp:730 */
 void freeCloverQuda(void);                                 /* ref quda.h:613 */
 

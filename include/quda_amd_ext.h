@@ -97,6 +97,11 @@ typedef struct QudaAmdSourceParam_s {
   int nsmearGauss;         /* qudaQKXTMinfo_Kepler::nsmearGauss (:46); 0: point source, gauge_APE may be NULL */
   double alphaGauss;       /* qudaQKXTMinfo_Kepler::alphaGauss (:48) */
 } QudaAmdSourceParam;
+/* The smeared field that performAPEnStep leaves inside the library (the reference keeps it in the file-scope gaugeSmeared and has
+ * no accessor): host copy, fp64, either in QDP order (lexicographic = 0: even sites then odd, as loadGaugeQuda takes it) or in
+ * the QKXTM lexicographic order gauge_APE uses (lexicographic = 1).  The two functions below also accept gauge_APE = NULL and
+ * then smear with that resident field — what the drivers' read-smeared-configuration step supplies otherwise. */
+void qudaAmdSaveSmearedGauge(void **h_gauge, int lexicographic);
 /* h_out = smear^nsmear(h_in) (QKXTM_Vector_Kepler::gaussianSmearing, lib/qudaQKXTM_Vector_Kepler.cpp:386-421); the lattice is
  * that of the resident gauge field */
 void qudaAmdGaussianSmear(void *h_out, const void *h_in, void **gauge_APE, int nsmear, double alpha);

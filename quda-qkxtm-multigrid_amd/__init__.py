@@ -191,6 +191,10 @@ def lib():
         L.qudaAmdMultigridGetV.argtypes = [_p, _i, _p]
         L.qudaAmdMultigridGetCoarseLinks.argtypes = [_p, _i, _p, _p]
         L.qudaAmdMultigridApply.argtypes = [_p, _i, _i, _p, _p]
+        L.plaqQuda.argtypes = [C.POINTER(_d)]
+        L.performAPEnStep.argtypes = [C.c_uint, _d]
+        L.saveGaugeQuda.argtypes = [_p, C.POINTER(QudaGaugeParam)]
+        L.qudaAmdSaveSmearedGauge.argtypes = [C.POINTER(_p), _i]
         L.qudaAmdGaussianSmear.argtypes = [_p, _p, C.POINTER(_p), _i, _d]
         L.qudaAmdCalcMGPropagators.argtypes = [_p, _p, C.POINTER(_p), C.POINTER(QudaInvertParam), C.POINTER(QudaAmdSourceParam)]
         _lib = L
@@ -311,6 +315,33 @@ def invert(h_b, ip):
     x = np.zeros_like(h_b)
     lib().invertQuda(_vp(x), _vp(h_b), C.byref(ip))
     return x
+
+
+def plaquette():
+    """plaqQuda: (total, spatial, temporal) plaquette averages of the resident links"""
+    pl = (_d * 3)()
+    lib().plaqQuda(pl)
+    return tuple(pl)
+
+
+def perform_ape(n_steps, alpha):
+    lib().performAPEnStep(int(n_steps), float(alpha))
+
+
+def save_gauge(gp):
+    """saveGaugeQuda: the resident links in host QDP order, (4, V*18) float64"""
+    V = int(np.prod([gp.X[d] for d in range(4)]))
+    out = np.zeros((4, V * 18))
+    ptr = (_p * 4)(*[_vp(out[d]) for d in range(4)])
+    lib().saveGaugeQuda(C.cast(ptr, _p), C.byref(gp))
+    return out
+
+
+def save_smeared_gauge(local_volume, lexicographic=False):
+    out = np.zeros((4, int(local_volume) * 18))
+    ptr = (_p * 4)(*[_vp(out[d]) for d in range(4)])
+    lib().qudaAmdSaveSmearedGauge(ptr, int(bool(lexicographic)))
+    return out
 
 
 def _lex_links(gauge_lex):

@@ -178,4 +178,10 @@ class CloverField {
   double GiB() const { return 2.0 * bytes / (double)(1 << 30); }
 };
 
+// gauge tools on the device (fields.hip): APE smearing of the spatial links (a new fp64 field), the plaquette averages, and the
+// forward links back in host QDP order
+GaugeField *apeSmear(const GaugeField &U, unsigned nSteps, double alpha);
+void plaquette(const GaugeField &U, double plq[3]);
+void saveGaugeQDP(const GaugeField &U, void *const h_gauge[4], QudaPrecision cpu_prec);
+
 }  // namespace quda

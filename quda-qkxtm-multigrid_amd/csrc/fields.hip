@@ -1060,4 +1060,275 @@ void CloverField::savePacked(void *h_inv, QudaPrecision cpu_prec) const {
   HIP_CHECK(hipStreamSynchronize(computeStream()));
 }
 
+
+void comm_allreduce(double *data, int n);   // comm.cpp
+
+// ================================================================================================================
+// APE smearing of the spatial links and the plaquette (reference lib/gauge_ape.cu:44-156,
+// include/su3_project.cuh:23-124, lib/interface_quda.cpp:5565-5640, lib/gauge_plaq.cu:38-152).  Same transport formulation as
+// the decomposed clover construction above: forward links as 3x3 matrix fields, neighbours through the ghost-aware
+// nearest-neighbour shift (applyShift), so a grid-decomposed lattice needs no extended gauge halo and no corner exchange
+// (the reference: copyExtendedGauge + exchangeExtendedGhost every step).  fp64 throughout.
+//   upper staple of (x, nu) in the mu-nu plane:  U_mu(x) U_nu(x+mu) U_mu(x+nu)^dag
+//   lower staple:                                [U_mu^dag U_nu T_nu(U_mu)](x - mu)      (built at x - mu, then shifted to x)
+__device__ __forceinline__ void m3_det(double &dr, double &di, const M3 &a) {
+  dr = 0; di = 0;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+    const double mr = (a.re[3 + c1] * a.re[6 + c2] - a.im[3 + c1] * a.im[6 + c2]) - (a.re[3 + c2] * a.re[6 + c1] - a.im[3 + c2] * a.im[6 + c1]);
+    const double mi = (a.re[3 + c1] * a.im[6 + c2] + a.im[3 + c1] * a.re[6 + c2]) - (a.re[3 + c2] * a.im[6 + c1] + a.im[3 + c2] * a.re[6 + c1]);
+    dr += a.re[c] * mr - a.im[c] * mi;
+    di += a.re[c] * mi + a.im[c] * mr;
+  }
+}
+__device__ __forceinline__ void m3_inverse(M3 &o, const M3 &a) {   // adjugate / determinant
+  double dr, di;
+  m3_det(dr, di, a);
+  const double n = dr * dr + di * di, ir = dr / n, ii = -di / n;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int r1 = (j + 1) % 3, r2 = (j + 2) % 3, c1 = (i + 1) % 3, c2 = (i + 2) % 3;
+      const double cr = (a.re[3 * r1 + c1] * a.re[3 * r2 + c2] - a.im[3 * r1 + c1] * a.im[3 * r2 + c2]) - (a.re[3 * r1 + c2] * a.re[3 * r2 + c1] - a.im[3 * r1 + c2] * a.im[3 * r2 + c1]);
+      const double ci = (a.re[3 * r1 + c1] * a.im[3 * r2 + c2] + a.im[3 * r1 + c1] * a.re[3 * r2 + c2]) - (a.re[3 * r1 + c2] * a.im[3 * r2 + c1] + a.im[3 * r1 + c2] * a.re[3 * r2 + c1]);
+      o.re[3 * i + j] = cr * ir - ci * ii;
+      o.im[3 * i + j] = cr * ii + ci * ir;
+    }
+}
+// su3_project.cuh polarSu3: Newton iteration X <- (X + X^-dag)/2 until X is unitary to tol (elementwise, X vs (X^-1)^dag),
+// then the phase of the determinant is divided out.  Capped at 100 sweeps (the reference loops until the test passes).
+__device__ __forceinline__ void polar_su3(M3 &m, double tol) {
+  M3 out = m, inv;
+  m3_inverse(inv, out);
+  for (int sweep = 0; sweep < 100; sweep++) {
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        out.re[3 * i + j] = 0.5 * (out.re[3 * i + j] + inv.re[3 * j + i]);
+        out.im[3 * i + j] = 0.5 * (out.im[3 * i + j] - inv.im[3 * j + i]);
+      }
+    m3_inverse(inv, out);
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) bad = bad || fabs(out.re[3 * i + j] - inv.re[3 * j + i]) > tol || fabs(out.im[3 * i + j] + inv.im[3 * j + i]) > tol;
+    if (!bad) break;
+  }
+  double dr, di;
+  m3_det(dr, di, out);
+  const double mod = pow(dr * dr + di * di, 1.0 / 6.0), angle = atan2(di, dr) / -3.0;
+  const double cr = cos(angle) / mod, ci = sin(angle) / mod;
+#pragma unroll
+  for (int k = 0; k < 9; k++) { m.re[k] = out.re[k] * cr - out.im[k] * ci; m.im[k] = out.re[k] * ci + out.im[k] * cr; }
+}
+
+// out (+)= op(A) op(B), op = identity or Hermitian conjugate
+__global__ void mf_mul_kernel(MatField out, MatField A, MatField B, int dagA, int dagB, int accumulate, int Vh) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= 2 * Vh) return;
+  const int par = gid >= Vh, idx = gid - par * Vh;
+  M3 a, b, t, c;
+  mf_load(a, A, par, idx); if (dagA) { m3_dag(t, a); a = t; }
+  mf_load(b, B, par, idx); if (dagB) { m3_dag(t, b); b = t; }
+  m3_mul(c, a, b);
+  if (accumulate) {
+    mf_load(t, out, par, idx);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { c.re[k] += t.re[k]; c.im[k] += t.im[k]; }
+  }
+  mf_store(c, out, par, idx);
+}
+__global__ void mf_add_kernel(MatField out, MatField in, int Vh) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= 2 * Vh) return;
+  const int par = gid >= Vh, idx = gid - par * Vh;
+  M3 a, b;
+  mf_load(a, out, par, idx); mf_load(b, in, par, idx);
+#pragma unroll
+  for (int k = 0; k < 9; k++) { a.re[k] += b.re[k]; a.im[k] += b.im[k]; }
+  mf_store(a, out, par, idx);
+}
+// computeAPEStep: TestU = (1 - alpha) + alpha/4 S U^dag, projected; U' = TestU U
+__global__ void ape_project_kernel(MatField Unew, MatField S, MatField U, double alpha, double tol, int Vh) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= 2 * Vh) return;
+  const int par = gid >= Vh, idx = gid - par * Vh;
+  M3 s, u, ud, t;
+  mf_load(s, S, par, idx); mf_load(u, U, par, idx);
+  const double f = alpha / 4.0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) { s.re[k] *= f; s.im[k] *= f; }
+  m3_dag(ud, u);
+  m3_mul(t, s, ud);
+  t.re[0] += 1.0 - alpha; t.re[4] += 1.0 - alpha; t.re[8] += 1.0 - alpha;
+  polar_su3(t, tol);
+  m3_mul(s, t, u);
+  mf_store(s, Unew, par, idx);
+}
+// sum over sites of Re tr [A B C^dag D^dag] into acc[slot] (block tree + one atomic per block)
+__global__ void __launch_bounds__(256) plaq_trace_kernel(double *acc, int slot, MatField A, MatField B, MatField Cm, MatField D, int Vh) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  double tr = 0;
+  if (gid < 2 * Vh) {
+    const int par = gid >= Vh, idx = gid - par * Vh;
+    M3 a, b, t, t2, d;
+    mf_load(a, A, par, idx); mf_load(b, B, par, idx);
+    m3_mul(t, a, b);
+    mf_load(a, Cm, par, idx); m3_dag(d, a); m3_mul(t2, t, d);
+    mf_load(a, D, par, idx); m3_dag(d, a); m3_mul(t, t2, d);
+    tr = t.re[0] + t.re[4] + t.re[8];
+  }
+  __shared__ double lds[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) tr += __shfl_down(tr, off, 64);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = tr;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc + slot, lds[0] + lds[1] + lds[2] + lds[3]);
+}
+// forward links of one direction -> host QDP order (even sites then odd, 18 reals per site)
+__global__ void mf_to_qdp_kernel(double *qdp, MatField F, int Vh) {
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= 2 * Vh) return;
+  const int par = gid >= Vh, idx = gid - par * Vh;
+  M3 u;
+  mf_load(u, F, par, idx);
+  double *o = qdp + (size_t)gid * 18;
+#pragma unroll
+  for (int k = 0; k < 9; k++) { o[2 * k] = u.re[k]; o[2 * k + 1] = u.im[k]; }
+}
+
+static GaugeView viewOf(const GaugeField &U) {
+  GaugeView g;
+  g.data = (const char *)U.data; g.link_bytes = U.link_bytes; g.stride = U.stride;
+  for (int d = 0; d < 4; d++) g.X[d] = U.geom.X[d];
+  const bool first_t = commGrid().coords[3] == 0, last_t = commGrid().coords[3] == commGrid().dims[3] - 1;
+  g.tsign = (U.t_boundary == QUDA_ANTI_PERIODIC_T && last_t) ? -1 : 1;
+  g.tsign_bwd = (U.t_boundary == QUDA_ANTI_PERIODIC_T && first_t) ? -1 : 1;
+  return g;
+}
+static void extractForwardLinks(MatField F, const GaugeField &U, int mu) {
+  const GaugeView g = viewOf(U);
+  const int Vh = U.geom.Vh, bs = 128, nb = (2 * Vh + bs - 1) / bs;
+  const bool r12 = U.reconstruct == QUDA_RECONSTRUCT_12;
+#define QA_EX(T) { if (r12) hipLaunchKernelGGL((cl_extract_kernel<T, 12>), dim3(nb), dim3(bs), 0, computeStream(), F, g, mu, Vh); \
+                   else hipLaunchKernelGGL((cl_extract_kernel<T, 18>), dim3(nb), dim3(bs), 0, computeStream(), F, g, mu, Vh); }
+  switch (U.precision) {
+    case QUDA_DOUBLE_PRECISION: QA_EX(double) break;
+    case QUDA_SINGLE_PRECISION: QA_EX(float) break;
+    case QUDA_HALF_PRECISION: QA_EX(short) break;
+    default: errorQuda("bad gauge precision %d", U.precision);
+  }
+#undef QA_EX
+  HIP_CHECK(hipGetLastError());
+}
+
+GaugeField *apeSmear(const GaugeField &U, unsigned nSteps, double alpha) {
+  const LatticeGeom &geom = U.geom;
+  const int Vh = geom.Vh, bs = 128, nb = (2 * Vh + bs - 1) / bs;
+  const size_t fieldDoubles = (size_t)2 * 24 * Vh;
+  double *pool = nullptr;
+  HIP_CHECK(hipMalloc((void **)&pool, 13 * fieldDoubles * sizeof(double)));
+  MatField F[4], G[3], S, W1, W2, T1, T2;
+  for (int i = 0; i < 4; i++) F[i] = {pool + i * fieldDoubles, Vh};
+  for (int i = 0; i < 3; i++) G[i] = {pool + (4 + i) * fieldDoubles, Vh};
+  S = {pool + 7 * fieldDoubles, Vh}; W1 = {pool + 8 * fieldDoubles, Vh}; W2 = {pool + 9 * fieldDoubles, Vh};
+  T1 = {pool + 10 * fieldDoubles, Vh}; T2 = {pool + 11 * fieldDoubles, Vh};
+  hipStream_t s = computeStream();
+  auto shift = [&](MatField out, MatField in, int dir) {   // out(x) = in(x + dhat(dir)), both parities
+    for (int par = 0; par < 2; par++) applyShift(out.par(par), in.par(1 - par), geom, Vh, par, dir);
+  };
+  for (int mu = 0; mu < 4; mu++) extractForwardLinks(F[mu], U, mu);
+  const double tol = 1e-15;   // DOUBLE_TOL, lib/gauge_ape.cu:9
+  for (unsigned step = 0; step < nSteps; step++) {
+    for (int nu = 0; nu < 3; nu++) {
+      HIP_CHECK(hipMemsetAsync(S.p, 0, fieldDoubles * sizeof(double), s));
+      for (int mu = 0; mu < 3; mu++) {
+        if (mu == nu) continue;
+        shift(W1, F[nu], 2 * mu);   // U_nu(x + mu)
+        shift(W2, F[mu], 2 * nu);   // U_mu(x + nu)
+        hipLaunchKernelGGL(mf_mul_kernel, dim3(nb), dim3(bs), 0, s, T1, F[mu], W1, 0, 0, 0, Vh);   // U_mu(x) U_nu(x+mu)
+        hipLaunchKernelGGL(mf_mul_kernel, dim3(nb), dim3(bs), 0, s, S, T1, W2, 0, 1, 1, Vh);       // S += ... U_mu(x+nu)^dag
+        hipLaunchKernelGGL(mf_mul_kernel, dim3(nb), dim3(bs), 0, s, T1, F[mu], F[nu], 1, 0, 0, Vh); // U_mu(x)^dag U_nu(x)
+        hipLaunchKernelGGL(mf_mul_kernel, dim3(nb), dim3(bs), 0, s, T2, T1, W2, 0, 0, 0, Vh);      // ... U_mu(x+nu)
+        shift(T1, T2, 2 * mu + 1);  // carried from x - mu to x
+        hipLaunchKernelGGL(mf_add_kernel, dim3(nb), dim3(bs), 0, s, S, T1, Vh);
+        HIP_CHECK(hipGetLastError());
+      }
+      hipLaunchKernelGGL(ape_project_kernel, dim3(nb), dim3(bs), 0, s, G[nu], S, F[nu], alpha, tol, Vh);
+      HIP_CHECK(hipGetLastError());
+    }
+    // every direction of a step is smeared from the links of the previous step (the reference reads a copy, :5621-5627)
+    for (int nu = 0; nu < 3; nu++) std::swap(F[nu], G[nu]);
+  }
+  // back through the loader: it builds the bidirectional layout and fetches the backward links that live on the neighbour ranks
+  std::vector<std::vector<double>> host(4, std::vector<double>((size_t)geom.V * 18));
+  void *ptr[4];
+  double *stage = (double *)stagingBuffer((size_t)geom.V * 18 * sizeof(double));
+  for (int mu = 0; mu < 4; mu++) {
+    hipLaunchKernelGGL(mf_to_qdp_kernel, dim3(nb), dim3(bs), 0, s, stage, F[mu], Vh);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(host[mu].data(), stage, (size_t)geom.V * 18 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    ptr[mu] = host[mu].data();
+  }
+  HIP_CHECK(hipFree(pool));
+  GaugeField *out = new GaugeField(geom, QUDA_DOUBLE_PRECISION, QUDA_RECONSTRUCT_NO, U.t_boundary, U.anisotropy);
+  out->loadQDP(ptr, QUDA_DOUBLE_PRECISION);
+  return out;
+}
+
+void saveGaugeQDP(const GaugeField &U, void *const h_gauge[4], QudaPrecision cpu_prec) {
+  if (cpu_prec != QUDA_DOUBLE_PRECISION) errorQuda("saving links: fp64 host fields only");
+  const LatticeGeom &geom = U.geom;
+  const int Vh = geom.Vh, bs = 128, nb = (2 * Vh + bs - 1) / bs;
+  double *pool = nullptr;
+  HIP_CHECK(hipMalloc((void **)&pool, (size_t)2 * 24 * Vh * sizeof(double)));
+  MatField F = {pool, Vh};
+  double *stage = (double *)stagingBuffer((size_t)geom.V * 18 * sizeof(double));
+  for (int mu = 0; mu < 4; mu++) {
+    extractForwardLinks(F, U, mu);
+    hipLaunchKernelGGL(mf_to_qdp_kernel, dim3(nb), dim3(bs), 0, computeStream(), stage, F, Vh);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(h_gauge[mu], stage, (size_t)geom.V * 18 * sizeof(double), hipMemcpyDeviceToHost, computeStream()));
+    HIP_CHECK(hipStreamSynchronize(computeStream()));
+  }
+  HIP_CHECK(hipFree(pool));
+}
+
+// plq[0] = mean of the spatial and temporal averages, plq[1] = spatial, plq[2] = temporal (lib/gauge_plaq.cu:129-153)
+void plaquette(const GaugeField &U, double plq[3]) {
+  const LatticeGeom &geom = U.geom;
+  const int Vh = geom.Vh, nb = (2 * Vh + 255) / 256;
+  const size_t fieldDoubles = (size_t)2 * 24 * Vh;
+  double *pool = nullptr, *d_acc = nullptr;
+  HIP_CHECK(hipMalloc((void **)&pool, 6 * fieldDoubles * sizeof(double)));
+  HIP_CHECK(hipMalloc((void **)&d_acc, 2 * sizeof(double)));
+  HIP_CHECK(hipMemsetAsync(d_acc, 0, 2 * sizeof(double), computeStream()));
+  MatField F[4], W1, W2;
+  for (int i = 0; i < 4; i++) F[i] = {pool + i * fieldDoubles, Vh};
+  W1 = {pool + 4 * fieldDoubles, Vh}; W2 = {pool + 5 * fieldDoubles, Vh};
+  auto shift = [&](MatField out, MatField in, int dir) {
+    for (int par = 0; par < 2; par++) applyShift(out.par(par), in.par(1 - par), geom, Vh, par, dir);
+  };
+  for (int mu = 0; mu < 4; mu++) extractForwardLinks(F[mu], U, mu);
+  for (int mu = 0; mu < 3; mu++)
+    for (int nu = mu + 1; nu < 4; nu++) {
+      shift(W1, F[nu], 2 * mu);
+      shift(W2, F[mu], 2 * nu);
+      hipLaunchKernelGGL(plaq_trace_kernel, dim3(nb), dim3(256), 0, computeStream(), d_acc, nu < 3 ? 0 : 1, F[mu], W1, W2, F[nu], Vh);
+      HIP_CHECK(hipGetLastError());
+    }
+  double h[2];
+  HIP_CHECK(hipMemcpyAsync(h, d_acc, 2 * sizeof(double), hipMemcpyDeviceToHost, computeStream()));
+  HIP_CHECK(hipStreamSynchronize(computeStream()));
+  HIP_CHECK(hipFree(pool)); HIP_CHECK(hipFree(d_acc));
+  comm_allreduce(h, 2);
+  const double norm = 9.0 * (double)geom.V * commGrid().size;
+  plq[1] = h[0] / norm; plq[2] = h[1] / norm; plq[0] = 0.5 * (plq[1] + plq[2]);
+}
+
 }  // namespace quda

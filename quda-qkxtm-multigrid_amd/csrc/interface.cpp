@@ -21,7 +21,7 @@ void destroyStreams();
 void freeStagingBuffer();
 
 // resident fields (reference lib/interface_quda.cpp:119-145)
-GaugeField *gaugePrecise = nullptr, *gaugeSloppy = nullptr, *gaugePrecondition = nullptr;
+GaugeField *gaugePrecise = nullptr, *gaugeSloppy = nullptr, *gaugePrecondition = nullptr, *gaugeSmeared = nullptr;
 CloverField *cloverPrecise = nullptr, *cloverSloppy = nullptr, *cloverPrecondition = nullptr;
 static bool g_initialized = false, g_comms_initialized = false;
 static int g_device = -1;
@@ -297,8 +297,57 @@ void loadGaugeQuda(void *h_gauge, QudaGaugeParam *param) {
 }
 
 void freeGaugeQuda(void) {
-  delete gaugePrecise; delete gaugeSloppy; delete gaugePrecondition;
-  gaugePrecise = gaugeSloppy = gaugePrecondition = nullptr;
+  delete gaugePrecise; delete gaugeSloppy; delete gaugePrecondition; delete gaugeSmeared;   // reference :1001-1008
+  gaugePrecise = gaugeSloppy = gaugePrecondition = gaugeSmeared = nullptr;
+}
+
+// reference lib/interface_quda.cpp:694-728: the resident (precise) links back to the host in the order of param
+void saveGaugeQuda(void *h_gauge, QudaGaugeParam *param) {
+  if (!g_initialized) errorQuda("QUDA not initialized");
+  if (!gaugePrecise) errorQuda("saveGaugeQuda: no resident gauge field");
+  if (param->gauge_order != QUDA_QDP_GAUGE_ORDER) errorQuda("gauge_order %d: only QUDA_QDP_GAUGE_ORDER host fields are supported", param->gauge_order);
+  saveGaugeQDP(*gaugePrecise, (void *const *)h_gauge, param->cpu_prec);
+}
+
+// reference lib/interface_quda.cpp:5510-5563 (lib/gauge_plaq.cu)
+void plaqQuda(double plaq[3]) {
+  if (!g_initialized) errorQuda("QUDA not initialized");
+  if (!gaugePrecise) errorQuda("Cannot compute plaquette as there is no resident gauge field");
+  plaquette(*gaugePrecise, plaq);
+}
+
+// reference lib/interface_quda.cpp:5565-5640 (lib/gauge_ape.cu): nSteps APE steps on a copy of the resident links; the result
+// stays inside the library (gaugeSmeared) until freeGaugeQuda / the next call
+void performAPEnStep(unsigned int nSteps, double alpha) {
+  if (!g_initialized) errorQuda("QUDA not initialized");
+  if (!gaugePrecise) errorQuda("Gauge field must be loaded");
+  delete gaugeSmeared;
+  gaugeSmeared = apeSmear(*gaugePrecise, nSteps, alpha);
+  if (getVerbosity() >= QUDA_VERBOSE) {
+    double p0[3], p1[3];
+    plaquette(*gaugePrecise, p0); plaquette(*gaugeSmeared, p1);
+    printfQuda("Plaquette after 0 APE steps: %le\nPlaquette after %u APE steps: %le\n", p0[0], nSteps, p1[0]);
+  }
+}
+
+void qudaAmdSaveSmearedGauge(void **h_gauge, int lexicographic) {
+  if (!gaugeSmeared) errorQuda("qudaAmdSaveSmearedGauge: no smeared field (call performAPEnStep first)");
+  if (!lexicographic) { saveGaugeQDP(*gaugeSmeared, (void *const *)h_gauge, QUDA_DOUBLE_PRECISION); return; }
+  const LatticeGeom &g = gaugeSmeared->geom;
+  std::vector<std::vector<double>> eo(4, std::vector<double>((size_t)g.V * 18));
+  void *ptr[4];
+  for (int d = 0; d < 4; d++) ptr[d] = eo[d].data();
+  saveGaugeQDP(*gaugeSmeared, ptr, QUDA_DOUBLE_PRECISION);
+  for (int d = 0; d < 4; d++) {
+    double *dst = (double *)h_gauge[d];
+    for (long iv = 0; iv < g.V; iv++) {
+      long l = iv / g.X[0];
+      const int x = (int)(iv % g.X[0]), y = (int)(l % g.X[1]); l /= g.X[1];
+      const int z = (int)(l % g.X[2]), t = (int)(l / g.X[2]);
+      const int parity = (x + y + z + t) & 1;
+      memcpy(dst + iv * 18, &eo[d][((size_t)parity * g.Vh + iv / 2) * 18], 18 * sizeof(double));
+    }
+  }
 }
 
 // reference :730-930.  Host order: QUDA_PACKED_CLOVER_ORDER.  If the inverse is not supplied (or

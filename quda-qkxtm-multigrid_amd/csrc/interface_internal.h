@@ -13,7 +13,7 @@ void commFinalize();
 void loadGaugeWithHalo(GaugeField &U, void *const h_gauge[4], QudaPrecision cpu_prec);
 
 // interface.cpp
-extern GaugeField *gaugePrecise, *gaugeSloppy, *gaugePrecondition;
+extern GaugeField *gaugePrecise, *gaugeSloppy, *gaugePrecondition, *gaugeSmeared;
 extern CloverField *cloverPrecise, *cloverSloppy, *cloverPrecondition;
 const LatticeGeom &residentGeom();
 GaugeField *residentGauge(int which);

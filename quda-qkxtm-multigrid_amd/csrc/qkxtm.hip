@@ -181,14 +181,15 @@ void qudaAmdGaussianSmear(void *h_out, const void *h_in, void **gauge_APE, int n
   if (!gaugePrecise) errorQuda("Gauge field not allocated");   // the lattice geometry comes from the resident field, as in the reference
   if (nsmear < 0) errorQuda("nsmear = %d", nsmear);
   const LatticeGeom &g = residentGeom();
-  GaugeField *U = loadLexGauge(gauge_APE, g);
+  if (!gauge_APE && !gaugeSmeared) errorQuda("qudaAmdGaussianSmear: gauge_APE is NULL and no smeared field is resident (performAPEnStep)");
+  GaugeField *U = gauge_APE ? loadLexGauge(gauge_APE, g) : gaugeSmeared;
   ColorSpinorParam cp = deviceSpinorParam(QUDA_DOUBLE_PRECISION, QUDA_FULL_SITE_SUBSET, QUDA_TWIST_NO);
   cp.create = QUDA_ZERO_FIELD_CREATE;
   ColorSpinorField v(cp);
   lexToDevice(v, (const double *)h_in, g, true);
   gaussianSmear(v, *U, alpha, nsmear);
   deviceToLex((double *)h_out, v, g, true, 1.0);
-  delete U;
+  if (gauge_APE) delete U;
 }
 
 void qudaAmdCalcMGPropagators(void *h_prop_up, void *h_prop_dn, void **gauge_APE, QudaInvertParam *param, const QudaAmdSourceParam *src) {
@@ -206,7 +207,8 @@ void qudaAmdCalcMGPropagators(void *h_prop_up, void *h_prop_dn, void **gauge_APE
   if (src->nsmearGauss < 0) errorQuda("%s: nsmearGauss = %d", fname, src->nsmearGauss);
   param->secs = 0; param->gflops = 0; param->iter = 0;
 
-  GaugeField *Uape = (src->nsmearGauss > 0) ? loadLexGauge(gauge_APE, g) : nullptr;
+  if (src->nsmearGauss > 0 && !gauge_APE && !gaugeSmeared) errorQuda("%s: gauge_APE is NULL and no smeared field is resident (performAPEnStep)", fname);
+  GaugeField *Uape = (src->nsmearGauss > 0) ? (gauge_APE ? loadLexGauge(gauge_APE, g) : gaugeSmeared) : nullptr;
 
   // reference createDirac :6291-6300, once, before the loop: the twist flavour travels with the fields
   const bool pc_solve = true;
@@ -275,7 +277,7 @@ void qudaAmdCalcMGPropagators(void *h_prop_up, void *h_prop_dn, void **gauge_APE
   param->secs = secs; param->gflops = gflops; param->iter = iters;
   delete b; delete x;
   delete d; delete dSloppy; delete dPre;
-  delete Uape;
+  if (gauge_APE) delete Uape;
 }
 
 }

@@ -173,6 +173,17 @@ class Oracle:
         self.lib.qo_lex_to_eo(_p(out), _p(np.ascontiguousarray(lex)), _x(X), C.c_int(n))
         return out
 
+    def ape_smear(self, gauge, X, alpha, nsteps):
+        """gauge: (4, V*18) QDP even-odd order -> APE-smeared links in the same order (oracle/qo_qkxtm.c)"""
+        out = np.zeros_like(gauge)
+        self.lib.qo_ape_smear(_g(out), _g(np.ascontiguousarray(gauge)), _x(X), C.c_double(alpha), C.c_int(nsteps))
+        return out
+
+    def plaquette(self, gauge, X):
+        pl = np.zeros(3)
+        self.lib.qo_plaquette(_p(pl), _g(np.ascontiguousarray(gauge)), _x(X))
+        return pl
+
     @staticmethod
     def ukqcd_to_dr(v):
         """host spinor(s) (..., 24) UKQCD -> DeGrand-Rossi: the reference's RelBasis (lib/copy_color_spinor.cuh:73-91)"""

@@ -113,3 +113,64 @@ def test_basis_rotations_are_inverse(oracle):
     rng = np.random.default_rng(0)
     v = rng.standard_normal((10, 24))
     assert np.allclose(oracle.ukqcd_to_dr(oracle.dr_to_ukqcd(v)), v, atol=1e-15)
+
+
+def _lex_links(oracle, gauge, X):
+    V = int(np.prod(X))
+    U = np.stack([oracle.eo_to_lex(np.ascontiguousarray(gauge[d]), X, 18) for d in range(4)]).reshape(4, V, 3, 3, 2)
+    return (U[..., 0] + 1j * U[..., 1]).reshape((4, X[3], X[2], X[1], X[0], 3, 3))
+
+
+def numpy_ape_step(U, alpha):
+    """U: (4, t, z, y, x, 3, 3).  Staples by array shifts; the projection in closed form: the unitary polar factor W = u v^dag
+    of the SVD (the fixed point of the Newton iteration X <- (X + X^-dag)/2) divided by det(W)^(1/3)"""
+    dag = lambda a: a.conj().swapaxes(-1, -2)
+    sh = lambda a, mu, s: np.roll(a, -s, axis=3 - mu)   # field at x + s mu
+    out = U.copy()
+    for nu in range(3):
+        S = np.zeros_like(U[0])
+        for mu in range(3):
+            if mu == nu:
+                continue
+            S += U[mu] @ sh(U[nu], mu, 1) @ dag(sh(U[mu], nu, 1))
+            low = dag(U[mu]) @ U[nu] @ sh(U[mu], nu, 1)
+            S += sh(low, mu, -1)
+        T = (1 - alpha) * np.eye(3) + (alpha / 4) * S @ dag(U[nu])
+        u, _, vh = np.linalg.svd(T)
+        W = u @ vh
+        det = np.linalg.det(W)
+        W = W * (np.exp(-1j * np.angle(det) / 3) / np.abs(det) ** (1 / 3))[..., None, None]
+        out[nu] = W @ U[nu]
+    return out
+
+
+@pytest.mark.parametrize("X", [[4, 4, 4, 4], [6, 4, 2, 4]])
+def test_ape_matches_array_formulation(oracle, X):
+    gauge, _, _ = oracle.make_fields(X, seed=21, antiperiodic_t=True, clover=False)
+    got = _lex_links(oracle, oracle.ape_smear(gauge, X, 0.5, 2), X)
+    want = _lex_links(oracle, gauge, X)
+    for _ in range(2):
+        want = numpy_ape_step(want, 0.5)
+    assert np.max(np.abs(got - want)) < 1e-12
+    assert np.array_equal(got[3], _lex_links(oracle, gauge, X)[3])            # time links untouched
+    eye = np.eye(3)
+    assert np.max(np.abs(got @ got.conj().swapaxes(-1, -2) - eye)) < 1e-13   # still SU(3)
+    assert np.max(np.abs(np.linalg.det(got[:3]) - 1)) < 1e-13                 # (the t links of the last slice carry the boundary sign)
+
+
+def test_plaquette_values(oracle):
+    X = [4, 4, 4, 6]
+    V = int(np.prod(X))
+    unit = np.zeros((4, V, 9, 2))
+    unit[:, :, [0, 4, 8], 0] = 1
+    assert np.allclose(oracle.plaquette(unit.reshape(4, -1), X), 1.0, atol=1e-15)
+    gauge, _, _ = oracle.make_fields(X, seed=4, antiperiodic_t=True, clover=False)
+    U = _lex_links(oracle, gauge, X)
+    dag = lambda a: a.conj().swapaxes(-1, -2)
+    sh = lambda a, mu: np.roll(a, -1, axis=3 - mu)
+    sp = sum(np.trace(U[m] @ sh(U[n], m) @ dag(sh(U[m], n)) @ dag(U[n]), axis1=-2, axis2=-1).real.sum() for m in range(3) for n in range(m + 1, 3))
+    tm = sum(np.trace(U[m] @ sh(U[3], m) @ dag(sh(U[m], 3)) @ dag(U[3]), axis1=-2, axis2=-1).real.sum() for m in range(3))
+    pl = oracle.plaquette(gauge, X)
+    assert abs(pl[1] - sp / (9 * V)) < 1e-13 and abs(pl[2] - tm / (9 * V)) < 1e-13 and abs(pl[0] - 0.5 * (pl[1] + pl[2])) < 1e-15
+    # smearing raises the spatial plaquette of a rough field
+    assert oracle.plaquette(oracle.ape_smear(gauge, X, 0.5, 3), X)[1] > pl[1] + 0.1

@@ -45,6 +45,34 @@ def test_gaussian_smearing_matches_oracle(qa, oracle, X, mask):
     assert np.max(np.abs(qa.gaussian_smear(v, g_lex, 0, 0.8) - v)) < 1e-14 * np.max(np.abs(v))
 
 
+@pytest.mark.parametrize("X", [(4, 4, 4, 4), (6, 4, 2, 8)])
+@pytest.mark.parametrize("mask,prec,recon", [(0, 8, 18), (0b0111, 8, 18), (0b1010, 4, 12)])
+def test_plaquette_and_ape_smearing_match_oracle(qa, oracle, X, mask, prec, recon):
+    """plaqQuda / performAPEnStep / saveGaugeQuda (reference lib/gauge_plaq.cu, lib/gauge_ape.cu) against oracle/qo_qkxtm.c; with a
+    partition mask the staples come through the ghost-aware shifts, exactly as on a decomposed lattice.  fp64 links: 1e-12;
+    fp32 recon-12 resident links: the smearing itself runs in fp64, the input rounding gives 1e-5."""
+    gauge, _, _ = oracle.make_fields(list(X), seed=31, antiperiodic_t=True, clover=False)
+    gp = qa.gauge_param(X, cuda_prec=prec, recon=recon)
+    tol = 1e-12 if prec == 8 else 2e-5
+    qa.lib().qudaAmdSetPartitionMask(mask)
+    try:
+        qa.load_gauge(gauge, gp)
+        assert np.max(np.abs(qa.save_gauge(gp) - gauge)) < (1e-15 if prec == 8 else 1e-6)
+        pl, want = np.array(qa.plaquette()), oracle.plaquette(gauge, list(X))
+        assert np.max(np.abs(pl - want)) < tol, (pl, want)
+        qa.perform_ape(3, 0.5)
+        got = qa.save_smeared_gauge(int(np.prod(X)))
+        want = oracle.ape_smear(gauge, list(X), 0.5, 3)
+        assert np.max(np.abs(got - want)) < tol
+        # the lexicographic copy is the layout gauge_APE takes, and NULL means "use the resident smeared field"
+        lex = qa.save_smeared_gauge(int(np.prod(X)), lexicographic=True)
+        assert np.array_equal(lex, _lex_gauge(oracle, got, X))
+        v = np.random.default_rng(3).standard_normal(int(np.prod(X)) * 24)
+        assert np.array_equal(qa.gaussian_smear(v, None, 2, 0.7), qa.gaussian_smear(v, lex, 2, 0.7))
+    finally:
+        qa.lib().qudaAmdSetPartitionMask(0)
+
+
 def _check_propagators(qa, oracle, gauge, g_lex, X, kappa, mu, ip, pos, nsmear, alpha, normalized):
     V = int(np.prod(X))
     up, dn = qa.calc_mg_propagators(g_lex, ip, pos, nsmear, alpha, V)

@@ -128,6 +128,17 @@ def main():
             want_n2 = float(np.dot(spinor[:nh_g], spinor[:nh_g]))
             assert abs(n2v - want_n2) < 1e-12 * want_n2, ("skewed all-reduce value", n2v, want_n2)
         spn.free()
+        # gauge tools on the decomposed lattice: plaquette (global average) and APE smearing through the ghost-aware shifts
+        qa.load_gauge(g_loc, qa.gauge_param(Xl, cuda_prec=8, prec_sloppy=4))
+        plq, plq_want = np.array(qa.plaquette()), oracle.plaquette(gauge, X)
+        assert np.max(np.abs(plq - plq_want)) < 1e-12, ("plaquette", X, grid, plq, plq_want)
+        qa.perform_ape(2, 0.5)
+        ape_got = qa.save_smeared_gauge(int(np.prod(Xl)))
+        ape_want = mg.scatter_gauge(oracle.ape_smear(gauge, X, 0.5, 2), X, grid, dist.coords)
+        err_ape = float(np.max(np.abs(ape_got - ape_want)))
+        assert err_ape < 1e-12, ("ape smearing", X, grid, err_ape)
+        if rank == 0:
+            print("OK lattice %s grid %s: plaquette %.12f, APE smearing %.1e against the global oracle field" % (X, grid, plq[0], err_ape), flush=True)
         # ---- QKXTM solve loop on the decomposed lattice: smearing through ghost-aware covariant shifts, the point source on the
         # rank that owns it, up / down propagators in the drivers' lexicographic UKQCD layout ----
         g_lex_glob = np.stack([oracle.eo_to_lex(np.ascontiguousarray(gauge[d]), X, 18) for d in range(4)])
