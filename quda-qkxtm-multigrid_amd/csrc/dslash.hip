@@ -20,6 +20,7 @@
 #include "dslash.h"
 
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "device_io.h"
@@ -79,7 +80,7 @@ template <typename real> struct DslashArg {
   int *errWord;
   // peer-store transport: the first packBlocks blocks of the interior launch pack the faces (pack_body) while the rest of
   // the grid does the interior stencil — one launch, the faces leave at time zero and travel during the interior pass
-  int packBlocks;
+  int packBlocks, packChunk;
   PackArg<real> pack;
   unsigned long long *timeline;   // QUDA_AMD_TIMELINE=1: per-block wall_clock64 stamps (measurement aid), else nullptr
 };
@@ -371,9 +372,14 @@ __device__ __forceinline__ void dslash_epilogue(real *acc, const DslashArg<real>
 
 // ---- face packing (reference packFaceWilsonKernel / packTwistedFaceWilsonKernel, lib/dslash_pack.cu:272, :610) ----
 // P2P: the send pointers are peer-mapped ghost zones — system-scope write-through stores (sc0 sc1), completion counter, flags
-template <typename T, bool PRETWIST, bool P2P, typename real> __device__ __forceinline__ void pack_body(const PackArg<real> &arg, int bid, int nblk) {
-  const int tid = bid * blockDim.x + threadIdx.x;
-  if (P2P && arg.timeline && threadIdx.x == 0) arg.timeline[bid] = wall_clock64();
+// Block `bid` packs the face sites [bid * chunk, (bid + 1) * chunk) of the concatenated (dim, dir) ranges, chunk <= blockDim.
+template <typename T, bool PRETWIST, bool P2P, typename real> __device__ __forceinline__ void pack_body(const PackArg<real> &arg, int bid, int chunk) {
+  const int tid = (int)threadIdx.x < chunk ? bid * chunk + (int)threadIdx.x : arg.start[8];
+  if (P2P && arg.timeline && threadIdx.x == 0) {
+    arg.timeline[bid] = wall_clock64();
+    // where the block runs: HW_ID (cu_id 11:8, sh_id 12, se_id 15:13) and XCC_ID, for the placement statistics of the timeline
+    arg.timeline[3072 + bid] = 0x100000000ull | ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xf) << 16) | (__builtin_amdgcn_s_getreg(4 | (31 << 11)) & 0xff00u);
+  }
   if (tid < arg.start[8]) {
     int slot = 0;
 #pragma unroll
@@ -510,7 +516,7 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
   if (KT == 3) {
     // single-launch peer-store path: [pack blocks | every site]; boundary sites do their local hops first, then poll the
     // incoming-face counters and add the off-node hops (stencil_site, KT == 3)
-    if (b < arg.packBlocks) { pack_body<T, VARIANT == 1, true>(arg.pack, b, arg.packBlocks); return; }
+    if (b < arg.packBlocks) { pack_body<T, VARIANT == 1, true>(arg.pack, b, arg.packChunk); return; }
     b -= arg.packBlocks;
   }
   // XCD-aware block remap: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch); give each XCD a
@@ -527,7 +533,10 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
   }
   const int idx = lb * blockDim.x + threadIdx.x;
   if (idx >= arg.Vh) return;
-  if (KT == 3 && arg.timeline && threadIdx.x == 0) arg.timeline[2048 + blockIdx.x] = wall_clock64();
+  if (KT == 3 && arg.timeline && threadIdx.x == 0) {
+    arg.timeline[2048 + blockIdx.x] = wall_clock64();
+    arg.timeline[3072 + blockIdx.x] = 0x100000000ull | ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xf) << 16) | (__builtin_amdgcn_s_getreg(4 | (31 << 11)) & 0xff00u);
+  }
   stencil_site<T, R, VARIANT, GAUX, KT, SAUX>(arg, idx);
   if (KT == 3 && arg.timeline && threadIdx.x == 0) arg.timeline[12288 + blockIdx.x] = wall_clock64();
 }
@@ -669,7 +678,7 @@ static int dslashBlockSize() {
 
 
 template <typename T, bool PRETWIST, bool P2P = false> __global__ void __launch_bounds__(256) pack_kernel(const PackArg<typename Store<T>::real> arg) {
-  pack_body<T, PRETWIST, P2P>(arg, blockIdx.x, gridDim.x);
+  pack_body<T, PRETWIST, P2P>(arg, blockIdx.x, (int)blockDim.x);
 }
 
 // ---- ghost-zone storage and the boundary-site lists ----
@@ -901,7 +910,12 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
     }
     pa.start[8] = nt;
     arg.waitTicks = p2pTimeoutTicks(); arg.errWord = p2pErrorWord();
-    arg.packBlocks = (nt + bs - 1) / bs;
+    // Full pack blocks (256 face sites each) in front of the grid.  They share CUs with site blocks, and the placement statistics of
+    // the timeline show what that costs on the 8-GPU sub-lattice: a site block next to a pack block ends 4.3 us later than one
+    // that has its CU to itself.  Spreading the packing thinly (one 96-thread pack block on EVERY CU) is far worse — 46 us
+    // instead of 29, every site block ends late — so the system-scope write-through stores of a pack wave appear to hold up the
+    // memory pipeline of the whole CU, and fewer CUs doing all of it is the better trade.
+    arg.packBlocks = (nt + bs - 1) / bs; arg.packChunk = bs;
     static unsigned long long *tl = nullptr;
     static int tlmode = -1;
     if (tlmode < 0) { const char *e = getenv("QUDA_AMD_TIMELINE"); tlmode = e ? atoi(e) : 0; if (tlmode) HIP_CHECK(hipHostMalloc((void **)&tl, 16384 * sizeof(unsigned long long), hipHostMallocMapped)); }
@@ -914,7 +928,7 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
         hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 3>), dim3(arg.packBlocks + nb), dim3(bs), 0, cs, arg);
         HIP_CHECK(hipStreamSynchronize(cs));
         unsigned long long t0 = ~0ull;
-        for (int i = 0; i < 16384; i++) if (tl[i] && tl[i] < t0) t0 = tl[i];
+        for (int i = 0; i < 16384; i++) if ((i < 3072 || i >= 4096) && tl[i] && tl[i] < t0) t0 = tl[i];   // 3072..4095 hold placement words
         auto stat = [&](int off, int n, const char *name) {
           double mn = 1e30, mx = 0, sum = 0; int c = 0;
           for (int i = 0; i < n; i++) if (tl[off + i]) { const double v = (tl[off + i] - t0) * 0.01; mn = v < mn ? v : mn; mx = v > mx ? v : mx; sum += v; c++; }
@@ -922,6 +936,21 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
         };
         stat(0, 1024, "pack block start"); stat(1024, 1024, "pack block end"); stat(2048, 1024, "stencil block start");
         stat(4096, 4096, "boundary wave ghost beg"); stat(8192, 4096, "boundary wave ghost end"); stat(12288, 1024, "stencil block end");
+        {   // placement: how many site / pack blocks share a CU, and when the site blocks of such CUs finish
+          std::map<unsigned, std::pair<int, int>> cu;   // key -> (site blocks, pack blocks)
+          const int npk = arg.packBlocks, ntot = arg.packBlocks + nb;
+          for (int i = 0; i < ntot && i < 1024; i++) if (tl[3072 + i]) { auto &c = cu[(unsigned)tl[3072 + i]]; if (i < npk) c.second++; else c.first++; }
+          double sum[4][2] = {}, mx[4][2] = {}; int cnt[4][2] = {};
+          for (int i = npk; i < ntot && i < 1024; i++) if (tl[3072 + i] && tl[12288 + i]) {
+            const auto &c = cu[(unsigned)tl[3072 + i]];
+            const int a = c.first > 3 ? 3 : c.first, b = c.second > 0 ? 1 : 0;
+            const double e = (tl[12288 + i] - t0) * 0.01;
+            sum[a][b] += e; mx[a][b] = e > mx[a][b] ? e : mx[a][b]; cnt[a][b]++;
+          }
+          printfQuda("timeline placement: %zu CUs in use\n", cu.size());
+          for (int a = 1; a < 4; a++) for (int b = 0; b < 2; b++)
+            if (cnt[a][b]) printfQuda("timeline   site blocks on a CU with %d site block(s)%s: n=%3d  mean end %6.2f  max end %6.2f us\n", a, b ? " + pack block(s)" : "", cnt[a][b], sum[a][b] / cnt[a][b], mx[a][b]);
+        }
         for (int x = 0; x < 8; x++) {   // per XCD (blocks are dealt round-robin): start / end of its stencil blocks
           double sb = 0, se = 0, mx = 0; int c = 0;
           for (int i = x; i < 1024; i += 8) if (tl[12288 + i]) { sb += (tl[2048 + i] - t0) * 0.01; const double e = (tl[12288 + i] - t0) * 0.01; se += e; mx = e > mx ? e : mx; c++; }

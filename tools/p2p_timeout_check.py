@@ -29,7 +29,13 @@ def main():
     if rank == 1:
         time.sleep(4.0)
         os._exit(0)
-    qa.dslash(src, ip, 0)           # rank 0 alone: its neighbour never packs
+    # rank 0 alone, through the device-field operator interface (dslashQuda itself meets the other ranks on the host first and
+    # would report the missing rank there): its neighbour never packs, the in-kernel wait has to run out
+    s_in, s_out = qa.Spinor(4), qa.Spinor(4)
+    s_in.load(src, ip)
+    d = qa.Dirac(ip, pc=True)
+    d.dslash(s_out, s_in, 0)
+    s_out.save(ip, src)             # reading the result back checks the device error word
     print("NOT REACHED: the missing face went unnoticed", flush=True)
 
 
