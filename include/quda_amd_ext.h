@@ -111,6 +111,15 @@ void qudaAmdGaussianSmear(void *h_out, const void *h_in, void **gauge_APE, int n
  * the 24 solves; twist_flavor and preconditioner are left at their last values (minus / DN), as in the reference. */
 void qudaAmdCalcMGPropagators(void *h_prop_up, void *h_prop_dn, void **gauge_APE, QudaInvertParam *inv_param, const QudaAmdSourceParam *source);
 
+/* ILDG gauge configurations in LIME containers (the step in front of loadGaugeQuda in the QKXTM drivers).  qudaAmdReadLimeGauge
+ * has the semantics of readLimeGauge / readLimeGaugeSmeared (qkxtm/QKXTM_read_conf.h:107-400, :819-835): every rank reads the
+ * sub-block of its grid coordinates from the "ildg-binary-data" record into the even-odd QDP arrays gauge[4] (fp64, allocated
+ * by the caller for the LOCAL volume), sets param->X to the local extents from "ildg-format", compares kappa of "xlf-info" with
+ * inv_param (may be NULL) and applies no boundary condition.  The container format is restated in csrc/lime_io.cpp (c-lime is
+ * not a dependency).  qudaAmdWriteLimeGauge writes such a file from one rank (xlf_info may be NULL). */
+void qudaAmdReadLimeGauge(void **gauge, const char *fname, QudaGaugeParam *param, QudaInvertParam *inv_param, const int gridSize[4]);
+void qudaAmdWriteLimeGauge(void **gauge, const char *fname, const QudaGaugeParam *param, const char *xlf_info);
+
 /* RCCL bootstrap (the transport that replaces the reference's MPI layer, lib/comm_mpi.cpp:50-155): rank 0 obtains a
  * 128-byte id, the launcher broadcasts it out of band, every rank calls qudaAmdCommInit BEFORE initCommsGridQuda / initQuda. */
 void qudaAmdCommGetUniqueId(void *out128);

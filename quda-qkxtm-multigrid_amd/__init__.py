@@ -191,6 +191,8 @@ def lib():
         L.qudaAmdMultigridGetV.argtypes = [_p, _i, _p]
         L.qudaAmdMultigridGetCoarseLinks.argtypes = [_p, _i, _p, _p]
         L.qudaAmdMultigridApply.argtypes = [_p, _i, _i, _p, _p]
+        L.qudaAmdReadLimeGauge.argtypes = [C.POINTER(_p), C.c_char_p, C.POINTER(QudaGaugeParam), C.POINTER(QudaInvertParam), C.POINTER(_i)]
+        L.qudaAmdWriteLimeGauge.argtypes = [C.POINTER(_p), C.c_char_p, C.POINTER(QudaGaugeParam), C.c_char_p]
         L.plaqQuda.argtypes = [C.POINTER(_d)]
         L.performAPEnStep.argtypes = [C.c_uint, _d]
         L.saveGaugeQuda.argtypes = [_p, C.POINTER(QudaGaugeParam)]
@@ -315,6 +317,22 @@ def invert(h_b, ip):
     x = np.zeros_like(h_b)
     lib().invertQuda(_vp(x), _vp(h_b), C.byref(ip))
     return x
+
+
+def read_lime_gauge(fname, gp, grid=(1, 1, 1, 1), ip=None, local_volume=None):
+    """qudaAmdReadLimeGauge: this rank's sub-block of an ILDG configuration as (4, V_local*18) QDP even-odd arrays; sets gp.X"""
+    if local_volume is None:
+        raise ValueError("local_volume (sites of this rank's sub-lattice) is needed to size the arrays")
+    out = np.zeros((4, int(local_volume) * 18))
+    ptr = (_p * 4)(*[_vp(out[d]) for d in range(4)])
+    lib().qudaAmdReadLimeGauge(ptr, str(fname).encode(), C.byref(gp), C.byref(ip) if ip is not None else None, (_i * 4)(*[int(v) for v in grid]))
+    return out
+
+
+def write_lime_gauge(fname, gauge, gp, xlf_info=None):
+    keep = [np.ascontiguousarray(gauge[d], dtype=np.float64) for d in range(4)]
+    ptr = (_p * 4)(*[_vp(a) for a in keep])
+    lib().qudaAmdWriteLimeGauge(ptr, str(fname).encode(), C.byref(gp), xlf_info.encode() if xlf_info else None)
 
 
 def plaquette():

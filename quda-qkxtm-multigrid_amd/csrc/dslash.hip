@@ -153,6 +153,9 @@ template <typename real> __device__ __forceinline__ void twist_inplace(real *p, 
 // about to use, and the sender just stores and leaves — no acknowledgement wait, no barrier, no atomic (those put the
 // slowest pack block, 18 us under a saturated memory system, on the critical path of a 10-20 us kernel; the same idea as the
 // LL protocol of the collective libraries).  Costs 2x the face bytes, which are a few hundred KB.
+#ifndef QA_LL_STORE_AUX
+#define QA_LL_STORE_AUX 17   // sc0 sc1: system scope, write-through
+#endif
 template <typename T> struct GhostLL;
 template <> struct GhostLL<double> {
   static constexpr int NV = 12;
@@ -207,7 +210,7 @@ template <typename T, typename real> __device__ __forceinline__ void ghost_ll_st
 #pragma unroll
   for (int v = 0; v < NV; v++) {
     u32x4_t q; q.x = w[2 * v]; q.y = flag; q.z = w[2 * v + 1]; q.w = flag;
-    __builtin_amdgcn_raw_buffer_store_b128(q, rs, f * 16, v * faceCB * 16, 17);
+    __builtin_amdgcn_raw_buffer_store_b128(q, rs, f * 16, v * faceCB * 16, QA_LL_STORE_AUX);
   }
 }
 // receiver: poll the site's own vectors (system-scope loads) until every half carries this exchange's flag; bounded by `ticks`

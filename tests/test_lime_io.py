@@ -1,0 +1,86 @@
+"""ILDG / LIME configuration reader and writer (csrc/lime_io.cpp; reference qkxtm/QKXTM_read_conf.h on top of c-lime).  Host-only
+code, so it runs without a GPU: the reader is fed a file assembled byte by byte here from the published container format
+(144-byte big-endian record headers, data padded to 8 bytes) and the ILDG site order, independently of the library's writer;
+then the library's own writer must produce a file with the same payload bytes."""
+import importlib
+import struct
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def qa():
+    return importlib.import_module("quda-qkxtm-multigrid_amd")
+
+
+def lime_record(rtype, data, mb, me):
+    head = struct.pack(">IHHQ", 0x456789AB, 1, (0x8000 if mb else 0) | (0x4000 if me else 0), len(data)) + rtype.encode().ljust(128, b"\0")
+    assert len(head) == 144
+    return head + data + b"\0" * (-len(data) % 8)
+
+
+def ildg_payload(X):
+    """value of every real number from its ILDG coordinates: site (t, z, y, x) with x fastest, then mu, then 18 reals"""
+    t, z, y, x, mu, k = np.meshgrid(*[np.arange(n) for n in (X[3], X[2], X[1], X[0], 4, 18)], indexing="ij")
+    return (((t * 100 + z) * 100 + y) * 100 + x) * 100.0 + mu * 20 + k + 0.25
+
+
+def expected_qdp(vals, X):
+    """QDP even-odd arrays of loadGaugeQuda: gauge[mu][(parity*Vh + lexicographic/2)*18 + k] (tests/test_util.cpp:419-443)"""
+    V = int(np.prod(X))
+    out = np.zeros((4, V * 18))
+    lex = vals.reshape(V, 4, 18)
+    t, z, y, x = np.meshgrid(*[np.arange(n) for n in (X[3], X[2], X[1], X[0])], indexing="ij")
+    parity = ((t + z + y + x) & 1).reshape(-1)
+    iv = np.arange(V)
+    dst = parity * (V // 2) + iv // 2
+    for mu in range(4):
+        o = out[mu].reshape(V, 18)
+        o[dst] = lex[:, mu]
+    return out
+
+
+@pytest.mark.parametrize("X", [(4, 4, 4, 4), (6, 4, 2, 8)])
+def test_reader_against_hand_built_file(qa, tmp_path, X):
+    vals = ildg_payload(X)
+    xml = ("<?xml version=\"1.0\" encoding=\"UTF-8\"?><ildgFormat><version>1.0</version><field>su3gauge</field><precision>64</precision>"
+           "<lx>%d</lx><ly>%d</ly><lz>%d</lz><lt>%d</lt></ildgFormat>" % tuple(X)).encode()
+    blob = (lime_record("xlf-info", b"plaquette = 0.5, kappa = 0.137000, mu = 0.0040", True, True)
+            + lime_record("ildg-format", xml, True, False)
+            + lime_record("ildg-binary-data", vals.astype(">f8").tobytes(), False, True)
+            + lime_record("scidac-checksum", b"<scidacChecksum/>", True, True))
+    path = tmp_path / "conf.lime"
+    path.write_bytes(blob)
+    gp = qa.lib().newQudaGaugeParam()
+    ip = qa.lib().newQudaInvertParam()
+    ip.kappa = 0.137
+    got = qa.read_lime_gauge(path, gp, (1, 1, 1, 1), ip, int(np.prod(X)))
+    assert [gp.X[d] for d in range(4)] == list(X)
+    assert np.array_equal(got, expected_qdp(vals, X))
+
+
+def test_writer_produces_the_same_payload(qa, tmp_path):
+    X = (4, 6, 2, 4)
+    vals = ildg_payload(X)
+    gauge = expected_qdp(vals, X)
+    gp = qa.lib().newQudaGaugeParam()
+    for d in range(4):
+        gp.X[d] = X[d]
+    path = tmp_path / "out.lime"
+    qa.write_lime_gauge(path, gauge, gp, "kappa = 0.125000, mu = 0.01")
+    raw = path.read_bytes()
+    # walk the records with the format description
+    pos, records = 0, {}
+    while pos < len(raw):
+        magic, version, flags, nbytes = struct.unpack(">IHHQ", raw[pos:pos + 16])
+        assert magic == 0x456789AB and version == 1
+        rtype = raw[pos + 16:pos + 144].split(b"\0")[0].decode()
+        records[rtype] = raw[pos + 144:pos + 144 + nbytes]
+        pos += 144 + (nbytes + 7) // 8 * 8
+    assert pos == len(raw) and list(records) == ["xlf-info", "ildg-format", "ildg-binary-data"]
+    assert records["ildg-binary-data"] == vals.astype(">f8").tobytes()
+    assert b"<precision>64</precision>" in records["ildg-format"] and b"<lx>4</lx><ly>6</ly><lz>2</lz><lt>4</lt>" in records["ildg-format"]
+    # and back through the reader
+    gp2 = qa.lib().newQudaGaugeParam()
+    assert np.array_equal(qa.read_lime_gauge(path, gp2, (1, 1, 1, 1), None, int(np.prod(X))), gauge)

@@ -128,6 +128,22 @@ def main():
             want_n2 = float(np.dot(spinor[:nh_g], spinor[:nh_g]))
             assert abs(n2v - want_n2) < 1e-12 * want_n2, ("skewed all-reduce value", n2v, want_n2)
         spn.free()
+        # every rank reads its sub-block of one ILDG / LIME file (written here byte by byte from the format description)
+        import struct
+        lime_path = os.path.join(os.environ.get("QUDA_AMD_SHM_DIR", "/tmp"), "conf_%s.lime" % "_".join(map(str, X + grid)))
+        if rank == 0:
+            def rec(rtype, data, mb, me):
+                return struct.pack(">IHHQ", 0x456789AB, 1, (0x8000 if mb else 0) | (0x4000 if me else 0), len(data)) + rtype.encode().ljust(128, b"\0") + data + b"\0" * (-len(data) % 8)
+            Vg = int(np.prod(X))
+            lexg = np.stack([oracle.eo_to_lex(np.ascontiguousarray(gauge[d]), X, 18).reshape(Vg, 18) for d in range(4)], axis=1)   # (V, 4, 18): ILDG site record
+            xml = ("<ildgFormat><precision>64</precision><lx>%d</lx><ly>%d</ly><lz>%d</lz><lt>%d</lt></ildgFormat>" % tuple(X)).encode()
+            with open(lime_path + ".tmp", "wb") as fh:
+                fh.write(rec("ildg-format", xml, True, False) + rec("ildg-binary-data", lexg.reshape(Vg, 72).astype(">f8").tobytes(), False, True))
+            os.replace(lime_path + ".tmp", lime_path)
+        qa.lib().qudaAmdCommBarrier()
+        gpl = qa.lib().newQudaGaugeParam()
+        g_read = qa.read_lime_gauge(lime_path, gpl, grid, None, int(np.prod(Xl)))
+        assert [gpl.X[d] for d in range(4)] == list(Xl) and np.array_equal(g_read, g_loc), ("lime reader", X, grid)
         # gauge tools on the decomposed lattice: plaquette (global average) and APE smearing through the ghost-aware shifts
         qa.load_gauge(g_loc, qa.gauge_param(Xl, cuda_prec=8, prec_sloppy=4))
         plq, plq_want = np.array(qa.plaquette()), oracle.plaquette(gauge, X)
