@@ -21,6 +21,7 @@ void init();
 void end();
 // when false, reductions stay rank-local (reference global_reduction switch, lib/face_buffer.cpp:409)
 void setGlobalReduction(bool on);
+bool globalReduction();
 
 void zero(ColorSpinorField &a);
 void copy(ColorSpinorField &dst, const ColorSpinorField &src);

@@ -210,6 +210,7 @@ void end() {
   d_count = nullptr;
 }
 void setGlobalReduction(bool on) { g_global_reduction = on; }
+bool globalReduction() { return g_global_reduction; }
 
 struct Seg {           // one contiguous parity block of a field
   void *v[2];

@@ -23,6 +23,7 @@
 #include <map>
 #include <vector>
 
+#include "blas.h"
 #include "device_io.h"
 #include "halo.h"
 
@@ -886,7 +887,39 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
   arg.commMask = mask;
   arg.blist = bl.d_idx[p.parity]; arg.nboundary = bl.count[p.parity];
 
-  if (hb.p2p) {
+  // First use of the peer-store transport for this precision: the start-up probe has exercised the access patterns, this checks
+  // the production kernel itself — the same application once through the staged transport and once through peer stores must
+  // agree on every rank, otherwise (wrong data, or a wait that ran out) all ranks drop back to the staged transport for good.
+  // Applications with an xpay field before that point go the staged way (the check runs the kernel twice on `out`).
+  if (hb.p2p && hb.verified == 0 && !p.x) {
+    hb.verified = 3;
+    hb.p2p = false;
+    launchDslash<T, R, VARIANT>(out, in, U, p);
+    HIP_CHECK(hipStreamSynchronize(cs));
+    ColorSpinorField ref(out);
+    hb.p2p = true;
+    launchDslash<T, R, VARIANT>(out, in, U, p);
+    HIP_CHECK(hipStreamSynchronize(cs));
+    double fail = p2pTakeError() ? 1.0 : 0.0;
+    const bool wasGlobal = blas::globalReduction();
+    blas::setGlobalReduction(false);   // rank-local sums; the verdict is shared through the host collective below
+    const double n2 = blas::norm2(out), d2 = blas::xmyNorm(out, ref);
+    blas::setGlobalReduction(wasGlobal);
+    const double tol = sizeof(T) == 8 ? 1e-10 : (sizeof(T) == 4 ? 1e-4 : 3e-2);
+    if (!(d2 <= tol * tol * n2)) fail = 1.0;
+    if (getenv("QUDA_AMD_P2P_VERIFY_FAIL")) fail = 1.0;   // test hook: exercise the fall-back
+    comm_allreduce(&fail, 1);
+    if (fail != 0.0) {
+      if (commGrid().rank == 0) warningQuda("peer-store halo disagrees with the staged transport on its first use: staying with RCCL send/recv");
+      p2pDisable();
+      for (HaloBuffers &h : g_halo) { h.p2p = false; h.verified = 0; }
+      launchDslash<T, R, VARIANT>(out, in, U, p);
+      return;
+    }
+    hb.verified = 1;
+    return;
+  }
+  if (hb.p2p && (hb.verified == 1 || hb.verified == 3)) {
     // peer-store transport: ONE launch on ONE stream, [pack blocks | every site].  The pack blocks store the faces straight into
     // the neighbours' ghost zones with the exchange's flag inside every word pair; a boundary site does its local hops first
     // and then polls exactly the ghost words it needs (ghost_hop).  Zones are double-buffered by the parity of the exchange

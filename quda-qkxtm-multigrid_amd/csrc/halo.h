@@ -42,6 +42,7 @@ struct HaloBuffers {
   char *window = nullptr;
   char *ghostBuf[4][2][2] = {};
   char *peerGhost[4][2][2] = {};   // [dim][to_fwd][buf]
+  int verified = 0;                // 0: not yet (staged until then), 1: agrees with the staged transport, 3: verification in progress
   unsigned seq = 0;
   unsigned uses[4][2] = {};        // exchanges that used (dim, buf) so far = the flag carried by the words of the current one
   PeerMap map;

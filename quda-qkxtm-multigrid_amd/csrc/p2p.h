@@ -33,6 +33,8 @@ bool commMapAllRanks(void *local, std::vector<void *> &byRank, std::vector<void 
 bool p2pHaloEnabled();
 void p2pReset();
 int p2pTransport();   // -1 not decided yet, 0 staged (RCCL send/recv), 1 direct peer stores
+void p2pDisable();    // fall back to the staged transport for the rest of the run (first-use verification failed)
+int p2pTakeError();   // value of the device error word, cleared
 
 // device word set by a wait that timed out (a neighbour never signalled); p2pCheck aborts with a message if it is set
 int *p2pErrorWord();

@@ -161,6 +161,15 @@ void p2pReset() {
   if (g_err) { (void)hipFree(g_err); g_err = nullptr; }
 }
 int p2pTransport() { return g_p2p; }
+// the production kernel disagreed with the staged transport on its first use (halo.h, verifyPeerStores): staged from now on
+void p2pDisable() { g_p2p = 0; }
+int p2pTakeError() {   // read and clear the device error word
+  if (!g_err) return 0;
+  int h = 0;
+  HIP_CHECK(hipMemcpy(&h, g_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (h) { HIP_CHECK(hipMemset(g_err, 0, sizeof(int))); HIP_CHECK(hipDeviceSynchronize()); }
+  return h;
+}
 
 bool p2pHaloEnabled() {
   if (g_p2p >= 0) return g_p2p != 0;

@@ -327,3 +327,20 @@ def test_missing_neighbour_face_is_an_error_not_a_hang():
         outs = [p.communicate(timeout=120)[0] for p in procs]
     assert "transport 1" in outs[0], outs[0][-1500:]
     assert procs[0].returncode == 1 and "a halo wait timed out" in outs[0] and "NOT REACHED" not in outs[0], outs[0][-1500:]
+
+
+@pytest.mark.parametrize("forced_failure", [False, True])
+def test_peer_store_halo_is_verified_on_first_use(forced_failure):
+    """The first partitioned application of every precision runs through both transports and compares (csrc/dslash.hip); a
+    failed comparison (forced here through the test hook) drops every rank back to the staged transport, results stay right."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("QUDA_AMD_HALO", None)
+    if forced_failure:
+        env["QUDA_AMD_P2P_VERIFY_FAIL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "p2p_verify_fallback.py")], capture_output=True, text=True, timeout=300, env=env)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-1500:]
+    assert ("transport 0" if forced_failure else "transport 1") in out, out[-1500:]
