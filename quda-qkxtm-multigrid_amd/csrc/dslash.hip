@@ -375,7 +375,7 @@ __device__ __forceinline__ void dslash_epilogue(real *acc, const DslashArg<real>
 }
 
 // ---- face packing (reference packFaceWilsonKernel / packTwistedFaceWilsonKernel, lib/dslash_pack.cu:272, :610) ----
-// P2P: the send pointers are peer-mapped ghost zones — system-scope write-through stores (sc0 sc1), completion counter, flags
+// P2P: the send pointers are peer-mapped ghost zones — flag-in-data vectors, system-scope write-through stores (GhostLL)
 // Block `bid` packs the face sites [bid * chunk, (bid + 1) * chunk) of the concatenated (dim, dir) ranges, chunk <= blockDim.
 template <typename T, bool PRETWIST, bool P2P, typename real> __device__ __forceinline__ void pack_body(const PackArg<real> &arg, int bid, int chunk) {
   const int tid = (int)threadIdx.x < chunk ? bid * chunk + (int)threadIdx.x : arg.start[8];
