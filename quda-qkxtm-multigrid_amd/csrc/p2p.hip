@@ -155,6 +155,38 @@ __global__ void p2p_probe_recv(ProbeWindow *mine, const int *fromRank, unsigned 
   if (!ok) atomicAdd(result, 1);
 }
 
+// Can this rank's device reach the devices of all other ranks directly?  PCI bus ids are exchanged (device ordinals mean nothing
+// across processes with different visibility masks); a peer that is visible here must be peer-accessible, and access is switched on
+// up front rather than left to the lazy path of hipIpcOpenMemHandle — a kernel touching a window that is not reachable would
+// fault, and a fault cannot be caught and turned into a fall-back.  Ranks on the same device (rehearsals) need nothing.
+static bool peersReachable() {
+  const CommGrid &g = commGrid();
+  if (g.size == 1) return true;
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  char mine[64];
+  memset(mine, 0, sizeof(mine));
+  if (hipDeviceGetPCIBusId(mine, (int)sizeof(mine) - 1, dev) != hipSuccess) { (void)hipGetLastError(); mine[0] = 0; }
+  std::vector<char> all((size_t)g.size * 64);
+  commAllgatherBytes(mine, all.data(), 64);
+  double fail = 0;
+  for (int r = 0; r < g.size && fail == 0; r++) {
+    if (r == g.rank) continue;
+    const char *bus = &all[(size_t)r * 64];
+    int peer = -1;
+    if (!bus[0] || hipDeviceGetByPCIBusId(&peer, bus) != hipSuccess) { (void)hipGetLastError(); continue; }   // not visible here: leave it to the IPC mapping
+    if (peer == dev) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, dev, peer) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+    if (!can) { fail = 1; break; }
+    const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) fail = 1;
+    (void)hipGetLastError();
+  }
+  comm_allreduce(&fail, 1);
+  return fail == 0;
+}
+
 static int g_p2p = -1;
 void p2pReset() {
   g_p2p = -1;
@@ -179,7 +211,7 @@ bool p2pHaloEnabled() {
   ProbeWindow *win = (ProbeWindow *)p2pAlloc(sizeof(ProbeWindow));
   PeerMap pm;
   double fail = 0;
-  if (!commMapPeers(win, pm)) {
+  if (!peersReachable() || !commMapPeers(win, pm)) {
     fail = 1;
   } else {
     ProbeWindow **d_peer = nullptr;
