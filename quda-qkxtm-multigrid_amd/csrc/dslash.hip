@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
   int b = blockIdx.x;
   if (KT == 3) {
     // single-launch peer-store path: [pack blocks | every site]; boundary sites do their local hops first, then poll the
-    // incoming-face counters and add the off-node hops (stencil_site, KT == 3)
+    // ghost words they need and add the off-node hops (stencil_site, KT == 3)
     if (b < arg.packBlocks) { pack_body<T, VARIANT == 1, true>(arg.pack, b, arg.packChunk); return; }
     b -= arg.packBlocks;
   }

@@ -1,10 +1,11 @@
-// p2p.h — peer-mapped halo windows: the pack kernel of one GPU stores its faces straight into the ghost zone of the
-// neighbouring GPU over xGMI and raises a flag there; the neighbour's exterior kernel polls the flag.  No host round
-// trip, no collective-library launch on the critical path (a grouped RCCL send/recv costs ~55 us per Dslash, measured;
-// the whole 32x16x16x16 interior kernel takes 18 us).  The reference's counterpart is its CUDA-IPC "p2p" policy
-// (lib/cuda_color_spinor_field.cu:1212-1400, lib/dslash_policy.cuh:838-998: cudaIpcOpenMemHandle'd ghost buffers,
-// cudaMemcpyAsync into the peer, IPC events); like the reference, the library falls back to the staged transport (RCCL
-// send/recv) when peer mapping is not possible.
+// p2p.h — peer-mapped windows: a kernel of one GPU stores straight into the memory of the neighbouring GPU over xGMI and the
+// neighbour's kernel finds the data there.  Fine-grid halo: the faces travel as flag-in-data vectors (dslash.hip GhostLL) that
+// the neighbour's boundary sites poll; coarse-grid halo and the all-reduce of the global sums: payload + a cumulative arrival
+// counter bumped by a remote atomic.  No host round trip, no collective-library launch on the critical path (a grouped RCCL
+// send/recv costs ~55 us per Dslash, measured; the whole 32x16x16x16 interior kernel takes 18 us).  The reference's counterpart
+// is its CUDA-IPC "p2p" policy (lib/cuda_color_spinor_field.cu:1212-1400, lib/dslash_policy.cuh:838-998: cudaIpcOpenMemHandle'd
+// ghost buffers, cudaMemcpyAsync into the peer, IPC events); like the reference, the library falls back to the staged transport
+// (RCCL send/recv) when peer mapping is not possible — or when the probe / the first-use verification says it does not work.
 #pragma once
 
 #include <vector>
