@@ -178,6 +178,7 @@ struct CoarseGhost {
   unsigned *flag[4][2], *peerFlag[4][2];             // + buf
   unsigned seq, uses[4][2][2];
   PeerMap *map;
+  int verified;   // 0: the peer-store exchange of this ghost has not been checked against the staged one yet, 1: it has, 3: being checked
 };
 static std::vector<CoarseGhost> g_cghosts;
 void freeCoarseGhosts() {
@@ -208,7 +209,7 @@ static CoarseGhost &coarseGhost(const int Xc[4], int n) {
   for (int d = 0; d < 4; d++)
     for (int k = 0; k < 2; k++) { c.send[d][k] = p; p += (size_t)2 * n * c.faceCB[d]; c.ghost[d][k] = p; p += (size_t)2 * n * c.faceCB[d]; }
   c.p2p = p2pHaloEnabled();
-  c.window = nullptr; c.map = nullptr; c.seq = 0;
+  c.window = nullptr; c.map = nullptr; c.seq = 0; c.verified = 0;
   memset(c.uses, 0, sizeof(c.uses));
   if (c.p2p) {
     size_t wbytes = 0;
@@ -343,6 +344,43 @@ static void exchangeCoarseGhost(CoarseArg &arg, const CoarseGauge &G, int single
 
 void applyCoarse(ColorSpinorField &out, const ColorSpinorField &in, const CoarseGauge &G, int mmask, int parity) {
   if (out.Precision() != QUDA_SINGLE_PRECISION || in.Precision() != QUDA_SINGLE_PRECISION) errorQuda("coarse operator is fp32");
+  {
+    // first partitioned application through a peer-store ghost: once staged, once with peer stores, and every rank must see the
+    // same field — otherwise all ranks keep the staged exchange (the fine stencil does the same, dslash.hip)
+    int mask = 0;
+    for (int d = 0; d < 4; d++) if (commGrid().partitioned(d) && ((mmask >> (2 * d)) & 3)) mask |= 1 << d;
+    if (mask) {
+      CoarseGhost &cg = coarseGhost(G.Xc, G.n);
+      if (cg.p2p && cg.verified == 0) {
+        cg.verified = 3;
+        cg.p2p = false;
+        applyCoarse(out, in, G, mmask, parity);
+        HIP_CHECK(hipStreamSynchronize(computeStream()));
+        ColorSpinorField ref(out);
+        CoarseGhost &cg2 = coarseGhost(G.Xc, G.n);   // (the vector may have grown in between)
+        cg2.p2p = true;
+        applyCoarse(out, in, G, mmask, parity);
+        HIP_CHECK(hipStreamSynchronize(computeStream()));
+        double fail = p2pTakeError() ? 1.0 : 0.0;
+        const bool wasGlobal = blas::globalReduction();
+        blas::setGlobalReduction(false);
+        const double n2 = blas::norm2(out), d2 = blas::xmyNorm(out, ref);
+        blas::setGlobalReduction(wasGlobal);
+        if (!(d2 <= 1e-8 * n2)) fail = 1.0;
+        if (getenv("QUDA_AMD_P2P_VERIFY_FAIL")) fail = 1.0;
+        comm_allreduce(&fail, 1);
+        CoarseGhost &cg3 = coarseGhost(G.Xc, G.n);
+        if (fail != 0.0) {
+          if (commGrid().rank == 0) warningQuda("peer-store coarse halo disagrees with the staged exchange on its first use: staying with RCCL send/recv");
+          for (CoarseGhost &c : g_cghosts) { c.p2p = false; c.verified = 1; }
+          applyCoarse(out, in, G, mmask, parity);
+          return;
+        }
+        cg3.verified = 1;
+        return;
+      }
+    }
+  }
   if (in.Nspin() != 2 || 2 * in.Ncolor() != G.n) errorQuda("coarse field (%d spins, %d colours) does not match the operator (n = %d)", in.Nspin(), in.Ncolor(), G.n);
   if (G.n > 64) errorQuda("2 Nc = %d exceeds one wavefront", G.n);
   if (in.V() == out.V()) errorQuda("in and out must not alias");

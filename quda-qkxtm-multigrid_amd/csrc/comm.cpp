@@ -38,16 +38,22 @@ static bool g_rccl_self = false;
 static std::string g_shm_dir;
 static std::vector<unsigned long> g_seq_send, g_seq_recv;
 static unsigned long g_seq_red = 0;
+// incarnation of the communicator inside this process: sequence numbers restart with every qudaAmdCommInit while the directory
+// (and the never-removed files of a communicator's last round) stays, so file names carry the incarnation — a rank that is
+// already in the next incarnation must not pick up a file the previous one left behind (seen as rare 2-rank rehearsal time-outs:
+// the 2-rank rehearsal re-initialises three times per run)
+static int g_shm_epoch = 0;
 
 static void shmWrite(const std::string &name, const void *p, size_t n) {
-  const std::string tmp = g_shm_dir + "/." + name + ".tmp", fin = g_shm_dir + "/" + name;
+  const std::string ep = "e" + std::to_string(g_shm_epoch) + "_";
+  const std::string tmp = g_shm_dir + "/." + ep + name + ".tmp", fin = g_shm_dir + "/" + ep + name;
   FILE *f = fopen(tmp.c_str(), "wb");
   if (!f || fwrite(p, 1, n, f) != n) errorQuda("shm transport: cannot write %s", tmp.c_str());
   fclose(f);
   if (rename(tmp.c_str(), fin.c_str())) errorQuda("shm transport: rename failed for %s", fin.c_str());
 }
 static void shmRead(const std::string &name, void *p, size_t n, bool consume) {
-  const std::string fin = g_shm_dir + "/" + name;
+  const std::string fin = g_shm_dir + "/e" + std::to_string(g_shm_epoch) + "_" + name;
   for (long spins = 0;; spins++) {
     FILE *f = fopen(fin.c_str(), "rb");
     if (f) {
@@ -133,7 +139,7 @@ static void shmAllreduce(double *data, int n, bool is_max) {
     for (int k = 0; k < n; k++) acc[k] = is_max ? (tmp[k] > acc[k] ? tmp[k] : acc[k]) : acc[k] + tmp[k];
   }
   // everyone has read round seq-1 once it writes round seq: clean up our own file of the previous round
-  if (seq > 0) remove((g_shm_dir + "/red_" + std::to_string(seq - 1) + "_" + std::to_string(g.rank)).c_str());
+  if (seq > 0) remove((g_shm_dir + "/e" + std::to_string(g_shm_epoch) + "_red_" + std::to_string(seq - 1) + "_" + std::to_string(g.rank)).c_str());
   for (int k = 0; k < n; k++) data[k] = acc[k];
 }
 
@@ -275,6 +281,7 @@ void qudaAmdCommInit(const void *id128, int rank, int size) {
     const char *dir = getenv("QUDA_AMD_SHM_DIR");
     if (!dir) errorQuda("QUDA_AMD_TRANSPORT=shm needs QUDA_AMD_SHM_DIR");
     g_shm = true;
+    g_shm_epoch++;
     g_shm_dir = dir;
     g_seq_send.assign(size, 0);
     g_seq_recv.assign(size, 0);
