@@ -30,7 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-from synth import make_clover, make_gauge, smooth_gauge  # noqa: E402
+from synth import make_clover, make_gauge, smooth_gauge, tiled_gauge  # noqa: E402
 
 
 def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)), gauge=None, extras=True):
@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--recon", type=int, default=18, choices=[18, 12])
     ap.add_argument("--dslash", default="tm", choices=["tm", "tmc", "wilson"])
     ap.add_argument("--lattice", default="32,32,32,32")
+    ap.add_argument("--fast-gauge", action="store_true", help="links = periodic repetition of 65536 random SU(3) matrices (profiling of big lattices)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the other-precision sweep")
     args = ap.parse_args()
@@ -140,7 +141,9 @@ def main():
     dtype_name = {8: "f64", 4: "f32", 2: "i16+f32scale"}
     kinds = {"tm": qa.QUDA_TWISTED_MASS_DSLASH, "tmc": qa.QUDA_TWISTED_CLOVER_DSLASH, "wilson": qa.QUDA_WILSON_DSLASH}
 
-    gauge = make_gauge(X) if dist is None else dist.scatter_gauge(make_gauge(X))
+    full_gauge = tiled_gauge(X) if args.fast_gauge else make_gauge(X)
+    gauge = full_gauge if dist is None else dist.scatter_gauge(full_gauge)
+    del full_gauge
     clover = None
     rng = np.random.default_rng(1234 + rank)
     src_h = rng.random(Vh_local * 24)

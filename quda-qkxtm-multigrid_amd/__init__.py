@@ -114,7 +114,7 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
                  "qudaAmdSpinorSetTwist", "qudaAmdDiracCreate", "qudaAmdDiracDestroy", "qudaAmdDiracDslash", "qudaAmdDiracDslashXpay",
                  "qudaAmdDiracM", "qudaAmdDiracMdag", "qudaAmdDiracMdagM", "qudaAmdDiracFlops", "qudaAmdTimeDslash", "qudaAmdTimeM",
                  "qudaAmdBlasNorm2", "qudaAmdBlasCDot", "qudaAmdBlasAxpy", "qudaAmdDslashBytesPerSite", "qudaAmdDslashFlopsPerSite",
-                 "qudaAmdSetPartitionMask", "qudaAmdComputeStream", "qudaAmdDeviceSynchronize", "qudaAmdHaloTransport", "qudaAmdCommGetUniqueId",
+                 "qudaAmdSetPartitionMask", "qudaAmdComputeStream", "qudaAmdDeviceSynchronize", "qudaAmdHaloTransport", "qudaAmdSetDslashTune", "qudaAmdCommGetUniqueId",
                  "qudaAmdCommInit", "qudaAmdCommRank", "qudaAmdCommSize", "qudaAmdCommCoords", "qudaAmdCommBarrier", "qudaAmdCommAllreduce", "qudaAmdCommAllreduceMax",
                  "qudaAmdMultigridVerify", "qudaAmdMultigridCycle", "qudaAmdTimeAxpy", "qudaAmdMultigridLevels", "qudaAmdMultigridLevelInfo",
                  "qudaAmdMultigridSetHalfStorage", "qudaAmdMultigridGetNullVector", "qudaAmdMultigridGetV", "qudaAmdMultigridGetCoarseLinks", "qudaAmdMultigridApply"]
@@ -180,6 +180,7 @@ def lib():
         L.qudaAmdCommGetUniqueId.argtypes = [_p]
         L.initCommsGridQuda.argtypes = [_i, C.POINTER(_i), _p, _p]
         L.qudaAmdSetPartitionMask.argtypes = [_i]
+        L.qudaAmdSetDslashTune.argtypes = [C.c_char_p, _i]
         L.qudaAmdMultigridVerify.argtypes = [_p, C.POINTER(_d)]
         L.qudaAmdMultigridCycle.argtypes = [_p, _p, _p, C.POINTER(QudaInvertParam)]
         L.qudaAmdTimeAxpy.argtypes = [_d, _p, _p, _i]

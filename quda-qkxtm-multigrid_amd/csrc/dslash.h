@@ -53,6 +53,19 @@ enum SiteOp {
 void applySite(ColorSpinorField &out, const ColorSpinorField &in, SiteOp op, double a, double b, const CloverField *clover,
                int parity, bool inverse);
 
+// launch geometry of the stencil kernel (block size, XCD mapping, block order); see launchDslash
+struct DslashTune {
+  int block = 0;       // threads per block; 0: the largest of 256/192/128/64 that divides an (x, y) plane
+  int remap = 1;       // XCD-aware block mapping on / off
+  int order = 1;       // legacy slab order: 1 = t-interleave over the whole XCD slab, n > 1 = over n slices
+  int store_aux = 0;   // cache policy of the output stores
+  int tiled = -1;      // plane-tiled order: -1 automatic, 0 off, 1 on
+  int nxz = 0, tz = 0, tt = 0;   // plane-tiled order: XCDs along z, tile extents in z and t (0: automatic)
+  int lds_pad = 0;     // dynamic LDS per block, only to cap the blocks per CU (measurement aid)
+};
+DslashTune &dslashTune();
+void setDslashTune(const char *key, int value);
+
 // analytic work model per checkerboard site
 long long dslashFlopsPerSite(DslashMode mode, bool xpay);
 long long dslashBytesPerSite(QudaPrecision prec, int recon, DslashMode mode, bool xpay);

@@ -21,6 +21,7 @@
 
 #include <cstring>
 #include <map>
+#include <string>
 #include <vector>
 
 #include "blas.h"
@@ -67,6 +68,10 @@ template <typename real> struct DslashArg {
   real tsign_fwd, tsign_bwd;  // recon-12: sign of the reconstructed row of t-links on the boundary slices
   int nblocks, xcd_q, xcd_r;
   int ts, bps;                // time-slab interleave: ts slices per slab, bps blocks per time slice (ts = 0: off)
+  // plane-tiled block order (tiled != 0): a block is chunk yc of the P chunks of one (z, t) plane; the 8 XCDs split the (z, t)
+  // lattice nxz x (8 / nxz) ways and each walks its region tile by tile (tz x tt planes per tile, t fastest inside a tile)
+  int tiled, P, nxz, Zs, Ts, tz, tt;
+  FastDiv dNxz, dPerTile, dNtz, dTzTt, dTt;
   // grid-decomposed lattices (halo.h)
   int commMask;               // bit d set: dimension d is partitioned
   const int *blist;           // exterior kernel: checkerboard indices of the boundary sites
@@ -526,14 +531,25 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
   // XCD-aware block remap: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch); give each XCD a
   // contiguous range of logical blocks (a slab of time slices) so t/z neighbours hit its own L2.
   const int xcd = b & 7, within = b >> 3;
-  int lb = (xcd < arg.xcd_r ? xcd * (arg.xcd_q + 1) : arg.xcd_r * (arg.xcd_q + 1) + (xcd - arg.xcd_r) * arg.xcd_q) + within;
-  if (arg.xcd_q < 0) lb = b;   // remap off: consecutive blocks dealt round-robin over the XCDs (even spread of the boundary work)
-  if (arg.ts > 0) {
-    // inside an XCD's slab of ts time slices walk t fastest: consecutive blocks are the same (y,z) chunk on ts successive
-    // slices, so the +-t neighbours of a chunk are touched within a few blocks of each other (L2-resident) instead of a
-    // whole 3 MB slice apart
-    const int per = arg.bps * arg.ts, s = lb / per, w = lb - s * per, c = w / arg.ts, tt = w - c * arg.ts;
-    lb = (s * arg.ts + tt) * arg.bps + c;
+  int lb;
+  if (arg.tiled) {
+    const uint32_t xt = arg.dNxz.div((uint32_t)xcd), xz = (uint32_t)xcd - xt * (uint32_t)arg.nxz;
+    const uint32_t tile = arg.dPerTile.div((uint32_t)within), r = (uint32_t)within - tile * arg.dPerTile.d;
+    const uint32_t tile_t = arg.dNtz.div(tile), tile_z = tile - tile_t * arg.dNtz.d;
+    const uint32_t yc = arg.dTzTt.div(r), r2 = r - yc * arg.dTzTt.d;
+    const uint32_t zi = arg.dTt.div(r2), ti = r2 - zi * arg.dTt.d;
+    const int z = (int)xz * arg.Zs + (int)tile_z * arg.tz + (int)zi, t = (int)xt * arg.Ts + (int)tile_t * arg.tt + (int)ti;
+    lb = (t * arg.Z + z) * arg.P + (int)yc;
+  } else {
+    lb = (xcd < arg.xcd_r ? xcd * (arg.xcd_q + 1) : arg.xcd_r * (arg.xcd_q + 1) + (xcd - arg.xcd_r) * arg.xcd_q) + within;
+    if (arg.xcd_q < 0) lb = b;   // remap off: consecutive blocks dealt round-robin over the XCDs (even spread of the boundary work)
+    if (arg.ts > 0) {
+      // inside an XCD's slab of ts time slices walk t fastest: consecutive blocks are the same (y,z) chunk on ts successive
+      // slices, so the +-t neighbours of a chunk are touched within a few blocks of each other (L2-resident) instead of a
+      // whole slice apart
+      const int per = arg.bps * arg.ts, s = lb / per, w = lb - s * per, c = w / arg.ts, tt = w - c * arg.ts;
+      lb = (s * arg.ts + tt) * arg.bps + c;
+    }
   }
   const int idx = lb * blockDim.x + threadIdx.x;
   if (idx >= arg.Vh) return;
@@ -670,16 +686,40 @@ __global__ void __launch_bounds__(256) site_kernel(const SiteArg<typename Store<
 }
 
 // ------------------------------------------------------------------------------------------------
-static int dslashBlockSize() {
-  static int bs = 0;
-  if (!bs) {
-    const char *e = getenv("QUDA_AMD_DSLASH_BLOCK");
-    bs = e ? atoi(e) : 256;
-    if (bs < 64 || bs > 256 || bs % 64) bs = 256;
+// launch-geometry knobs of the stencil (defaults from the environment, once; qudaAmdSetDslashTune changes them at run time so one
+// process can sweep them — tools/dslash_sweep.py)
+DslashTune &dslashTune() {
+  static DslashTune t;
+  static bool init = false;
+  if (!init) {
+    init = true;
+    auto env = [](const char *n, int d) { const char *e = getenv(n); return e ? atoi(e) : d; };
+    t.block = env("QUDA_AMD_DSLASH_BLOCK", 0);
+    t.remap = env("QUDA_AMD_XCD_REMAP", 1);
+    t.order = env("QUDA_AMD_DSLASH_ORDER", 1);
+    t.store_aux = env("QUDA_AMD_STORE_AUX", 0);
+    t.tiled = env("QUDA_AMD_DSLASH_TILED", -1);
+    t.nxz = env("QUDA_AMD_DSLASH_NXZ", 0);
+    t.tz = env("QUDA_AMD_DSLASH_TZ", 0);
+    t.tt = env("QUDA_AMD_DSLASH_TT", 0);
+    t.lds_pad = env("QUDA_AMD_DSLASH_LDS", 0);
   }
-  return bs;
+  return t;
 }
-
+void setDslashTune(const char *key, int value) {
+  DslashTune &t = dslashTune();
+  const std::string k(key);
+  if (k == "block") t.block = value;
+  else if (k == "remap") t.remap = value;
+  else if (k == "order") t.order = value;
+  else if (k == "store_aux") t.store_aux = value;
+  else if (k == "tiled") t.tiled = value;
+  else if (k == "nxz") t.nxz = value;
+  else if (k == "tz") t.tz = value;
+  else if (k == "tt") t.tt = value;
+  else if (k == "lds_pad") t.lds_pad = value;
+  else errorQuda("unknown stencil tuning key '%s'", key);
+}
 
 template <typename T, bool PRETWIST, bool P2P = false> __global__ void __launch_bounds__(256) pack_kernel(const PackArg<typename Store<T>::real> arg) {
   pack_body<T, PRETWIST, P2P>(arg, blockIdx.x, (int)blockDim.x);
@@ -833,25 +873,41 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
   const bool first_t = commGrid().coords[3] == 0, last_t = commGrid().coords[3] == commGrid().dims[3] - 1;
   arg.tsign_fwd = (R == 12 && U.t_boundary == QUDA_ANTI_PERIODIC_T && last_t) ? -1 : 1;
   arg.tsign_bwd = (R == 12 && U.t_boundary == QUDA_ANTI_PERIODIC_T && first_t) ? -1 : 1;
-  const int bs = dslashBlockSize();
+  const DslashTune &tune = dslashTune();
+  // block size: the largest of 256 / 192 / 128 / 64 threads that cuts an (x, y) plane into whole blocks (needed by the
+  // plane-tiled order), 256 otherwise; QUDA_AMD_DSLASH_BLOCK overrides
+  const int plane = g.Xh * g.X[1];
+  int bs = tune.block;
+  if (bs < 64 || bs > 256 || bs % 64) {
+    bs = 256;
+    for (int c : {256, 192, 128, 64}) if (plane % c == 0) { bs = c; break; }
+  }
   const int nb = (g.Vh + bs - 1) / bs;
   arg.nblocks = nb; arg.xcd_q = nb / 8; arg.xcd_r = nb % 8;
+  if (!tune.remap) arg.xcd_q = -1;
   {
-    static int remap = -1;
-    if (remap < 0) { const char *e = getenv("QUDA_AMD_XCD_REMAP"); remap = e ? atoi(e) : 1; }
-    if (!remap) arg.xcd_q = -1;
-  }
-  {
-    static int order = -1;
-    if (order < 0) { const char *e = getenv("QUDA_AMD_DSLASH_ORDER"); order = e ? atoi(e) : 1; }
     const int slice = g.Vh / g.X[3];
     arg.ts = 0; arg.bps = 0;
-    if (order > 0 && slice % bs == 0 && g.X[3] % 8 == 0 && nb % 8 == 0) {
+    if (tune.order > 0 && slice % bs == 0 && g.X[3] % 8 == 0 && nb % 8 == 0) {
       arg.bps = slice / bs;
-      arg.ts = order == 1 ? g.X[3] / 8 : order;   // order > 1: explicit slab thickness (must divide T/8)
+      arg.ts = tune.order == 1 ? g.X[3] / 8 : tune.order;   // order > 1: explicit slab thickness (must divide T/8)
       if ((g.X[3] / 8) % arg.ts != 0) arg.ts = g.X[3] / 8;
     }
     if (arg.xcd_q < 0) arg.ts = 0;
+  }
+  // plane-tiled order (see DslashArg): needs whole blocks per plane and an even split of the (z, t) lattice over the 8 XCDs
+  arg.tiled = 0;
+  if (tune.tiled > 0 && tune.remap && plane % bs == 0 && g.Vh % bs == 0) {
+    int nxz = tune.nxz > 0 ? tune.nxz : 1;
+    if (8 % nxz == 0 && g.X[2] % nxz == 0 && g.X[3] % (8 / nxz) == 0) {
+      const int Zs = g.X[2] / nxz, Ts = g.X[3] / (8 / nxz);
+      int tz = tune.tz > 0 ? tune.tz : Zs, tt = tune.tt > 0 ? tune.tt : 2;
+      if (tz > Zs || Zs % tz) tz = Zs;
+      if (tt > Ts || Ts % tt) tt = Ts % 2 == 0 ? 2 : 1;
+      arg.tiled = 1; arg.P = plane / bs; arg.nxz = nxz; arg.Zs = Zs; arg.Ts = Ts; arg.tz = tz; arg.tt = tt;
+      arg.dNxz = FastDiv((uint32_t)nxz); arg.dPerTile = FastDiv((uint32_t)(arg.P * tz * tt)); arg.dNtz = FastDiv((uint32_t)(Zs / tz));
+      arg.dTzTt = FastDiv((uint32_t)(tz * tt)); arg.dTt = FastDiv((uint32_t)tt);
+    }
   }
   arg.commMask = 0; arg.blist = nullptr; arg.nboundary = 0;
   arg.waitTicks = 0; arg.errWord = nullptr; arg.packBlocks = 0;
@@ -865,10 +921,9 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
   for (int d = 0; d < 4; d++) if (commGrid().partitioned(d)) mask |= 1 << d;
   hipStream_t cs = computeStream();
   if (mask == 0) {
-    static int saux = -1;
-    if (saux < 0) { const char *e = getenv("QUDA_AMD_STORE_AUX"); saux = e ? atoi(e) : 0; }
-    if (saux == 2) hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 0, 2>), dim3(nb), dim3(bs), 0, cs, arg);
-    else hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 0>), dim3(nb), dim3(bs), 0, cs, arg);
+    const size_t lds = tune.lds_pad > 0 ? (size_t)tune.lds_pad : 0;   // measurement aid: dynamic LDS only to cap the blocks per CU
+    if (tune.store_aux == 2) hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 0, 2>), dim3(nb), dim3(bs), lds, cs, arg);
+    else hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 0>), dim3(nb), dim3(bs), lds, cs, arg);
     HIP_CHECK(hipGetLastError());
     return;
   }
@@ -951,7 +1006,8 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
     // that has its CU to itself.  Spreading the packing thinly (one 96-thread pack block on EVERY CU) is far worse — 46 us
     // instead of 29, every site block ends late — so the system-scope write-through stores of a pack wave appear to hold up the
     // memory pipeline of the whole CU, and fewer CUs doing all of it is the better trade.
-    arg.packBlocks = (nt + bs - 1) / bs; arg.packChunk = bs;
+    // rounded up to a multiple of 8: blockIdx.x and the site-block number then agree mod 8, i.e. on the XCD (surplus pack blocks leave at once)
+    arg.packBlocks = ((nt + bs - 1) / bs + 7) / 8 * 8; arg.packChunk = bs;
     static unsigned long long *tl = nullptr;
     static int tlmode = -1;
     if (tlmode < 0) { const char *e = getenv("QUDA_AMD_TIMELINE"); tlmode = e ? atoi(e) : 0; if (tlmode) HIP_CHECK(hipHostMalloc((void **)&tl, 16384 * sizeof(unsigned long long), hipHostMallocMapped)); }

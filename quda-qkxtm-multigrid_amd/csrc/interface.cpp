@@ -602,6 +602,7 @@ void qudaAmdSetPartitionMask(int mask) {
 }
 void *qudaAmdComputeStream(void) { return (void *)computeStream(); }
 int qudaAmdHaloTransport(void) { return p2pTransport(); }
+void qudaAmdSetDslashTune(const char *key, int value) { setDslashTune(key, value); }
 void qudaAmdDeviceSynchronize(void) { HIP_CHECK(hipDeviceSynchronize()); p2pCheck(__func__); }
 
 }  // extern "C"

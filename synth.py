@@ -34,6 +34,19 @@ def make_gauge(X, seed=137, antiperiodic=True):
     return out
 
 
+def tiled_gauge(X, seed=137, base=1 << 16):
+    """links for TIMING runs on big lattices: a periodic repetition of `base` Haar-random SU(3) matrices (seconds instead of
+    minutes at 48^3 x 96; kernel time does not depend on the values)"""
+    rng = np.random.default_rng(seed)
+    V = int(np.prod(X))
+    out = np.empty((4, V * 18))
+    base = int(np.gcd(V, base))
+    for mu in range(4):
+        q = random_su3(rng, base)
+        out[mu].reshape(V // base, base * 18)[:] = np.stack([q.real, q.imag], axis=-1).reshape(-1)
+    return out
+
+
 def smooth_gauge(X, eps, seed=3):
     rng = np.random.default_rng(seed)
     V = int(np.prod(X))
