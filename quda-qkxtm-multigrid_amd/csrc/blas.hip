@@ -48,7 +48,11 @@ __device__ __forceinline__ double peer_allreduce(const double *mine, double *con
     double *slot = peerSlots[threadIdx.x] + ((size_t)buf * nranks + rank) * kSlotDoubles;
     for (int k = 0; k < NRED; k++)
       __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot + k), __builtin_bit_cast(unsigned long long, mine[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // the slot stores are write-through (sc0 sc1) and must have been acknowledged before the counter can announce them: a
+    // workgroup-scope fence emits nothing here, so drain this wave's stores explicitly (inline asm: the compiler may drop a
+    // builtin wait it believes redundant), then bump the peer's counter.  The add itself stays relaxed: a release at system scope
+    // would add a write-back of the whole dirty L2 (buffer_wbl2), which orders nothing these write-through stores need
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     (void)__hip_atomic_fetch_add(peerCount[threadIdx.x] + buf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (threadIdx.x == 0) {
@@ -58,6 +62,9 @@ __device__ __forceinline__ double peer_allreduce(const double *mine, double *con
       if (wall_clock64() - t0 > waitTicks) { ok = 0; break; }
       __builtin_amdgcn_s_sleep(1);
     }
+    // one acquire after the poll (not inside it): nothing read below may come from a line cached before the counter matched
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     *done = ok;
   }
   __syncthreads();
@@ -407,7 +414,10 @@ __global__ void __launch_bounds__(256) blas_kernel(BlasArg<F> arg) {
       __hip_atomic_store(&arg.part[(size_t)blockIdx.x * F::nred + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __shared__ int isLast;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // the partials are sc1 (write-through) stores; the storing wave waits for their acknowledgement BEFORE the barrier, so the
+    // counter bump below cannot overtake them on their way to memory (the last block may sit on another XCD with its own L2);
+    // it then reads them with sc1 loads behind its own barrier — the drained-sc1 hand-off of MI355X_MICROARCH.md
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) isLast = __hip_atomic_fetch_add(arg.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();

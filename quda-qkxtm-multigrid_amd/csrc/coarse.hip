@@ -97,6 +97,8 @@ __global__ void __launch_bounds__(256) coarse_apply_kernel(const CoarseArg arg) 
         if (wall_clock64() - t0 > arg.waitTicks) { __hip_atomic_store(arg.errWord, 17 + (int)threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         __builtin_amdgcn_s_sleep(1);
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // once, after the poll: the face words read below are newer than the counter
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
   }
@@ -279,8 +281,9 @@ __global__ void __launch_bounds__(256) coarse_pack_kernel(const CoarsePackArg ar
   }
   }
   if (arg.p2p) {
-    // as pack_body of the fine stencil: wait for this block's stores, then add the threads it contributed to each face counter
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // every storing wave waits until its write-through stores have been acknowledged, THEN the barrier, THEN one lane per
+    // face adds the threads this block contributed to the neighbour's arrival counter (release, system scope)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x < 8 && arg.peerFlag[threadIdx.x]) {
       const int beg = blockIdx.x * (int)blockDim.x, end = beg + (int)blockDim.x;

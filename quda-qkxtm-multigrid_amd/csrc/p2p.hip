@@ -120,7 +120,7 @@ __global__ void p2p_probe_send(ProbeWindow *const *peer, int rank, int round) {
   if (s >= 8 || !peer[s]) return;
   ProbeWindow *w = peer[s];
   __hip_atomic_store(&w->data[s][k], probe_token(rank, s, k, round), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores acknowledged before the barrier and the counter (as the production kernels)
   __syncthreads();
   if (k == 0) (void)__hip_atomic_fetch_add(&w->flag[s], 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // the fine-grid halo's flag-in-data vectors {word, flag, word, flag}: 16-byte buffer stores, sc0 sc1, no ordering, no signal

@@ -229,6 +229,7 @@ def test_two_process_decomposition_on_one_gpu():
         env = dict(os.environ, QUDA_AMD_P2P_TIMEOUT_S="5")
         subprocess.run([os.path.join(root, "tools", "mgpu_rehearsal.sh"), "2", log], cwd=root, env=env, timeout=400, check=True)
         text = open(log).read()
+    assert "rehearsal rc=0" in text, text[-3000:]
     assert "rank 0: all checks passed" in text and "rank 1: all checks passed" in text, text[-3000:]
     assert text.count("MG-GCR") >= 6
 
@@ -320,7 +321,7 @@ def test_missing_neighbour_face_is_an_error_not_a_hang():
     import tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory(dir="/dev/shm") as shm:
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29811", WORLD_SIZE="2", QUDA_AMD_FORCE_DEVICE="0", QUDA_AMD_TRANSPORT="shm",
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(20000 + os.getpid() % 20000), WORLD_SIZE="2", QUDA_AMD_FORCE_DEVICE="0", QUDA_AMD_TRANSPORT="shm",
                    QUDA_AMD_SHM_DIR=shm, QUDA_AMD_P2P_TIMEOUT_S="1")
         procs = [subprocess.Popen([sys.executable, os.path.join(root, "tools", "p2p_timeout_check.py")], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]

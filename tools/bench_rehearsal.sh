@@ -2,7 +2,7 @@
 # Rehearse `bench.py --gpus N` (the N>1 code path the driver launches with torch.distributed.run) on ONE GPU: N processes on
 # device 0, collectives over the file transport, halo over the IPC peer-store transport.  usage: tools/bench_rehearsal.sh <N> <log> [bench args]
 N=${1:-2}; LOG=${2:-gpurun_out/bench_rehearsal.log}; shift 2
-export MASTER_ADDR=127.0.0.1 MASTER_PORT=29711 WORLD_SIZE=$N QUDA_AMD_FORCE_DEVICE=0
+export MASTER_ADDR=127.0.0.1 MASTER_PORT=$((20000 + $$ % 20000)) WORLD_SIZE=$N QUDA_AMD_FORCE_DEVICE=0
 export QUDA_AMD_TRANSPORT=shm QUDA_AMD_SHM_DIR=$(mktemp -d /dev/shm/quda_amd_XXXXXX)
 pids=()
 for r in $(seq 0 $((N-1))); do
@@ -14,4 +14,4 @@ for p in "${pids[@]}"; do wait $p || rc=$?; done
 cat ${LOG}.rank* > $LOG
 echo "rehearsal rc=$rc" >> $LOG
 rm -rf $QUDA_AMD_SHM_DIR
-exit 0
+exit $rc
