@@ -93,19 +93,32 @@ template <int NR> struct Planar<float, NR> {
 };
 
 // 16-bit fixed point.  norm == nullptr: fixed unit scale (links); else per-site scale at norm[nidx].
+// Planes of EIGHT int16 (16 bytes per lane, like the fp32 / fp64 orders) followed, where NR is not a multiple of 8, by one
+// narrower plane with the remaining 4 or 2 values: [NR/8 planes x stride x 16 B][tail plane].  The reference's 16-bit order
+// is short4 (8 bytes per lane, lib/io_spinor.h:49-62); on gfx950 8-byte-per-lane loads run at 0.54-0.70 of the 16-byte
+// rate (MI355X_MICROARCH.md), and the 16-bit twisted-clover stencil measured 4.9 TB/s of real traffic against 6.3 for the
+// 16-byte formats with only 6 % traffic overhead (profiles/r02a_before_tmc_i16_32x4_*) — so the vector length, not the
+// bytes, was what held it back.  Block size (NR x stride x 2 B), stride, norm array and alignment are unchanged.
+typedef short short8_t __attribute__((ext_vector_type(8)));
 template <int NR> struct Planar<short, NR> {
+  static constexpr int NV = NR / 8, TAIL = NR % 8;   // TAIL: 0, 4 (one 8-byte plane) or 2 (one 4-byte plane)
+  static_assert(TAIL == 0 || TAIL == 4 || TAIL == 2, "16-bit planar blocks hold 8k, 8k+4 or 8k+2 values");
   template <int AUX = 0> static __device__ __forceinline__ void load(float *r, const void *base, int stride, int x, const float *norm, int nidx) {
     // AUX with sc1 (bit 4): the block may have been written by another GPU / process -> the scale is read at system scope too
     const float s = norm ? ((AUX & 16) ? __hip_atomic_load(&norm[nidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : norm[nidx]) * kShortInv : kShortInv;
     const __amdgpu_buffer_rsrc_t rs = planar_rsrc<short, NR>(base, stride);
-    const int off = x * 8;
+    const int off = x * 16;
 #pragma unroll
-    for (int k = 0; k < NR / 4; k++) {
-      const short4 t = __builtin_bit_cast(short4, __builtin_amdgcn_raw_buffer_load_b64(rs, off, k * stride * 8, AUX));
-      r[4 * k] = t.x * s; r[4 * k + 1] = t.y * s; r[4 * k + 2] = t.z * s; r[4 * k + 3] = t.w * s;
+    for (int k = 0; k < NV; k++) {
+      const short8_t t = __builtin_bit_cast(short8_t, __builtin_amdgcn_raw_buffer_load_b128(rs, off, k * stride * 16, AUX));
+#pragma unroll
+      for (int j = 0; j < 8; j++) r[8 * k + j] = t[j] * s;
     }
-    if (NR % 4) {
-      const short2 t = __builtin_bit_cast(short2, __builtin_amdgcn_raw_buffer_load_b32(rs, x * 4, (NR / 4) * stride * 8, AUX));
+    if (TAIL == 4) {
+      const short4 t = __builtin_bit_cast(short4, __builtin_amdgcn_raw_buffer_load_b64(rs, x * 8, NV * stride * 16, AUX));
+      r[NR - 4] = t.x * s; r[NR - 3] = t.y * s; r[NR - 2] = t.z * s; r[NR - 1] = t.w * s;
+    } else if (TAIL == 2) {
+      const short2 t = __builtin_bit_cast(short2, __builtin_amdgcn_raw_buffer_load_b32(rs, x * 4, NV * stride * 16, AUX));
       r[NR - 2] = t.x * s; r[NR - 1] = t.y * s;
     }
   }
@@ -121,15 +134,21 @@ template <int NR> struct Planar<short, NR> {
       s = m > 0.f ? kShortMax / m : 0.f;
     }
     const __amdgpu_buffer_rsrc_t rs = planar_rsrc<short, NR>(base, stride);
-    const int off = x * 8;
+    const int off = x * 16;
 #pragma unroll
-    for (int k = 0; k < NR / 4; k++)
+    for (int k = 0; k < NV; k++) {
+      short8_t t;
+#pragma unroll
+      for (int j = 0; j < 8; j++) t[j] = q16(r[8 * k + j] * s);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, t), rs, off, k * stride * 16, AUX);
+    }
+    if (TAIL == 4)
       __builtin_amdgcn_raw_buffer_store_b64(
-          __builtin_bit_cast(u32x2_t, make_short4(q16(r[4 * k] * s), q16(r[4 * k + 1] * s), q16(r[4 * k + 2] * s), q16(r[4 * k + 3] * s))), rs, off,
-          k * stride * 8, AUX);
-    if (NR % 4)
+          __builtin_bit_cast(u32x2_t, make_short4(q16(r[NR - 4] * s), q16(r[NR - 3] * s), q16(r[NR - 2] * s), q16(r[NR - 1] * s))), rs, x * 8,
+          NV * stride * 16, AUX);
+    else if (TAIL == 2)
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, make_short2(q16(r[NR - 2] * s), q16(r[NR - 1] * s))), rs, x * 4,
-                                            (NR / 4) * stride * 8, AUX);
+                                            NV * stride * 16, AUX);
   }
 };
 

@@ -71,7 +71,7 @@ template <typename real> struct DslashArg {
   // plane-tiled block order (tiled != 0): a block is chunk yc of the P chunks of one (z, t) plane; the 8 XCDs split the (z, t)
   // lattice nxz x (8 / nxz) ways and each walks its region tile by tile (tz x tt planes per tile, t fastest inside a tile)
   int tiled, P, nxz, Zs, Ts, tz, tt;
-  FastDiv dNxz, dPerTile, dNtz, dTzTt, dTt;
+  FastDiv dNxz, dPerTile, dNtz, dTzTt, dTt, dPTt;
   // grid-decomposed lattices (halo.h)
   int commMask;               // bit d set: dimension d is partitioned
   const int *blist;           // exterior kernel: checkerboard indices of the boundary sites
@@ -475,22 +475,24 @@ __device__ __forceinline__ void stencil_site(const DslashArg<real> &arg, const i
 #define QA_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define QA_PIN()                                                   \
   _Pragma("unroll") for (int k_ = 0; k_ < 24; k_++) asm volatile("" : "+v"(acc[k_]))
-  hop_load<T, R, 0, GAUX, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(pA, uA, arg, idx, n_xp, one, o_xp, f_x);
-  hop_load<T, R, 1, GAUX, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(pB, uB, arg, idx, n_xm, one, o_xm, f_x);
-  QA_FENCE(); hop_compute<T, 0, PT, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(acc, pA, uA, arg, o_xp, f_x); QA_PIN(); QA_FENCE();
-  hop_load<T, R, 2, GAUX, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(pA, uA, arg, idx, n_yp, one, o_yp, f_y);
-  QA_FENCE(); hop_compute<T, 1, PT, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(acc, pB, uB, arg, o_xm, f_x); QA_PIN(); QA_FENCE();
-  hop_load<T, R, 3, GAUX, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(pB, uB, arg, idx, n_ym, one, o_ym, f_y);
-  QA_FENCE(); hop_compute<T, 2, PT, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(acc, pA, uA, arg, o_yp, f_y); QA_PIN(); QA_FENCE();
-  hop_load<T, R, 4, GAUX, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(pA, uA, arg, idx, n_zp, one, o_zp, f_z);
-  QA_FENCE(); hop_compute<T, 3, PT, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(acc, pB, uB, arg, o_ym, f_y); QA_PIN(); QA_FENCE();
-  hop_load<T, R, 5, GAUX, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(pB, uB, arg, idx, n_zm, one, o_zm, f_z);
-  QA_FENCE(); hop_compute<T, 4, PT, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(acc, pA, uA, arg, o_zp, f_z); QA_PIN(); QA_FENCE();
-  hop_load<T, R, 6, GAUX, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(pA, uA, arg, idx, n_tp, sg_tp, o_tp, f_t);
-  QA_FENCE(); hop_compute<T, 5, PT, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(acc, pB, uB, arg, o_zm, f_z); QA_PIN(); QA_FENCE();
-  hop_load<T, R, 7, GAUX, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(pB, uB, arg, idx, n_tm, sg_tm, o_tm, f_t);
-  QA_FENCE(); hop_compute<T, 6, PT, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(acc, pA, uA, arg, o_tp, f_t); QA_PIN(); QA_FENCE();
-  hop_compute<T, 7, PT, (KT == 2 ? 1 : (KT == 3 ? 2 : 0))>(acc, pB, uB, arg, o_tm, f_t);
+  // Hop order x+ x- y+ y- z+ z- t+ t- (the reference's direction numbering).  Measured and dropped: t- z- y- x- x+ y+ z+ t+
+  // (aligned with an increasing sweep, so that the reads of one input site by different blocks fall closer together in time)
+  // changed nothing at 32^4 or 48^3 x 96 in any precision (gpurun_out/sweep48b.log of round 2).
+  constexpr int GH = KT == 2 ? 1 : (KT == 3 ? 2 : 0);
+  const int nb[8] = {n_xp, n_xm, n_yp, n_ym, n_zp, n_zm, n_tp, n_tm};
+  const real sg[8] = {one, one, one, one, one, one, sg_tp, sg_tm};
+  const bool of[8] = {o_xp, o_xm, o_yp, o_ym, o_zp, o_zm, o_tp, o_tm};
+  const int fc[8] = {f_x, f_x, f_y, f_y, f_z, f_z, f_t, f_t};
+#define QA_LD(B, D) hop_load<T, R, D, GAUX, GH>(p##B, u##B, arg, idx, nb[D], sg[D], of[D], fc[D])
+#define QA_CP(B, D) QA_FENCE(); hop_compute<T, D, PT, GH>(acc, p##B, u##B, arg, of[D], fc[D]); QA_PIN(); QA_FENCE()
+#define QA_PIPE(d0, d1, d2, d3, d4, d5, d6, d7)                                                      \
+  QA_LD(A, d0); QA_LD(B, d1); QA_CP(A, d0); QA_LD(A, d2); QA_CP(B, d1); QA_LD(B, d3); QA_CP(A, d2);  \
+  QA_LD(A, d4); QA_CP(B, d3); QA_LD(B, d5); QA_CP(A, d4); QA_LD(A, d6); QA_CP(B, d5); QA_LD(B, d7);  \
+  QA_CP(A, d6); QA_FENCE(); hop_compute<T, d7, PT, GH>(acc, pB, uB, arg, of[d7], fc[d7])
+  QA_PIPE(0, 1, 2, 3, 4, 5, 6, 7);
+#undef QA_PIPE
+#undef QA_LD
+#undef QA_CP
 #undef QA_FENCE
 #undef QA_PIN
 
@@ -536,8 +538,14 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
     const uint32_t xt = arg.dNxz.div((uint32_t)xcd), xz = (uint32_t)xcd - xt * (uint32_t)arg.nxz;
     const uint32_t tile = arg.dPerTile.div((uint32_t)within), r = (uint32_t)within - tile * arg.dPerTile.d;
     const uint32_t tile_t = arg.dNtz.div(tile), tile_z = tile - tile_t * arg.dNtz.d;
-    const uint32_t yc = arg.dTzTt.div(r), r2 = r - yc * arg.dTzTt.d;
-    const uint32_t zi = arg.dTt.div(r2), ti = r2 - zi * arg.dTt.d;
+    uint32_t yc, zi, ti;
+    if (arg.tiled == 2) {   // inside a tile: z slowest, then the chunk of the plane, t fastest (lexicographic for tt = 1)
+      zi = arg.dPTt.div(r); const uint32_t r2 = r - zi * arg.dPTt.d;
+      yc = arg.dTt.div(r2); ti = r2 - yc * arg.dTt.d;
+    } else {                // chunk slowest, then z, t fastest
+      yc = arg.dTzTt.div(r); const uint32_t r2 = r - yc * arg.dTzTt.d;
+      zi = arg.dTt.div(r2); ti = r2 - zi * arg.dTt.d;
+    }
     const int z = (int)xz * arg.Zs + (int)tile_z * arg.tz + (int)zi, t = (int)xt * arg.Ts + (int)tile_t * arg.tt + (int)ti;
     lb = (t * arg.Z + z) * arg.P + (int)yc;
   } else {
@@ -697,7 +705,7 @@ DslashTune &dslashTune() {
     t.block = env("QUDA_AMD_DSLASH_BLOCK", 0);
     t.remap = env("QUDA_AMD_XCD_REMAP", 1);
     t.order = env("QUDA_AMD_DSLASH_ORDER", 1);
-    t.store_aux = env("QUDA_AMD_STORE_AUX", 0);
+    t.store_aux = env("QUDA_AMD_STORE_AUX", -1);
     t.tiled = env("QUDA_AMD_DSLASH_TILED", -1);
     t.nxz = env("QUDA_AMD_DSLASH_NXZ", 0);
     t.tz = env("QUDA_AMD_DSLASH_TZ", 0);
@@ -883,6 +891,7 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
     for (int c : {256, 192, 128, 64}) if (plane % c == 0) { bs = c; break; }
   }
   const int nb = (g.Vh + bs - 1) / bs;
+  setLastKernel(VARIANT == 2 ? "dslash_kernel (clover)" : "dslash_kernel", g.X, (int)sizeof(T), R, bs);
   arg.nblocks = nb; arg.xcd_q = nb / 8; arg.xcd_r = nb % 8;
   if (!tune.remap) arg.xcd_q = -1;
   {
@@ -896,15 +905,19 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
     if (arg.xcd_q < 0) arg.ts = 0;
   }
   // plane-tiled order (see DslashArg): needs whole blocks per plane and an even split of the (z, t) lattice over the 8 XCDs
+  // Default since round 2: the 8 XCDs split z (or z x t where z has too few planes), every XCD walks its slab one time slice
+  // after the other (tt = 1), all of them in the same time slices at the same time: 48^3 x 96 fp32 0.59 -> 0.61 of the
+  // roofline, 32^4 fp32 0.70 -> 0.73 (with nt stores 0.64 / 0.73); tiles in t, t-slabs per XCD and deeper z tiles are all slower.
   arg.tiled = 0;
-  if (tune.tiled > 0 && tune.remap && plane % bs == 0 && g.Vh % bs == 0) {
-    int nxz = tune.nxz > 0 ? tune.nxz : 1;
-    if (8 % nxz == 0 && g.X[2] % nxz == 0 && g.X[3] % (8 / nxz) == 0) {
+  if (tune.tiled != 0 && tune.remap && plane % bs == 0 && g.Vh % bs == 0) {
+    int nxz = 0;
+    for (int c : {8, 4, 2, 1}) if ((tune.nxz <= 0 || tune.nxz == c) && g.X[2] % c == 0 && g.X[3] % (8 / c) == 0) { nxz = c; break; }
+    if (nxz) {
       const int Zs = g.X[2] / nxz, Ts = g.X[3] / (8 / nxz);
-      int tz = tune.tz > 0 ? tune.tz : Zs, tt = tune.tt > 0 ? tune.tt : 2;
+      int tz = tune.tz > 0 ? tune.tz : Zs, tt = tune.tt > 0 ? tune.tt : 1;
       if (tz > Zs || Zs % tz) tz = Zs;
-      if (tt > Ts || Ts % tt) tt = Ts % 2 == 0 ? 2 : 1;
-      arg.tiled = 1; arg.P = plane / bs; arg.nxz = nxz; arg.Zs = Zs; arg.Ts = Ts; arg.tz = tz; arg.tt = tt;
+      if (tt > Ts || Ts % tt) tt = 1;
+      arg.tiled = tune.tiled == 1 ? 1 : 2; arg.dPTt = FastDiv((uint32_t)((plane / bs) * tt)); arg.P = plane / bs; arg.nxz = nxz; arg.Zs = Zs; arg.Ts = Ts; arg.tz = tz; arg.tt = tt;
       arg.dNxz = FastDiv((uint32_t)nxz); arg.dPerTile = FastDiv((uint32_t)(arg.P * tz * tt)); arg.dNtz = FastDiv((uint32_t)(Zs / tz));
       arg.dTzTt = FastDiv((uint32_t)(tz * tt)); arg.dTt = FastDiv((uint32_t)tt);
     }
@@ -922,8 +935,11 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
   hipStream_t cs = computeStream();
   if (mask == 0) {
     const size_t lds = tune.lds_pad > 0 ? (size_t)tune.lds_pad : 0;   // measurement aid: dynamic LDS only to cap the blocks per CU
-    if (tune.store_aux == 2) hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 0, 2>), dim3(nb), dim3(bs), lds, cs, arg);
-    else hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 0>), dim3(nb), dim3(bs), lds, cs, arg);
+    // output stores: nt for fields beyond the caches (measured +1...+5 % at 32^4 and 48^3 x 96 in every precision and action;
+    // on the 65k-site sub-lattice of an 8-GPU split it costs fp32 5 %), QUDA_AMD_STORE_AUX / "store_aux" = 0 | 2 overrides
+    const bool ntStore = tune.store_aux >= 0 ? tune.store_aux == 2 : (size_t)g.Vh * 24 * sizeof(T) >= ((size_t)32 << 20);
+    if (ntStore) hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 0, 2>), dim3(nb), dim3(bs), lds, cs, arg);
+    else hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 0, 0>), dim3(nb), dim3(bs), lds, cs, arg);
     HIP_CHECK(hipGetLastError());
     return;
   }

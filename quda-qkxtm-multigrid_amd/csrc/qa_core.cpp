@@ -21,6 +21,23 @@ void setVerbosityInternal(QudaVerbosity v, const char *prefix, FILE *f) {
   if (f) g_out = f;
 }
 
+const char *outputPrefixInternal() { return g_prefix; }
+FILE *outputFileInternal() { return g_out ? g_out : stdout; }
+
+// identification of the last stencil launch for error messages (the reference quotes its last tune-cache key there);
+// recorded as raw values per launch, formatted only when an error message asks for it
+static const char *g_lastKernel = "none";
+static int g_lastX[4] = {0, 0, 0, 0}, g_lastPrec = 0, g_lastRecon = 0, g_lastBlock = 0;
+void setLastKernel(const char *kernel, const int X[4], int prec, int recon, int block) {
+  g_lastKernel = kernel; g_lastPrec = prec; g_lastRecon = recon; g_lastBlock = block;
+  for (int d = 0; d < 4; d++) g_lastX[d] = X[d];
+}
+void lastKernelKey(char *volume, int vn, char *name, int nn, char *aux, int an) {
+  snprintf(volume, vn, "%dx%dx%dx%d", g_lastX[0], g_lastX[1], g_lastX[2], g_lastX[3]);
+  snprintf(name, nn, "%s", g_lastKernel);
+  snprintf(aux, an, "prec=%d,recon=%d,block=%d", g_lastPrec, g_lastRecon, g_lastBlock);
+}
+
 void qa_printf(const char *fmt, ...) {
   if (commGrid().rank != 0) return;
   FILE *f = g_out ? g_out : stdout;

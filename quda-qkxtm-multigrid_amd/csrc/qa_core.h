@@ -95,6 +95,8 @@ void *poolDeviceMalloc(size_t bytes);
 void poolDeviceFree(void *ptr, size_t bytes);
 void poolDeviceFlush();
 
+void setLastKernel(const char *kernel, const int X[4], int prec, int recon, int block);
+
 hipStream_t computeStream();
 hipStream_t commStream();
 
