@@ -6,6 +6,7 @@
 #ifndef _FACE_QUDA_H
 #define _FACE_QUDA_H
 
+#include <sys/time.h>   /* callers of the reference header get it through quda_internal.h */
 #include <quda.h>
 #include <comm_quda.h>
 

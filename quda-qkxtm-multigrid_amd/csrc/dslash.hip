@@ -935,9 +935,9 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
   hipStream_t cs = computeStream();
   if (mask == 0) {
     const size_t lds = tune.lds_pad > 0 ? (size_t)tune.lds_pad : 0;   // measurement aid: dynamic LDS only to cap the blocks per CU
-    // output stores: nt for fields beyond the caches (measured +1...+5 % at 32^4 and 48^3 x 96 in every precision and action;
-    // on the 65k-site sub-lattice of an 8-GPU split it costs fp32 5 %), QUDA_AMD_STORE_AUX / "store_aux" = 0 | 2 overrides
-    const bool ntStore = tune.store_aux >= 0 ? tune.store_aux == 2 : (size_t)g.Vh * 24 * sizeof(T) >= ((size_t)32 << 20);
+    // output stores: nt from 2^18 checkerboard sites up (measured +1...+5 % at 32^4 and 48^3 x 96 in every precision and action,
+    // +10 % for 16-bit twisted clover; on the 65k-site sub-lattice of an 8-GPU split it costs fp32 5 %), QUDA_AMD_STORE_AUX / "store_aux" = 0 | 2 overrides
+    const bool ntStore = tune.store_aux >= 0 ? tune.store_aux == 2 : g.Vh >= (1 << 18);
     if (ntStore) hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 0, 2>), dim3(nb), dim3(bs), lds, cs, arg);
     else hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 0, 0>), dim3(nb), dim3(bs), lds, cs, arg);
     HIP_CHECK(hipGetLastError());
