@@ -83,6 +83,27 @@ def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2,
     # PCIe transfers and the operator / field set-up); solver_secs: the GCR loop alone (QudaInvertParam.secs)
     out = dict(lattice="x".join(map(str, X)), kappa=kappa, mu=mu, levels=3, n_vec=24, blocks=[list(bk) for bk in blocks[:2]], setup_secs=round(mp.secs, 3), solve_secs=round(wall, 4),
                solver_secs=round(inner, 4), iters=iters, true_res=res, plain_gcr=plain, timing="best of 3 after 1 warm-up solve")
+    # the multi-right-hand-side coarse operator on the matrix cores (level 1: 2 Nvec = 48 rows, 9 dense matrices per site) against
+    # the single-vector kernel: seconds per application, HBM rate on the ALGORITHMIC bytes (links once + in/out panels) and MFMA rate
+    try:
+        info = mg.level_info(0)
+        Vc, nn = int(np.prod(info["Xc"])), 2 * info["Nvec"]
+        single = mg.time_apply(1, 20)
+        cb = dict(coarse_lattice="x".join(map(str, info["Xc"])), n=nn, single_vector_us=round(1e6 * single, 1),
+                  single_vector_hbm_gbs=round(Vc * (9 * nn * nn * 8 + 10 * nn * 8) / single * 1e-9, 1))
+        rng = np.random.default_rng(2)
+        for nrhs in (8, 16, 24):
+            eta = (rng.standard_normal((nrhs, Vc, 2, info["Nvec"])) + 1j * rng.standard_normal((nrhs, Vc, 2, info["Nvec"]))).astype(np.complex64)
+            _, secs = mg.apply_block(1, eta, niter=20)
+            nbytes = Vc * (9 * nn * nn * 8 + 2 * nn * nrhs * 8)
+            flops = Vc * 9 * 8 * nn * nn * nrhs
+            cb["nrhs_%d" % nrhs] = dict(us=round(1e6 * secs, 1), us_per_rhs=round(1e6 * secs / nrhs, 2), hbm_gbs=round(nbytes / secs * 1e-9, 1),
+                                        hbm_frac=round(nbytes / secs * 1e-9 / HBM_PEAK_GBS, 4), mfma_tflops=round(flops / secs * 1e-12, 2),
+                                        mfma_frac_of_157=round(flops / secs * 1e-12 / 157.3, 4), speedup_vs_single=round(single * nrhs / secs, 2))
+        cb["bound"] = "hbm (links read once per site: AI = nrhs flop/B; fp32 MFMA peak 157 TFLOP/s is reached only near nrhs = 24)"
+        out["coarse_block_mfma"] = cb
+    except Exception as e:  # e.g. a hierarchy whose level 1 does not qualify (n not a multiple of 16)
+        out["coarse_block_mfma"] = dict(skipped=str(e)[:200])
     if not extras:
         mg.free()
         return out

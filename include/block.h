@@ -1,0 +1,70 @@
+// block.h — multi-right-hand-side ("block") fields, BLAS and solver for the multigrid setup.
+//
+// The reference carries several right-hand sides through its coarse operator as a fifth field dimension
+// (lib/dslash_coarse.cu:278, :294-333, src_idx :306-308; benchmarked by tests/multigrid_benchmark_test.cu:253-256) and
+// keeps them in composite ColorSpinorFields (include/color_spinor_field.h:84-90 is_composite / composite_dim).  Here the
+// consumer is the null-vector generation of the coarse levels (reference MG::generateNullVectors, lib/multigrid.cpp:693-779:
+// Nvec independent BiCGstab solves of M x = 0): the Nvec solves run in lockstep on ONE block field, so every application of
+// the coarse operator reads its dense link matrices once for all of them and runs on the matrix cores (block.hip).
+//
+// Layout of a block field: SITE-major, right-hand side fastest —
+//     v[((parity * Vh + x_cb) * ncomp + j) * nrhs + i]   (float2, j = spin * Ncolor + colour, i = right-hand side)
+// so the ncomp x nrhs panel of a site is one contiguous chunk (9 KB for 48 x 24): the operator stages a neighbour's panel with
+// full-line 16-byte loads, and a BLAS thread always meets the same pair of right-hand sides.
+#pragma once
+
+#include <vector>
+
+#include "blas.h"
+#include "coarse.h"
+
+namespace quda {
+
+constexpr int kMaxBlockRhs = 32;
+
+struct BlockField {
+  float2 *v = nullptr;
+  int nSites = 0, Vh = 0, ncomp = 0, nrhs = 0;
+  size_t bytes = 0;
+  BlockField() {}
+  BlockField(int nSites, int ncomp, int nrhs);
+  BlockField(const BlockField &) = delete;
+  BlockField &operator=(const BlockField &) = delete;
+  ~BlockField();
+  size_t elems() const { return (size_t)nSites * ncomp * nrhs; }
+};
+
+// gather / scatter between nrhs ordinary (plane-major, full, fp32) fields and one block field
+void blockPack(BlockField &dst, const std::vector<ColorSpinorField *> &src);
+void blockUnpack(const std::vector<ColorSpinorField *> &dst, const BlockField &src);
+
+// out = M in for every right-hand side: X in + sum_d H_d in(x + dhat(d)) with the links read ONCE per site for all of them,
+// on v_mfma_f32_16x16x4_f32 (exact fp32).  Needs n = 2 Nc a multiple of 16, nrhs a multiple of 8 (<= 32), an unpartitioned
+// lattice and fp32 links; blockCoarseSupported() says whether a given operator / batch qualifies.
+bool blockCoarseSupported(const CoarseGauge &G, int nrhs);
+void applyCoarseBlock(BlockField &out, const BlockField &in, const CoarseGauge &G);
+
+// per-right-hand-side BLAS on block fields (coefficients indexed by right-hand side)
+namespace blockblas {
+void zero(BlockField &x);
+void copy(BlockField &dst, const BlockField &src);
+void norm2(double *out, const BlockField &x);                                         // out[i] = |x_i|^2
+void cDot(Complex *out, const BlockField &x, const BlockField &y);                    // out[i] = (x_i, y_i)
+void caxpy(const Complex *a, const BlockField &x, BlockField &y);                     // y_i += a_i x_i
+// (t_i, r_i) and |t_i|^2: the omega of BiCGstab
+void cDotNormA(Complex *dot, double *norm, const BlockField &t, const BlockField &r);
+// x_i += a_i p_i + w_i r_i ; r_i -= w_i t_i ; rho_i = (r0_i, r_i), r2_i = |r_i|^2   (one pass, as blas::caxpbypzYmbw + cDotProductNormB)
+void bicgstabUpdate(Complex *rho, double *r2, const Complex *a, const BlockField &p, const Complex *w, BlockField &r, BlockField &x, const BlockField &t,
+                    const BlockField &r0);
+// p_i = r_i + a_i v_i + b_i p_i   (as blas::cxpaypbz)
+void cxpaypbz(const BlockField &r, const Complex *a, const BlockField &v, const Complex *b, BlockField &p);
+void negate(BlockField &x);                                                           // x = -x
+}  // namespace blockblas
+
+// Nvec BiCGstab solves of M x_i = 0 in lockstep (null-vector mode of the reference's BiCGstab, lib/inv_bicgstab_quda.cpp:96-127:
+// b = 0, x_i the initial guesses, b2_i := |M x_i|^2, shadow residual r0 = r), each stopping at |r_i|^2 <= tol^2 b2_i or maxiter.
+// Returns the number of iterations of the slowest right-hand side; iters[i] per right-hand side if not null.
+typedef void (*BlockMatVec)(BlockField &out, const BlockField &in, void *ctx);
+int blockBiCGstabNull(BlockField &x, BlockMatVec mat, void *ctx, double tol, int maxiter, int *iters);
+
+}  // namespace quda

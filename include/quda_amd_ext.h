@@ -15,6 +15,7 @@
 #ifndef QUDA_AMD_EXT_H
 #define QUDA_AMD_EXT_H
 
+#include <stddef.h>
 #include "quda.h"
 
 #ifdef __cplusplus
@@ -81,6 +82,13 @@ void qudaAmdMultigridGetV(void *mg_instance, int level, float *h_out);
 void qudaAmdMultigridGetCoarseLinks(void *mg_instance, int level, float *h_Y, float *h_X);
 /* op 0: R (level -> level+1; lib/restrictor.cu), 1: P (level+1 -> level; lib/prolongator.cu), 2: M of `level` */
 void qudaAmdMultigridApply(void *mg_instance, int level, int op, float *h_out, const float *h_in);
+/* The operator of a COARSE level applied to nrhs (8, 16, 24 or 32) host vectors at once through the multi-right-hand-side kernel
+ * on the matrix cores (v_mfma_f32_16x16x4_f32; the reference's multi-source coarse Dslash, lib/dslash_coarse.cu:294-333): the
+ * vectors lie back to back in h_in / h_out, each in the layout of qudaAmdMultigridApply.  niter > 0 additionally times niter
+ * back-to-back applications with device events and returns the seconds per application (0 otherwise).
+ * qudaAmdMultigridTimeApply times the single-vector operator of a level the same way. */
+double qudaAmdMultigridApplyBlock(void *mg_instance, int level, int nrhs, float *h_out, const float *h_in, int niter);
+double qudaAmdMultigridTimeApply(void *mg_instance, int level, int niter);
 
 /* ---- the solve loop of the QKXTM correlator drivers ----
  * calcMG_threepTwop_EvenOdd / calcMG_loop_wOneD_TSM_* (lib/interface_quda.cpp:6018-6531, :7093, :8535) open with the same
@@ -110,6 +118,13 @@ void qudaAmdGaussianSmear(void *h_out, const void *h_in, void **gauge_APE, int n
  * QUDA_DIRAC_ORDER, symmetric even-even / odd-odd preconditioning, QUDA_MAT_SOLUTION; iter / secs / gflops are summed over
  * the 24 solves; twist_flavor and preconditioner are left at their last values (minus / DN), as in the reference. */
 void qudaAmdCalcMGPropagators(void *h_prop_up, void *h_prop_dn, void **gauge_APE, QudaInvertParam *inv_param, const QudaAmdSourceParam *source);
+
+/* Sink for the solutions of the QKXTM entry points of qudaQKXTM_Kepler.h (calcMG_threepTwop_EvenOdd, calcMG_loop_wOneD_TSM_*):
+ * called once per finished solve with host vectors in the QKXTM layout (lexicographic sites of the LOCAL lattice, UKQCD spin,
+ * V * 24 doubles; h_source may be NULL) that are valid only during the call.  This is where a driver runs the contractions the
+ * reference does inside those functions.  No sink registered: the solutions are dropped after their norm has been printed. */
+typedef void (*QudaAmdSolutionSink)(void *ctx, const char *kind, int index, int twist_flavor, const double *h_source, const double *h_solution, size_t nreal);
+void qudaAmdSetSolutionSink(QudaAmdSolutionSink sink, void *ctx);
 
 /* ILDG gauge configurations in LIME containers (the step in front of loadGaugeQuda in the QKXTM drivers).  qudaAmdReadLimeGauge
  * has the semantics of readLimeGauge / readLimeGaugeSmeared (qkxtm/QKXTM_read_conf.h:107-400, :819-835): every rank reads the

@@ -117,7 +117,8 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
                  "qudaAmdSetPartitionMask", "qudaAmdComputeStream", "qudaAmdDeviceSynchronize", "qudaAmdHaloTransport", "qudaAmdSetDslashTune", "qudaAmdCommGetUniqueId",
                  "qudaAmdCommInit", "qudaAmdCommRank", "qudaAmdCommSize", "qudaAmdCommCoords", "qudaAmdCommBarrier", "qudaAmdCommAllreduce", "qudaAmdCommAllreduceMax",
                  "qudaAmdMultigridVerify", "qudaAmdMultigridCycle", "qudaAmdTimeAxpy", "qudaAmdMultigridLevels", "qudaAmdMultigridLevelInfo",
-                 "qudaAmdMultigridSetHalfStorage", "qudaAmdMultigridGetNullVector", "qudaAmdMultigridGetV", "qudaAmdMultigridGetCoarseLinks", "qudaAmdMultigridApply"]
+                 "qudaAmdMultigridSetHalfStorage", "qudaAmdMultigridGetNullVector", "qudaAmdMultigridGetV", "qudaAmdMultigridGetCoarseLinks", "qudaAmdMultigridApply", "qudaAmdMultigridApplyBlock",
+                 "qudaAmdMultigridTimeApply"]
 
 _lib = None
 
@@ -192,6 +193,10 @@ def lib():
         L.qudaAmdMultigridGetV.argtypes = [_p, _i, _p]
         L.qudaAmdMultigridGetCoarseLinks.argtypes = [_p, _i, _p, _p]
         L.qudaAmdMultigridApply.argtypes = [_p, _i, _i, _p, _p]
+        L.qudaAmdMultigridApplyBlock.argtypes = [_p, _i, _i, _p, _p, _i]
+        L.qudaAmdMultigridApplyBlock.restype = _d
+        L.qudaAmdMultigridTimeApply.argtypes = [_p, _i, _i]
+        L.qudaAmdMultigridTimeApply.restype = _d
         L.qudaAmdReadLimeGauge.argtypes = [C.POINTER(_p), C.c_char_p, C.POINTER(QudaGaugeParam), C.POINTER(QudaInvertParam), C.POINTER(_i)]
         L.qudaAmdWriteLimeGauge.argtypes = [C.POINTER(_p), C.c_char_p, C.POINTER(QudaGaugeParam), C.c_char_p]
         L.plaqQuda.argtypes = [C.POINTER(_d)]
@@ -532,6 +537,17 @@ class Multigrid:
         X = np.zeros((Vc, n, n), dtype=np.complex64)
         lib().qudaAmdMultigridGetCoarseLinks(self.h, level, _vp(Y), _vp(X))
         return Y, X
+
+    def apply_block(self, level, h_in, niter=0):
+        """M of coarse `level` on a batch (nrhs, sites, 2, Nc) complex64 through the multi-right-hand-side MFMA kernel;
+        returns (out, seconds per application if niter > 0)"""
+        h_in = np.ascontiguousarray(h_in, dtype=np.complex64)
+        out = np.zeros_like(h_in)
+        secs = lib().qudaAmdMultigridApplyBlock(self.h, int(level), int(h_in.shape[0]), _vp(out), _vp(h_in), int(niter))
+        return out, secs
+
+    def time_apply(self, level, niter=20):
+        return lib().qudaAmdMultigridTimeApply(self.h, int(level), int(niter))
 
     def apply(self, level, op, h_in):
         """op 'R' (level -> level+1), 'P' (level+1 -> level), 'M' (operator of `level`); fields as (sites, spin, colour) complex64"""

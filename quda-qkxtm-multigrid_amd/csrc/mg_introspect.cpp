@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "interface_internal.h"
+#include "block.h"
 #include "multigrid.h"
 #include "quda_amd_ext.h"
 
@@ -153,6 +154,68 @@ void qudaAmdMultigridApply(void *mg_instance, int level, int op, float *h_out, c
   else m->residualMatrix()(*fout, *fin);
   hout = *fout;
   delete fin; delete fout;
+}
+
+// M of a COARSE level applied to nrhs host vectors at once through the multi-right-hand-side MFMA kernel (block.h): h_in / h_out
+// hold nrhs vectors back to back, each in the host layout of qudaAmdMultigridApply.  niter > 0: the application is repeated
+// niter times between device events on the compute stream and the seconds per application are returned (else 0).
+double qudaAmdMultigridApplyBlock(void *mg_instance, int level, int nrhs, float *h_out, const float *h_in, int niter) {
+  MG *m = levelOf(mg_instance, level);
+  const DiracCoarse *dc = dynamic_cast<const DiracCoarse *>(m->residualMatrix().Expose());
+  if (!dc || dc->getDiracType() != QUDA_COARSE_DIRAC) errorQuda("level %d does not carry a (full) coarse operator", level);
+  if (!blockCoarseSupported(dc->Links(), nrhs)) errorQuda("block coarse operator not available for n = %d, nrhs = %d on this lattice", dc->Links().n, nrhs);
+  const ColorSpinorField &proto = *m->nullVectors()[0];
+  std::vector<ColorSpinorField *> f(nrhs);
+  const size_t len = (size_t)proto.Volume() * proto.Nspin() * proto.Ncolor() * 2;
+  for (int i = 0; i < nrhs; i++) {
+    ColorSpinorParam p = proto.param(); p.create = QUDA_ZERO_FIELD_CREATE;
+    f[i] = new ColorSpinorField(p);
+    ColorSpinorField hin = hostView(*f[i], const_cast<float *>(h_in) + i * len);
+    *f[i] = hin;
+  }
+  BlockField in(dc->Links().nSites, dc->Links().n, nrhs), out(dc->Links().nSites, dc->Links().n, nrhs);
+  blockPack(in, f);
+  applyCoarseBlock(out, in, dc->Links());
+  double secs = 0;
+  if (niter > 0) {
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+    HIP_CHECK(hipEventRecord(e0, computeStream()));
+    for (int k = 0; k < niter; k++) applyCoarseBlock(out, in, dc->Links());
+    HIP_CHECK(hipEventRecord(e1, computeStream()));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    HIP_CHECK(hipEventDestroy(e0)); HIP_CHECK(hipEventDestroy(e1));
+    secs = 1e-3 * ms / niter;
+  }
+  blockUnpack(f, out);
+  for (int i = 0; i < nrhs; i++) {
+    ColorSpinorField hout = hostView(*f[i], h_out + i * len);
+    hout = *f[i];
+    delete f[i];
+  }
+  return secs;
+}
+// the single-right-hand-side coarse operator of the same level, timed the same way (seconds per application)
+double qudaAmdMultigridTimeApply(void *mg_instance, int level, int niter) {
+  MG *m = levelOf(mg_instance, level);
+  const ColorSpinorField &proto = *m->nullVectors()[0];
+  ColorSpinorParam p = proto.param(); p.create = QUDA_ZERO_FIELD_CREATE;
+  ColorSpinorField a(p), b(p);
+  blas::copy(a, proto);
+  a.twistFlavor = b.twistFlavor = proto.twistFlavor;
+  m->residualMatrix()(b, a);
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+  HIP_CHECK(hipEventRecord(e0, computeStream()));
+  for (int k = 0; k < niter; k++) m->residualMatrix()(b, a);
+  HIP_CHECK(hipEventRecord(e1, computeStream()));
+  HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  HIP_CHECK(hipEventDestroy(e0)); HIP_CHECK(hipEventDestroy(e1));
+  return 1e-3 * ms / niter;
 }
 
 }

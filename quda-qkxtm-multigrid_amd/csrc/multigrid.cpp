@@ -1,5 +1,6 @@
 // multigrid.cpp — MG setup and cycle (see multigrid.h).
 #include "multigrid.h"
+#include "block.h"
 
 #include <cmath>
 #include <sys/time.h>
@@ -221,6 +222,39 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
   sp.is_preconditioner = true;
   sp.global_reduction = true;
   sp.precision = sp.precision_sloppy = sp.precision_precondition = QUDA_SINGLE_PRECISION;
+  // Coarse levels: the Nvec solves run in lockstep on one block field, so every operator application reads the dense coarse
+  // links once for all of them and runs on the matrix cores (block.h; reference: the multi-source 5th dimension of its coarse
+  // kernel, lib/dslash_coarse.cu:294-333).  Same recurrences per vector as the loop below; the orthonormalisation that the loop
+  // interleaves with the solves only touches finished vectors, so it is done afterwards.
+  const DiracCoarse *dc = dynamic_cast<const DiracCoarse *>(mgp.matResidual.Expose());
+  if (dc && dc->getDiracType() == QUDA_COARSE_DIRAC && blockCoarseSupported(dc->Links(), mgp.Nvec) && !coarseHalfStorage()) {
+    const double t0 = now();
+    for (int i = 0; i < mgp.Nvec; i++) { B[i]->twistFlavor = mgp.fineFlavor; spinorRandom(*B[i], 0x5eedULL + 7919ULL * (mgp.level * 131 + i)); }
+    BlockField X(dc->Links().nSites, dc->Links().n, mgp.Nvec);
+    std::vector<ColorSpinorField *> Bv(B.begin(), B.begin() + mgp.Nvec);
+    blockPack(X, Bv);
+    struct Ctx { const CoarseGauge *G; long applies; } ctx = {&dc->Links(), 0};
+    int iters[kMaxBlockRhs];
+    const int kmax = blockBiCGstabNull(X, [](BlockField &out, const BlockField &in, void *c) { Ctx *x = (Ctx *)c; applyCoarseBlock(out, in, *x->G); x->applies++; }, &ctx, sp.tol, sp.maxiter, iters);
+    blockUnpack(Bv, X);
+    for (int i = 0; i < mgp.Nvec; i++) {
+      ColorSpinorField &x = *B[i];
+      for (int j = 0; j < i; j++) {
+        const Complex alpha = blas::cDotProduct(*B[j], x);
+        blas::caxpy(-alpha, *B[j], x);
+      }
+      const double nrm2 = blas::norm2(x);
+      if (nrm2 > 1e-16) blas::ax(1.0 / sqrt(nrm2), x);
+      else errorQuda("Cannot orthogonalize %d vector", i);
+    }
+    if (getVerbosity() >= QUDA_SUMMARIZE || mgProfiling()) {
+      int imin = iters[0], imax = iters[0];
+      for (int i = 1; i < mgp.Nvec; i++) { imin = iters[i] < imin ? iters[i] : imin; imax = iters[i] > imax ? iters[i] : imax; }
+      printfQuda("MG level %d: %d null vectors by block BiCGstab on the MFMA coarse operator: %d lockstep iterations (per vector %d..%d), %ld block applications, %.3f s\n",
+                 mgp.level + 1, mgp.Nvec, kmax, imin, imax, ctx.applies, now() - t0);
+    }
+    return;
+  }
   ColorSpinorField *b = likeField(*B[0]);
   b->twistFlavor = mgp.fineFlavor;
   const QudaVerbosity v0 = getVerbosity();

@@ -192,12 +192,16 @@ void qudaAmdGaussianSmear(void *h_out, const void *h_in, void **gauge_APE, int n
   if (gauge_APE) delete U;
 }
 
-void qudaAmdCalcMGPropagators(void *h_prop_up, void *h_prop_dn, void **gauge_APE, QudaInvertParam *param, const QudaAmdSourceParam *src) {
-  const char *fname = "qudaAmdCalcMGPropagators";
+}  // extern "C"
+
+namespace quda {
+// the solve loop itself; every finished propagator (isc = spin * 3 + colour of the source, flavour +1 up / -1 down) is handed to
+// `each` as a lexicographic UKQCD host vector of V * 24 doubles that is only valid during the call
+void calcMGPropagatorsEach(void **gauge_APE, QudaInvertParam *param, const QudaAmdSourceParam *src, const char *fname,
+                           void (*each)(void *ctx, int isc, int flavor, const double *h_prop, size_t nreal), void *ctx) {
   if (!gaugePrecise) errorQuda("%s: Gauge field not allocated", fname);
   if (!cloverPrecise && param->dslash_type == QUDA_TWISTED_CLOVER_DSLASH) errorQuda("%s: Clover field not allocated", fname);
   if (!src) errorQuda("%s: source description is NULL", fname);
-  if (!h_prop_up || !h_prop_dn) errorQuda("%s: propagator buffers are NULL", fname);
   checkCalcParam(param, fname);
   const bool flag_eo = param->matpc_type == QUDA_MATPC_EVEN_EVEN;
   const LatticeGeom &g = residentGeom();
@@ -241,6 +245,7 @@ void qudaAmdCalcMGPropagators(void *h_prop_up, void *h_prop_dn, void **gauge_APE
   if (Uape) gaussianSmear(phi, *Uape, src->alphaGauss, src->nsmearGauss);
 
   const size_t vec = (size_t)g.V * 24;
+  std::vector<double> h_one(vec);
   double secs = 0, gflops = 0;
   int iters = 0;
   const bool rescale = param->mass_normalization == QUDA_MASS_NORMALIZATION || param->mass_normalization == QUDA_ASYMMETRIC_MASS_NORMALIZATION;
@@ -271,7 +276,8 @@ void qudaAmdCalcMGPropagators(void *h_prop_up, void *h_prop_dn, void **gauge_APE
       dirac.reconstruct(*x, *b, param->solution_type);
       delete solve;
       result = *x;
-      deviceToLex((double *)(fl == 0 ? h_prop_up : h_prop_dn) + isc * vec, result, g, true, rescale ? 2.0 * param->kappa : 1.0);
+      deviceToLex(h_one.data(), result, g, true, rescale ? 2.0 * param->kappa : 1.0);
+      each(ctx, isc, fl == 0 ? +1 : -1, h_one.data(), vec);
     }
   }
   param->secs = secs; param->gflops = gflops; param->iter = iters;
@@ -279,5 +285,169 @@ void qudaAmdCalcMGPropagators(void *h_prop_up, void *h_prop_dn, void **gauge_APE
   delete d; delete dSloppy; delete dPre;
   if (gauge_APE) delete Uape;
 }
+}  // namespace quda
 
+extern "C" {
+
+void qudaAmdCalcMGPropagators(void *h_prop_up, void *h_prop_dn, void **gauge_APE, QudaInvertParam *param, const QudaAmdSourceParam *src) {
+  if (!h_prop_up || !h_prop_dn) errorQuda("qudaAmdCalcMGPropagators: propagator buffers are NULL");
+  struct Out { double *up, *dn; } out = {(double *)h_prop_up, (double *)h_prop_dn};
+  calcMGPropagatorsEach(gauge_APE, param, src, "qudaAmdCalcMGPropagators",
+                        [](void *c, int isc, int flavor, const double *h, size_t n) { Out *o = (Out *)c; memcpy((flavor > 0 ? o->up : o->dn) + (size_t)isc * n, h, n * sizeof(double)); }, &out);
+}
+
+}
+
+// ================================================================================================
+// the reference's entry-point names (include/qudaQKXTM_Kepler.h): solve loops only, solutions go to the registered sink
+// ================================================================================================
+#include "qudaQKXTM_Kepler.h"
+
+namespace quda {
+
+static QudaAmdSolutionSink g_sink = nullptr;
+static void *g_sinkCtx = nullptr;
+
+static void toSink(const char *kind, int index, int flavor, const double *h_source, const double *h_solution, size_t nreal) {
+  if (g_sink) { g_sink(g_sinkCtx, kind, index, flavor, h_source, h_solution, nreal); return; }
+  double n2 = 0;
+  for (size_t i = 0; i < nreal; i++) n2 += h_solution[i] * h_solution[i];
+  comm_allreduce(&n2, 1);
+  printfQuda("%s %d (flavour %+d): |solution|^2 = %.12e (no sink registered: dropped)\n", kind, index, flavor, n2);
+}
+
+// Z4 noise on every spin-colour component of every local site (reference getStochasticRandomSource<Float>,
+// lib/qudaQKXTM_Kepler_utils.cpp:149-180: 1, -1, i, -i with equal probability; UNITY: all ones).  The reference draws from GSL's
+// ranlux seeded with seed + rank * seed; GSL is not a dependency here: a counter-based generator keyed by (seed, rank, source
+// number, component) — the same stream for a given decomposition, independent of how many sources came before.
+static void stochasticSource(double *h, size_t ncomplex, unsigned long seed, int isrc, SOURCE_T type) {
+  const unsigned long long key = (unsigned long long)seed * 0x9E3779B97F4A7C15ull + (unsigned long long)commGrid().rank * 0xD1B54A32D192ED03ull + (unsigned long long)isrc * 0x94D049BB133111EBull;
+  for (size_t i = 0; i < ncomplex; i++) {
+    if (type == UNITY) { h[2 * i] = 1.0; h[2 * i + 1] = 0.0; continue; }
+    unsigned long long z = key + (unsigned long long)i * 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+    const int r = (int)(z >> 62);
+    h[2 * i] = r == 0 ? 1.0 : (r == 1 ? -1.0 : 0.0);
+    h[2 * i + 1] = r == 2 ? 1.0 : (r == 3 ? -1.0 : 0.0);
+  }
+}
+
+// the loop of calcMG_loop_wOneD_TSM_EvenOdd (reference lib/interface_quda.cpp:8535-9230) without its contractions
+static void loopSolves(QudaInvertParam *param, const qudaQKXTM_loopInfo &loopInfo, const qudaQKXTMinfo_Kepler &info, const char *fname) {
+  if (!gaugePrecise) errorQuda("%s: Gauge field not allocated", fname);
+  if (!cloverPrecise && param->dslash_type == QUDA_TWISTED_CLOVER_DSLASH) errorQuda("%s: Clover field not allocated", fname);
+  if (param->solve_type != QUDA_DIRECT_PC_SOLVE) errorQuda("%s: This function works only with Direct solve and even odd preconditioning", fname);
+  if (param->gamma_basis != QUDA_UKQCD_GAMMA_BASIS) errorQuda("%s: This function works only with ukqcd gamma basis", fname);
+  if (param->dirac_order != QUDA_DIRAC_ORDER) errorQuda("%s: This function works only with colors inside the spins", fname);
+  if (param->solution_type != QUDA_MAT_SOLUTION) errorQuda("%s: solution_type %d not supported (QUDA_MAT_SOLUTION)", fname, param->solution_type);
+  if (info.isEven && param->matpc_type != QUDA_MATPC_EVEN_EVEN) errorQuda("%s: Inconsistency between operator types!", fname);        // :8560
+  if (!info.isEven && param->matpc_type != QUDA_MATPC_ODD_ODD) errorQuda("%s: Inconsistency between operator types!", fname);
+
+  // truncated-solver-method stopping criterion (:8595-8625): iterations if given, else tolerance; both given -> iterations
+  const bool useTSM = loopInfo.useTSM;
+  long TSM_maxiter = 0;
+  double TSM_tol = 0.0;
+  if (loopInfo.TSM_tol == 0 && loopInfo.TSM_maxiter != 0) TSM_maxiter = loopInfo.TSM_maxiter;
+  else if (loopInfo.TSM_tol != 0 && loopInfo.TSM_maxiter == 0) TSM_tol = loopInfo.TSM_tol;
+  else if (useTSM && loopInfo.TSM_tol != 0 && loopInfo.TSM_maxiter != 0) {
+    warningQuda("Both max-iter = %ld and tolerance = %lf defined as criterions for the TSM. Proceeding with max-iter = %ld criterion.", loopInfo.TSM_maxiter, loopInfo.TSM_tol, loopInfo.TSM_maxiter);
+    TSM_maxiter = loopInfo.TSM_maxiter;
+  } else if (useTSM) errorQuda("%s: the truncated solver method needs TSM_tol or TSM_maxiter", fname);
+
+  const LatticeGeom &g = residentGeom();
+  const size_t vec = (size_t)g.V * 24;
+  param->secs = 0; param->gflops = 0; param->iter = 0;
+  const bool pc_solve = true;
+  DiracParam dp, dpSloppy, dpPre;
+  setDiracParam(dp, param, pc_solve);
+  setDiracSloppyParam(dpSloppy, param, pc_solve);
+  setDiracPreParam(dpPre, param, pc_solve);
+  Dirac *d = Dirac::create(dp), *dSloppy = Dirac::create(dpSloppy), *dPre = Dirac::create(dpPre);
+  Dirac &dirac = *d;
+  DiracM m(dirac), mSloppy(*dSloppy), mPre(*dPre);
+  ColorSpinorParam cp64 = deviceSpinorParam(QUDA_DOUBLE_PRECISION, QUDA_FULL_SITE_SUBSET, param->twist_flavor);
+  cp64.create = QUDA_ZERO_FIELD_CREATE;
+  ColorSpinorField stage(cp64);
+  ColorSpinorParam cp = deviceSpinorParam(param->cuda_prec, QUDA_FULL_SITE_SUBSET, param->twist_flavor);
+  cp.create = QUDA_ZERO_FIELD_CREATE;
+  ColorSpinorField b(cp), x(cp);
+  std::vector<double> h_src(vec), h_sol(vec);
+  const bool rescale = param->mass_normalization == QUDA_MASS_NORMALIZATION || param->mass_normalization == QUDA_ASYMMETRIC_MASS_NORMALIZATION;
+  double secs = 0, gflops = 0;
+  int iters = 0;
+
+  auto solve = [&](bool lowPrecision, const char *kind, int index) {
+    lexToDevice(stage, h_src.data(), g, true);
+    b = stage;
+    blas::zero(x);
+    ColorSpinorField *in = nullptr, *out = nullptr;
+    dirac.prepare(in, out, x, b, param->solution_type);
+    const double tol0 = param->tol;
+    const int maxiter0 = param->maxiter;
+    if (lowPrecision) { if (TSM_maxiter == 0) param->tol = TSM_tol; else param->maxiter = (int)TSM_maxiter; }   // :9025-9030
+    param->secs = 0; param->gflops = 0; param->iter = 0;
+    SolverParam sp(*param);
+    Solver *s = Solver::create(sp, m, mSloppy, mPre);
+    (*s)(*out, *in);
+    sp.updateInvertParam(*param);
+    delete s;
+    param->tol = tol0; param->maxiter = maxiter0;
+    secs += param->secs; gflops += param->gflops; iters += param->iter;
+    dirac.reconstruct(x, b, param->solution_type);
+    stage = x;
+    deviceToLex(h_sol.data(), stage, g, true, rescale ? 2.0 * param->kappa : 1.0);
+    toSink(kind, index, (int)param->twist_flavor, h_src.data(), h_sol.data(), vec);
+  };
+
+  // production sources: low-precision solves under the truncated solver method, full solves otherwise (:9000-9050)
+  const int Nrun = useTSM ? loopInfo.TSM_NLP : loopInfo.Nstoch;
+  for (int is = 0; is < Nrun; is++) {
+    stochasticSource(h_src.data(), (size_t)g.V * 12, loopInfo.seed, is, info.source_type);
+    solve(useTSM, useTSM ? "loop_LP" : "loop_stoch", is);
+  }
+  // bias correction of the truncated solver method: TSM_NHP fresh sources solved to both precisions (:9170-9230)
+  if (useTSM)
+    for (int is = 0; is < loopInfo.TSM_NHP; is++) {
+      stochasticSource(h_src.data(), (size_t)g.V * 12, loopInfo.seed, Nrun + is, info.source_type);
+      solve(false, "loop_HP", is);
+      solve(true, "loop_HP_LP", is);
+    }
+  param->secs = secs; param->gflops = gflops; param->iter = iters;
+  delete d; delete dSloppy; delete dPre;
+}
+
+}  // namespace quda
+
+extern "C" void qudaAmdSetSolutionSink(QudaAmdSolutionSink sink, void *ctx) { quda::g_sink = sink; quda::g_sinkCtx = ctx; }
+
+void calcMG_threepTwop_EvenOdd(void **gaugeSmeared, void **gauge, QudaGaugeParam *gauge_param, QudaInvertParam *param, quda::qudaQKXTMinfo_Kepler info,
+                               char *filename_twop, char *filename_threep, quda::WHICHPARTICLE NUCLEON) {
+  (void)gauge; (void)gauge_param; (void)filename_twop; (void)filename_threep; (void)NUCLEON;   // consumed by the contractions / writers only
+  if (info.Nsources < 0 || info.Nsources > MAX_NSOURCES) errorQuda("calcMG_threepTwop_EvenOdd: Nsources = %d", info.Nsources);
+  double secs = 0, gflops = 0;
+  int iters = 0;
+  for (int isource = 0; isource < info.Nsources; isource++) {
+    QudaAmdSourceParam src;
+    for (int k = 0; k < 4; k++) src.sourcePosition[k] = info.sourcePosition[isource][k];
+    src.nsmearGauss = info.nsmearGauss;
+    src.alphaGauss = info.alphaGauss;
+    int base = 12 * isource;
+    quda::calcMGPropagatorsEach(gaugeSmeared, param, &src, "calcMG_threepTwop_EvenOdd",
+                                [](void *c, int isc, int flavor, const double *h, size_t n) { quda::toSink(flavor > 0 ? "prop_up" : "prop_dn", *(int *)c + isc, flavor, nullptr, h, n); }, &base);
+    secs += param->secs; gflops += param->gflops; iters += param->iter;
+  }
+  param->secs = secs; param->gflops = gflops; param->iter = iters;
+}
+
+void calcMG_loop_wOneD_TSM_EvenOdd(void **gaugeToPlaquette, QudaInvertParam *param, QudaGaugeParam *gauge_param, quda::qudaQKXTM_loopInfo loopInfo,
+                                   quda::qudaQKXTMinfo_Kepler info) {
+  (void)gaugeToPlaquette; (void)gauge_param;   // plaquette check and covariant derivatives of the contraction stage
+  quda::loopSolves(param, loopInfo, info, "calcMG_loop_wOneD_TSM_EvenOdd");
+}
+
+void calcMG_loop_wOneD_TSM_wExact(void **gaugeToPlaquette, QudaInvertParam *EVparam, QudaInvertParam *param, QudaGaugeParam *gauge_param,
+                                  quda::qudaQKXTM_arpackInfo arpackInfo, quda::qudaQKXTM_loopInfo loopInfo, quda::qudaQKXTMinfo_Kepler info) {
+  (void)gaugeToPlaquette; (void)gauge_param; (void)EVparam;
+  if (arpackInfo.nEv != 0) errorQuda("calcMG_loop_wOneD_TSM_wExact: exact deflation with %d eigenvectors needs ARPACK, which this library does not link; nEv = 0 runs the undeflated loop", arpackInfo.nEv);
+  quda::loopSolves(param, loopInfo, info, "calcMG_loop_wOneD_TSM_wExact");
 }

@@ -35,10 +35,30 @@ def build_consumers(outdir):
     return cdrv, cxx
 
 
+def build_qkxtm_driver(outdir):
+    """tests/consumer/qkxtm_driver.cpp: includes <qudaQKXTM_Kepler.h> and calls the reference's calcMG_* entry points by name"""
+    exe = os.path.join(outdir, "qkxtm_driver")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I", INC, "-I", "/opt/rocm/include",
+                    os.path.join(ROOT, "tests", "consumer", "qkxtm_driver.cpp"), "-o", exe, "-L" + LIBDIR, "-lquda", "-L/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath," + LIBDIR, "-Wl,-rpath,/opt/rocm/lib"], check=True, capture_output=True, text=True)
+    return exe
+
+
 @needs_lib
 def test_committed_c_and_cxx_consumers_build(tmp_path):
     cdrv, cxx = build_consumers(str(tmp_path))
     assert os.path.exists(cdrv) and os.path.exists(cxx)
+    assert os.path.exists(build_qkxtm_driver(str(tmp_path)))
+
+
+@needs_lib
+def test_qkxtm_entry_points_are_exported_under_the_reference_names():
+    """calcMG_threepTwop_EvenOdd / calcMG_loop_wOneD_TSM_EvenOdd / calcMG_loop_wOneD_TSM_wExact with the reference's C++ signatures
+    (include/qudaQKXTM_Kepler.h:484-508): the mangled names a driver compiled against the reference header would ask for"""
+    sym = subprocess.run(["nm", "-DC", os.path.join(LIBDIR, "libquda.so")], capture_output=True, text=True).stdout
+    assert "calcMG_threepTwop_EvenOdd(void**, void**, QudaGaugeParam_s*, QudaInvertParam_s*, quda::qudaQKXTMinfo_Kepler, char*, char*, quda::WHICHPARTICLE)" in sym
+    assert "calcMG_loop_wOneD_TSM_EvenOdd(void**, QudaInvertParam_s*, QudaGaugeParam_s*, quda::qudaQKXTM_loopInfo, quda::qudaQKXTMinfo_Kepler)" in sym
+    assert "calcMG_loop_wOneD_TSM_wExact(void**, QudaInvertParam_s*, QudaInvertParam_s*, QudaGaugeParam_s*, quda::qudaQKXTM_arpackInfo, quda::qudaQKXTM_loopInfo, quda::qudaQKXTMinfo_Kepler)" in sym
 
 
 def test_public_headers_are_self_contained_c(tmp_path):

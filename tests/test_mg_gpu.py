@@ -59,7 +59,7 @@ def test_verify_identities_and_mg_gcr_solve(qa, oracle, X, levels, blocks, nvec,
     ip.inv_type_precondition = qa.QUDA_INVALID_ENUM
     x0 = qa.invert(b, ip)
     iters_plain = ip.iter
-    assert _true_residual(oracle, gauge, X, kappa, mu, x0, b) < 5e-10
+    assert _true_residual(oracle, gauge, X, kappa, mu, x0, b) < 1e-10
 
     mp = qa.multigrid_param(ip, n_level=levels, geo_block=blocks, n_vec=nvec, setup_maxiter=300, setup_tol=1e-5, smoother_pc=smoother_pc)
     mg = qa.Multigrid(mp)
@@ -76,7 +76,7 @@ def test_verify_identities_and_mg_gcr_solve(qa, oracle, X, levels, blocks, nvec,
         x = qa.invert(b, ip)
         iters_mg = ip.iter
         res = _true_residual(oracle, gauge, X, kappa, mu, x, b)
-        assert res < 5e-10, res
+        assert res < 1e-10, res
         assert abs(ip.true_res - res) < 1e-9
         assert iters_mg < iters_plain, (iters_mg, iters_plain)
         print("MG-GCR %s pc=%s: %d iterations (plain GCR %d), true residual %.2e, setup %.2f s, solve %.3f s" % (X, smoother_pc, iters_mg, iters_plain, res, mp.secs, ip.secs))
@@ -163,11 +163,70 @@ def test_hierarchy_against_oracle_restatement(qa, oracle, mask):
         ip.preconditioner = mg.h
         ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
         x = qa.invert(b, ip)
-        assert _true_residual(oracle, gauge, X, kappa, mu, x, b) < 5e-10
+        assert _true_residual(oracle, gauge, X, kappa, mu, x, b) < 1e-10
         assert ip.iter < 40, ip.iter
     finally:
         mg.free()
         qa.lib().qudaAmdSetPartitionMask(0)
+
+
+@pytest.mark.parametrize("nvec,nrhs_list", [(8, (8, 16, 24, 32)), (24, (24, 8))], ids=["n16", "n48"])
+def test_block_coarse_operator_on_mfma(qa, oracle, nvec, nrhs_list):
+    """The multi-right-hand-side coarse operator on the matrix cores (csrc/block.hip, v_mfma_f32_16x16x4_f32; reference: the
+    multi-source 5th dimension of coarseDslashKernel, lib/dslash_coarse.cu:294-333) against the oracle's restatement of the
+    reference's CPU coarse operator (lib/dslash_coarse.cu:50-290) applied to every right-hand side separately, with the device's
+    own links, and against the single-vector device kernel.  fp32 MFMA is exact fp32 arithmetic: same 2e-5 bar as the
+    single-vector kernel.  n = 2 Nvec = 16 and the production 48 x 24 shape."""
+    X, kappa, mu = (8, 8, 8, 16), 0.124, 0.005
+    gauge, ip = _setup(qa, X, kappa, mu)
+    mp = qa.multigrid_param(ip, n_level=2, geo_block=[(4, 4, 4, 4), (2, 2, 2, 2)], n_vec=nvec, setup_maxiter=50, setup_tol=1e-3)
+    mg = qa.Multigrid(mp)
+    rng = np.random.default_rng(23)
+
+    def rel(a, b):
+        return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+    try:
+        i = mg.level_info(0)
+        Xc, Nv = i["Xc"], i["Nvec"]
+        Vc = int(np.prod(Xc))
+        Yd, Xd = mg.coarse_links(0)
+        Yref = Yd.astype(np.complex128) / (-kappa)
+        for nrhs in nrhs_list:
+            eta = (rng.standard_normal((nrhs, Vc, 2, Nv)) + 1j * rng.standard_normal((nrhs, Vc, 2, Nv))).astype(np.complex64)
+            # right-hand sides of very different size: a slip in the column map would mix them visibly
+            eta *= (10.0 ** rng.integers(-2, 3, size=nrhs)).astype(np.float32)[:, None, None, None]
+            got, _ = mg.apply_block(1, eta)
+            for k in range(nrhs):
+                want = oracle.mg_coarse_apply(eta[k].astype(np.complex128), Yref, Xd.astype(np.complex128), kappa, Xc, Nv)
+                assert rel(got[k], want) < 2e-5, (nrhs, k, rel(got[k], want))
+                if k in (0, nrhs - 1):
+                    assert rel(got[k], mg.apply(1, "M", eta[k])) < 2e-5
+    finally:
+        mg.free()
+
+
+def test_block_bicgstab_null_vectors_give_the_same_hierarchy_quality(qa, oracle):
+    """The coarse-level null vectors now come from ONE lockstep block BiCGstab on the MFMA operator (multigrid.cpp,
+    MG::generateNullVectors) instead of Nvec sequential solves (QUDA_AMD_BLOCK_COARSE=0 keeps the latter): the reference's
+    MG::verify() identities (lib/multigrid.cpp:372-486) hold on every level and the 3-level MG-GCR still converges to 1e-10
+    in the same few iterations, the solution checked with the oracle's tm_mat."""
+    X, kappa, mu = (8, 8, 8, 16), 0.124, 0.005
+    gauge, ip = _setup(qa, X, kappa, mu)
+    mp = qa.multigrid_param(ip, n_level=3, geo_block=[(4, 4, 4, 4), (1, 1, 1, 2), (2, 2, 2, 2)], n_vec=8, setup_maxiter=100, setup_tol=1e-4)
+    mg = qa.Multigrid(mp)
+    try:
+        dev = mg.verify()
+        assert max(dev) < 1e-4, dev
+        b = np.random.default_rng(3).random(int(np.prod(X)) * 24)
+        ip.inv_type_precondition = qa.QUDA_MG_INVERTER
+        ip.preconditioner = mg.h
+        ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
+        x = qa.invert(b, ip)
+        assert _true_residual(oracle, gauge, X, kappa, mu, x, b) < 1e-10
+        assert ip.iter < 40, ip.iter
+    finally:
+        mg.free()
 
 
 def test_outer_even_odd_solve_with_up_and_down_hierarchies(qa, oracle):
@@ -205,7 +264,7 @@ def test_outer_even_odd_solve_with_up_and_down_hierarchies(qa, oracle):
             res = float(np.linalg.norm(b - oracle.tm_mat(gauge, x, list(X), kappa, mu, flavor, 0)) / np.linalg.norm(b))
             oracle.set_threads(1)
             print("outer even-odd MG-GCR flavour %+d: %d iterations (plain even-odd GCR %d), true residual %.2e" % (flavor, ip.iter, plain, res))
-            assert res < 5e-10, (flavor, res)
+            assert res < 1e-10, (flavor, res)
             assert ip.iter * 3 < plain, (flavor, ip.iter, plain)
         # the same hierarchies under a full-system outer solve (outer QUDA_MAT_SOLUTION / inner QUDA_MATPC_SOLUTION, lib/multigrid.cpp:513-560)
         ip.solve_type = qa.QUDA_DIRECT_SOLVE
@@ -215,7 +274,7 @@ def test_outer_even_odd_solve_with_up_and_down_hierarchies(qa, oracle):
         oracle.set_threads(8)
         res = float(np.linalg.norm(b - oracle.tm_mat(gauge, x, list(X), kappa, mu, +1, 0)) / np.linalg.norm(b))
         oracle.set_threads(1)
-        assert res < 5e-10 and ip.iter < 30, (res, ip.iter)
+        assert res < 1e-10 and ip.iter < 30, (res, ip.iter)
     finally:
         for h, _, _ in hier.values():
             h.free()
@@ -266,7 +325,7 @@ def test_half_precision_storage_of_the_hierarchy(qa, oracle):
         mg.set_half_storage(True)
         x16 = qa.invert(b, ip)
         it16 = ip.iter
-        assert _true_residual(oracle, gauge, X, kappa, mu, x16, b) < 5e-10
+        assert _true_residual(oracle, gauge, X, kappa, mu, x16, b) < 1e-10
         assert it16 <= it32 + 2, (it16, it32)
         mg.set_half_storage(False)
         x32b = qa.invert(b, ip)
@@ -310,6 +369,6 @@ def test_c5_full_size_on_one_gpu(qa, oracle):
             oracle.set_threads(1)
         print("48^3 x 96 on one GPU: setup %.2f s, MG-GCR %d iterations, %.3f s wall (%.3f s in the solver), host-verified |r|/|b| = %.2e"
               % (mp.secs, ip.iter, wall, ip.secs, res))
-        assert res < 5e-10 and ip.iter < 40, (res, ip.iter)
+        assert res < 1e-10 and ip.iter < 40, (res, ip.iter)
     finally:
         mg.free()

@@ -158,3 +158,75 @@ def test_parameter_checks(case):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "error_cases.py"), case], capture_output=True, text=True, timeout=300)
     assert r.returncode == 1, (case, r.returncode, r.stdout[-300:], r.stderr[-300:])
     assert "ERROR" in r.stdout + r.stderr and "works only with" in r.stdout + r.stderr
+
+
+def test_reference_entry_point_names_from_a_cxx_driver(oracle, tmp_path):
+    """tests/consumer/qkxtm_driver.cpp — a driver in the shape of qkxtm/CalcMG_2pt3pt_EvenOdd.cpp / CalcMG_Loops_w_oneD_TSM_EvenOdd.cpp —
+    calls calcMG_threepTwop_EvenOdd (2 source positions = 48 solves), calcMG_loop_wOneD_TSM_EvenOdd (truncated solver method: 3 LP
+    solves + 2 HP/LP pairs) and calcMG_loop_wOneD_TSM_wExact (nEv = 0, 2 sources, down flavour) by the reference's names; every
+    solution that reaches the sink is checked with the oracle's tm_mat (the reference's own check of a solve,
+    tests/multigrid_invert_test.cpp:529-577): full-precision solves to 5e-10, truncated ones between the two tolerances."""
+    import os
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_dropin_build import build_qkxtm_driver
+    X, kappa, mu = (8, 8, 8, 8), 0.124, 0.005
+    V = int(np.prod(X))
+    gauge = smooth_gauge(X, 0.35)
+    gfile, ofile = tmp_path / "gauge.bin", tmp_path / "out.bin"
+    np.ascontiguousarray(gauge).tofile(str(gfile))
+    exe = build_qkxtm_driver(str(tmp_path))
+    r = subprocess.run([exe, str(gfile)] + [str(v) for v in X] + [str(ofile)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "calcMG_threepTwop_EvenOdd" in r.stdout and "calcMG_loop_wOneD_TSM_wExact" in r.stdout
+    g_ape_eo = oracle.ape_smear(gauge, list(X), 0.5, 2)
+    g_ape = _lex_gauge(oracle, g_ape_eo, X)
+    raw = open(str(ofile), "rb").read()
+    off, recs = 0, []
+    while off < len(raw):
+        kind = raw[off:off + 16].split(b"\0")[0].decode(); off += 16
+        index, flavor, has_src, nreal = np.frombuffer(raw, dtype=np.int32, count=4, offset=off); off += 16
+        src = None
+        if has_src:
+            src = np.frombuffer(raw, dtype=np.float64, count=nreal, offset=off); off += 8 * nreal
+        sol = np.frombuffer(raw, dtype=np.float64, count=nreal, offset=off); off += 8 * nreal
+        recs.append((kind, int(index), int(flavor), src, sol))
+    kinds = [k for k, *_ in recs]
+    assert kinds.count("prop_up") == 24 and kinds.count("prop_dn") == 24
+    assert kinds.count("loop_LP") == 3 and kinds.count("loop_HP") == 2 and kinds.count("loop_HP_LP") == 2 and kinds.count("loop_stoch") == 2
+    pos = [(1, 2, 3, 5), (0, 3, 1, 2)]
+    oracle.set_threads(8)
+    try:
+        def residual(src_lex, sol_lex, flavor):
+            b = oracle.lex_to_eo(oracle.ukqcd_to_dr(src_lex.reshape(-1, 24)).reshape(-1), list(X), 24)
+            x = oracle.lex_to_eo(oracle.ukqcd_to_dr(sol_lex.reshape(-1, 24)).reshape(-1), list(X), 24)
+            return float(np.linalg.norm(b - oracle.tm_mat(gauge, x, list(X), kappa, mu, flavor, 0)) / np.linalg.norm(b))
+        seen_lp = []
+        for kind, index, flavor, src, sol in recs:
+            if kind.startswith("prop"):
+                isource, isc = divmod(index, 12)
+                p = [pos[isource][d] % X[d] for d in range(4)]
+                point = np.zeros(V * 24)
+                point[(((p[3] * X[2] + p[2]) * X[1] + p[1]) * X[0] + p[0]) * 24 + isc * 2] = 1.0
+                src = oracle.gauss_smear(point, g_ape, list(X), 0.8, 3)
+                assert flavor == (+1 if kind == "prop_up" else -1)
+                assert residual(src, sol, flavor) < 5e-10, (kind, index)
+            else:
+                # Z4 noise: every component is one of 1, -1, i, -i
+                c = src.reshape(-1, 2)
+                assert np.all(np.abs(c).sum(axis=1) == 1.0) and set(np.unique(c)) <= {-1.0, 0.0, 1.0}
+                res = residual(src, sol, flavor)
+                if kind in ("loop_LP", "loop_HP_LP"):
+                    assert 1e-8 < res < 5e-3, (kind, index, res)   # stopped at TSM_tol = 1e-3 (even-odd system), well short of 1e-10
+                    seen_lp.append(res)
+                else:
+                    assert res < 5e-10, (kind, index, res)
+                assert flavor == (-1 if kind == "loop_stoch" else +1)
+        assert len(seen_lp) == 5
+        # the HP / LP pair of the truncated solver method is solved from the SAME source
+        hp = {i: s for k, i, f, s, x in recs if k == "loop_HP"}
+        lp = {i: s for k, i, f, s, x in recs if k == "loop_HP_LP"}
+        assert all(np.array_equal(hp[i], lp[i]) for i in hp)
+    finally:
+        oracle.set_threads(1)
