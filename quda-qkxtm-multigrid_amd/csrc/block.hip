@@ -9,11 +9,13 @@
 // so M = n, K = 2 n per matrix (9 matrices = one K of 18 n), N = 2 nrhs, all multiples of 16 / 4 for n = 48, nrhs = 24.
 // One work-group (4 waves) per site.  A operand: a lane (row l & 15, kq = l >> 4) loads the float4 of row l & 15, column pair
 // 4 s + kq — one 16-byte load feeds FOUR k-steps (component t of the float4 is k-step t; which four K elements make a k-step is
-// free as long as B agrees), 1 KiB per wave instruction straight from HBM, prefetched 12 deep in registers.  B operand: the 9
-// neighbour panels are staged once per site in LDS with full-line loads (the site-major block layout makes a panel one
-// contiguous chunk) and read as 8-byte pairs (re, im), conflict-free with an 8-float row pad.  The 54 (matrix, 4-column-pair
-// group) items of a site are dealt round-robin to the 4 waves, each accumulating all 3 x 3 output tiles; partial tiles are
-// summed through LDS and the n x nrhs output panel is written with 16-byte unit-stride stores.
+// free as long as B agrees), 1 KiB per wave instruction straight from HBM, prefetched 12 deep in registers.  B operand: 8-byte
+// (re, im) pairs read straight from the neighbour panels, one group ahead of the matrix instructions (the whole input field is a
+// few MB and every panel is wanted by 9 sites: L2 traffic, not HBM).  A first version staged the 9 panels of a site in LDS
+// (97 KB: one work-group per CU, staging and matrix instructions in series) and reached 47 TFLOP/s at nrhs = 24; without the
+// staging three work-groups share a CU.  The 54 (matrix, 4-column-pair group) items of a site are dealt round-robin to the 4
+// waves, each accumulating all 3 x 3 output tiles; partial tiles are summed through LDS and the n x nrhs output panel is written
+// with 16-byte unit-stride stores.
 // Roofline (n = 48, fp32): 9 n^2 8 B = 166 KB of links per site against 72 n^2 nrhs flops: AI = nrhs flop/B — HBM-bound up to
 // nrhs ~ 24 (6 TB/s x 24 = 144 TFLOP/s against the 157 TFLOP/s fp32 MFMA peak), where both limits meet.
 #include "block.h"
@@ -88,6 +90,7 @@ struct BlockCoarseArg {
   const float *G;
   int Xc[4];
   int Vh;
+  unsigned inBytes;
 };
 
 template <int N, int NRHS> struct BlockCoarseTraits {
@@ -97,17 +100,29 @@ template <int N, int NRHS> struct BlockCoarseTraits {
   static constexpr int SG = JP / 4;          // 4-column-pair groups per matrix: one A load (per row tile) = 4 k-steps
   static constexpr int NG = 9 * SG;          // groups per site
   static constexpr int GI = (NG + 3) / 4;    // groups per wave (round-robin over the 4 waves)
-  static constexpr int CSTR = 2 * NRHS + 8;  // floats per component row of a staged panel (pad: kq rows land 16 banks apart)
-  static constexpr int DEPTH = 12;           // A loads in flight per wave (12 KiB; 48 KiB per CU)
-  static constexpr size_t ldsBytes = (size_t)9 * N * CSTR * sizeof(float);
+  static constexpr int DEPTH = 12;           // A loads in flight per wave (12 KiB)
+  static constexpr size_t ldsBytes = (size_t)4 * RT * NT * 256 * sizeof(float) + 64;   // partial tiles of the 4 waves + the 9 panel offsets
 };
+
+// B fragments of one group (matrix m, column-pair group s): for h = 0, 1 (component rows c0 = 2 (4 s + kq), c0 + 1) and every column
+// tile the pair (re, im) of right-hand side (16 nt + ncol) / 2 — 8-byte loads straight from the panel (L2-resident: the input field
+// is a few MB and every panel is wanted by 9 sites), no LDS staging, so several work-groups fit a CU and cover each other's waits
+template <int N, int NRHS, int NT> __device__ __forceinline__ void load_bfrag(float2 (&bf)[2][NT], const __amdgpu_buffer_rsrc_t &irs, unsigned panelOff, int s, int kq, int ncol) {
+  const unsigned rowOff = panelOff + (unsigned)((2 * (4 * s + kq)) * NRHS * 8 + (ncol & ~1) * 4);
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+      bf[h][nt] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(irs, (int)(rowOff + (unsigned)(h * NRHS * 8 + nt * 64)), 0, 0));
+}
 
 template <int N, int NRHS> __global__ void __launch_bounds__(256) coarse_block_kernel(const BlockCoarseArg arg) {
   using Tr = BlockCoarseTraits<N, NRHS>;
-  constexpr int RT = Tr::RT, NT = Tr::NT, JP = Tr::JP, SG = Tr::SG, NG = Tr::NG, GI = Tr::GI, CSTR = Tr::CSTR, DEPTH = Tr::DEPTH;
-  extern __shared__ float lds[];   // staged panels [9][N][CSTR]; later the partial tiles [4 waves][RT][NT][4][64]
+  constexpr int RT = Tr::RT, NT = Tr::NT, JP = Tr::JP, SG = Tr::SG, NG = Tr::NG, GI = Tr::GI, DEPTH = Tr::DEPTH;
+  extern __shared__ float lds[];   // [4 waves][RT][NT][4][64] partial tiles, then 9 panel offsets (unsigned)
+  unsigned *panel = reinterpret_cast<unsigned *>(lds + 4 * RT * NT * 256);
   const int A = blockIdx.x, Vh = arg.Vh;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row16 = lane & 15, kq = lane >> 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row16 = lane & 15, kq = lane >> 4, ncol = lane & 15, odd = ncol & 1;
 
   // ---- A operand: this site's 9 link matrices through a buffer descriptor (out-of-range offsets read 0: no tail branches) ----
   constexpr unsigned siteBytes = 9u * JP * N * 16u;
@@ -126,33 +141,26 @@ template <int N, int NRHS> __global__ void __launch_bounds__(256) coarse_block_k
   for (int d = 0; d < DEPTH; d++)
     abuf[d] = d < NIT ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, (int)a_offset(d), 0, 2)) : (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- B operand: stage the 9 panels (8 neighbours + the site itself) ----
-  {
+  // ---- byte offsets of the 9 input panels (8 neighbours + the site itself) ----
+  if (threadIdx.x < 9) {
+    const int m = threadIdx.x;
     const int par = A >= Vh, xcb = A - par * Vh;
     const int Xh = arg.Xc[0] >> 1;
     int l = xcb;
     const int xh = l % Xh; l /= Xh;
     const int y = l % arg.Xc[1]; l /= arg.Xc[1];
     const int z = l % arg.Xc[2]; const int t = l / arg.Xc[2];
-    const int c[4] = {2 * xh + ((y + z + t + par) & 1), y, z, t};
-    constexpr int Q = N * NRHS / 2;   // float4 per panel
-#pragma unroll
-    for (int m = 0; m < 9; m++) {
-      int cn[4] = {c[0], c[1], c[2], c[3]};
-      if (m < 8) {
-        const int mu = m >> 1, L = arg.Xc[mu];
-        cn[mu] = (m & 1) ? (c[mu] == 0 ? L - 1 : c[mu] - 1) : (c[mu] == L - 1 ? 0 : c[mu] + 1);
-      }
-      const int npar = (cn[0] + cn[1] + cn[2] + cn[3]) & 1;
-      const int nx = (((cn[3] * arg.Xc[2] + cn[2]) * arg.Xc[1] + cn[1]) * arg.Xc[0] + cn[0]) >> 1;
-      const float4 *src = reinterpret_cast<const float4 *>(arg.in + (size_t)(npar * Vh + nx) * (N * NRHS));
-      for (int q = threadIdx.x; q < Q; q += 256) {
-        const int cc = q / (NRHS / 2), i2 = q - cc * (NRHS / 2);
-        *reinterpret_cast<float4 *>(&lds[(m * N + cc) * CSTR + 4 * i2]) = src[q];
-      }
+    int cn[4] = {2 * xh + ((y + z + t + par) & 1), y, z, t};
+    if (m < 8) {
+      const int mu = m >> 1, L = arg.Xc[mu];
+      cn[mu] = (m & 1) ? (cn[mu] == 0 ? L - 1 : cn[mu] - 1) : (cn[mu] == L - 1 ? 0 : cn[mu] + 1);
     }
+    const int npar = (cn[0] + cn[1] + cn[2] + cn[3]) & 1;
+    const int nx = (((cn[3] * arg.Xc[2] + cn[2]) * arg.Xc[1] + cn[1]) * arg.Xc[0] + cn[0]) >> 1;
+    panel[m] = (unsigned)(npar * Vh + nx) * (unsigned)(N * NRHS * 8);
   }
   __syncthreads();
+  const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(arg.in), 0, (int)arg.inBytes, 0x00020000);
 
   f32x4 acc[RT][NT];
 #pragma unroll
@@ -160,43 +168,41 @@ template <int N, int NRHS> __global__ void __launch_bounds__(256) coarse_block_k
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) acc[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int ncol = lane & 15, odd = ncol & 1;
+  auto group_ms = [&](int gi, int &m, int &s) { const int g = wave + 4 * gi; const int gg = g < NG ? g : 0; m = gg / SG; s = gg - m * SG; };
+  float2 bnext[2][NT];
+  { int m, s; group_ms(0, m, s); load_bfrag<N, NRHS, NT>(bnext, irs, panel[m], s, kq, ncol); }
 #pragma unroll
   for (int gi = 0; gi < GI; gi++) {
-    const int g = wave + 4 * gi;
-    const int gg = g < NG ? g : 0;           // a surplus group multiplies zeros (its A loads were out of range)
-    const int m = gg / SG, s = gg - m * SG;
-    // B fragments of the group: component rows c0 = 2 (4 s + kq) and c0 + 1; column n = 16 nt + ncol = 2 i + o reads the pair (re, im) of rhs i
+    // this group's fragments; the next group's are requested before the matrix instructions of this one
     float bre[2][NT], bim[2][NT];
-    const float *prow = &lds[(m * N + 2 * (4 * s + kq)) * CSTR + (ncol & ~1)];
 #pragma unroll
     for (int h = 0; h < 2; h++)
 #pragma unroll
       for (int nt = 0; nt < NT; nt++) {
-        const float2 v = *reinterpret_cast<const float2 *>(prow + h * CSTR + 16 * nt);
+        const float2 v = bnext[h][nt];
         // k-step with p = re:  o = re -> Re in, o = im -> Im in;   p = im:  o = re -> -Im in, o = im -> Re in
         bre[h][nt] = odd ? v.y : v.x;
         bim[h][nt] = odd ? v.x : -v.y;
       }
+    if (gi + 1 < GI) { int m, s; group_ms(gi + 1, m, s); load_bfrag<N, NRHS, NT>(bnext, irs, panel[m], s, kq, ncol); }
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) {
       const int it = gi * RT + rt;
       const f32x4 a = abuf[it % DEPTH];
       if (it + DEPTH < NIT) abuf[it % DEPTH] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, (int)a_offset(it + DEPTH), 0, 2));
+      // k-step outermost: consecutive matrix instructions go to DIFFERENT accumulators (dependent latency 40 > issue 32 cycles)
 #pragma unroll
-      for (int nt = 0; nt < NT; nt++) {
-        f32x4 d = acc[rt][nt];
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], bre[0][nt], d, 0, 0, 0);   // K element (c0, re)
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], bim[0][nt], d, 0, 0, 0);   // (c0, im)
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], bre[1][nt], d, 0, 0, 0);   // (c0 + 1, re)
-        d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], bim[1][nt], d, 0, 0, 0);   // (c0 + 1, im)
-        acc[rt][nt] = d;
-      }
+      for (int nt = 0; nt < NT; nt++) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], bre[0][nt], acc[rt][nt], 0, 0, 0);   // K element (c0, re)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], bim[0][nt], acc[rt][nt], 0, 0, 0);   // (c0, im)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], bre[1][nt], acc[rt][nt], 0, 0, 0);   // (c0 + 1, re)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], bim[1][nt], acc[rt][nt], 0, 0, 0);   // (c0 + 1, im)
     }
   }
 
   // ---- sum the 4 waves' partial tiles through LDS, write the output panel ----
-  __syncthreads();   // every wave is done with the staged panels
 #pragma unroll
   for (int rt = 0; rt < RT; rt++)
 #pragma unroll
@@ -231,7 +237,6 @@ template <int N, int NRHS> static void launchCoarseBlock(const BlockCoarseArg &a
 bool blockCoarseSupported(const CoarseGauge &G, int nrhs) {
   if (G.n != 16 && G.n != 32 && G.n != 48 && G.n != 64) return false;
   if (nrhs != 8 && nrhs != 16 && nrhs != 24 && nrhs != 32) return false;
-  if ((size_t)9 * G.n * (2 * nrhs + 8) * sizeof(float) > 160 * 1024) return false;
   for (int d = 0; d < 4; d++) if (commGrid().partitioned(d)) return false;
   static int off = -1;
   if (off < 0) { const char *e = getenv("QUDA_AMD_BLOCK_COARSE"); off = (e && !atoi(e)) ? 1 : 0; }
@@ -244,6 +249,8 @@ void applyCoarseBlock(BlockField &out, const BlockField &in, const CoarseGauge &
   if (in.v == out.v) errorQuda("in and out must not alias");
   BlockCoarseArg arg;
   arg.out = out.v; arg.in = in.v; arg.G = G.data; arg.Vh = G.nSites / 2;
+  if (in.bytes >= ((size_t)1 << 32)) errorQuda("block field of %zu bytes exceeds the 4 GiB a buffer descriptor addresses", in.bytes);
+  arg.inBytes = (unsigned)in.bytes;
   for (int d = 0; d < 4; d++) arg.Xc[d] = G.Xc[d];
 #define QA_CASE(NN, RR) if (G.n == NN && in.nrhs == RR) { launchCoarseBlock<NN, RR>(arg, G.nSites); return; }
   QA_CASE(48, 24) QA_CASE(48, 8) QA_CASE(48, 16) QA_CASE(48, 32)
