@@ -149,6 +149,20 @@ void qudaAmdCommAllreduceMax(double *data, int n);
 /* single-process emulation of a partitioned dimension (reference tests --partition, commDimPartitionedSet) */
 void qudaAmdSetPartitionMask(int mask);
 
+/* Raw device images of the resident fields, for checks of the layout contract (reference lib/color_spinor_field.cpp:129-216:
+ * stride = volumeCB + pad, bytes per parity rounded up to 1 KiB, odd half at bytes / 2, fp32 norm array for 16-bit fields):
+ * spinor info = {volume, volumeCB, stride, pad, nSpin, nColor, precision, fieldOrder, siteSubset, gammaBasis, bytes, norm_bytes,
+ *   device address of v, of norm, byte offset of the odd half, of the odd norms, reals per plane entry (2 fp64 | 4 fp32 | 8 16-bit),
+ *   twistFlavor, x[0], location};
+ * gauge info (which: 0 precise, 1 sloppy, 2 precondition) = {address, bytes, stride, bytes of one (parity, direction) block,
+ *   precision, reconstruct, Vh, boundary sign folded into the links, t_boundary};
+ * clover info = {address of A, of the inverse, of the A norms, of the inverse norms, stride, bytes per parity, norm bytes per parity,
+ *   precision, bytes, Vh, twisted}.  qudaAmdRawDeviceCopy copies `bytes` from a device address to the host. */
+void qudaAmdSpinorRawInfo(const void *field, long long info[20]);
+void qudaAmdGaugeRawInfo(int which, long long info[12]);
+void qudaAmdCloverRawInfo(int which, long long info[12]);
+void qudaAmdRawDeviceCopy(void *h_dst, long long device_address, size_t bytes);
+
 /* stream the kernels are launched on (hipStream_t), for callers that bracket work with their own events */
 void *qudaAmdComputeStream(void);
 void qudaAmdDeviceSynchronize(void);

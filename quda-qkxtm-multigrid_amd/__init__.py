@@ -118,7 +118,8 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
                  "qudaAmdCommInit", "qudaAmdCommRank", "qudaAmdCommSize", "qudaAmdCommCoords", "qudaAmdCommBarrier", "qudaAmdCommAllreduce", "qudaAmdCommAllreduceMax",
                  "qudaAmdMultigridVerify", "qudaAmdMultigridCycle", "qudaAmdTimeAxpy", "qudaAmdMultigridLevels", "qudaAmdMultigridLevelInfo",
                  "qudaAmdMultigridSetHalfStorage", "qudaAmdMultigridGetNullVector", "qudaAmdMultigridGetV", "qudaAmdMultigridGetCoarseLinks", "qudaAmdMultigridApply", "qudaAmdMultigridApplyBlock",
-                 "qudaAmdMultigridTimeApply"]
+                 "qudaAmdMultigridTimeApply", "qudaAmdSpinorRawInfo", "qudaAmdGaugeRawInfo", "qudaAmdCloverRawInfo", "qudaAmdRawDeviceCopy",
+                 "qudaAmdSetSolutionSink"]
 
 _lib = None
 
@@ -181,6 +182,10 @@ def lib():
         L.qudaAmdCommGetUniqueId.argtypes = [_p]
         L.initCommsGridQuda.argtypes = [_i, C.POINTER(_i), _p, _p]
         L.qudaAmdSetPartitionMask.argtypes = [_i]
+        L.qudaAmdSpinorRawInfo.argtypes = [_p, C.POINTER(C.c_longlong)]
+        L.qudaAmdGaugeRawInfo.argtypes = [_i, C.POINTER(C.c_longlong)]
+        L.qudaAmdCloverRawInfo.argtypes = [_i, C.POINTER(C.c_longlong)]
+        L.qudaAmdRawDeviceCopy.argtypes = [_p, C.c_longlong, C.c_size_t]
         L.qudaAmdSetDslashTune.argtypes = [C.c_char_p, _i]
         L.qudaAmdMultigridVerify.argtypes = [_p, C.POINTER(_d)]
         L.qudaAmdMultigridCycle.argtypes = [_p, _p, _p, C.POINTER(QudaInvertParam)]
@@ -416,10 +421,37 @@ class Spinor:
     def norm2(self):
         return lib().qudaAmdBlasNorm2(self.h)
 
+    def raw_info(self):
+        """qudaAmdSpinorRawInfo as a dict"""
+        a = (C.c_longlong * 20)()
+        lib().qudaAmdSpinorRawInfo(self.h, a)
+        keys = ("volume", "volumeCB", "stride", "pad", "nSpin", "nColor", "precision", "fieldOrder", "siteSubset", "gammaBasis", "bytes", "norm_bytes",
+                "v", "norm", "odd_offset", "odd_norm_offset", "N", "twistFlavor", "x0", "location")
+        return dict(zip(keys, [int(v) for v in a]))
+
     def free(self):
         if self.h:
             lib().qudaAmdSpinorDestroy(self.h)
             self.h = None
+
+
+def raw_device_copy(address, nbytes):
+    """bytes of device memory as a uint8 array (layout tests)"""
+    out = np.zeros(int(nbytes), dtype=np.uint8)
+    lib().qudaAmdRawDeviceCopy(_vp(out), int(address), int(nbytes))
+    return out
+
+
+def gauge_raw_info(which=0):
+    a = (C.c_longlong * 12)()
+    lib().qudaAmdGaugeRawInfo(int(which), a)
+    return dict(zip(("data", "bytes", "stride", "link_bytes", "precision", "reconstruct", "Vh", "tbc_folded", "t_boundary"), [int(v) for v in a][:9]))
+
+
+def clover_raw_info(which=0):
+    a = (C.c_longlong * 12)()
+    lib().qudaAmdCloverRawInfo(int(which), a)
+    return dict(zip(("A", "Ainv", "norm", "invNorm", "stride", "parity_bytes", "parity_norm_bytes", "precision", "bytes", "Vh", "twisted"), [int(v) for v in a][:11]))
 
 
 class Dirac:

@@ -603,6 +603,39 @@ void qudaAmdSetPartitionMask(int mask) {
 void *qudaAmdComputeStream(void) { return (void *)computeStream(); }
 int qudaAmdHaloTransport(void) { return p2pTransport(); }
 void qudaAmdSetDslashTune(const char *key, int value) { setDslashTune(key, value); }
+
+// ---- raw device images (layout contract checks, tests/test_layout_gpu.py) ----
+void qudaAmdSpinorRawInfo(const void *field, long long info[20]) {
+  const ColorSpinorField &f = *(const ColorSpinorField *)field;
+  ColorSpinorField &g = const_cast<ColorSpinorField &>(f);
+  const bool full = f.SiteSubset() == QUDA_FULL_SITE_SUBSET;
+  info[0] = f.Volume(); info[1] = f.VolumeCB(); info[2] = f.Stride(); info[3] = f.pad; info[4] = f.Nspin(); info[5] = f.Ncolor();
+  info[6] = f.Precision(); info[7] = f.fieldOrder; info[8] = f.SiteSubset(); info[9] = f.gammaBasis;
+  info[10] = (long long)f.bytes; info[11] = (long long)f.norm_bytes;
+  info[12] = (long long)(uintptr_t)f.V(); info[13] = (long long)(uintptr_t)f.Norm();
+  info[14] = full ? (long long)((const char *)g.Odd().V() - (const char *)f.V()) : 0;
+  info[15] = full && f.Norm() ? (long long)((const char *)g.Odd().Norm() - (const char *)f.Norm()) : 0;
+  info[16] = f.Precision() == QUDA_DOUBLE_PRECISION || f.Nspin() != 4 ? 2 : (f.Precision() == QUDA_SINGLE_PRECISION ? 4 : 8);   // reals per plane entry
+  info[17] = f.twistFlavor; info[18] = f.x[0]; info[19] = f.Location();
+}
+void qudaAmdGaugeRawInfo(int which, long long info[12]) {
+  const GaugeField *U = residentGauge(which);
+  if (!U) errorQuda("no resident gauge field %d", which);
+  info[0] = (long long)(uintptr_t)U->data; info[1] = (long long)U->bytes; info[2] = U->stride; info[3] = (long long)U->link_bytes;
+  info[4] = U->precision; info[5] = U->reconstruct; info[6] = U->geom.Vh; info[7] = U->tbc_folded ? 1 : 0;
+  info[8] = U->t_boundary; info[9] = 0; info[10] = 0; info[11] = 0;
+}
+void qudaAmdCloverRawInfo(int which, long long info[12]) {
+  const CloverField *C = residentClover(which);
+  if (!C) errorQuda("no resident clover field %d", which);
+  info[0] = (long long)(uintptr_t)C->clover; info[1] = (long long)(uintptr_t)C->cloverInv; info[2] = (long long)(uintptr_t)C->norm; info[3] = (long long)(uintptr_t)C->invNorm;
+  info[4] = C->stride; info[5] = (long long)C->parity_bytes; info[6] = (long long)C->parity_norm_bytes; info[7] = C->precision;
+  info[8] = (long long)C->bytes; info[9] = C->geom.Vh; info[10] = C->twisted ? 1 : 0; info[11] = 0;
+}
+void qudaAmdRawDeviceCopy(void *h_dst, long long device_address, size_t bytes) {
+  HIP_CHECK(hipDeviceSynchronize());
+  HIP_CHECK(hipMemcpy(h_dst, (const void *)(uintptr_t)device_address, bytes, hipMemcpyDeviceToHost));
+}
 void qudaAmdDeviceSynchronize(void) { HIP_CHECK(hipDeviceSynchronize()); p2pCheck(__func__); }
 
 }  // extern "C"
