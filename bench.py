@@ -5,7 +5,7 @@ A "step" is ONE application of DiracTwistedMassPC::Dslash (stencil + fused inver
 fields, exactly what tests/dslash_test.cpp times with transfer=0 (:455-616).  `value` is GFLOP/s with the
 reference's kernel-level flop count (1368 / checkerboard site, lib/dslash_twisted_mass.cu:144-160).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--prec 8|4|2] [--recon 18|12] [--dslash tm|tmc|wilson]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--prec 8|4|2] [--recon 18|12] [--dslash tm|tmc|wilson] [--lattice X,Y,Z,T]
 
 N > 1 (launched by torch.distributed.run): the global lattice is 4-D block-decomposed over the ranks and the
 halo exchange rides RCCL (strong scaling: the global volume is fixed).
@@ -191,8 +191,10 @@ def main():
         if dist is not None:
             dist.barrier()
         wall = time.perf_counter() - t0
+        sec_min = sec_kernel
         if dist is not None:
             wall = dist.max_over_ranks(wall)
+            sec_min = -dist.max_over_ranks(-sec_kernel)   # fastest and slowest rank: the spread shows an uneven halo wait
             sec_kernel = dist.max_over_ranks(sec_kernel)
         flops_site = qa.lib().qudaAmdDslashFlopsPerSite(ip, 0)
         bytes_site = qa.lib().qudaAmdDslashBytesPerSite(ip, 0, 0)
@@ -200,7 +202,7 @@ def main():
         for f in (src, dst):
             f.free()
         d.free()
-        return dict(wall=wall, sec=sec_kernel, flops_site=flops_site, bytes_site=bytes_site, norm2=n2)
+        return dict(wall=wall, sec=sec_kernel, sec_min=sec_min, flops_site=flops_site, bytes_site=bytes_site, norm2=n2)
 
     r = run(args.prec, args.recon, args.dslash, args.steps, args.warmup)
     ms_per_step = 1e3 * r["wall"] / args.steps
@@ -222,8 +224,10 @@ def main():
         extra["stream_axpy_f64"] = dict(hbm_gbs=round(3 * 2 * Vh_local * 24 * 8 / sec * 1e-9, 1), us=round(1e6 * sec, 2))
         sx.free(); sy.free()
 
+    g32 = None
     if not args.no_extra and rank == 0 and world == 1:
-        extra["mg_gcr"] = run_mg(qa, (32, 32, 32, 32))
+        g32 = smooth_gauge((32, 32, 32, 32), 0.35)   # kept for the CPU solver baseline below
+        extra["mg_gcr"] = run_mg(qa, (32, 32, 32, 32), gauge=g32)
         # BASELINE.json configs[4] (48^3 x 96, quoted by the reference on 8 GPUs) resident on this one GPU: 288 GB holds the whole
         # hierarchy; levels by the reference's blocking rule 48^3 x 96 -> 12^3 x 24 -> 6^4 (lib/transfer.cpp:31-44)
         from synth import smooth_gauge_cayley
@@ -255,10 +259,19 @@ def main():
         for _ in range(n_all):
             oracle.tm_dslash(g_cpu, inp, Xc, kappa, mu, +1, 0, "ee", 0)
         tall = (time.perf_counter() - t0) / n_all
-        oracle.set_threads(1)
         cpu = dict(value=round(1368.0 * Vh_local / tall * 1e-9, 3), unit="GFLOP/s", cores=cores, kind="port",
                    sample="%d x tm_dslash fp64 on %s (oracle/liboracle.so, outer parallel-for over sites); 1 thread = %.3f GFLOP/s"
                    % (n_all, "x".join(str(v) for v in Xc), 1368.0 * Vh_local / t1 * 1e-9))
+        if g32 is not None:
+            # the solver half of the metric on the host: the reference's restarted GCR(20) (lib/inv_gcr_quda.cpp, plainest configuration)
+            # on the host tm_mat with lib/blas_cpu.cpp-style BLAS (oracle/qo_solver.c), fp64, SAME 32^4 problem (field, kappa, mu,
+            # source, tolerance) as extra.mg_gcr / extra.mg_gcr.plain_gcr on the GPU
+            bsol = np.random.default_rng(5).random(32 ** 4 * 24)
+            _, it_cpu, secs_cpu, res_cpu = oracle.gcr_tm(g32, bsol, [32, 32, 32, 32], 0.124, 0.005, +1, tol=1e-10, nkrylov=20, maxiter=5000)
+            cpu["solver"] = dict(what="plain GCR(20) to 1e-10 on tm_mat, fp64, 32x32x32x32, kappa 0.124 mu 0.005 (same problem as extra.mg_gcr)",
+                                 secs=round(secs_cpu, 2), iters=it_cpu, true_res=res_cpu, cores=cores,
+                                 gpu_plain_gcr_secs=extra.get("mg_gcr", {}).get("plain_gcr", {}).get("secs"), gpu_mg_gcr_secs=extra.get("mg_gcr", {}).get("solve_secs"))
+        oracle.set_threads(1)
 
     traffic, traffic_source = None, None
     if rank == 0 and world == 1:
@@ -282,7 +295,9 @@ def main():
             "vs_baseline": None, "dtype": dtype_name[args.prec], "data": "synthetic",
             "config": {"workload": "%s even-odd Dslash (DiracTwistedMassPC::Dslash, kappa=%g mu=%g), %s lattice, recon-%d, fields resident in HBM"
                        % ({"tm": "twisted-mass", "tmc": "twisted-clover", "wilson": "Wilson"}[args.dslash], kappa, mu, "x".join(map(str, X)), args.recon),
-                       "local_lattice": Xl, "halo_transport": {1: "direct peer stores (IPC-mapped ghost zones over xGMI)", 0: "RCCL send/recv", -1: "none (single rank)"}[int(qa.lib().qudaAmdHaloTransport())], "process_grid": dist.grid if dist else [1, 1, 1, 1], "flops_per_site": r["flops_site"]},
+                       "local_lattice": Xl, "halo_transport": {1: "direct peer stores (IPC-mapped ghost zones over xGMI)", 0: "RCCL send/recv", -1: "none (single rank)"}[int(qa.lib().qudaAmdHaloTransport())], "process_grid": dist.grid if dist else [1, 1, 1, 1], "flops_per_site": r["flops_site"],
+                       "ranks_in_communicator": int(qa.lib().qudaAmdCommSize()), "per_rank_kernel_us": {"slowest": round(1e6 * r["sec"], 2), "fastest": round(1e6 * r["sec_min"], 2)},
+                       "other_configs": "BASELINE configs[3] (32^3 x 64 over 8 GPUs): --lattice 32,32,32,64 (grid 1x2x2x2, local 32x16x16x32)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": traffic_source, "bytes_per_site": r["bytes_site"], "kernel_us": round(1e6 * r["sec"], 3)},
             "cpu_baseline": cpu,

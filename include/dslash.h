@@ -43,6 +43,11 @@ void applyCovariantShift(ColorSpinorField &out, const ColorSpinorField &in, cons
 // out(x) = in(x + dhat(dir)) for a 24-real fp64 planar site field (out: parity block `parity`, in: the other parity's block), ghost-aware
 void applyShift(double *out, const double *in, const LatticeGeom &g, int stride, int parity, int dir);
 
+// multi-right-hand-side FULL operator on block fields ([parity * Vh + x][12 spin-colour][nrhs] float2, see block.h):
+// out = (1 + i a g5) in - kappa D in for nrhs vectors per link load (fp32, recon 18, unpartitioned lattice)
+bool fineBlockSupported(const GaugeField &U, int nrhs);
+void applyFineBlockM(float2 *out, const float2 *in, int nrhs, const GaugeField &U, double kappa, double a);
+
 // site-local kernels
 enum SiteOp {
   SITE_TWIST = 0,              // out = b (1 + i a g5) in

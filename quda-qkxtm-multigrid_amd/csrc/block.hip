@@ -30,14 +30,18 @@ namespace quda {
 BlockField::BlockField(int nSites_, int ncomp_, int nrhs_) : nSites(nSites_), Vh(nSites_ / 2), ncomp(ncomp_), nrhs(nrhs_) {
   if (nrhs < 1 || nrhs > kMaxBlockRhs) errorQuda("block field with %d right-hand sides (1..%d supported)", nrhs, kMaxBlockRhs);
   bytes = elems() * sizeof(float2);
-  v = (float2 *)poolDeviceMalloc(bytes);
+  // work fields of the setup only: straight from / back to the runtime (the size-bucketed pool would keep tens of GB for good)
+  HIP_CHECK(hipMalloc((void **)&v, bytes));
   HIP_CHECK(hipMemsetAsync(v, 0, bytes, computeStream()));
 }
-BlockField::~BlockField() { if (v) poolDeviceFree(v, bytes); }
+BlockField::~BlockField() {
+  if (v) { HIP_CHECK(hipStreamSynchronize(computeStream())); (void)hipFree(v); }
+}
 
 // ---- gather / scatter ----
 struct BlockPtrs { float *v[2][kMaxBlockRhs]; };
-template <bool PACK> __global__ void __launch_bounds__(256) block_pack_kernel(float2 *blk, BlockPtrs f, int stride, int Vh, int ncomp, int nrhs, long total) {
+// NV: reals per plane entry of the ordinary fields (2: FLOAT2 order of the coarse levels, 4: FLOAT4 order of fp32 nSpin = 4 fields)
+template <bool PACK, int NV> __global__ void __launch_bounds__(256) block_pack_kernel(float2 *blk, BlockPtrs f, int stride, int Vh, int ncomp, int nrhs, long total) {
   const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (t >= total) return;
   const int i = (int)(t % nrhs);
@@ -45,7 +49,7 @@ template <bool PACK> __global__ void __launch_bounds__(256) block_pack_kernel(fl
   const int j = (int)(u % ncomp);
   const int A = (int)(u / ncomp);
   const int par = A >= Vh, x = A - par * Vh;
-  float2 *p = reinterpret_cast<float2 *>(f.v[par][i]) + ((size_t)j * stride + x);
+  float2 *p = reinterpret_cast<float2 *>(f.v[par][i] + ((size_t)((2 * j) / NV) * stride + x) * NV + (2 * j) % NV);
   if (PACK) blk[t] = *p;
   else *p = blk[t];
 }
@@ -67,14 +71,16 @@ void blockPack(BlockField &dst, const std::vector<ColorSpinorField *> &src) {
   int stride;
   const BlockPtrs p = blockPtrs(src, dst, stride);
   const long total = (long)dst.elems();
-  hipLaunchKernelGGL((block_pack_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), dst.v, p, stride, dst.Vh, dst.ncomp, dst.nrhs, total);
+  if (src[0]->Nspin() == 4) hipLaunchKernelGGL((block_pack_kernel<true, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), dst.v, p, stride, dst.Vh, dst.ncomp, dst.nrhs, total);
+  else hipLaunchKernelGGL((block_pack_kernel<true, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), dst.v, p, stride, dst.Vh, dst.ncomp, dst.nrhs, total);
   HIP_CHECK(hipGetLastError());
 }
 void blockUnpack(const std::vector<ColorSpinorField *> &dst, const BlockField &src) {
   int stride;
   const BlockPtrs p = blockPtrs(dst, src, stride);
   const long total = (long)src.elems();
-  hipLaunchKernelGGL((block_pack_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), src.v, p, stride, src.Vh, src.ncomp, src.nrhs, total);
+  if (dst[0]->Nspin() == 4) hipLaunchKernelGGL((block_pack_kernel<false, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), src.v, p, stride, src.Vh, src.ncomp, src.nrhs, total);
+  else hipLaunchKernelGGL((block_pack_kernel<false, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), src.v, p, stride, src.Vh, src.ncomp, src.nrhs, total);
   HIP_CHECK(hipGetLastError());
 }
 

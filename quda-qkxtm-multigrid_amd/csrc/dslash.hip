@@ -22,6 +22,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "blas.h"
@@ -567,6 +568,171 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
   }
   stencil_site<T, R, VARIANT, GAUX, KT, SAUX>(arg, idx);
   if (KT == 3 && arg.timeline && threadIdx.x == 0) arg.timeline[12288 + blockIdx.x] = wall_clock64();
+}
+
+// ================================================================================================
+// Multi-right-hand-side full operator on block fields (block.h layout: [site][spin-colour j][rhs i] float2), fp32, recon 18:
+//     out(x) = (1 + i a g5) in(x) - kappa sum_{8 hops} U P in(x + mu)          on the sites of ONE parity per launch
+// for NRHS right-hand sides per link load — the operator behind the lockstep null-vector solves of the multigrid setup
+// (multigrid.cpp; reference MG::generateNullVectors, lib/multigrid.cpp:693-779, where every one of the Nvec BiCGstab solves
+// re-reads the links: 576 of the 768 B per site of the fp32 stencil).  One thread per (site, right-hand side); the links of the
+// work-group's sites are staged once in LDS (full-line loads from the planar link blocks, broadcast reads), the spinor panels are
+// read as 8-byte pairs, NRHS x 8 B contiguous per (site, component).  NRHS = 8 keeps the panel of a site at 768 B so that the
+// neighbour re-use still fits the caches in the XCD-slab order of the single-vector kernel: 72 + ~110 + 96 + 96 B per site and
+// right-hand side instead of 768 + 96.
+// ================================================================================================
+struct BlockOrder {   // the plane-tiled XCD mapping of dslash_kernel for work-groups of `bs` consecutive checkerboard sites
+  int tiled, P, nxz, Zs, Ts, tz, tt, Z;
+  FastDiv dNxz, dPerTile, dNtz, dPTt, dTt;
+  __device__ __forceinline__ int map(int b) const {
+    if (!tiled) return b;
+    const int xcd = b & 7, within = b >> 3;
+    const uint32_t xt = dNxz.div((uint32_t)xcd), xz = (uint32_t)xcd - xt * (uint32_t)nxz;
+    const uint32_t tile = dPerTile.div((uint32_t)within), r = (uint32_t)within - tile * dPerTile.d;
+    const uint32_t tile_t = dNtz.div(tile), tile_z = tile - tile_t * dNtz.d;
+    const uint32_t zi = dPTt.div(r), r2 = r - zi * dPTt.d;
+    const uint32_t yc = dTt.div(r2), ti = r2 - yc * dTt.d;
+    const int z = (int)xz * Zs + (int)tile_z * tz + (int)zi, t = (int)xt * Ts + (int)tile_t * tt + (int)ti;
+    return (t * Z + z) * P + (int)yc;
+  }
+};
+static BlockOrder makeBlockOrder(const LatticeGeom &g, int bs) {
+  BlockOrder o;
+  memset(&o, 0, sizeof(o));
+  const int plane = g.Xh * g.X[1];
+  if (plane % bs || (g.Vh / bs) % 8) return o;
+  int nxz = 0;
+  for (int c : {8, 4, 2, 1}) if (g.X[2] % c == 0 && g.X[3] % (8 / c) == 0) { nxz = c; break; }
+  if (!nxz) return o;
+  o.tiled = 1; o.P = plane / bs; o.nxz = nxz; o.Zs = g.X[2] / nxz; o.Ts = g.X[3] / (8 / nxz); o.tz = o.Zs; o.tt = 1; o.Z = g.X[2];
+  o.dNxz = FastDiv((uint32_t)nxz); o.dPerTile = FastDiv((uint32_t)(o.P * o.tz * o.tt)); o.dNtz = FastDiv((uint32_t)(o.Zs / o.tz));
+  o.dPTt = FastDiv((uint32_t)(o.P * o.tt)); o.dTt = FastDiv((uint32_t)o.tt);
+  return o;
+}
+
+struct FineBlockArg {
+  float2 *out;             // panels of the output parity
+  const float2 *in_same;   // panels of the same parity (twist term)
+  const float2 *in_other;  // panels of the other parity (hops)
+  const char *gauge;       // this parity's 8 direction blocks
+  size_t link_bytes;
+  int g_stride;
+  int Vh, Xh, Y, Z, T, parity;
+  FastDiv dXh, dY, dZ;
+  float a, mkappa;
+  BlockOrder order;
+};
+
+template <int NRHS> __global__ void __launch_bounds__(256) fine_block_kernel(const FineBlockArg arg) {
+  constexpr int SPB = NRHS == 24 ? 8 : 256 / NRHS;   // sites per work-group (192 threads for 24 right-hand sides, else 256)
+  constexpr int USTR = 8 * 18 + 8;                    // floats per site of staged links (pad: 3 neighbouring sites on distinct banks)
+  __shared__ float ulds[SPB * USTR];
+  const int lb = arg.order.map(blockIdx.x);
+  const int s = threadIdx.x / NRHS, i = threadIdx.x - s * NRHS;
+  const int idx0 = lb * SPB, idx = idx0 + s;
+  // ---- stage the links of the SPB sites: [site][dir][18]; planes 0..3 are float4, plane 4 the trailing float2 ----
+  for (int e = threadIdx.x; e < 8 * 5 * SPB; e += blockDim.x) {
+    const int ss = e % SPB, pl = (e / SPB) % 5, d = e / (5 * SPB);
+    const char *blk = arg.gauge + (size_t)d * arg.link_bytes;
+    float *dst = &ulds[ss * USTR + d * 18 + pl * 4];
+    if (idx0 + ss < arg.Vh) {
+      if (pl < 4) {
+        const float4 v = reinterpret_cast<const float4 *>(blk)[(size_t)pl * arg.g_stride + idx0 + ss];
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+      } else {
+        const float2 v = reinterpret_cast<const float2 *>(blk + (size_t)4 * arg.g_stride * 16)[idx0 + ss];
+        dst[0] = v.x; dst[1] = v.y;
+      }
+    }
+  }
+  __syncthreads();
+  if (idx >= arg.Vh) return;
+  // coordinates and neighbours (as stencil_site)
+  const uint32_t za = arg.dXh.div((uint32_t)idx);
+  const int xh = idx - (int)za * arg.Xh;
+  const uint32_t zb = arg.dY.div(za);
+  const int y = (int)za - (int)zb * arg.Y;
+  const int t = (int)arg.dZ.div(zb);
+  const int z = (int)zb - t * arg.Z;
+  const int xodd = (y + z + t + arg.parity) & 1;
+  const int Xh = arg.Xh, sy = Xh, sz = Xh * arg.Y, st = Xh * arg.Y * arg.Z;
+  int nb[8];
+  nb[0] = xodd ? (xh == Xh - 1 ? idx - (Xh - 1) : idx + 1) : idx;
+  nb[1] = xodd ? idx : (xh == 0 ? idx + (Xh - 1) : idx - 1);
+  nb[2] = y == arg.Y - 1 ? idx - (arg.Y - 1) * sy : idx + sy;
+  nb[3] = y == 0 ? idx + (arg.Y - 1) * sy : idx - sy;
+  nb[4] = z == arg.Z - 1 ? idx - (arg.Z - 1) * sz : idx + sz;
+  nb[5] = z == 0 ? idx + (arg.Z - 1) * sz : idx - sz;
+  nb[6] = t == arg.T - 1 ? idx - (arg.T - 1) * st : idx + st;
+  nb[7] = t == 0 ? idx + (arg.T - 1) * st : idx - st;
+
+  float acc[24];
+#pragma unroll
+  for (int k = 0; k < 24; k++) acc[k] = 0.f;
+  const float *U0 = &ulds[s * USTR];
+  auto hop = [&](auto DIRC, int nbr) {
+    constexpr int DIR = decltype(DIRC)::value, MU = DIR / 2;
+    const float2 *p = arg.in_other + ((size_t)nbr * 12) * NRHS + i;
+    float psi[24], h[12], g[12], U[18];
+#pragma unroll
+    for (int j = 0; j < 12; j++) { const float2 v = p[j * NRHS]; psi[2 * j] = v.x; psi[2 * j + 1] = v.y; }
+#pragma unroll
+    for (int k = 0; k < 18; k++) U[k] = U0[DIR * 18 + k];
+    const float sgn = (DIR & 1) ? -1.f : 1.f;
+    spin_project<MU>(h, psi, sgn);
+    su3_mv(g, U, h);
+    su3_mv(g + 6, U, h + 6);
+    spin_reconstruct<MU>(acc, g, sgn);
+  };
+  hop(std::integral_constant<int, 0>{}, nb[0]); hop(std::integral_constant<int, 1>{}, nb[1]);
+  hop(std::integral_constant<int, 2>{}, nb[2]); hop(std::integral_constant<int, 3>{}, nb[3]);
+  hop(std::integral_constant<int, 4>{}, nb[4]); hop(std::integral_constant<int, 5>{}, nb[5]);
+  hop(std::integral_constant<int, 6>{}, nb[6]); hop(std::integral_constant<int, 7>{}, nb[7]);
+  // out = (1 + i a g5) in(x) - kappa acc
+  const float2 *q = arg.in_same + ((size_t)idx * 12) * NRHS + i;
+  float2 *o = arg.out + ((size_t)idx * 12) * NRHS + i;
+#pragma unroll
+  for (int j = 0; j < 12; j++) {
+    const float2 v = q[j * NRHS];
+    const float a = j < 6 ? arg.a : -arg.a;   // g5 = diag(+,+,-,-): spins 0,1 are components 0..5
+    o[j * NRHS] = make_float2(v.x - a * v.y + arg.mkappa * acc[2 * j], v.y + a * v.x + arg.mkappa * acc[2 * j + 1]);
+  }
+}
+
+bool fineBlockSupported(const GaugeField &U, int nrhs) {
+  if (U.precision != QUDA_SINGLE_PRECISION || U.reconstruct != QUDA_RECONSTRUCT_NO) return false;
+  if (nrhs != 8 && nrhs != 16 && nrhs != 24 && nrhs != 32) return false;
+  for (int d = 0; d < 4; d++) if (commGrid().partitioned(d)) return false;
+  static int off = -1;
+  if (off < 0) { const char *e = getenv("QUDA_AMD_BLOCK_FINE"); off = (e && !atoi(e)) ? 1 : 0; }
+  return !off;
+}
+
+// out = (1 + i a g5) in - kappa D in on full block fields of 12 components (both parities, two launches)
+void applyFineBlockM(float2 *out, const float2 *in, int nrhs, const GaugeField &U, double kappa, double a) {
+  if (!fineBlockSupported(U, nrhs)) errorQuda("multi-right-hand-side fine operator: fp32 recon-18 links on an unpartitioned lattice, 8/16/24/32 right-hand sides");
+  const LatticeGeom &g = U.geom;
+  const int spb = nrhs == 24 ? 8 : 256 / nrhs, threads = spb * nrhs;
+  FineBlockArg arg;
+  arg.link_bytes = U.link_bytes; arg.g_stride = U.stride;
+  arg.Vh = g.Vh; arg.Xh = g.Xh; arg.Y = g.X[1]; arg.Z = g.X[2]; arg.T = g.X[3];
+  arg.dXh = g.dXh; arg.dY = g.dY; arg.dZ = g.dZ;
+  arg.a = (float)a; arg.mkappa = (float)(-kappa);
+  arg.order = makeBlockOrder(g, spb);
+  const int nb = (g.Vh + spb - 1) / spb;
+  const size_t par = (size_t)g.Vh * 12 * nrhs;
+  for (int p = 0; p < 2; p++) {
+    arg.parity = p;
+    arg.out = out + p * par; arg.in_same = in + p * par; arg.in_other = in + (1 - p) * par;
+    arg.gauge = (const char *)U.parityBase(p);
+    switch (nrhs) {
+      case 8: hipLaunchKernelGGL((fine_block_kernel<8>), dim3(nb), dim3(threads), 0, computeStream(), arg); break;
+      case 16: hipLaunchKernelGGL((fine_block_kernel<16>), dim3(nb), dim3(threads), 0, computeStream(), arg); break;
+      case 24: hipLaunchKernelGGL((fine_block_kernel<24>), dim3(nb), dim3(threads), 0, computeStream(), arg); break;
+      default: hipLaunchKernelGGL((fine_block_kernel<32>), dim3(nb), dim3(threads), 0, computeStream(), arg); break;
+    }
+  }
+  HIP_CHECK(hipGetLastError());
 }
 
 // ---- single-direction hop (setup-time helper for the multigrid coarse-operator construction) ----

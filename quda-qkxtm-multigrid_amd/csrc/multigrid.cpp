@@ -255,6 +255,46 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
     }
     return;
   }
+  // Fine level: the same lockstep solve on the multi-right-hand-side stencil (dslash.h applyFineBlockM), 8 vectors per link load —
+  // batches of 8 keep a site's panel small enough for the neighbour re-use of the XCD-slab block order
+  {
+    const Dirac *df = mgp.matResidual.Expose();
+    const QudaDiracType ty = df ? df->getDiracType() : QUDA_INVALID_DIRAC;
+    constexpr int nb = 8;
+    if (df && (ty == QUDA_TWISTED_MASS_DIRAC || ty == QUDA_WILSON_DIRAC) && B[0]->Nspin() == 4 && B[0]->Precision() == QUDA_SINGLE_PRECISION &&
+        mgp.Nvec % nb == 0 && df->Gauge() && fineBlockSupported(*df->Gauge(), nb)) {
+      const double t0 = now();
+      const double a = ty == QUDA_TWISTED_MASS_DIRAC ? 2.0 * df->Kappa() * (double)mgp.fineFlavor * df->Mu() : 0.0;
+      struct Ctx { const GaugeField *U; double kappa, a; long applies; } ctx = {df->Gauge(), df->Kappa(), a, 0};
+      int kmaxAll = 0, imin = 1 << 30, imax = 0;
+      for (int i = 0; i < mgp.Nvec; i++) { B[i]->twistFlavor = mgp.fineFlavor; spinorRandom(*B[i], 0x5eedULL + 7919ULL * (mgp.level * 131 + i)); }
+      for (int g0 = 0; g0 < mgp.Nvec; g0 += nb) {
+        std::vector<ColorSpinorField *> Bv(B.begin() + g0, B.begin() + g0 + nb);
+        BlockField X(B[0]->Volume(), 12, nb);
+        blockPack(X, Bv);
+        int iters[kMaxBlockRhs];
+        const int kmax = blockBiCGstabNull(X, [](BlockField &out, const BlockField &in, void *c) { Ctx *x = (Ctx *)c; applyFineBlockM(out.v, in.v, in.nrhs, *x->U, x->kappa, x->a); x->applies++; },
+                                           &ctx, sp.tol, sp.maxiter, iters);
+        blockUnpack(Bv, X);
+        kmaxAll = kmax > kmaxAll ? kmax : kmaxAll;
+        for (int i = 0; i < nb; i++) { imin = iters[i] < imin ? iters[i] : imin; imax = iters[i] > imax ? iters[i] : imax; }
+      }
+      for (int i = 0; i < mgp.Nvec; i++) {
+        ColorSpinorField &x = *B[i];
+        for (int j = 0; j < i; j++) {
+          const Complex alpha = blas::cDotProduct(*B[j], x);
+          blas::caxpy(-alpha, *B[j], x);
+        }
+        const double nrm2 = blas::norm2(x);
+        if (nrm2 > 1e-16) blas::ax(1.0 / sqrt(nrm2), x);
+        else errorQuda("Cannot orthogonalize %d vector", i);
+      }
+      if (getVerbosity() >= QUDA_SUMMARIZE || mgProfiling())
+        printfQuda("MG level %d: %d null vectors by block BiCGstab on the %d-right-hand-side stencil: up to %d lockstep iterations (per vector %d..%d), %ld block applications, %.3f s\n",
+                   mgp.level + 1, mgp.Nvec, nb, kmaxAll, imin, imax, ctx.applies, now() - t0);
+      return;
+    }
+  }
   ColorSpinorField *b = likeField(*B[0]);
   b->twistFlavor = mgp.fineFlavor;
   const QudaVerbosity v0 = getVerbosity();

@@ -452,6 +452,143 @@ __global__ void block_gs_kernel(float *V, int blockVol, int K, int ncf, int spin
   }
 }
 
+// ---- CholeskyQR: the same block orthonormalisation in two passes over the block instead of nvec (nvec - 1) / 2 -----------------
+// Q R = V with R upper triangular and a positive diagonal is unique, so Q = V R^-1 with R from the Cholesky factorisation of the
+// Gram matrix G = V^dagger V (= R^dagger R) IS the Gram-Schmidt result — but G needs one sweep over the block (all 300 inner
+// products of 24 vectors at once, fp64 sums, the block staged through LDS in chunks of 256 elements) and V R^-1 a second one,
+// where modified Gram-Schmidt makes 276 dependent sweeps with two block reductions each (0.44 - 0.6 s at 48^3 x 96).  Run twice
+// (CholeskyQR2): the second round removes the orthogonality the first one loses to the conditioning of the block.  A block whose
+// Gram matrix is not numerically positive definite is left to the Gram-Schmidt kernel (fail flag).
+// Reference semantics: blockGramSchmidt, lib/transfer_util.cu:328-363.
+constexpr int kQrChunk = 256;
+template <int NVEC> __global__ void __launch_bounds__(256) block_cholqr_kernel(float *V, int blockVol, int K, int ncf, int spin_bs, int *failed) {
+  constexpr int nvec = NVEC;
+  extern __shared__ double smem[];
+  // layout: tile [kQrChunk][nvec + 1] float2 | G / L [nvec][nvec] double2 | Rinv [nvec][nvec] float2 | flag
+  float2 *tile = reinterpret_cast<float2 *>(smem);
+  constexpr int tstride = nvec + 1;
+  double2 *G = reinterpret_cast<double2 *>(tile + (size_t)kQrChunk * tstride + (kQrChunk * tstride & 1));
+  float2 *Rinv = reinterpret_cast<float2 *>(G + nvec * nvec);
+  int *bad = reinterpret_cast<int *>(Rinv + nvec * nvec);
+  const int A = blockIdx.x >> 1, chi = blockIdx.x & 1;
+  const int Kc = K / 2, n = Kc * blockVol, nsc = spin_bs * ncf;
+  constexpr int nvp = nvec / 2, npairs = nvec * (nvec + 1) / 2;
+  auto addr4 = [&](int e, int vp) -> size_t {   // float4 index of (element e, vector pair vp)
+    const int kk = e / blockVol, b = e - kk * blockVol;
+    return (((size_t)A * K + chi * nsc + kk) * nvp + vp) * blockVol + b;
+  };
+  float4 *V4 = reinterpret_cast<float4 *>(V);
+  if (threadIdx.x == 0) *bad = 0;
+  for (int round = 0; round < 2; round++) {
+    // ---- Gram matrix: pair p = (i <= j) per thread (up to 3 pairs for nvec = 32) ----
+    int pi[3], pj[3];
+    double2 acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int p = threadIdx.x + 256 * q;
+      acc[q] = make_double2(0.0, 0.0);
+      pi[q] = pj[q] = -1;
+      if (p < npairs) {   // row-major enumeration of the upper triangle
+        int i = 0, rem = p;
+        while (rem >= nvec - i) { rem -= nvec - i; i++; }
+        pi[q] = i; pj[q] = i + rem;
+      }
+    }
+    for (int c0 = 0; c0 < n; c0 += kQrChunk) {
+      __syncthreads();
+      const int e = c0 + threadIdx.x;
+#pragma unroll
+      for (int vp = 0; vp < nvp; vp++) {
+        const float4 w = e < n ? V4[addr4(e, vp)] : make_float4(0.f, 0.f, 0.f, 0.f);
+        tile[threadIdx.x * tstride + 2 * vp] = make_float2(w.x, w.y);
+        tile[threadIdx.x * tstride + 2 * vp + 1] = make_float2(w.z, w.w);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        if (pi[q] < 0) continue;
+        double re = 0, im = 0;
+        for (int t = 0; t < kQrChunk; t++) {
+          const float2 a = tile[t * tstride + pi[q]], b = tile[t * tstride + pj[q]];
+          re += (double)a.x * b.x + (double)a.y * b.y;
+          im += (double)a.x * b.y - (double)a.y * b.x;
+        }
+        acc[q].x += re; acc[q].y += im;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+      if (pi[q] >= 0) { G[pi[q] * nvec + pj[q]] = acc[q]; G[pj[q] * nvec + pi[q]] = make_double2(acc[q].x, -acc[q].y); }
+    __syncthreads();
+    // ---- Cholesky G = L L^dagger in place (lower triangle), column by column; thread i owns row i ----
+    for (int j = 0; j < nvec; j++) {
+      if ((int)threadIdx.x == j) {
+        double d = G[j * nvec + j].x;
+        for (int k = 0; k < j; k++) { const double2 l = G[j * nvec + k]; d -= l.x * l.x + l.y * l.y; }
+        if (!(d > 1e-12 * G[j * nvec + j].x) || !(d > 0.0)) { *bad = 1; d = 1.0; }
+        G[j * nvec + j] = make_double2(sqrt(d), 0.0);
+      }
+      __syncthreads();
+      const int i = threadIdx.x;
+      if (i > j && i < nvec) {
+        double2 v = G[i * nvec + j];
+        for (int k = 0; k < j; k++) {   // -= L[i][k] conj(L[j][k])
+          const double2 a = G[i * nvec + k], b = G[j * nvec + k];
+          v.x -= a.x * b.x + a.y * b.y; v.y -= a.y * b.x - a.x * b.y;
+        }
+        const double inv = 1.0 / G[j * nvec + j].x;
+        G[i * nvec + j] = make_double2(v.x * inv, v.y * inv);
+      }
+      __syncthreads();
+    }
+    if (*bad) break;
+    // ---- R = L^dagger (upper); column j of R^-1 by back substitution, thread j ----
+    if ((int)threadIdx.x < nvec) {
+      const int j = threadIdx.x;
+      double2 x[NVEC];
+#pragma unroll
+      for (int i = nvec - 1; i >= 0; i--) {
+        double2 v = make_double2(i == j ? 1.0 : 0.0, 0.0);
+#pragma unroll
+        for (int k = i + 1; k < nvec; k++) {   // R[i][k] = conj(L[k][i])
+          if (k > j) continue;
+          const double2 r = G[k * nvec + i];
+          v.x -= r.x * x[k].x + r.y * x[k].y; v.y -= r.x * x[k].y - r.y * x[k].x;
+        }
+        const double inv = 1.0 / G[i * nvec + i].x;
+        x[i] = i <= j ? make_double2(v.x * inv, v.y * inv) : make_double2(0.0, 0.0);
+      }
+#pragma unroll
+      for (int i = 0; i < nvec; i++) Rinv[i * nvec + j] = make_float2((float)x[i].x, (float)x[i].y);
+    }
+    __syncthreads();
+    // ---- V <- V R^-1: thread per element ----
+    for (int c0 = 0; c0 < n; c0 += 256) {
+      const int e = c0 + threadIdx.x;
+      if (e >= n) continue;
+      float2 v[NVEC];
+#pragma unroll
+      for (int vp = 0; vp < nvp; vp++) { const float4 w = V4[addr4(e, vp)]; v[2 * vp] = make_float2(w.x, w.y); v[2 * vp + 1] = make_float2(w.z, w.w); }
+#pragma unroll
+      for (int vp = nvp - 1; vp >= 0; vp--) {   // columns from the right: column j only needs v[0..j], so v can be overwritten in place
+        float2 o[2];
+#pragma unroll
+        for (int h = 1; h >= 0; h--) {
+          const int j = 2 * vp + h;
+          float re = 0.f, im = 0.f;
+#pragma unroll
+          for (int i = 0; i <= j; i++) { const float2 r = Rinv[i * nvec + j]; re += v[i].x * r.x - v[i].y * r.y; im += v[i].x * r.y + v[i].y * r.x; }
+          o[h] = make_float2(re, im);
+        }
+        v[2 * vp] = o[0]; v[2 * vp + 1] = o[1];
+        V4[addr4(e, vp)] = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && *bad) atomicAdd(failed, 1);
+}
+
 // ---- random source ----
 __device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long i) {
   unsigned long long z = seed + 0x9E3779B97F4A7C15ULL * (i + 1);
@@ -570,7 +707,40 @@ void Transfer::fillAndOrthonormalise(const std::vector<ColorSpinorField *> &B) {
   if (fineSpin == 4) hipLaunchKernelGGL((fillv_kernel<4>), dim3((total + 255) / 256), dim3(256), 0, computeStream(), V, vl, f0.stride, f0.Vh, block_to_fine, blockVol, K, Nvec, total);
   else hipLaunchKernelGGL((fillv_kernel<2>), dim3((total + 255) / 256), dim3(256), 0, computeStream(), V, vl, f0.stride, f0.Vh, block_to_fine, blockVol, K, Nvec, total);
   HIP_CHECK(hipGetLastError());
-  hipLaunchKernelGGL(block_gs_kernel, dim3(2 * nAgg), dim3(256), 0, computeStream(), V, blockVol, K, fineColor, spin_bs, Nvec);
+  static int useQr = -1;
+  if (useQr < 0) { const char *e = getenv("QUDA_AMD_BLOCK_ORTHO"); useQr = (e && !strcmp(e, "gs")) ? 0 : 1; }
+  int nfail = useQr ? 0 : 1;
+  if (useQr) {
+    int *d_fail = nullptr;
+    HIP_CHECK(hipMalloc((void **)&d_fail, sizeof(int)));
+    HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(int), computeStream()));
+    const size_t tileFloats2 = (size_t)kQrChunk * (Nvec + 1) + 1;
+    const size_t lds = tileFloats2 * sizeof(float2) + (size_t)Nvec * Nvec * (sizeof(double2) + sizeof(float2)) + 64;
+#define QA_QR(NV)                                                                                                                  \
+  {                                                                                                                                \
+    HIP_CHECK(hipFuncSetAttribute((const void *)block_cholqr_kernel<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
+    hipLaunchKernelGGL((block_cholqr_kernel<NV>), dim3(2 * nAgg), dim3(256), lds, computeStream(), V, blockVol, K, fineColor, spin_bs, d_fail); \
+  }
+    switch (Nvec) {
+      case 4: QA_QR(4) break;
+      case 8: QA_QR(8) break;
+      case 24: QA_QR(24) break;
+      case 32: QA_QR(32) break;
+      default: nfail = 1;   // not instantiated: Gram-Schmidt
+    }
+#undef QA_QR
+    HIP_CHECK(hipGetLastError());
+    if (!nfail) HIP_CHECK(hipMemcpyAsync(&nfail, d_fail, sizeof(int), hipMemcpyDeviceToHost, computeStream()));
+    HIP_CHECK(hipStreamSynchronize(computeStream()));
+    HIP_CHECK(hipFree(d_fail));
+    if (nfail && (Nvec == 4 || Nvec == 8 || Nvec == 24 || Nvec == 32)) {
+      warningQuda("block orthonormalisation: %d blocks with a numerically singular Gram matrix, falling back to Gram-Schmidt", nfail);
+      // the failed blocks left V untouched or partially updated: refill and run the sequential kernel on everything
+      if (fineSpin == 4) hipLaunchKernelGGL((fillv_kernel<4>), dim3((total + 255) / 256), dim3(256), 0, computeStream(), V, vl, f0.stride, f0.Vh, block_to_fine, blockVol, K, Nvec, total);
+      else hipLaunchKernelGGL((fillv_kernel<2>), dim3((total + 255) / 256), dim3(256), 0, computeStream(), V, vl, f0.stride, f0.Vh, block_to_fine, blockVol, K, Nvec, total);
+    }
+  }
+  if (nfail) hipLaunchKernelGGL(block_gs_kernel, dim3(2 * nAgg), dim3(256), 0, computeStream(), V, blockVol, K, fineColor, spin_bs, Nvec);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(computeStream()));
 }

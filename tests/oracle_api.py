@@ -89,6 +89,16 @@ class Oracle:
                                                          flavor, dagger, _x(X))
         return out
 
+    def gcr_tm(self, gauge, b, X, kappa, mu, flavor, tol=1e-10, nkrylov=20, maxiter=5000):
+        """plain restarted GCR on tm_mat (oracle/qo_solver.c): returns (x, iterations, seconds, true residual)"""
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        x = np.zeros_like(b)
+        secs, res = C.c_double(0), C.c_double(0)
+        self.lib.qo_gcr_tm_d.restype = C.c_int
+        it = self.lib.qo_gcr_tm_d(_p(x), _g(gauge), _p(b), _x(X), C.c_double(kappa), C.c_double(mu), int(flavor), C.c_double(tol), int(nkrylov), int(maxiter),
+                                  C.byref(secs), C.byref(res))
+        return x, int(it), secs.value, res.value
+
     def wil_mat(self, gauge, inp, X, kappa, dagger):
         out = np.empty_like(inp)
         self.lib.qo_wil_mat_d(_p(out), _g(gauge), _p(inp), C.c_double(kappa), dagger, _x(X))

@@ -72,6 +72,7 @@ def test_ctypes_mirrors_have_the_same_size():
 def _declared(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"^\s*typedef[^;]*\(\s*\*\s*\w+\s*\)[^;]*;", "", txt, flags=re.M)   # function-pointer typedefs declare no symbol
     return set(re.findall(r"^\s*(?:[A-Za-z_][\w\s\*]*?)\b(\w+)\s*\([^;{]*\)\s*;", txt, flags=re.M)) - {"defined"}
 
 
