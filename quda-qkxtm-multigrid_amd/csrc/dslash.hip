@@ -625,7 +625,7 @@ struct FineBlockArg {
 
 template <int NRHS> __global__ void __launch_bounds__(256) fine_block_kernel(const FineBlockArg arg) {
   constexpr int SPB = NRHS == 24 ? 8 : 256 / NRHS;   // sites per work-group (192 threads for 24 right-hand sides, else 256)
-  constexpr int USTR = 8 * 18 + 8;                    // floats per site of staged links (pad: 3 neighbouring sites on distinct banks)
+  constexpr int USTR = 8 * 18 + 4;                    // floats per site of staged links: 148 = 20 mod 32, the up to 8 sites of a wave start on 8 different banks
   __shared__ float ulds[SPB * USTR];
   const int lb = arg.order.map(blockIdx.x);
   const int s = threadIdx.x / NRHS, i = threadIdx.x - s * NRHS;
@@ -670,12 +670,18 @@ template <int NRHS> __global__ void __launch_bounds__(256) fine_block_kernel(con
 #pragma unroll
   for (int k = 0; k < 24; k++) acc[k] = 0.f;
   const float *U0 = &ulds[s * USTR];
-  auto hop = [&](auto DIRC, int nbr) {
-    constexpr int DIR = decltype(DIRC)::value, MU = DIR / 2;
-    const float2 *p = arg.in_other + ((size_t)nbr * 12) * NRHS + i;
-    float psi[24], h[12], g[12], U[18];
+  // Same register discipline as stencil_site: two panel buffers, the loads of hop d + 1 issued before the arithmetic of hop d,
+  // fenced so the compiler neither hoists all 108 loads to the top (256 registers, one wave per SIMD: 12.7 ms per launch at
+  // 48^3 x 96, four times the bandwidth bound) nor serialises them.
+  float pA[24], pB[24];
+  auto load_panel = [&](float *psi, const float2 *base, int site) {
+    const float2 *p = base + ((size_t)site * 12) * NRHS + i;
 #pragma unroll
     for (int j = 0; j < 12; j++) { const float2 v = p[j * NRHS]; psi[2 * j] = v.x; psi[2 * j + 1] = v.y; }
+  };
+  auto hop = [&](auto DIRC, float *psi) {
+    constexpr int DIR = decltype(DIRC)::value, MU = DIR / 2;
+    float h[12], g[12], U[18];
 #pragma unroll
     for (int k = 0; k < 18; k++) U[k] = U0[DIR * 18 + k];
     const float sgn = (DIR & 1) ? -1.f : 1.f;
@@ -684,18 +690,25 @@ template <int NRHS> __global__ void __launch_bounds__(256) fine_block_kernel(con
     su3_mv(g + 6, U, h + 6);
     spin_reconstruct<MU>(acc, g, sgn);
   };
-  hop(std::integral_constant<int, 0>{}, nb[0]); hop(std::integral_constant<int, 1>{}, nb[1]);
-  hop(std::integral_constant<int, 2>{}, nb[2]); hop(std::integral_constant<int, 3>{}, nb[3]);
-  hop(std::integral_constant<int, 4>{}, nb[4]); hop(std::integral_constant<int, 5>{}, nb[5]);
-  hop(std::integral_constant<int, 6>{}, nb[6]); hop(std::integral_constant<int, 7>{}, nb[7]);
+#define FB_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define FB_PIN() _Pragma("unroll") for (int k_ = 0; k_ < 24; k_++) asm volatile("" : "+v"(acc[k_]))
+#define FB_LD(B, D) load_panel(p##B, arg.in_other, nb[D])
+#define FB_CP(B, D) FB_FENCE(); hop(std::integral_constant<int, D>{}, p##B); FB_PIN(); FB_FENCE()
+  FB_LD(A, 0); FB_LD(B, 1); FB_CP(A, 0); FB_LD(A, 2); FB_CP(B, 1); FB_LD(B, 3); FB_CP(A, 2);
+  FB_LD(A, 4); FB_CP(B, 3); FB_LD(B, 5); FB_CP(A, 4); FB_LD(A, 6); FB_CP(B, 5); FB_LD(B, 7);
+  FB_CP(A, 6);
+  load_panel(pA, arg.in_same, idx);   // the site's own panel (twist term) travels while the last hop is computed
+  FB_CP(B, 7);
+#undef FB_FENCE
+#undef FB_PIN
+#undef FB_LD
+#undef FB_CP
   // out = (1 + i a g5) in(x) - kappa acc
-  const float2 *q = arg.in_same + ((size_t)idx * 12) * NRHS + i;
   float2 *o = arg.out + ((size_t)idx * 12) * NRHS + i;
 #pragma unroll
   for (int j = 0; j < 12; j++) {
-    const float2 v = q[j * NRHS];
     const float a = j < 6 ? arg.a : -arg.a;   // g5 = diag(+,+,-,-): spins 0,1 are components 0..5
-    o[j * NRHS] = make_float2(v.x - a * v.y + arg.mkappa * acc[2 * j], v.y + a * v.x + arg.mkappa * acc[2 * j + 1]);
+    o[j * NRHS] = make_float2(pA[2 * j] - a * pA[2 * j + 1] + arg.mkappa * acc[2 * j], pA[2 * j + 1] + a * pA[2 * j] + arg.mkappa * acc[2 * j + 1]);
   }
 }
 

@@ -260,7 +260,9 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
   {
     const Dirac *df = mgp.matResidual.Expose();
     const QudaDiracType ty = df ? df->getDiracType() : QUDA_INVALID_DIRAC;
-    constexpr int nb = 8;
+    static int nbEnv = -1;
+    if (nbEnv < 0) { const char *e = getenv("QUDA_AMD_BLOCK_FINE_NRHS"); nbEnv = e ? atoi(e) : 8; if (nbEnv != 8 && nbEnv != 16 && nbEnv != 24 && nbEnv != 32) nbEnv = 8; }
+    const int nb = nbEnv;
     if (df && (ty == QUDA_TWISTED_MASS_DIRAC || ty == QUDA_WILSON_DIRAC) && B[0]->Nspin() == 4 && B[0]->Precision() == QUDA_SINGLE_PRECISION &&
         mgp.Nvec % nb == 0 && df->Gauge() && fineBlockSupported(*df->Gauge(), nb)) {
       const double t0 = now();
@@ -324,7 +326,10 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
 // not have; the container here is a 64-byte header (magic, lattice, nSpin, nColor, Nvec, process grid) followed by the
 // vectors in the order the reference gives QIO — site-major (parity*Vh + x_cb, spin, colour, re/im), fp32 — one file per
 // rank ("….rank<r>" when there is more than one). ----
-struct NullVecHeader { char magic[8]; int X[4]; int nSpin, nColor, Nvec, precision; int grid[4]; int rank, pad; };
+// `order` = 0x01020304 as written by the producer: a reader on a machine of the other endianness sees 0x04030201 and refuses the
+// file (version 1 files, "QAMDNV01", carry 0 there and are read as native)
+struct NullVecHeader { char magic[8]; int X[4]; int nSpin, nColor, Nvec, precision; int grid[4]; int rank, order; };
+constexpr int kNullVecOrder = 0x01020304;
 static std::string nullVecFile(const char *base, int level) {
   std::string f(base);
   f += "_level_" + std::to_string(level);
@@ -345,7 +350,8 @@ void MG::saveVectors(std::vector<ColorSpinorField *> &B) {
   if (!fp) errorQuda("cannot open %s for writing", f.c_str());
   NullVecHeader h;
   memset(&h, 0, sizeof(h));
-  memcpy(h.magic, "QAMDNV01", 8);
+  memcpy(h.magic, "QAMDNV02", 8);
+  h.order = kNullVecOrder;
   for (int d = 0; d < 4; d++) { h.X[d] = B[0]->X(d); h.grid[d] = commGrid().dims[d]; }
   h.nSpin = B[0]->Nspin(); h.nColor = B[0]->Ncolor(); h.Nvec = (int)B.size(); h.precision = 4; h.rank = commGrid().rank;
   const size_t n = (size_t)B[0]->Volume() * h.nSpin * h.nColor * 2;
@@ -366,10 +372,13 @@ void MG::loadVectors(std::vector<ColorSpinorField *> &B) {
   FILE *fp = fopen(f.c_str(), "rb");
   if (!fp) errorQuda("cannot open %s", f.c_str());
   NullVecHeader h;
-  if (fread(&h, sizeof(h), 1, fp) != 1 || memcmp(h.magic, "QAMDNV01", 8)) errorQuda("%s is not a null-vector file of this library", f.c_str());
+  if (fread(&h, sizeof(h), 1, fp) != 1 || (memcmp(h.magic, "QAMDNV01", 8) && memcmp(h.magic, "QAMDNV02", 8)))
+    errorQuda("%s is not a null-vector file of this library (the reference's QIO / LIME vector files are a different container, see INTEGRATION.md)", f.c_str());
+  if (!memcmp(h.magic, "QAMDNV02", 8) && h.order != kNullVecOrder) errorQuda("%s was written on a machine of the other byte order", f.c_str());
   for (int d = 0; d < 4; d++)
     if (h.X[d] != B[0]->X(d) || h.grid[d] != commGrid().dims[d]) errorQuda("%s was written for lattice %d %d %d %d on grid %d %d %d %d", f.c_str(), h.X[0], h.X[1], h.X[2], h.X[3], h.grid[0], h.grid[1], h.grid[2], h.grid[3]);
   if (h.nSpin != B[0]->Nspin() || h.nColor != B[0]->Ncolor() || h.Nvec < (int)B.size() || h.rank != commGrid().rank) errorQuda("%s does not match this level (nSpin %d nColor %d Nvec %d rank %d)", f.c_str(), h.nSpin, h.nColor, h.Nvec, h.rank);
+  if (h.Nvec > (int)B.size()) warningQuda("%s holds %d vectors, this level uses the first %zu", f.c_str(), h.Nvec, B.size());
   const size_t n = (size_t)B[0]->Volume() * h.nSpin * h.nColor * 2;
   std::vector<float> buf(n);
   for (size_t i = 0; i < B.size(); i++) {
