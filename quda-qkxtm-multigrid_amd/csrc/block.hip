@@ -30,13 +30,14 @@ namespace quda {
 BlockField::BlockField(int nSites_, int ncomp_, int nrhs_) : nSites(nSites_), Vh(nSites_ / 2), ncomp(ncomp_), nrhs(nrhs_) {
   if (nrhs < 1 || nrhs > kMaxBlockRhs) errorQuda("block field with %d right-hand sides (1..%d supported)", nrhs, kMaxBlockRhs);
   bytes = elems() * sizeof(float2);
-  // work fields of the setup only: straight from / back to the runtime (the size-bucketed pool would keep tens of GB for good)
-  HIP_CHECK(hipMalloc((void **)&v, bytes));
+  // From the size-bucketed pool (qa_core.h): the solver's six work fields have the same size in every batch of right-hand sides and
+  // in every hierarchy (up / down flavour), so they are allocated once per process.  Allocating and releasing them per batch was
+  // measured at 48^3 x 96: 5 of the 8 s of the null-vector stage went into hipMalloc / hipFree of ~150 GB (the runtime unmaps
+  // at tens of ms per GB, and the next large hipMalloc waits for it).  endQuda returns the pool.
+  v = (float2 *)poolDeviceMalloc(bytes);
   HIP_CHECK(hipMemsetAsync(v, 0, bytes, computeStream()));
 }
-BlockField::~BlockField() {
-  if (v) { HIP_CHECK(hipStreamSynchronize(computeStream())); (void)hipFree(v); }
-}
+BlockField::~BlockField() { if (v) poolDeviceFree(v, bytes); }
 
 // ---- gather / scatter ----
 struct BlockPtrs { float *v[2][kMaxBlockRhs]; };

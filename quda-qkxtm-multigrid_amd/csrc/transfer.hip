@@ -185,6 +185,7 @@ __global__ void __launch_bounds__(256) restrict4_kernel(Multi4 a, const float4 *
       for (int k = 0; k < K; k++) { const size_t i = fidx<NV>(a.in[q].stride, x, k); r[q][k] = make_float2(base[i], base[i + 1]); }
     }
   }
+#pragma unroll 1
   for (int it = 0; it < NIT; it++) {
     const int chi = it / (NVEC / 2), vp = it - chi * (NVEC / 2);
     float4 acc[4];
@@ -202,16 +203,33 @@ __global__ void __launch_bounds__(256) restrict4_kernel(Multi4 a, const float4 *
         }
       }
     }
+    // wave sum of the 32 partial reals (4 right-hand sides x {leaving, staying} x float4) by a reduce-scatter butterfly: at every
+    // stage a lane keeps one half of its values and adds the partner's copy of that half, so the five xor stages move
+    // 16 + 8 + 4 + 2 + 1 values instead of 32 each, one more adds the two half-waves: 32 cross-lane moves instead of 192
+    // (the shuffle chains, not the V stream, held this kernel at 2.3 TB/s)
+    float w[32];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 so = (site && outside[q]) ? acc[q] : z, si = (site && !outside[q]) ? acc[q] : z;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        so.x += __shfl_down(so.x, off, 64); so.y += __shfl_down(so.y, off, 64); so.z += __shfl_down(so.z, off, 64); so.w += __shfl_down(so.w, off, 64);
-        si.x += __shfl_down(si.x, off, 64); si.y += __shfl_down(si.y, off, 64); si.z += __shfl_down(si.z, off, 64); si.w += __shfl_down(si.w, off, 64);
-      }
-      if (lane == 0) { part[wave][it][2 * q] = so; part[wave][it][2 * q + 1] = si; }
+      const bool so = site && outside[q], si = site && !outside[q];
+      w[8 * q + 0] = so ? acc[q].x : 0.f; w[8 * q + 1] = so ? acc[q].y : 0.f; w[8 * q + 2] = so ? acc[q].z : 0.f; w[8 * q + 3] = so ? acc[q].w : 0.f;
+      w[8 * q + 4] = si ? acc[q].x : 0.f; w[8 * q + 5] = si ? acc[q].y : 0.f; w[8 * q + 6] = si ? acc[q].z : 0.f; w[8 * q + 7] = si ? acc[q].w : 0.f;
+    }
+    // (written out stage by stage: with the stage as a loop variable the register array was indexed dynamically, 1900 selects per step)
+#define QA_BFLY(HALF, M)                                                                 \
+    {                                                                                    \
+      const bool up = (lane & M) != 0;                                                   \
+      _Pragma("unroll") for (int j = 0; j < HALF; j++) {                                 \
+        const float keep = up ? w[HALF + j] : w[j], give = up ? w[j] : w[HALF + j];     \
+        w[j] = keep + __shfl_xor(give, M, 64);                                           \
+      }                                                                                  \
+    }
+    QA_BFLY(16, 1) QA_BFLY(8, 2) QA_BFLY(4, 4) QA_BFLY(2, 8) QA_BFLY(1, 16)
+#undef QA_BFLY
+    w[0] += __shfl_xor(w[0], 32, 64);
+    // lane l < 32 now holds the total of value index sum_s bit_s(l) * (16 >> s)
+    if (lane < 32) {
+      const int vi = ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+      reinterpret_cast<float *>(&part[wave][it][0])[vi] = w[0];
     }
   }
   __syncthreads();
