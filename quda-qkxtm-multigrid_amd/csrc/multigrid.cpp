@@ -270,14 +270,19 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
       struct Ctx { const GaugeField *U; double kappa, a; long applies; } ctx = {df->Gauge(), df->Kappa(), a, 0};
       int kmaxAll = 0, imin = 1 << 30, imax = 0;
       for (int i = 0; i < mgp.Nvec; i++) { B[i]->twistFlavor = mgp.fineFlavor; spinorRandom(*B[i], 0x5eedULL + 7919ULL * (mgp.level * 131 + i)); }
+      double tPack = 0, tSolve = 0;
       for (int g0 = 0; g0 < mgp.Nvec; g0 += nb) {
         std::vector<ColorSpinorField *> Bv(B.begin() + g0, B.begin() + g0 + nb);
+        double tp = now();
         BlockField X(B[0]->Volume(), 12, nb);
         blockPack(X, Bv);
+        if (mgProfiling()) { HIP_CHECK(hipStreamSynchronize(computeStream())); tPack += now() - tp; tp = now(); }
         int iters[kMaxBlockRhs];
         const int kmax = blockBiCGstabNull(X, [](BlockField &out, const BlockField &in, void *c) { Ctx *x = (Ctx *)c; applyFineBlockM(out.v, in.v, in.nrhs, *x->U, x->kappa, x->a); x->applies++; },
                                            &ctx, sp.tol, sp.maxiter, iters);
+        if (mgProfiling()) { HIP_CHECK(hipStreamSynchronize(computeStream())); tSolve += now() - tp; tp = now(); }
         blockUnpack(Bv, X);
+        if (mgProfiling()) { HIP_CHECK(hipStreamSynchronize(computeStream())); tPack += now() - tp; }
         kmaxAll = kmax > kmaxAll ? kmax : kmaxAll;
         for (int i = 0; i < nb; i++) { imin = iters[i] < imin ? iters[i] : imin; imax = iters[i] > imax ? iters[i] : imax; }
       }
@@ -291,6 +296,7 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
         if (nrm2 > 1e-16) blas::ax(1.0 / sqrt(nrm2), x);
         else errorQuda("Cannot orthogonalize %d vector", i);
       }
+      if (mgProfiling()) printfQuda("MG level %d: block null-vector stage: pack/unpack + field allocation %.3f s, lockstep solves %.3f s, orthonormalisation %.3f s\n", mgp.level + 1, tPack, tSolve, now() - t0 - tPack - tSolve);
       if (getVerbosity() >= QUDA_SUMMARIZE || mgProfiling())
         printfQuda("MG level %d: %d null vectors by block BiCGstab on the %d-right-hand-side stencil: up to %d lockstep iterations (per vector %d..%d), %ld block applications, %.3f s\n",
                    mgp.level + 1, mgp.Nvec, nb, kmaxAll, imin, imax, ctx.applies, now() - t0);
