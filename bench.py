@@ -33,13 +33,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 from synth import make_clover, make_gauge, smooth_gauge, tiled_gauge  # noqa: E402
 
 
-def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)), gauge=None, extras=True):
+def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)), gauge=None, extras=True, kappa=0.124, mu=0.005, plain_maxiter=5000,
+           coarse_bench=True):
     """MG-preconditioned GCR to |r|/|b| <= 1e-10 (the second half of the metric) on one GPU: 3-level K-cycle, 24 null
     vectors, 4^4 then 2^4 aggregates, even-odd preconditioned MR smoother — the reference harness' default shape
     (tests/multigrid_invert_test.cpp:224-286) on a smooth synthetic gauge field (synth.smooth_gauge: far easier than a production
     configuration — plain GCR needs only 76 iterations — so the MG / plain ratio here understates what MG buys at the physical point).  Setup (null
     vectors + Galerkin operators) and solve are timed separately; the residual is re-computed with MatQuda."""
-    kappa, mu = 0.124, 0.005
     qa.lib().freeCloverQuda()
     if gauge is None:
         gauge = smooth_gauge(X, 0.35)
@@ -52,7 +52,7 @@ def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2,
     ip.inv_type = qa.QUDA_GCR_INVERTER
     ip.gcrNkrylov = 20
     ip.tol = 1e-10
-    ip.maxiter = 5000
+    ip.maxiter = plain_maxiter
     b = np.random.default_rng(5).random(int(np.prod(X)) * 24)
 
     def timed_solve():
@@ -70,8 +70,13 @@ def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2,
         return best
 
     ip.inv_type_precondition = qa.QUDA_INVALID_ENUM
-    wall, inner, iters, _ = timed_solve()
-    plain = dict(iters=iters, secs=round(wall, 4), solver_secs=round(inner, 4))
+    if plain_maxiter > 5000:   # thousands of iterations: one solve, not best-of-three
+        t0 = time.perf_counter(); xp = qa.invert(b, ip); wall = time.perf_counter() - t0
+        inner, iters = ip.secs, ip.iter
+    else:
+        wall, inner, iters, xp = timed_solve()
+    plain = dict(iters=iters, secs=round(wall, 4), solver_secs=round(inner, 4), true_res=float(np.linalg.norm(b - qa.mat(xp, ip)) / np.linalg.norm(b)))
+    ip.maxiter = 5000
     mp = qa.multigrid_param(ip, n_level=3, geo_block=[tuple(bk) for bk in blocks], n_vec=24, setup_maxiter=500, setup_tol=5e-6, smoother_pc=True)
     mg = qa.Multigrid(mp)
     ip.inv_type_precondition = qa.QUDA_MG_INVERTER
@@ -86,6 +91,8 @@ def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2,
     # the multi-right-hand-side coarse operator on the matrix cores (level 1: 2 Nvec = 48 rows, 9 dense matrices per site) against
     # the single-vector kernel: seconds per application, HBM rate on the ALGORITHMIC bytes (links once + in/out panels) and MFMA rate
     try:
+        if not coarse_bench:
+            raise RuntimeError("not requested for this leg")
         info = mg.level_info(0)
         Vc, nn = int(np.prod(info["Xc"])), 2 * info["Nvec"]
         single = mg.time_apply(1, 20)
@@ -224,10 +231,17 @@ def main():
         extra["stream_axpy_f64"] = dict(hbm_gbs=round(3 * 2 * Vh_local * 24 * 8 / sec * 1e-9, 1), us=round(1e6 * sec, 2))
         sx.free(); sy.free()
 
-    g32 = None
+    g16 = None
     if not args.no_extra and rank == 0 and world == 1:
-        g32 = smooth_gauge((32, 32, 32, 32), 0.35)   # kept for the CPU solver baseline below
+        g32 = smooth_gauge((32, 32, 32, 32), 0.35)
         extra["mg_gcr"] = run_mg(qa, (32, 32, 32, 32), gauge=g32)
+        # where multigrid matters: the same field at its critical kappa (tools/mg_kappa_scan.py, profiles/r02_mg_kappa_scan_32x4_c.json:
+        # plain GCR(20) needs > 10^4 iterations there and stagnates beyond it; the twisted mass keeps the operator regular)
+        extra["mg_gcr_critical"] = run_mg(qa, (32, 32, 32, 32), gauge=g32, extras=False, kappa=0.147, mu=0.001, plain_maxiter=30000, coarse_bench=False)
+        del g32
+        # the SAME small problem on the GPU and, below, on the host cores (cpu_baseline.solver): 16^4, same field family, kappa, mu
+        g16 = smooth_gauge((16, 16, 16, 16), 0.35)
+        extra["mg_gcr_16x4"] = run_mg(qa, (16, 16, 16, 16), gauge=g16, extras=False, coarse_bench=False)
         # BASELINE.json configs[4] (48^3 x 96, quoted by the reference on 8 GPUs) resident on this one GPU: 288 GB holds the whole
         # hierarchy; levels by the reference's blocking rule 48^3 x 96 -> 12^3 x 24 -> 6^4 (lib/transfer.cpp:31-44)
         from synth import smooth_gauge_cayley
@@ -262,15 +276,16 @@ def main():
         cpu = dict(value=round(1368.0 * Vh_local / tall * 1e-9, 3), unit="GFLOP/s", cores=cores, kind="port",
                    sample="%d x tm_dslash fp64 on %s (oracle/liboracle.so, outer parallel-for over sites); 1 thread = %.3f GFLOP/s"
                    % (n_all, "x".join(str(v) for v in Xc), 1368.0 * Vh_local / t1 * 1e-9))
-        if g32 is not None:
+        if g16 is not None:
             # the solver half of the metric on the host: the reference's restarted GCR(20) (lib/inv_gcr_quda.cpp, plainest configuration)
-            # on the host tm_mat with lib/blas_cpu.cpp-style BLAS (oracle/qo_solver.c), fp64, SAME 32^4 problem (field, kappa, mu,
-            # source, tolerance) as extra.mg_gcr / extra.mg_gcr.plain_gcr on the GPU
-            bsol = np.random.default_rng(5).random(32 ** 4 * 24)
-            _, it_cpu, secs_cpu, res_cpu = oracle.gcr_tm(g32, bsol, [32, 32, 32, 32], 0.124, 0.005, +1, tol=1e-10, nkrylov=20, maxiter=5000)
-            cpu["solver"] = dict(what="plain GCR(20) to 1e-10 on tm_mat, fp64, 32x32x32x32, kappa 0.124 mu 0.005 (same problem as extra.mg_gcr)",
-                                 secs=round(secs_cpu, 2), iters=it_cpu, true_res=res_cpu, cores=cores,
-                                 gpu_plain_gcr_secs=extra.get("mg_gcr", {}).get("plain_gcr", {}).get("secs"), gpu_mg_gcr_secs=extra.get("mg_gcr", {}).get("solve_secs"))
+            # on the host tm_mat with lib/blas_cpu.cpp-style BLAS (oracle/qo_solver.c), fp64, on the SAME 16^4 problem (field, kappa, mu,
+            # source, tolerance) as extra.mg_gcr_16x4 on the GPU — a size the host finishes in seconds (at 32^4 it took 244 s on 16 cores)
+            bsol = np.random.default_rng(5).random(16 ** 4 * 24)
+            _, it_cpu, secs_cpu, res_cpu = oracle.gcr_tm(g16, bsol, [16, 16, 16, 16], 0.124, 0.005, +1, tol=1e-10, nkrylov=20, maxiter=5000)
+            g = extra.get("mg_gcr_16x4", {})
+            cpu["solver"] = dict(what="plain GCR(20) to 1e-10 on tm_mat, fp64, 16x16x16x16, kappa 0.124 mu 0.005 (same problem as extra.mg_gcr_16x4)",
+                                 secs=round(secs_cpu, 3), iters=it_cpu, true_res=res_cpu, cores=cores,
+                                 gpu_plain_gcr_secs=g.get("plain_gcr", {}).get("secs"), gpu_mg_gcr_secs=g.get("solve_secs"), gpu_mg_setup_secs=g.get("setup_secs"))
         oracle.set_threads(1)
 
     traffic, traffic_source = None, None
@@ -280,10 +295,13 @@ def main():
         tname = {8: "double", 4: "float", 2: "short"}[args.prec]
         variant = {"tm": 0, "wilson": 0, "tmc": 2}[args.dslash]
         key = "dslash_kernel<%s, %d, %d," % (tname, args.recon, variant)
+        lat_tag = "_%s_" % ("32x4" if X == [32, 32, 32, 32] else "x".join(map(str, X)))
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
+            if lat_tag not in os.path.basename(path):   # the summaries are named after their lattice: never quote another volume's traffic
+                continue
             try:
                 for k, v in json.load(open(path))["kernels"].items():
-                    if key in k and "hbm_bytes_per_launch" in v and X == [32, 32, 32, 32]:
+                    if key in k and "hbm_bytes_per_launch" in v:
                         traffic, traffic_source = round(v["hbm_bytes_per_launch"]), os.path.basename(path)
             except Exception:
                 pass

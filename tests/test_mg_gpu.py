@@ -229,6 +229,36 @@ def test_block_bicgstab_null_vectors_give_the_same_hierarchy_quality(qa, oracle)
         mg.free()
 
 
+def test_mg_gcr_where_plain_gcr_stalls(qa, oracle):
+    """The regime multigrid is for (reference tests/multigrid_invert_test.cpp:529-577 for the check): the synthetic
+    warm-start field at its critical kappa (0.147 at 32^4, mu = 0.001: smallest singular value ~ 2 kappa mu; scan in
+    profiles/r02_mg_kappa_scan_32x4_c.json — plain GCR(20) needs 11 258 iterations there and stagnates beyond it).  Plain GCR is
+    nowhere near converged after 1000 iterations; the 3-level MG-GCR reaches 1e-10, the residual recomputed on the HOST with the
+    oracle's tm_mat."""
+    X, kappa, mu = (32, 32, 32, 32), 0.147, 0.001
+    gauge, ip = _setup(qa, X, kappa, mu)
+    b = np.random.default_rng(5).random(int(np.prod(X)) * 24)
+    ip.inv_type_precondition = qa.QUDA_INVALID_ENUM
+    ip.maxiter = 1000
+    x_plain = qa.invert(b, ip)
+    res_plain = _true_residual(oracle, gauge, X, kappa, mu, x_plain, b)
+    assert ip.iter >= 1000 and res_plain > 1e-6, (ip.iter, res_plain)
+    mp = qa.multigrid_param(ip, n_level=3, geo_block=[(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)], n_vec=24, setup_maxiter=500, setup_tol=5e-6, smoother_pc=True)
+    mg = qa.Multigrid(mp)
+    try:
+        ip.inv_type_precondition = qa.QUDA_MG_INVERTER
+        ip.preconditioner = mg.h
+        ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
+        ip.maxiter, ip.tol = 2000, 5e-11
+        x = qa.invert(b, ip)
+        res = _true_residual(oracle, gauge, X, kappa, mu, x, b)
+        print("critical kappa: plain GCR %.1e after 1000 iterations; MG-GCR %d iterations, %.3f s in the solver, host residual %.2e" % (res_plain, ip.iter, ip.secs, res))
+        assert res < 1e-10, res
+        assert ip.iter < 400, ip.iter
+    finally:
+        mg.free()
+
+
 def test_outer_even_odd_solve_with_up_and_down_hierarchies(qa, oracle):
     """The QKXTM production shape (reference lib/interface_quda.cpp:6041, :6389-6520; qkxtm/CalcMG_2pt3pt_EvenOdd.cpp:649-747):
     outer GCR on the even-odd preconditioned system (solve_type = QUDA_DIRECT_PC_SOLVE, full-field MAT solution through
