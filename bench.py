@@ -21,6 +21,11 @@ import os
 import sys
 import time
 
+# the CPU-baseline legs run OpenMP loops with many short parallel regions (BLAS-1 of the host GCR): on a box whose CPU share is a
+# cgroup quota, spinning at the barriers eats the quota and the solve took 229 s instead of 2 s — make idle threads sleep
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -281,10 +286,12 @@ def main():
             # on the host tm_mat with lib/blas_cpu.cpp-style BLAS (oracle/qo_solver.c), fp64, on the SAME 16^4 problem (field, kappa, mu,
             # source, tolerance) as extra.mg_gcr_16x4 on the GPU — a size the host finishes in seconds (at 32^4 it took 244 s on 16 cores)
             bsol = np.random.default_rng(5).random(16 ** 4 * 24)
+            cores_solver = min(cores, 8)   # 12.6 MB vectors: more threads only add barrier cost
+            oracle.set_threads(cores_solver)
             _, it_cpu, secs_cpu, res_cpu = oracle.gcr_tm(g16, bsol, [16, 16, 16, 16], 0.124, 0.005, +1, tol=1e-10, nkrylov=20, maxiter=5000)
             g = extra.get("mg_gcr_16x4", {})
             cpu["solver"] = dict(what="plain GCR(20) to 1e-10 on tm_mat, fp64, 16x16x16x16, kappa 0.124 mu 0.005 (same problem as extra.mg_gcr_16x4)",
-                                 secs=round(secs_cpu, 3), iters=it_cpu, true_res=res_cpu, cores=cores,
+                                 secs=round(secs_cpu, 3), iters=it_cpu, true_res=res_cpu, cores=cores_solver,
                                  gpu_plain_gcr_secs=g.get("plain_gcr", {}).get("secs"), gpu_mg_gcr_secs=g.get("solve_secs"), gpu_mg_setup_secs=g.get("setup_secs"))
         oracle.set_threads(1)
 
