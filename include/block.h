@@ -35,8 +35,9 @@ struct BlockField {
 };
 
 // gather / scatter between nrhs ordinary (plane-major, full, fp32) fields and one block field
-void blockPack(BlockField &dst, const std::vector<ColorSpinorField *> &src);
-void blockUnpack(const std::vector<ColorSpinorField *> &dst, const BlockField &src);
+// parity >= 0: the block holds only that parity half of the fields (nSites = VolumeCB)
+void blockPack(BlockField &dst, const std::vector<ColorSpinorField *> &src, int parity = -1);
+void blockUnpack(const std::vector<ColorSpinorField *> &dst, const BlockField &src, int parity = -1);
 
 // out = M in for every right-hand side: X in + sum_d H_d in(x + dhat(d)) with the links read ONCE per site for all of them,
 // on v_mfma_f32_16x16x4_f32 (exact fp32).  Needs n = 2 Nc a multiple of 16, nrhs a multiple of 8 (<= 32), an unpartitioned

@@ -47,6 +47,9 @@ void applyShift(double *out, const double *in, const LatticeGeom &g, int stride,
 // out = (1 + i a g5) in - kappa D in for nrhs vectors per link load (fp32, recon 18, unpartitioned lattice)
 bool fineBlockSupported(const GaugeField &U, int nrhs);
 void applyFineBlockM(float2 *out, const float2 *in, int nrhs, const GaugeField &U, double kappa, double a);
+// one parity of the generalised form: out = s0 (1 + i a0 g5) in_same + k1 (1 + i a1 g5) [8 hops of in_other], single-parity panels
+void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_other, int nrhs, const GaugeField &U, int parity, double s0, double a0, double k1,
+                          double a1);
 
 // site-local kernels
 enum SiteOp {

@@ -54,7 +54,7 @@ template <bool PACK, int NV> __global__ void __launch_bounds__(256) block_pack_k
   if (PACK) blk[t] = *p;
   else *p = blk[t];
 }
-static BlockPtrs blockPtrs(const std::vector<ColorSpinorField *> &f, const BlockField &b, int &stride) {
+static BlockPtrs blockPtrs(const std::vector<ColorSpinorField *> &f, const BlockField &b, int &stride, int parity, int &Vh) {
   if ((int)f.size() < b.nrhs) errorQuda("%zu fields for a block of %d right-hand sides", f.size(), b.nrhs);
   BlockPtrs p;
   memset(&p, 0, sizeof(p));
@@ -62,26 +62,27 @@ static BlockPtrs blockPtrs(const std::vector<ColorSpinorField *> &f, const Block
   for (int i = 0; i < b.nrhs; i++) {
     ColorSpinorField &g = *f[i];
     if (g.Precision() != QUDA_SINGLE_PRECISION || g.SiteSubset() != QUDA_FULL_SITE_SUBSET || g.Location() != QUDA_CUDA_FIELD_LOCATION) errorQuda("block fields are built from fp32 full device fields");
-    if (g.Volume() != b.nSites || g.Nspin() * g.Ncolor() != b.ncomp || g.Stride() != stride) errorQuda("field %d does not match the block (%d sites x %d components)", i, b.nSites, b.ncomp);
-    p.v[0][i] = (float *)g.Even().V();
-    p.v[1][i] = (float *)g.Odd().V();
+    if ((parity < 0 ? g.Volume() : g.VolumeCB()) != b.nSites || g.Nspin() * g.Ncolor() != b.ncomp || g.Stride() != stride) errorQuda("field %d does not match the block (%d sites x %d components)", i, b.nSites, b.ncomp);
+    if (parity < 0) { p.v[0][i] = (float *)g.Even().V(); p.v[1][i] = (float *)g.Odd().V(); }
+    else p.v[0][i] = p.v[1][i] = (float *)(parity ? g.Odd().V() : g.Even().V());
   }
+  Vh = parity < 0 ? b.nSites / 2 : b.nSites;   // single parity: every block site is a site of that half
   return p;
 }
-void blockPack(BlockField &dst, const std::vector<ColorSpinorField *> &src) {
-  int stride;
-  const BlockPtrs p = blockPtrs(src, dst, stride);
+void blockPack(BlockField &dst, const std::vector<ColorSpinorField *> &src, int parity) {
+  int stride, Vh;
+  const BlockPtrs p = blockPtrs(src, dst, stride, parity, Vh);
   const long total = (long)dst.elems();
-  if (src[0]->Nspin() == 4) hipLaunchKernelGGL((block_pack_kernel<true, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), dst.v, p, stride, dst.Vh, dst.ncomp, dst.nrhs, total);
-  else hipLaunchKernelGGL((block_pack_kernel<true, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), dst.v, p, stride, dst.Vh, dst.ncomp, dst.nrhs, total);
+  if (src[0]->Nspin() == 4) hipLaunchKernelGGL((block_pack_kernel<true, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), dst.v, p, stride, Vh, dst.ncomp, dst.nrhs, total);
+  else hipLaunchKernelGGL((block_pack_kernel<true, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), dst.v, p, stride, Vh, dst.ncomp, dst.nrhs, total);
   HIP_CHECK(hipGetLastError());
 }
-void blockUnpack(const std::vector<ColorSpinorField *> &dst, const BlockField &src) {
-  int stride;
-  const BlockPtrs p = blockPtrs(dst, src, stride);
+void blockUnpack(const std::vector<ColorSpinorField *> &dst, const BlockField &src, int parity) {
+  int stride, Vh;
+  const BlockPtrs p = blockPtrs(dst, src, stride, parity, Vh);
   const long total = (long)src.elems();
-  if (dst[0]->Nspin() == 4) hipLaunchKernelGGL((block_pack_kernel<false, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), src.v, p, stride, src.Vh, src.ncomp, src.nrhs, total);
-  else hipLaunchKernelGGL((block_pack_kernel<false, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), src.v, p, stride, src.Vh, src.ncomp, src.nrhs, total);
+  if (dst[0]->Nspin() == 4) hipLaunchKernelGGL((block_pack_kernel<false, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), src.v, p, stride, Vh, src.ncomp, src.nrhs, total);
+  else hipLaunchKernelGGL((block_pack_kernel<false, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), src.v, p, stride, Vh, src.ncomp, src.nrhs, total);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -98,6 +99,7 @@ struct BlockCoarseArg {
   int Xc[4];
   int Vh;
   unsigned inBytes;
+  int spw;   // consecutive sites per work-group
 };
 
 template <int N, int NRHS> struct BlockCoarseTraits {
@@ -107,7 +109,10 @@ template <int N, int NRHS> struct BlockCoarseTraits {
   static constexpr int SG = JP / 4;          // 4-column-pair groups per matrix: one A load (per row tile) = 4 k-steps
   static constexpr int NG = 9 * SG;          // groups per site
   static constexpr int GI = (NG + 3) / 4;    // groups per wave (round-robin over the 4 waves)
-  static constexpr int DEPTH = 12;           // A loads in flight per wave (12 KiB)
+  static constexpr int NIT = GI * RT;        // A loads (items) per wave and site
+  // A loads in flight per wave; divides NIT so that the register ring carries on across the sites a work-group processes
+  static constexpr int DEPTH = N == 48 ? 14 : (N == 32 ? 9 : (N == 16 ? 5 : 12));
+  static_assert(NIT % DEPTH == 0, "prefetch ring must wrap at a site boundary");
   static constexpr size_t ldsBytes = (size_t)4 * RT * NT * 256 * sizeof(float) + 64;   // partial tiles of the 4 waves + the 9 panel offsets
 };
 
@@ -125,111 +130,123 @@ template <int N, int NRHS, int NT> __device__ __forceinline__ void load_bfrag(fl
 
 template <int N, int NRHS> __global__ void __launch_bounds__(256) coarse_block_kernel(const BlockCoarseArg arg) {
   using Tr = BlockCoarseTraits<N, NRHS>;
-  constexpr int RT = Tr::RT, NT = Tr::NT, JP = Tr::JP, SG = Tr::SG, NG = Tr::NG, GI = Tr::GI, DEPTH = Tr::DEPTH;
+  constexpr int RT = Tr::RT, NT = Tr::NT, JP = Tr::JP, SG = Tr::SG, NG = Tr::NG, GI = Tr::GI, DEPTH = Tr::DEPTH, NIT = Tr::NIT;
   extern __shared__ float lds[];   // [4 waves][RT][NT][4][64] partial tiles, then 9 panel offsets (unsigned)
   unsigned *panel = reinterpret_cast<unsigned *>(lds + 4 * RT * NT * 256);
-  const int A = blockIdx.x, Vh = arg.Vh;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, row16 = lane & 15, kq = lane >> 4, ncol = lane & 15, odd = ncol & 1;
-
-  // ---- A operand: this site's 9 link matrices through a buffer descriptor (out-of-range offsets read 0: no tail branches) ----
+  const int Vh = arg.Vh, nSites = 2 * arg.Vh;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: everything derived from it stays in SGPRs
+  const int lane = threadIdx.x & 63, row16 = lane & 15, kq = lane >> 4, ncol = lane & 15, odd = ncol & 1;
   constexpr unsigned siteBytes = 9u * JP * N * 16u;
-  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(arg.G) + (size_t)A * (siteBytes / 4), 0, (int)siteBytes, 0x00020000);
-  // item it of this wave = (group gi, row tile rt); group g = wave + 4 gi = (matrix m, column-pair group s)
-  auto a_offset = [&](int it) -> unsigned {
-    const int gi = it / RT, rt = it - gi * RT;
-    const int g = wave + 4 * gi;
-    if (g >= NG) return 0xffffff00u;
-    const int m = g / SG, s = g - m * SG;
-    return (unsigned)(((m * JP + 4 * s + kq) * N + rt * 16 + row16) * 16);
+  // item it of this wave = (group gi, row tile rt); group g = wave + 4 gi = (matrix m, column-pair group s).  Because a matrix holds
+  // JP = 4 SG column pairs, (m JP + 4 s) = 4 g: the byte offset is  g * (4 N 16) + rt * 256 + lane part  — one per-lane register plus
+  // a compile-time term per item (soffset); a surplus group (g >= NG) lands past the site's 9 matrices and reads zeros
+  const int aLane = (wave * 4 * N + kq * N + row16) * 16;
+  auto a_soff = [](int it) -> int { const int gi = it / RT, rt = it - gi * RT; return gi * (16 * N * 16) + rt * 256; };
+  auto site_rsrc = [&](int A) -> __amdgpu_buffer_rsrc_t {   // the 9 link matrices of site A; past the lattice: zero records, every load returns 0
+    const bool ok = A < nSites;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(arg.G) + (size_t)(ok ? A : 0) * (siteBytes / 4), 0, ok ? (int)siteBytes : 0, 0x00020000);
   };
-  constexpr int NIT = GI * RT;
-  f32x4 abuf[DEPTH];
-#pragma unroll
-  for (int d = 0; d < DEPTH; d++)
-    abuf[d] = d < NIT ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, (int)a_offset(d), 0, 2)) : (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // ---- byte offsets of the 9 input panels (8 neighbours + the site itself) ----
-  if (threadIdx.x < 9) {
-    const int m = threadIdx.x;
-    const int par = A >= Vh, xcb = A - par * Vh;
-    const int Xh = arg.Xc[0] >> 1;
-    int l = xcb;
-    const int xh = l % Xh; l /= Xh;
-    const int y = l % arg.Xc[1]; l /= arg.Xc[1];
-    const int z = l % arg.Xc[2]; const int t = l / arg.Xc[2];
-    int cn[4] = {2 * xh + ((y + z + t + par) & 1), y, z, t};
-    if (m < 8) {
-      const int mu = m >> 1, L = arg.Xc[mu];
-      cn[mu] = (m & 1) ? (cn[mu] == 0 ? L - 1 : cn[mu] - 1) : (cn[mu] == L - 1 ? 0 : cn[mu] + 1);
-    }
-    const int npar = (cn[0] + cn[1] + cn[2] + cn[3]) & 1;
-    const int nx = (((cn[3] * arg.Xc[2] + cn[2]) * arg.Xc[1] + cn[1]) * arg.Xc[0] + cn[0]) >> 1;
-    panel[m] = (unsigned)(npar * Vh + nx) * (unsigned)(N * NRHS * 8);
-  }
-  __syncthreads();
   const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(arg.in), 0, (int)arg.inBytes, 0x00020000);
-
-  f32x4 acc[RT][NT];
-#pragma unroll
-  for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) acc[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
   auto group_ms = [&](int gi, int &m, int &s) { const int g = wave + 4 * gi; const int gg = g < NG ? g : 0; m = gg / SG; s = gg - m * SG; };
-  float2 bnext[2][NT];
-  { int m, s; group_ms(0, m, s); load_bfrag<N, NRHS, NT>(bnext, irs, panel[m], s, kq, ncol); }
-#pragma unroll
-  for (int gi = 0; gi < GI; gi++) {
-    // this group's fragments; the next group's are requested before the matrix instructions of this one
-    float bre[2][NT], bim[2][NT];
-#pragma unroll
-    for (int h = 0; h < 2; h++)
-#pragma unroll
-      for (int nt = 0; nt < NT; nt++) {
-        const float2 v = bnext[h][nt];
-        // k-step with p = re:  o = re -> Re in, o = im -> Im in;   p = im:  o = re -> -Im in, o = im -> Re in
-        bre[h][nt] = odd ? v.y : v.x;
-        bim[h][nt] = odd ? v.x : -v.y;
-      }
-    if (gi + 1 < GI) { int m, s; group_ms(gi + 1, m, s); load_bfrag<N, NRHS, NT>(bnext, irs, panel[m], s, kq, ncol); }
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++) {
-      const int it = gi * RT + rt;
-      const f32x4 a = abuf[it % DEPTH];
-      if (it + DEPTH < NIT) abuf[it % DEPTH] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, (int)a_offset(it + DEPTH), 0, 2));
-      // k-step outermost: consecutive matrix instructions go to DIFFERENT accumulators (dependent latency 40 > issue 32 cycles)
-#pragma unroll
-      for (int nt = 0; nt < NT; nt++) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], bre[0][nt], acc[rt][nt], 0, 0, 0);   // K element (c0, re)
-#pragma unroll
-      for (int nt = 0; nt < NT; nt++) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], bim[0][nt], acc[rt][nt], 0, 0, 0);   // (c0, im)
-#pragma unroll
-      for (int nt = 0; nt < NT; nt++) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], bre[1][nt], acc[rt][nt], 0, 0, 0);   // (c0 + 1, re)
-#pragma unroll
-      for (int nt = 0; nt < NT; nt++) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], bim[1][nt], acc[rt][nt], 0, 0, 0);   // (c0 + 1, im)
-    }
-  }
 
-  // ---- sum the 4 waves' partial tiles through LDS, write the output panel ----
+  // A work-group takes arg.spw consecutive sites.  The register ring of A loads (DEPTH x 1 KiB per wave, straight from HBM) runs on
+  // across the site boundary — the last DEPTH items of a site already fetch the first DEPTH of the next — so only the first site
+  // of a work-group pays the fill latency (one site per work-group: 85 TFLOP/s at 24 right-hand sides, a third of each site's
+  // time went into fill, panel offsets and the tile reduction).
+  const int A0 = blockIdx.x * arg.spw;
+  f32x4 abuf[DEPTH];
+  {
+    const __amdgpu_buffer_rsrc_t g0 = site_rsrc(A0);
 #pragma unroll
-  for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-      for (int k = 0; k < 4; k++) lds[(((wave * RT + rt) * NT + nt) * 4 + k) * 64 + lane] = acc[rt][nt][k];
-  __syncthreads();
-  float4 *dst = reinterpret_cast<float4 *>(arg.out + (size_t)A * (N * NRHS));
-  constexpr int Q = N * NRHS / 2;
-  for (int q = threadIdx.x; q < Q; q += 256) {
-    float o[4];
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const int f = 4 * q + e;                   // float index inside the panel: (r * NRHS + i) * 2 + re/im
-      const int r = f / (2 * NRHS), n = f - r * (2 * NRHS);
-      const int rt = r >> 4, nt = n >> 4, ln = ((r & 15) >> 2) * 16 + (n & 15), k = r & 3;   // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
-      const int base = ((rt * NT + nt) * 4 + k) * 64 + ln;
-      o[e] = lds[base] + lds[base + RT * NT * 256] + lds[base + 2 * RT * NT * 256] + lds[base + 3 * RT * NT * 256];
+    for (int d = 0; d < DEPTH; d++) abuf[d] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g0, aLane, a_soff(d), 2));
+  }
+  for (int si = 0; si < arg.spw; si++) {
+    const int A = A0 + si;
+    if (A >= nSites) break;
+    const __amdgpu_buffer_rsrc_t grs = site_rsrc(A), grsNext = site_rsrc(si + 1 < arg.spw ? A + 1 : nSites);
+    // ---- byte offsets of the 9 input panels (8 neighbours + the site itself) ----
+    if (threadIdx.x < 9) {
+      const int m = threadIdx.x;
+      const int par = A >= Vh, xcb = A - par * Vh;
+      const int Xh = arg.Xc[0] >> 1;
+      int l = xcb;
+      const int xh = l % Xh; l /= Xh;
+      const int y = l % arg.Xc[1]; l /= arg.Xc[1];
+      const int z = l % arg.Xc[2]; const int t = l / arg.Xc[2];
+      int cn[4] = {2 * xh + ((y + z + t + par) & 1), y, z, t};
+      if (m < 8) {
+        const int mu = m >> 1, L = arg.Xc[mu];
+        cn[mu] = (m & 1) ? (cn[mu] == 0 ? L - 1 : cn[mu] - 1) : (cn[mu] == L - 1 ? 0 : cn[mu] + 1);
+      }
+      const int npar = (cn[0] + cn[1] + cn[2] + cn[3]) & 1;
+      const int nx = (((cn[3] * arg.Xc[2] + cn[2]) * arg.Xc[1] + cn[1]) * arg.Xc[0] + cn[0]) >> 1;
+      panel[m] = (unsigned)(npar * Vh + nx) * (unsigned)(N * NRHS * 8);
     }
-    dst[q] = make_float4(o[0], o[1], o[2], o[3]);
+    __syncthreads();
+
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) acc[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float2 bnext[2][NT];
+    { int m, s; group_ms(0, m, s); load_bfrag<N, NRHS, NT>(bnext, irs, panel[m], s, kq, ncol); }
+#pragma unroll
+    for (int gi = 0; gi < GI; gi++) {
+      // this group's fragments; the next group's are requested before the matrix instructions of this one
+      float bre[2][NT], bim[2][NT];
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+          const float2 v = bnext[h][nt];
+          // k-step with p = re:  o = re -> Re in, o = im -> Im in;   p = im:  o = re -> -Im in, o = im -> Re in
+          bre[h][nt] = odd ? v.y : v.x;
+          bim[h][nt] = odd ? v.x : -v.y;
+        }
+      if (gi + 1 < GI) { int m, s; group_ms(gi + 1, m, s); load_bfrag<N, NRHS, NT>(bnext, irs, panel[m], s, kq, ncol); }
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) {
+        const int it = gi * RT + rt;
+        const f32x4 a = abuf[it % DEPTH];
+        if (it + DEPTH < NIT) abuf[it % DEPTH] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, aLane, a_soff(it + DEPTH), 2));
+        else abuf[it % DEPTH] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grsNext, aLane, a_soff(it + DEPTH - NIT), 2));
+        // k-step outermost: consecutive matrix instructions go to DIFFERENT accumulators (dependent latency 40 > issue 32 cycles)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], bre[0][nt], acc[rt][nt], 0, 0, 0);   // K element (c0, re)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], bim[0][nt], acc[rt][nt], 0, 0, 0);   // (c0, im)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], bre[1][nt], acc[rt][nt], 0, 0, 0);   // (c0 + 1, re)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], bim[1][nt], acc[rt][nt], 0, 0, 0);   // (c0 + 1, im)
+      }
+    }
+
+    // ---- sum the 4 waves' partial tiles through LDS, write the output panel ----
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) lds[(((wave * RT + rt) * NT + nt) * 4 + k) * 64 + lane] = acc[rt][nt][k];
+    __syncthreads();
+    float4 *dst = reinterpret_cast<float4 *>(arg.out + (size_t)A * (N * NRHS));
+    constexpr int Q = N * NRHS / 2;
+    for (int q = threadIdx.x; q < Q; q += 256) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int f = 4 * q + e;                   // float index inside the panel: (r * NRHS + i) * 2 + re/im
+        const int r = f / (2 * NRHS), n = f - r * (2 * NRHS);
+        const int rt = r >> 4, nt = n >> 4, ln = ((r & 15) >> 2) * 16 + (n & 15), k = r & 3;   // C/D map: col = lane & 15, row = 4 (lane >> 4) + reg
+        const int base = ((rt * NT + nt) * 4 + k) * 64 + ln;
+        o[e] = lds[base] + lds[base + RT * NT * 256] + lds[base + 2 * RT * NT * 256] + lds[base + 3 * RT * NT * 256];
+      }
+      dst[q] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();   // the partial tiles and the panel offsets are rewritten by the next site
   }
 }
 
@@ -237,7 +254,7 @@ template <int N, int NRHS> static void launchCoarseBlock(const BlockCoarseArg &a
   using Tr = BlockCoarseTraits<N, NRHS>;
   static bool attr = false;
   if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void *)coarse_block_kernel<N, NRHS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Tr::ldsBytes)); attr = true; }
-  hipLaunchKernelGGL((coarse_block_kernel<N, NRHS>), dim3(nSites), dim3(256), Tr::ldsBytes, computeStream(), arg);
+  hipLaunchKernelGGL((coarse_block_kernel<N, NRHS>), dim3((nSites + arg.spw - 1) / arg.spw), dim3(256), Tr::ldsBytes, computeStream(), arg);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -258,6 +275,14 @@ void applyCoarseBlock(BlockField &out, const BlockField &in, const CoarseGauge &
   arg.out = out.v; arg.in = in.v; arg.G = G.data; arg.Vh = G.nSites / 2;
   if (in.bytes >= ((size_t)1 << 32)) errorQuda("block field of %zu bytes exceeds the 4 GiB a buffer descriptor addresses", in.bytes);
   arg.inBytes = (unsigned)in.bytes;
+  {
+    // sites per work-group: enough work-groups left to fill 256 CUs x 3 several times over
+    static int spwEnv = -1;
+    if (spwEnv < 0) { const char *e = getenv("QUDA_AMD_BLOCK_COARSE_SPW"); spwEnv = e ? atoi(e) : 0; }
+    int spw = spwEnv > 0 ? spwEnv : 8;
+    while (spw > 1 && G.nSites / spw < 4 * 768) spw /= 2;
+    arg.spw = spw;
+  }
   for (int d = 0; d < 4; d++) arg.Xc[d] = G.Xc[d];
 #define QA_CASE(NN, RR) if (G.n == NN && in.nrhs == RR) { launchCoarseBlock<NN, RR>(arg, G.nSites); return; }
   QA_CASE(48, 24) QA_CASE(48, 8) QA_CASE(48, 16) QA_CASE(48, 32)

@@ -619,7 +619,8 @@ struct FineBlockArg {
   int g_stride;
   int Vh, Xh, Y, Z, T, parity;
   FastDiv dXh, dY, dZ;
-  float a, mkappa;
+  // out = s0 (1 + i a0 g5) in_same + k1 (1 + i a1 g5) [sum of the 8 hops of in_other]; s0 = 0: in_same is not read
+  float s0, a0, k1, a1;
   BlockOrder order;
 };
 
@@ -697,18 +698,23 @@ template <int NRHS> __global__ void __launch_bounds__(256) fine_block_kernel(con
   FB_LD(A, 0); FB_LD(B, 1); FB_CP(A, 0); FB_LD(A, 2); FB_CP(B, 1); FB_LD(B, 3); FB_CP(A, 2);
   FB_LD(A, 4); FB_CP(B, 3); FB_LD(B, 5); FB_CP(A, 4); FB_LD(A, 6); FB_CP(B, 5); FB_LD(B, 7);
   FB_CP(A, 6);
-  load_panel(pA, arg.in_same, idx);   // the site's own panel (twist term) travels while the last hop is computed
+  if (arg.s0 != 0.f) load_panel(pA, arg.in_same, idx);   // the site's own panel travels while the last hop is computed
   FB_CP(B, 7);
 #undef FB_FENCE
 #undef FB_PIN
 #undef FB_LD
 #undef FB_CP
-  // out = (1 + i a g5) in(x) - kappa acc
   float2 *o = arg.out + ((size_t)idx * 12) * NRHS + i;
 #pragma unroll
   for (int j = 0; j < 12; j++) {
-    const float a = j < 6 ? arg.a : -arg.a;   // g5 = diag(+,+,-,-): spins 0,1 are components 0..5
-    o[j * NRHS] = make_float2(pA[2 * j] - a * pA[2 * j + 1] + arg.mkappa * acc[2 * j], pA[2 * j + 1] + a * pA[2 * j] + arg.mkappa * acc[2 * j + 1]);
+    const float sg = j < 6 ? 1.f : -1.f;   // g5 = diag(+,+,-,-): spins 0,1 are components 0..5
+    const float a1 = sg * arg.a1;
+    float re = arg.k1 * (acc[2 * j] - a1 * acc[2 * j + 1]), im = arg.k1 * (acc[2 * j + 1] + a1 * acc[2 * j]);
+    if (arg.s0 != 0.f) {
+      const float a0 = sg * arg.a0;
+      re += arg.s0 * (pA[2 * j] - a0 * pA[2 * j + 1]); im += arg.s0 * (pA[2 * j + 1] + a0 * pA[2 * j]);
+    }
+    o[j * NRHS] = make_float2(re, im);
   }
 }
 
@@ -721,31 +727,38 @@ bool fineBlockSupported(const GaugeField &U, int nrhs) {
   return !off;
 }
 
-// out = (1 + i a g5) in - kappa D in on full block fields of 12 components (both parities, two launches)
-void applyFineBlockM(float2 *out, const float2 *in, int nrhs, const GaugeField &U, double kappa, double a) {
+// one parity of the generalised multi-right-hand-side stencil:
+//   out(x) = s0 (1 + i a0 g5) in_same(x) + k1 (1 + i a1 g5) sum_{8 hops} U P in_other(x + mu)       x of parity `parity`
+// all three fields are single-parity block panels [Vh][12][nrhs]; in_same may be nullptr when s0 = 0
+void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_other, int nrhs, const GaugeField &U, int parity, double s0, double a0, double k1,
+                          double a1) {
   if (!fineBlockSupported(U, nrhs)) errorQuda("multi-right-hand-side fine operator: fp32 recon-18 links on an unpartitioned lattice, 8/16/24/32 right-hand sides");
+  if (s0 != 0.0 && !in_same) errorQuda("same-parity input missing");
   const LatticeGeom &g = U.geom;
   const int spb = nrhs == 24 ? 8 : 256 / nrhs, threads = spb * nrhs;
   FineBlockArg arg;
   arg.link_bytes = U.link_bytes; arg.g_stride = U.stride;
   arg.Vh = g.Vh; arg.Xh = g.Xh; arg.Y = g.X[1]; arg.Z = g.X[2]; arg.T = g.X[3];
   arg.dXh = g.dXh; arg.dY = g.dY; arg.dZ = g.dZ;
-  arg.a = (float)a; arg.mkappa = (float)(-kappa);
+  arg.s0 = (float)s0; arg.a0 = (float)a0; arg.k1 = (float)k1; arg.a1 = (float)a1;
   arg.order = makeBlockOrder(g, spb);
   const int nb = (g.Vh + spb - 1) / spb;
-  const size_t par = (size_t)g.Vh * 12 * nrhs;
-  for (int p = 0; p < 2; p++) {
-    arg.parity = p;
-    arg.out = out + p * par; arg.in_same = in + p * par; arg.in_other = in + (1 - p) * par;
-    arg.gauge = (const char *)U.parityBase(p);
-    switch (nrhs) {
-      case 8: hipLaunchKernelGGL((fine_block_kernel<8>), dim3(nb), dim3(threads), 0, computeStream(), arg); break;
-      case 16: hipLaunchKernelGGL((fine_block_kernel<16>), dim3(nb), dim3(threads), 0, computeStream(), arg); break;
-      case 24: hipLaunchKernelGGL((fine_block_kernel<24>), dim3(nb), dim3(threads), 0, computeStream(), arg); break;
-      default: hipLaunchKernelGGL((fine_block_kernel<32>), dim3(nb), dim3(threads), 0, computeStream(), arg); break;
-    }
+  arg.parity = parity;
+  arg.out = out; arg.in_same = in_same ? in_same : in_other; arg.in_other = in_other;
+  arg.gauge = (const char *)U.parityBase(parity);
+  switch (nrhs) {
+    case 8: hipLaunchKernelGGL((fine_block_kernel<8>), dim3(nb), dim3(threads), 0, computeStream(), arg); break;
+    case 16: hipLaunchKernelGGL((fine_block_kernel<16>), dim3(nb), dim3(threads), 0, computeStream(), arg); break;
+    case 24: hipLaunchKernelGGL((fine_block_kernel<24>), dim3(nb), dim3(threads), 0, computeStream(), arg); break;
+    default: hipLaunchKernelGGL((fine_block_kernel<32>), dim3(nb), dim3(threads), 0, computeStream(), arg); break;
   }
   HIP_CHECK(hipGetLastError());
+}
+
+// out = (1 + i a g5) in - kappa D in on full block fields of 12 components (both parities, two launches)
+void applyFineBlockM(float2 *out, const float2 *in, int nrhs, const GaugeField &U, double kappa, double a) {
+  const size_t par = (size_t)U.geom.Vh * 12 * nrhs;
+  for (int p = 0; p < 2; p++) applyFineBlockParity(out + p * par, in + p * par, in + (1 - p) * par, nrhs, U, p, 1.0, a, -kappa, 0.0);
 }
 
 // ---- single-direction hop (setup-time helper for the multigrid coarse-operator construction) ----
