@@ -7,17 +7,23 @@
 //     B[(c,re)][(i,re)] =  Re in[c][i]   B[(c,im)][(i,re)] = -Im in[c][i]
 //     B[(c,re)][(i,im)] =  Im in[c][i]   B[(c,im)][(i,im)] =  Re in[c][i]
 // so M = n, K = 2 n per matrix (9 matrices = one K of 18 n), N = 2 nrhs, all multiples of 16 / 4 for n = 48, nrhs = 24.
-// One work-group (4 waves) per site.  A operand: a lane (row l & 15, kq = l >> 4) loads the float4 of row l & 15, column pair
-// 4 s + kq — one 16-byte load feeds FOUR k-steps (component t of the float4 is k-step t; which four K elements make a k-step is
-// free as long as B agrees), 1 KiB per wave instruction straight from HBM, prefetched 12 deep in registers.  B operand: 8-byte
-// (re, im) pairs read straight from the neighbour panels, one group ahead of the matrix instructions (the whole input field is a
-// few MB and every panel is wanted by 9 sites: L2 traffic, not HBM).  A first version staged the 9 panels of a site in LDS
-// (97 KB: one work-group per CU, staging and matrix instructions in series) and reached 47 TFLOP/s at nrhs = 24; without the
-// staging three work-groups share a CU.  The 54 (matrix, 4-column-pair group) items of a site are dealt round-robin to the 4
-// waves, each accumulating all 3 x 3 output tiles; partial tiles are summed through LDS and the n x nrhs output panel is written
-// with 16-byte unit-stride stores.
+// A work-group (4 waves) takes a few consecutive sites.  A operand: a lane (row l & 15, kq = l >> 4) loads the float4 of row
+// l & 15, column pair 4 s + kq — one 16-byte load feeds FOUR k-steps (component t of the float4 is k-step t; which four K elements
+// make a k-step is free as long as B agrees), 1 KiB per wave instruction straight from HBM.  B operand: 8-byte (re, im) pairs read
+// straight from the neighbour panels (L2 / Infinity Cache: every panel is wanted by 9 sites; no LDS staging, so two to three
+// work-groups share a CU).  Both go through ONE first-in-first-out ring of requests per wave, four (matrix, 4-column-pair) groups
+// deep, that runs on across the sites: vector memory operations of a wave return in order, so B fragments requested later than the
+// A tiles would drain the A ring at every group; the neighbour indices come from a table through scalar loads and the barriers are
+// LDS-only for the same reason (coarse_block_kernel).  The 54 groups of a site are dealt round-robin to the 4 waves, each
+// accumulating all 3 x 3 output tiles; partial tiles are summed through LDS and the n x nrhs output panel is written with 16-byte
+// unit-stride stores.  Measured at 12^3 x 24, n = 48 (MI355X): 8 / 16 / 24 right-hand sides in 1084 / 1429 / 1864 us against
+// 1167 us for ONE vector through the single-vector kernel — 0.82 of the HBM roofline at 8, 88.6 TFLOP/s (0.56 of the fp32 MFMA
+// peak, with the link stream at 0.51 of HBM at the same time) at 24.  History: LDS-staged panels, one work-group per CU: 47
+// TFLOP/s; B fragments from L2 one group ahead of a 12-deep A ring: 85; several sites per work-group with __syncthreads and the B
+// fragments still behind the A tiles: 76 (every barrier and every group drained the ring).
 // Roofline (n = 48, fp32): 9 n^2 8 B = 166 KB of links per site against 72 n^2 nrhs flops: AI = nrhs flop/B — HBM-bound up to
 // nrhs ~ 24 (6 TB/s x 24 = 144 TFLOP/s against the 157 TFLOP/s fp32 MFMA peak), where both limits meet.
+#include <type_traits>
 #include "block.h"
 
 #include <cmath>
@@ -100,6 +106,7 @@ struct BlockCoarseArg {
   int Vh;
   unsigned inBytes;
   int spw;   // consecutive sites per work-group
+  const int *nbr;   // [site][9]: index (parity * Vh + x_cb) of the 8 neighbours and of the site itself (neighbour_table)
 };
 
 template <int N, int NRHS> struct BlockCoarseTraits {
@@ -109,11 +116,11 @@ template <int N, int NRHS> struct BlockCoarseTraits {
   static constexpr int SG = JP / 4;          // 4-column-pair groups per matrix: one A load (per row tile) = 4 k-steps
   static constexpr int NG = 9 * SG;          // groups per site
   static constexpr int GI = (NG + 3) / 4;    // groups per wave (round-robin over the 4 waves)
-  static constexpr int NIT = GI * RT;        // A loads (items) per wave and site
-  // A loads in flight per wave; divides NIT so that the register ring carries on across the sites a work-group processes
-  static constexpr int DEPTH = N == 48 ? 14 : (N == 32 ? 9 : (N == 16 ? 5 : 12));
-  static_assert(NIT % DEPTH == 0, "prefetch ring must wrap at a site boundary");
-  static constexpr size_t ldsBytes = (size_t)4 * RT * NT * 256 * sizeof(float) + 64;   // partial tiles of the 4 waves + the 9 panel offsets
+  // depth of the request ring in groups (B fragments + RT A tiles each) and the period of its phase over the sites
+  static constexpr int GD = 4;
+  static constexpr int gcd_(int a, int b) { return b ? gcd_(b, a % b) : a; }
+  static constexpr int U = GD / gcd_(GI % GD == 0 ? GD : GI % GD, GD);
+  static constexpr size_t ldsBytes = (size_t)4 * RT * NT * 256 * sizeof(float);   // partial tiles of the 4 waves
 };
 
 // B fragments of one group (matrix m, column-pair group s): for h = 0, 1 (component rows c0 = 2 (4 s + kq), c0 + 1) and every column
@@ -128,61 +135,116 @@ template <int N, int NRHS, int NT> __device__ __forceinline__ void load_bfrag(fl
       bf[h][nt] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(irs, (int)(rowOff + (unsigned)(h * NRHS * 8 + nt * 64)), 0, 0));
 }
 
+// index table of the 9 input panels of every site (8 neighbours in the order of the link matrices, then the site itself): read
+// by the MFMA kernel with SCALAR loads — its waves must not spend vector registers, vector memory requests or barriers on the
+// lattice arithmetic (see the request ring below).  Built once per coarse lattice.
+__global__ void neighbour_table_kernel(int *tab, int X0, int X1, int X2, int X3, int Vh) {
+  const int t9 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t9 >= 2 * Vh * 9) return;
+  const int A = t9 / 9, m = t9 - 9 * A;
+  const int par = A >= Vh, xcb = A - par * Vh;
+  const int Xh = X0 >> 1;
+  int l = xcb;
+  const int xh = l % Xh; l /= Xh;
+  const int y = l % X1; l /= X1;
+  const int z = l % X2; const int t = l / X2;
+  int cn[4] = {2 * xh + ((y + z + t + par) & 1), y, z, t};
+  const int L[4] = {X0, X1, X2, X3};
+  if (m < 8) {
+    const int mu = m >> 1;
+    cn[mu] = (m & 1) ? (cn[mu] == 0 ? L[mu] - 1 : cn[mu] - 1) : (cn[mu] == L[mu] - 1 ? 0 : cn[mu] + 1);
+  }
+  const int npar = (cn[0] + cn[1] + cn[2] + cn[3]) & 1;
+  tab[t9] = npar * Vh + ((((cn[3] * X2 + cn[2]) * X1 + cn[1]) * X0 + cn[0]) >> 1);
+}
+struct NbrTable { int Xc[4]; int *d; };
+static std::vector<NbrTable> g_nbrTables;
+static const int *neighbourTable(const int Xc[4]) {
+  for (const NbrTable &t : g_nbrTables) if (t.Xc[0] == Xc[0] && t.Xc[1] == Xc[1] && t.Xc[2] == Xc[2] && t.Xc[3] == Xc[3]) return t.d;
+  NbrTable t;
+  for (int d = 0; d < 4; d++) t.Xc[d] = Xc[d];
+  const int nSites = Xc[0] * Xc[1] * Xc[2] * Xc[3];
+  HIP_CHECK(hipMalloc((void **)&t.d, (size_t)(nSites + 1) * 9 * sizeof(int)));   // + one row: the table is read one site ahead
+  HIP_CHECK(hipMemsetAsync(t.d, 0, (size_t)(nSites + 1) * 9 * sizeof(int), computeStream()));
+  hipLaunchKernelGGL(neighbour_table_kernel, dim3((nSites * 9 + 255) / 256), dim3(256), 0, computeStream(), t.d, Xc[0], Xc[1], Xc[2], Xc[3], nSites / 2);
+  HIP_CHECK(hipGetLastError());
+  g_nbrTables.push_back(t);
+  return t.d;
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <int N, int I = 0, typename F> static __device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+
+// Work-group barrier for LDS hand-offs only.  __syncthreads() is a full fence: it also waits for every outstanding GLOBAL load
+// (s_waitcnt vmcnt(0)), i.e. it drains the register ring of link loads that is supposed to run on across the sites — three exposed
+// HBM latencies per site, which is what held the first multi-site version below the single-site one.
+static __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int N, int NRHS> __global__ void __launch_bounds__(256) coarse_block_kernel(const BlockCoarseArg arg) {
   using Tr = BlockCoarseTraits<N, NRHS>;
-  constexpr int RT = Tr::RT, NT = Tr::NT, JP = Tr::JP, SG = Tr::SG, NG = Tr::NG, GI = Tr::GI, DEPTH = Tr::DEPTH, NIT = Tr::NIT;
-  extern __shared__ float lds[];   // [4 waves][RT][NT][4][64] partial tiles, then 9 panel offsets (unsigned)
-  unsigned *panel = reinterpret_cast<unsigned *>(lds + 4 * RT * NT * 256);
+  constexpr int RT = Tr::RT, NT = Tr::NT, JP = Tr::JP, SG = Tr::SG, NG = Tr::NG, GI = Tr::GI, GD = Tr::GD;
+  extern __shared__ float lds[];   // [4 waves][RT][NT][4][64] partial tiles
   const int Vh = arg.Vh, nSites = 2 * arg.Vh;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: everything derived from it stays in SGPRs
   const int lane = threadIdx.x & 63, row16 = lane & 15, kq = lane >> 4, ncol = lane & 15, odd = ncol & 1;
   constexpr unsigned siteBytes = 9u * JP * N * 16u;
-  // item it of this wave = (group gi, row tile rt); group g = wave + 4 gi = (matrix m, column-pair group s).  Because a matrix holds
+  // item (group gi, row tile rt) of this wave; group g = wave + 4 gi = (matrix m, column-pair group s).  Because a matrix holds
   // JP = 4 SG column pairs, (m JP + 4 s) = 4 g: the byte offset is  g * (4 N 16) + rt * 256 + lane part  — one per-lane register plus
   // a compile-time term per item (soffset); a surplus group (g >= NG) lands past the site's 9 matrices and reads zeros
   const int aLane = (wave * 4 * N + kq * N + row16) * 16;
-  auto a_soff = [](int it) -> int { const int gi = it / RT, rt = it - gi * RT; return gi * (16 * N * 16) + rt * 256; };
   auto site_rsrc = [&](int A) -> __amdgpu_buffer_rsrc_t {   // the 9 link matrices of site A; past the lattice: zero records, every load returns 0
     const bool ok = A < nSites;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(arg.G) + (size_t)(ok ? A : 0) * (siteBytes / 4), 0, ok ? (int)siteBytes : 0, 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(arg.in), 0, (int)arg.inBytes, 0x00020000);
   auto group_ms = [&](int gi, int &m, int &s) { const int g = wave + 4 * gi; const int gg = g < NG ? g : 0; m = gg / SG; s = gg - m * SG; };
+  // work-group -> chunk of sites: the 8 XCDs (work-groups are dealt to them round-robin) each walk a contiguous eighth of the
+  // lattice, so the panels a site shares with its y and z neighbours are met again in the same L2
+  const int nwg = (int)gridDim.x;
+  const int chunk = (nwg & 7) == 0 ? ((int)blockIdx.x & 7) * (nwg >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  const int A0 = chunk * arg.spw;
+  if (A0 >= nSites) return;
 
-  // A work-group takes arg.spw consecutive sites.  The register ring of A loads (DEPTH x 1 KiB per wave, straight from HBM) runs on
-  // across the site boundary — the last DEPTH items of a site already fetch the first DEPTH of the next — so only the first site
-  // of a work-group pays the fill latency (one site per work-group: 85 TFLOP/s at 24 right-hand sides, a third of each site's
-  // time went into fill, panel offsets and the tile reduction).
-  const int A0 = blockIdx.x * arg.spw;
-  f32x4 abuf[DEPTH];
+  // ONE first-in-first-out ring of requests per wave, GD groups deep: for every group its B fragments (8-byte loads from the input
+  // panels, L2 / Infinity Cache) and then its RT A tiles (16-byte loads of the link matrices, straight from HBM), requested GD
+  // groups before they are used and consumed in the order of the requests.  Vector memory operations of a wave return in order, so
+  // a wait for a B fragment that was requested AFTER a batch of A tiles is a wait for those tiles too: with the B fragments one
+  // group ahead and the A tiles 14 ahead, as the previous version had it, every group drained the A ring (s_waitcnt vmcnt(3)).
+  // The ring runs on across the sites of the work-group (its phase after a site is (GI mod GD), hence the site loop unrolled over
+  // the phases); the barriers inside are LDS-only (lds_barrier), they do not drain it either.
+  f32x4 abuf[GD * RT];
+  float2 bring[GD][2][NT];
+  // (site A, group gi): B fragments of the panel of neighbour m — its index comes from the table through the scalar cache (an
+  // s_load, counted by lgkmcnt, not by the vector-memory counter the ring lives on) and goes into the load's scalar offset
+  typedef const int __attribute__((address_space(4))) *ConstIntPtr;   // constant address space + uniform index: s_load_dword
+  const ConstIntPtr nbrc = (ConstIntPtr)(uintptr_t)arg.nbr;
+  auto request = [&](auto posc, auto gic, const __amdgpu_buffer_rsrc_t &rs, int A) {
+    constexpr int pos = decltype(posc)::value, gi = decltype(gic)::value;
+    int m, s;
+    group_ms(gi, m, s);
+    const unsigned pan = (unsigned)nbrc[9 * A + m] * (unsigned)(N * NRHS * 8);
+    load_bfrag<N, NRHS, NT>(bring[pos], irs, pan, s, kq, ncol);
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+      abuf[pos * RT + rt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, aLane, gi * (16 * N * 16) + rt * 256, 2));
+  };
+
   {
     const __amdgpu_buffer_rsrc_t g0 = site_rsrc(A0);
-#pragma unroll
-    for (int d = 0; d < DEPTH; d++) abuf[d] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g0, aLane, a_soff(d), 2));
+    static_for<GD>([&](auto j) { request(j, j, g0, A0); __builtin_amdgcn_sched_barrier(0); });
   }
-  for (int si = 0; si < arg.spw; si++) {
+
+  auto site_body = [&](auto phc, int si) {
+    constexpr int PH = decltype(phc)::value;
     const int A = A0 + si;
-    if (A >= nSites) break;
-    const __amdgpu_buffer_rsrc_t grs = site_rsrc(A), grsNext = site_rsrc(si + 1 < arg.spw ? A + 1 : nSites);
-    // ---- byte offsets of the 9 input panels (8 neighbours + the site itself) ----
-    if (threadIdx.x < 9) {
-      const int m = threadIdx.x;
-      const int par = A >= Vh, xcb = A - par * Vh;
-      const int Xh = arg.Xc[0] >> 1;
-      int l = xcb;
-      const int xh = l % Xh; l /= Xh;
-      const int y = l % arg.Xc[1]; l /= arg.Xc[1];
-      const int z = l % arg.Xc[2]; const int t = l / arg.Xc[2];
-      int cn[4] = {2 * xh + ((y + z + t + par) & 1), y, z, t};
-      if (m < 8) {
-        const int mu = m >> 1, L = arg.Xc[mu];
-        cn[mu] = (m & 1) ? (cn[mu] == 0 ? L - 1 : cn[mu] - 1) : (cn[mu] == L - 1 ? 0 : cn[mu] + 1);
-      }
-      const int npar = (cn[0] + cn[1] + cn[2] + cn[3]) & 1;
-      const int nx = (((cn[3] * arg.Xc[2] + cn[2]) * arg.Xc[1] + cn[1]) * arg.Xc[0] + cn[0]) >> 1;
-      panel[m] = (unsigned)(npar * Vh + nx) * (unsigned)(N * NRHS * 8);
-    }
-    __syncthreads();
+    const bool more = si + 1 < arg.spw && A + 1 < nSites;
+    const __amdgpu_buffer_rsrc_t grs = site_rsrc(A), grsNext = site_rsrc(more ? A + 1 : nSites);
+    const int Anext = more ? A + 1 : A;   // past the range: fragments of a valid panel, multiplied by zero tiles or never used
 
     f32x4 acc[RT][NT];
 #pragma unroll
@@ -190,28 +252,23 @@ template <int N, int NRHS> __global__ void __launch_bounds__(256) coarse_block_k
 #pragma unroll
       for (int nt = 0; nt < NT; nt++) acc[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float2 bnext[2][NT];
-    { int m, s; group_ms(0, m, s); load_bfrag<N, NRHS, NT>(bnext, irs, panel[m], s, kq, ncol); }
-#pragma unroll
-    for (int gi = 0; gi < GI; gi++) {
-      // this group's fragments; the next group's are requested before the matrix instructions of this one
+    static_for<GI>([&](auto gic) {
+      constexpr int gi = decltype(gic)::value, pos = (PH + gi) % GD;
       float bre[2][NT], bim[2][NT];
 #pragma unroll
       for (int h = 0; h < 2; h++)
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) {
-          const float2 v = bnext[h][nt];
+          const float2 v = bring[pos][h][nt];
           // k-step with p = re:  o = re -> Re in, o = im -> Im in;   p = im:  o = re -> -Im in, o = im -> Re in
           bre[h][nt] = odd ? v.y : v.x;
           bim[h][nt] = odd ? v.x : -v.y;
         }
-      if (gi + 1 < GI) { int m, s; group_ms(gi + 1, m, s); load_bfrag<N, NRHS, NT>(bnext, irs, panel[m], s, kq, ncol); }
+      // fences: the machine scheduler would otherwise sink every request down to its use (load, wait, use: no ring at all)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int rt = 0; rt < RT; rt++) {
-        const int it = gi * RT + rt;
-        const f32x4 a = abuf[it % DEPTH];
-        if (it + DEPTH < NIT) abuf[it % DEPTH] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, aLane, a_soff(it + DEPTH), 2));
-        else abuf[it % DEPTH] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grsNext, aLane, a_soff(it + DEPTH - NIT), 2));
+        const f32x4 a = abuf[pos * RT + rt];
         // k-step outermost: consecutive matrix instructions go to DIFFERENT accumulators (dependent latency 40 > issue 32 cycles)
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], bre[0][nt], acc[rt][nt], 0, 0, 0);   // K element (c0, re)
@@ -222,7 +279,12 @@ template <int N, int NRHS> __global__ void __launch_bounds__(256) coarse_block_k
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], bim[1][nt], acc[rt][nt], 0, 0, 0);   // (c0 + 1, im)
       }
-    }
+      __builtin_amdgcn_sched_barrier(0);
+      // the slot is free: request group gi + GD (of the next site once this one is through)
+      if constexpr (gi + GD < GI) request(std::integral_constant<int, pos>{}, std::integral_constant<int, gi + GD>{}, grs, A);
+      else request(std::integral_constant<int, pos>{}, std::integral_constant<int, gi + GD - GI>{}, grsNext, Anext);
+      __builtin_amdgcn_sched_barrier(0);
+    });
 
     // ---- sum the 4 waves' partial tiles through LDS, write the output panel ----
 #pragma unroll
@@ -231,7 +293,7 @@ template <int N, int NRHS> __global__ void __launch_bounds__(256) coarse_block_k
       for (int nt = 0; nt < NT; nt++)
 #pragma unroll
         for (int k = 0; k < 4; k++) lds[(((wave * RT + rt) * NT + nt) * 4 + k) * 64 + lane] = acc[rt][nt][k];
-    __syncthreads();
+    lds_barrier();
     float4 *dst = reinterpret_cast<float4 *>(arg.out + (size_t)A * (N * NRHS));
     constexpr int Q = N * NRHS / 2;
     for (int q = threadIdx.x; q < Q; q += 256) {
@@ -246,8 +308,25 @@ template <int N, int NRHS> __global__ void __launch_bounds__(256) coarse_block_k
       }
       dst[q] = make_float4(o[0], o[1], o[2], o[3]);
     }
-    __syncthreads();   // the partial tiles and the panel offsets are rewritten by the next site
+    lds_barrier();   // the partial tiles are rewritten by the next site
+  };
+
+  // phase of the ring at the start of site si: (si GI) mod GD, period U = GD / gcd(GI, GD) sites
+  constexpr int U = Tr::U;
+  for (int s0 = 0; s0 < arg.spw; s0 += U) {
+    bool done = false;
+    static_for<U>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      if (!done) {
+        const int si = s0 + u;
+        if (si >= arg.spw || A0 + si >= nSites) done = true;
+        else site_body(std::integral_constant<int, (u * GI) % GD>{}, si);
+      }
+    });
+    if (done) break;
   }
+  // requests still in flight (of a site past the work-group's range: zero-record reads, or fragments of a valid panel) land in
+  // registers nobody reads
 }
 
 template <int N, int NRHS> static void launchCoarseBlock(const BlockCoarseArg &arg, int nSites) {
@@ -284,6 +363,7 @@ void applyCoarseBlock(BlockField &out, const BlockField &in, const CoarseGauge &
     arg.spw = spw;
   }
   for (int d = 0; d < 4; d++) arg.Xc[d] = G.Xc[d];
+  arg.nbr = neighbourTable(G.Xc);
 #define QA_CASE(NN, RR) if (G.n == NN && in.nrhs == RR) { launchCoarseBlock<NN, RR>(arg, G.nSites); return; }
   QA_CASE(48, 24) QA_CASE(48, 8) QA_CASE(48, 16) QA_CASE(48, 32)
   QA_CASE(16, 8) QA_CASE(16, 16) QA_CASE(16, 24) QA_CASE(16, 32)

@@ -84,10 +84,14 @@ template <typename real> struct DslashArg {
   // off-node hop in direction dir expects, waitTicks bounds the polling, a time-out lands in *errWord
   unsigned waitCount[8];
   unsigned long long waitTicks;
+  int siteDelay, packPrio;   // peer-store launch: site blocks start siteDelay x 64 x 8 cycles late; pack waves raise their issue priority
   int *errWord;
   // peer-store transport: the first packBlocks blocks of the interior launch pack the faces (pack_body) while the rest of
   // the grid does the interior stencil — one launch, the faces leave at time zero and travel during the interior pass
   int packBlocks, packChunk;
+  // folded packing (small grids): the first packFoldBlocks blocks of the grid pack packShare face sites each, inside their site threads
+  int packShare, packFoldBlocks;
+  int edgeFirst;   // plane-tiled order of a partitioned launch: boundary planes first in every XCD (dslash_kernel)
   PackArg<real> pack;
   unsigned long long *timeline;   // QUDA_AMD_TIMELINE=1: per-block wall_clock64 stamps (measurement aid), else nullptr
 };
@@ -162,6 +166,9 @@ template <typename real> __device__ __forceinline__ void twist_inplace(real *p, 
 // LL protocol of the collective libraries).  Costs 2x the face bytes, which are a few hundred KB.
 #ifndef QA_LL_STORE_AUX
 #define QA_LL_STORE_AUX 17   // sc0 sc1: system scope, write-through
+#endif
+#ifndef QA_P2P_FOLD
+#define QA_P2P_FOLD 1   // face packing inside the site threads compiled in (stencil_site); used with QUDA_AMD_P2P_FOLD=1 / "p2p_fold", measured slower than pack blocks
 #endif
 template <typename T> struct GhostLL;
 template <> struct GhostLL<double> {
@@ -245,7 +252,6 @@ __device__ __forceinline__ void ghost_ll_load(real *h, const void *zone, int fac
   }
   GhostLL<T>::decode(h, w);
 }
-
 // One hop = load (neighbour spinor + this site's pre-daggered link) then project / multiply / reconstruct.
 // The two phases are separate so the kernel can software-pipeline them: loads of direction d+1 are issued
 // before the arithmetic of direction d (register double-buffering), fenced with sched_barrier so hipcc neither
@@ -383,6 +389,43 @@ __device__ __forceinline__ void dslash_epilogue(real *acc, const DslashArg<real>
 // ---- face packing (reference packFaceWilsonKernel / packTwistedFaceWilsonKernel, lib/dslash_pack.cu:272, :610) ----
 // P2P: the send pointers are peer-mapped ghost zones — flag-in-data vectors, system-scope write-through stores (GhostLL)
 // Block `bid` packs the face sites [bid * chunk, (bid + 1) * chunk) of the concatenated (dim, dir) ranges, chunk <= blockDim.
+// The work of one face site in two steps, so that a caller can put other loads between the load and the stores:
+// pack_locate: face item `tid` of the concatenated (dim, dir) ranges -> (slot = 2 dim + to_fwd, face index f, checkerboard index)
+template <typename real> __device__ __forceinline__ int pack_locate(const PackArg<real> &arg, int tid, int &slot, int &f) {
+  slot = 0;
+#pragma unroll
+  for (int k = 1; k < 8; k++) slot += tid >= arg.start[k];
+  const int d = slot >> 1, to_fwd = slot & 1;
+  f = tid - arg.start[slot];
+  // other three coordinates from the face index (lexicographic, halved), then the site's full index
+  int c[4], L[3], o[3], n = 0;
+  for (int k = 0; k < 4; k++) if (k != d) { L[n] = arg.X[k]; o[n] = k; n++; }
+  int l = 2 * f;
+  const int c0 = l % L[0]; l /= L[0];
+  const int c1 = l % L[1]; const int c2 = l / L[1];
+  c[d] = to_fwd ? arg.X[d] - 1 : 0;
+  c[o[0]] = c0; c[o[1]] = c1; c[o[2]] = c2;
+  c[o[0]] += (arg.parity_in + c[0] + c[1] + c[2] + c[3]) & 1;  // pick the site of the pair that has the input parity
+  return (((c[3] * arg.X[2] + c[2]) * arg.X[1] + c[1]) * arg.X[0] + c[0]) >> 1;
+}
+// pack_emit: (pre-twist,) project for the receiver's hop and store — flag-in-data vectors into the neighbour's zone (P2P) or planes
+// of the send buffer
+template <typename T, bool PRETWIST, bool P2P, typename real> __device__ __forceinline__ void pack_emit(const PackArg<real> &arg, real *psi, int slot, int f) {
+  const int d = slot >> 1, to_fwd = slot & 1;
+  real h[12];
+  if (PRETWIST) twist_inplace(psi, arg.a);
+  // the receiver uses this face for its hop in direction -d (if we send forward) / +d (if we send backward)
+  const real s = to_fwd ? -arg.sfwd : arg.sfwd;
+  switch (d) {
+    case 0: spin_project<0>(h, psi, s); break;
+    case 1: spin_project<1>(h, psi, s); break;
+    case 2: spin_project<2>(h, psi, s); break;
+    default: spin_project<3>(h, psi, s); break;
+  }
+  char *sb = arg.send[d][to_fwd];
+  if (P2P) ghost_ll_store<T>(h, sb, arg.faceCB[d], f, arg.llFlag[d]);   // straight into the neighbour's zone, flag in the data
+  else Planar<T, 12>::store(h, sb, arg.faceCB[d], f, reinterpret_cast<float *>(sb + arg.normOff[d]), f);
+}
 template <typename T, bool PRETWIST, bool P2P, typename real> __device__ __forceinline__ void pack_body(const PackArg<real> &arg, int bid, int chunk) {
   const int tid = (int)threadIdx.x < chunk ? bid * chunk + (int)threadIdx.x : arg.start[8];
   if (P2P && arg.timeline && threadIdx.x == 0) {
@@ -391,34 +434,15 @@ template <typename T, bool PRETWIST, bool P2P, typename real> __device__ __force
     arg.timeline[3072 + bid] = 0x100000000ull | ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xf) << 16) | (__builtin_amdgcn_s_getreg(4 | (31 << 11)) & 0xff00u);
   }
   if (tid < arg.start[8]) {
-    int slot = 0;
-#pragma unroll
-    for (int k = 1; k < 8; k++) slot += tid >= arg.start[k];
-    const int d = slot >> 1, to_fwd = slot & 1, f = tid - arg.start[slot];
-    // other three coordinates from the face index (lexicographic, halved), then the site's full index
-    int c[4], L[3], o[3], n = 0;
-    for (int k = 0; k < 4; k++) if (k != d) { L[n] = arg.X[k]; o[n] = k; n++; }
-    int l = 2 * f;
-    const int c0 = l % L[0]; l /= L[0];
-    const int c1 = l % L[1]; const int c2 = l / L[1];
-    c[d] = to_fwd ? arg.X[d] - 1 : 0;
-    c[o[0]] = c0; c[o[1]] = c1; c[o[2]] = c2;
-    c[o[0]] += (arg.parity_in + c[0] + c[1] + c[2] + c[3]) & 1;  // pick the site of the pair that has the input parity
-    const int idx = (((c[3] * arg.X[2] + c[2]) * arg.X[1] + c[1]) * arg.X[0] + c[0]) >> 1;
-    real psi[24], h[12];
+    int slot, f;
+    const int idx = pack_locate(arg, tid, slot, f);
+    real psi[24];
     Planar<T, 24>::load(psi, arg.in, arg.sp_stride, idx, arg.inNorm, idx);
-    if (PRETWIST) twist_inplace(psi, arg.a);
-    // the receiver uses this face for its hop in direction -d (if we send forward) / +d (if we send backward)
-    const real s = to_fwd ? -arg.sfwd : arg.sfwd;
-    switch (d) {
-      case 0: spin_project<0>(h, psi, s); break;
-      case 1: spin_project<1>(h, psi, s); break;
-      case 2: spin_project<2>(h, psi, s); break;
-      default: spin_project<3>(h, psi, s); break;
+    if (P2P && arg.timeline) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (threadIdx.x == 0) arg.timeline[13312 + bid] = wall_clock64();
     }
-    char *sb = arg.send[d][to_fwd];
-    if (P2P) ghost_ll_store<T>(h, sb, arg.faceCB[d], f, arg.llFlag[d]);   // straight into the neighbour's zone, flag in the data
-    else Planar<T, 12>::store(h, sb, arg.faceCB[d], f, reinterpret_cast<float *>(sb + arg.normOff[d]), f);
+    pack_emit<T, PRETWIST, P2P>(arg, psi, slot, f);
   }
   if (P2P && arg.timeline && threadIdx.x == 0) arg.timeline[1024 + bid] = wall_clock64();
 }
@@ -490,7 +514,36 @@ __device__ __forceinline__ void stencil_site(const DslashArg<real> &arg, const i
   QA_LD(A, d0); QA_LD(B, d1); QA_CP(A, d0); QA_LD(A, d2); QA_CP(B, d1); QA_LD(B, d3); QA_CP(A, d2);  \
   QA_LD(A, d4); QA_CP(B, d3); QA_LD(B, d5); QA_CP(A, d4); QA_LD(A, d6); QA_CP(B, d5); QA_LD(B, d7);  \
   QA_CP(A, d6); QA_FENCE(); hop_compute<T, d7, PT, GH>(acc, pB, uB, arg, of[d7], fc[d7])
+#if QA_P2P_FOLD
+  if (KT == 3) {
+    // Folded packing (launchDslash decides): thread `threadIdx.x` < packShare of one of the first packFoldBlocks blocks also packs one
+    // face site.  Its load is issued in front of the first two hops' loads and its stores behind them, so the stores — whose
+    // acknowledgement a later s_waitcnt would have to sit out, vector memory operations of a wave retire in order — are older than
+    // everything the pipeline waits for from hop 2 on, and by then long acknowledged.
+    const int item = (int)blockIdx.x * arg.packShare + (int)threadIdx.x;
+    const bool packs = (int)blockIdx.x < arg.packFoldBlocks && (int)threadIdx.x < arg.packShare && item < arg.pack.start[8];
+    if (__builtin_amdgcn_ballot_w64(packs) != 0) {
+      real pk[24];
+      int slot, f;
+      const int pidx = pack_locate(arg.pack, packs ? item : 0, slot, f);
+      Planar<T, 24>::load(pk, arg.pack.in, arg.pack.sp_stride, pidx, arg.pack.inNorm, pidx);
+      QA_LD(A, 0);
+      QA_FENCE();
+      if (!packs) f = 0x07ffffff;   // beyond the zone's record count: the buffer stores of this lane are dropped
+      pack_emit<T, PT, true>(arg.pack, pk, slot, f);
+      QA_FENCE();
+    } else {
+      QA_LD(A, 0);
+    }
+    QA_LD(B, 1); QA_CP(A, 0); QA_LD(A, 2); QA_CP(B, 1); QA_LD(B, 3); QA_CP(A, 2);
+    QA_LD(A, 4); QA_CP(B, 3); QA_LD(B, 5); QA_CP(A, 4); QA_LD(A, 6); QA_CP(B, 5); QA_LD(B, 7);
+    QA_CP(A, 6); QA_FENCE(); hop_compute<T, 7, PT, GH>(acc, pB, uB, arg, of[7], fc[7]);
+  } else {
+    QA_PIPE(0, 1, 2, 3, 4, 5, 6, 7);
+  }
+#else
   QA_PIPE(0, 1, 2, 3, 4, 5, 6, 7);
+#endif
 #undef QA_PIPE
 #undef QA_LD
 #undef QA_CP
@@ -502,6 +555,8 @@ __device__ __forceinline__ void stencil_site(const DslashArg<real> &arg, const i
     const bool anyoff = o_xp || o_xm || o_yp || o_ym || o_zp || o_zm || o_tp || o_tm;
     if (__builtin_amdgcn_ballot_w64(anyoff) != 0) {
       if (arg.timeline && (threadIdx.x & 63) == 0) arg.timeline[4096 + (blockIdx.x * 4 + (threadIdx.x >> 6))] = wall_clock64();
+      // (two directions in flight per wave — requests of the next while working on this one — measured slower: 26.6 against 25.2 us
+      // fp64 on the 8-GPU sub-lattice, the exec-masked merges of the forward and backward lanes cost more than the overlap gains)
       ghost_hop<T, R, 0, GAUX>(acc, arg, idx, o_xp, f_x, one);
       ghost_hop<T, R, 1, GAUX>(acc, arg, idx, o_xm, f_x, one);
       ghost_hop<T, R, 2, GAUX>(acc, arg, idx, o_yp, f_y, one);
@@ -528,8 +583,15 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
   if (KT == 3) {
     // single-launch peer-store path: [pack blocks | every site]; boundary sites do their local hops first, then poll the
     // ghost words they need and add the off-node hops (stencil_site, KT == 3)
-    if (b < arg.packBlocks) { pack_body<T, VARIANT == 1, true>(arg.pack, b, arg.packChunk); return; }
+    if (b < arg.packBlocks) {
+      if (arg.packPrio) __builtin_amdgcn_s_setprio(3);
+      pack_body<T, VARIANT == 1, true>(arg.pack, b, arg.packChunk);
+      return;
+    }
     b -= arg.packBlocks;
+    // the pack blocks' loads go first: a site wave keeps ~8 us worth of requests queued in its CU, and a pack wave that starts
+    // together with it needs 12 (up to 18) us for its two round trips instead of 4
+    for (int i = 0; i < arg.siteDelay; i++) __builtin_amdgcn_s_sleep(8);
   }
   // XCD-aware block remap: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch); give each XCD a
   // contiguous range of logical blocks (a slab of time slices) so t/z neighbours hit its own L2.
@@ -547,7 +609,17 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
       yc = arg.dTzTt.div(r); const uint32_t r2 = r - yc * arg.dTzTt.d;
       zi = arg.dTt.div(r2); ti = r2 - zi * arg.dTt.d;
     }
-    const int z = (int)xz * arg.Zs + (int)tile_z * arg.tz + (int)zi, t = (int)xt * arg.Ts + (int)tile_t * arg.tt + (int)ti;
+    int zl = (int)tile_z * arg.tz + (int)zi, tl = (int)tile_t * arg.tt + (int)ti;
+    if (arg.edgeFirst) {
+      // partitioned launch: an XCD starts with the blocks that own boundary sites (they have the most to do: the off-node hops come
+      // on top, after a wait), and the blocks dispatched last — the ones that share a CU with a pack block — are interior ones.
+      // z: the upper half of the XCDs walks its slab downwards; t: a slab that spans the whole extent starts at T - 1 and wraps to
+      // 0 (still a contiguous sweep on the periodic lattice), otherwise the upper half walks downwards as well.
+      if (2 * (int)xz >= arg.nxz) zl = arg.Zs - 1 - zl;
+      if (arg.nxz == 8) tl = tl == 0 ? arg.Ts - 1 : tl - 1;
+      else if (xt) tl = arg.Ts - 1 - tl;
+    }
+    const int z = (int)xz * arg.Zs + zl, t = (int)xt * arg.Ts + tl;
     lb = (t * arg.Z + z) * arg.P + (int)yc;
   } else {
     lb = (xcd < arg.xcd_r ? xcd * (arg.xcd_q + 1) : arg.xcd_r * (arg.xcd_q + 1) + (xcd - arg.xcd_r) * arg.xcd_q) + within;
@@ -918,6 +990,10 @@ void setDslashTune(const char *key, int value) {
   else if (k == "tz") t.tz = value;
   else if (k == "tt") t.tt = value;
   else if (k == "lds_pad") t.lds_pad = value;
+  else if (k == "p2p_fold") t.p2p_fold = value;
+  else if (k == "site_delay") t.site_delay = value;
+  else if (k == "pack_prio") t.pack_prio = value;
+  else if (k == "edge_first") t.edge_first = value;
   else errorQuda("unknown stencil tuning key '%s'", key);
 }
 
@@ -1115,7 +1191,7 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
     }
   }
   arg.commMask = 0; arg.blist = nullptr; arg.nboundary = 0;
-  arg.waitTicks = 0; arg.errWord = nullptr; arg.packBlocks = 0;
+  arg.waitTicks = 0; arg.errWord = nullptr; arg.packBlocks = 0; arg.siteDelay = 0; arg.packPrio = 0; arg.packShare = 0; arg.packFoldBlocks = 0; arg.edgeFirst = 0;
   for (int k = 0; k < 8; k++) arg.waitCount[k] = 0;
   for (int d = 0; d < 4; d++) { arg.ghost[d][0] = arg.ghost[d][1] = nullptr; arg.faceCB[d] = g.faceCB[d]; arg.ghostNormOff[d] = 0; }
   // link/clover stream cache policy: nt for the 16-byte-per-lane formats (measured on 32^4: fp64 4.67 -> 5.2 TB/s, fp32
@@ -1209,6 +1285,7 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
     }
     pa.start[8] = nt;
     arg.waitTicks = p2pTimeoutTicks(); arg.errWord = p2pErrorWord();
+    arg.siteDelay = tune.site_delay; arg.packPrio = tune.pack_prio; arg.edgeFirst = tune.edge_first;
     // Full pack blocks (256 face sites each) in front of the grid.  They share CUs with site blocks, and the placement statistics of
     // the timeline show what that costs on the 8-GPU sub-lattice: a site block next to a pack block ends 4.3 us later than one
     // that has its CU to itself.  Spreading the packing thinly (one 96-thread pack block on EVERY CU) is far worse — 46 us
@@ -1216,6 +1293,20 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
     // memory pipeline of the whole CU, and fewer CUs doing all of it is the better trade.
     // rounded up to a multiple of 8: blockIdx.x and the site-block number then agree mod 8, i.e. on the XCD (surplus pack blocks leave at once)
     arg.packBlocks = ((nt + bs - 1) / bs + 7) / 8 * 8; arg.packChunk = bs;
+    // Folded packing where the face sites fit the threads of the first blocks of the grid (one wave of blocks: they are running
+    // before any block that could wait for them, so the faces always get out): no pack blocks at all, see stencil_site.
+    // Measured on the 8-GPU sub-lattice 32 x 16 x 16 x 16 (y, z, t partitioned, self-neighbour emulation): the pack blocks need
+    // 11 us (up to 18) next to the stencil traffic against 3 us on an idle device (tools/ubench_ll_store.hip) and the site block
+    // that shares their CU ends 4-6 us late.  QUDA_AMD_P2P_FOLD=0 keeps the pack blocks.
+    {
+      static int foldEnv = -1;
+      if (foldEnv < 0) { const char *e = getenv("QUDA_AMD_P2P_FOLD"); foldEnv = e ? atoi(e) : 0; }
+      const int fold = tune.p2p_fold >= 0 ? tune.p2p_fold : foldEnv;
+      const int nbp = nb < 256 ? nb : 256;
+      const int share = (nt + nbp - 1) / nbp;
+      arg.packShare = 0; arg.packFoldBlocks = 0;
+      if (QA_P2P_FOLD && fold && share <= bs) { arg.packShare = share; arg.packFoldBlocks = nbp; arg.packBlocks = 0; }
+    }
     static unsigned long long *tl = nullptr;
     static int tlmode = -1;
     if (tlmode < 0) { const char *e = getenv("QUDA_AMD_TIMELINE"); tlmode = e ? atoi(e) : 0; if (tlmode) HIP_CHECK(hipHostMalloc((void **)&tl, 16384 * sizeof(unsigned long long), hipHostMallocMapped)); }
@@ -1234,7 +1325,7 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
           for (int i = 0; i < n; i++) if (tl[off + i]) { const double v = (tl[off + i] - t0) * 0.01; mn = v < mn ? v : mn; mx = v > mx ? v : mx; sum += v; c++; }
           if (c) printfQuda("timeline %-22s n=%4d  min %6.2f  mean %6.2f  max %6.2f us\n", name, c, mn, sum / c, mx);
         };
-        stat(0, 1024, "pack block start"); stat(1024, 1024, "pack block end"); stat(2048, 1024, "stencil block start");
+        stat(0, 1024, "pack block start"); stat(13312, 1024, "pack loads returned"); stat(1024, 1024, "pack block end"); stat(2048, 1024, "stencil block start");
         stat(4096, 4096, "boundary wave ghost beg"); stat(8192, 4096, "boundary wave ghost end"); stat(12288, 1024, "stencil block end");
         {   // placement: how many site / pack blocks share a CU, and when the site blocks of such CUs finish
           std::map<unsigned, std::pair<int, int>> cu;   // key -> (site blocks, pack blocks)

@@ -208,6 +208,28 @@ unsigned long long MG::flops() const {
 }
 
 // reference generateNullVectors :693-779
+// After the lockstep solves.  The reference orthonormalises every finished vector against its predecessors
+// (lib/multigrid.cpp:757-771) before Transfer orthonormalises them again block by block.  For the hierarchy that global pass is a
+// no-op in exact arithmetic: it replaces V by V T with T upper triangular with a positive diagonal, and the block-local QR of
+// V_b T has the same Q as that of V_b (R_b T is again upper triangular with a positive diagonal, QR is unique).  It costs
+// Nvec (Nvec - 1) field passes (0.27 s of a 3.2 s setup at 48^3 x 96), so the block path only NORMALISES the vectors, which keeps
+// the Gram matrices of the block CholeskyQR (transfer.hip) well scaled; QUDA_AMD_NULL_ORTHO=gs restores the global pass.
+static void orthonormaliseNullVectors(std::vector<ColorSpinorField *> &B, int Nvec) {
+  static int gs = -1;
+  if (gs < 0) { const char *e = getenv("QUDA_AMD_NULL_ORTHO"); gs = e && !strcmp(e, "gs") ? 1 : 0; }
+  for (int i = 0; i < Nvec; i++) {
+    ColorSpinorField &x = *B[i];
+    if (gs)
+      for (int j = 0; j < i; j++) {
+        const Complex alpha = blas::cDotProduct(*B[j], x);
+        blas::caxpy(-alpha, *B[j], x);
+      }
+    const double nrm2 = blas::norm2(x);
+    if (nrm2 > 1e-16) blas::ax(1.0 / sqrt(nrm2), x);
+    else errorQuda("Cannot orthogonalize %d vector", i);
+  }
+}
+
 void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
   if (getVerbosity() >= QUDA_SUMMARIZE) printfQuda("MG level %d: generating %d null vectors (BiCGstab, maxiter %d, tol %g)\n", mgp.level + 1, mgp.Nvec, mgp.mg_global.setup_maxiter, mgp.mg_global.setup_tol);
   SolverParam sp(mgp);
@@ -237,16 +259,7 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
     int iters[kMaxBlockRhs];
     const int kmax = blockBiCGstabNull(X, [](BlockField &out, const BlockField &in, void *c) { Ctx *x = (Ctx *)c; applyCoarseBlock(out, in, *x->G); x->applies++; }, &ctx, sp.tol, sp.maxiter, iters);
     blockUnpack(Bv, X);
-    for (int i = 0; i < mgp.Nvec; i++) {
-      ColorSpinorField &x = *B[i];
-      for (int j = 0; j < i; j++) {
-        const Complex alpha = blas::cDotProduct(*B[j], x);
-        blas::caxpy(-alpha, *B[j], x);
-      }
-      const double nrm2 = blas::norm2(x);
-      if (nrm2 > 1e-16) blas::ax(1.0 / sqrt(nrm2), x);
-      else errorQuda("Cannot orthogonalize %d vector", i);
-    }
+    orthonormaliseNullVectors(B, mgp.Nvec);
     if (getVerbosity() >= QUDA_SUMMARIZE || mgProfiling()) {
       int imin = iters[0], imax = iters[0];
       for (int i = 1; i < mgp.Nvec; i++) { imin = iters[i] < imin ? iters[i] : imin; imax = iters[i] > imax ? iters[i] : imax; }
@@ -314,16 +327,7 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
         kmaxAll = kmax > kmaxAll ? kmax : kmaxAll;
         for (int i = 0; i < nb; i++) { imin = iters[i] < imin ? iters[i] : imin; imax = iters[i] > imax ? iters[i] : imax; }
       }
-      for (int i = 0; i < mgp.Nvec; i++) {
-        ColorSpinorField &x = *B[i];
-        for (int j = 0; j < i; j++) {
-          const Complex alpha = blas::cDotProduct(*B[j], x);
-          blas::caxpy(-alpha, *B[j], x);
-        }
-        const double nrm2 = blas::norm2(x);
-        if (nrm2 > 1e-16) blas::ax(1.0 / sqrt(nrm2), x);
-        else errorQuda("Cannot orthogonalize %d vector", i);
-      }
+      orthonormaliseNullVectors(B, mgp.Nvec);
       if (mgProfiling()) printfQuda("MG level %d: block null-vector stage: pack/unpack + field allocation %.3f s, lockstep solves %.3f s, orthonormalisation %.3f s\n", mgp.level + 1, tPack, tSolve, now() - t0 - tPack - tSolve);
       if (getVerbosity() >= QUDA_SUMMARIZE || mgProfiling())
         printfQuda("MG level %d: %d null vectors by block BiCGstab on the %d-right-hand-side stencil: up to %d lockstep iterations (per vector %d..%d), %ld block applications, %.3f s\n",

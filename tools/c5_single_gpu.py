@@ -36,7 +36,7 @@ def main():
     b1 = tuple(4 if (x % 4 == 0 and (x // 4) % 2 == 0) else 2 for x in lvl1)
     qa.init(0)
     t0 = time.perf_counter()
-    out = bench.run_mg(qa, X, blocks=((4, 4, 4, 4), b1, (2, 2, 2, 2)), gauge=gauge, extras=not args.no_extras)
+    out = bench.run_mg(qa, X, blocks=((4, 4, 4, 4), b1, (2, 2, 2, 2)), gauge=gauge, extras=not args.no_extras, setup_repeats=2)
     out["wall_secs_total"] = round(time.perf_counter() - t0, 1)
     out["gauge_gen_secs"] = round(t_gauge, 1)
     out["n_gpus"] = 1

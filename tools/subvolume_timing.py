@@ -21,6 +21,10 @@ Vh = int(np.prod(X)) // 2
 src_h = np.random.default_rng(1).random(Vh * 24)
 out = []
 pmask = int(sys.argv[3]) if len(sys.argv) > 3 else 0b1110
+# optional 4th argument: stencil tuning variants "key=value[+key=value...],..." measured alternately in this one process (A/B on the
+# same box and clock state), e.g. "p2p_fold=1,p2p_fold=0"; 5th: rounds
+variants = [v for v in (sys.argv[4].split(",") if len(sys.argv) > 4 else [""])]
+rounds = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 for mask in (0, pmask):
     qa.lib().qudaAmdSetPartitionMask(mask)
     qa.load_gauge(gauge, qa.gauge_param(X, cuda_prec=prec))
@@ -29,8 +33,19 @@ for mask in (0, pmask):
     src.load(src_h, ip)
     d = qa.Dirac(ip, pc=True)
     d.time_dslash(dst, src, 0, 50)
-    best = min(d.time_dslash(dst, src, 0, 500) for _ in range(3))
-    out.append("mask %2d: %.2f us" % (mask, 1e6 * best))
+    if mask == 0 or variants == [""]:
+        best = min(d.time_dslash(dst, src, 0, 500) for _ in range(3))
+        out.append("mask %2d: %.2f us" % (mask, 1e6 * best))
+    else:
+        res = {v: [] for v in variants}
+        for _ in range(rounds):
+            for v in variants:
+                for kv in v.split("+"):
+                    k, val = kv.split("=")
+                    qa.lib().qudaAmdSetDslashTune(k.encode(), int(val))
+                d.time_dslash(dst, src, 0, 20)
+                res[v].append(1e6 * min(d.time_dslash(dst, src, 0, 500) for _ in range(2)))
+        out.append("mask %2d: " % mask + "; ".join("%s: %s" % (v, " ".join("%.2f" % t for t in res[v])) for v in variants))
     src.free(); dst.free(); d.free()
 print("prec %d lattice %s remap %s: %s" % (prec, X, os.environ.get("QUDA_AMD_XCD_REMAP", "1"), "; ".join(out)))
 qa.lib().qudaAmdSetPartitionMask(0)
