@@ -290,8 +290,28 @@ def main():
         # BASELINE.json configs[4] (48^3 x 96, quoted by the reference on 8 GPUs) resident on this one GPU: 288 GB holds the whole
         # hierarchy; levels by the reference's blocking rule 48^3 x 96 -> 12^3 x 24 -> 6^4 (lib/transfer.cpp:31-44)
         from synth import smooth_gauge_cayley
-        extra["mg_gcr_c5_one_gpu"] = run_mg(qa, (48, 48, 48, 96), blocks=((4, 4, 4, 4), (2, 2, 2, 4), (2, 2, 2, 2)),
-                                            gauge=smooth_gauge_cayley((48, 48, 48, 96), 0.35, workers=min(16, os.cpu_count() or 8)), setup_repeats=2)
+        Xc5 = (48, 48, 48, 96)
+        gc5 = smooth_gauge_cayley(Xc5, 0.35, workers=min(16, os.cpu_count() or 8))
+        extra["mg_gcr_c5_one_gpu"] = run_mg(qa, Xc5, blocks=((4, 4, 4, 4), (2, 2, 2, 4), (2, 2, 2, 2)), gauge=gc5, setup_repeats=2)
+        # the stencil at that production volume (Vh = 5.3 M sites: one time slice is 10.6 MB, the fields no longer sit in the 256 MB
+        # Infinity Cache as they do at 32^4), same byte model
+        Vh5 = int(np.prod(Xc5)) // 2
+        h5 = np.random.default_rng(3).random(Vh5 * 24)
+        row5 = {}
+        for prec in (8, 4, 2):
+            qa.load_gauge(gc5, qa.gauge_param(list(Xc5), cuda_prec=prec))
+            ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=prec)
+            src, dst = qa.Spinor(prec), qa.Spinor(prec)
+            src.load(h5, ip)
+            d = qa.Dirac(ip, pc=True)
+            d.time_dslash(dst, src, 0, 5)
+            sec = min(d.time_dslash(dst, src, 0, 30) for _ in range(2))
+            bs = qa.lib().qudaAmdDslashBytesPerSite(ip, 0, 0)
+            row5["tm_%s_r18" % dtype_name[prec].split("+")[0]] = dict(us=round(1e6 * sec, 1), hbm_gbs=round(bs * Vh5 / sec * 1e-9, 1), frac=round(bs * Vh5 / sec * 1e-9 / HBM_PEAK_GBS, 4),
+                                                                    gflops=round(qa.lib().qudaAmdDslashFlopsPerSite(ip, 0) * Vh5 / sec * 1e-9, 1), bytes_per_site=bs)
+            src.free(); dst.free(); d.free()
+        extra["dslash_48x48x48x96"] = row5
+        del gc5, h5
 
     cpu = None
     if rank == 0 and not args.no_cpu:

@@ -152,6 +152,75 @@ template <int NR> struct Planar<short, NR> {
   }
 };
 
+// ---- raw register image of one site of a planar block: the LOADS of Planar<T, NR>::load without anything that depends on the
+// loaded data.  The stencil requests the operands of hop d + 1 before the arithmetic of hop d and fences the two phases against the
+// scheduler; a conversion (16-bit -> fp32: 24 + 18 v_cvt + scale per hop) or a row reconstruction inside the request phase sits on
+// the wrong side of that fence — it waits for the data right there and the hop is not overlapped at all.  load() only requests;
+// unpack() is called at the start of the arithmetic phase.  Register cost of a 16-bit block in flight: NR / 2 + 1 instead of NR. ----
+template <typename T, int NR> struct RawBlock {
+  using real = typename Store<T>::real;
+  real r[NR];
+  template <int AUX = 0> __device__ __forceinline__ void load(const void *base, int stride, int x, const float *norm, int nidx) {
+    Planar<T, NR>::template load<AUX>(r, base, stride, x, norm, nidx);
+  }
+  // first 12 reals only, from a 12-real block (half spinor of a ghost zone)
+  template <int AUX = 0> __device__ __forceinline__ void load12(const void *base, int stride, int x, const float *norm, int nidx) {
+    Planar<T, 12>::template load<AUX>(r, base, stride, x, norm, nidx);
+  }
+  __device__ __forceinline__ void unpack(real *out) const {
+#pragma unroll
+    for (int k = 0; k < NR; k++) out[k] = r[k];
+  }
+};
+template <int NR> struct RawBlock<short, NR> {
+  static constexpr int NV = NR / 8, TAIL = NR % 8, NW = NR / 2;
+  unsigned w[NW];   // plane k (8 values) in w[4k .. 4k+3], then the tail plane; value j of a dword pair in the low / high half
+  float nrm;        // per-site scale (spinors, clover blocks); links: fixed unit scale
+  template <int AUX = 0> __device__ __forceinline__ void load(const void *base, int stride, int x, const float *norm, int nidx) {
+    nrm = norm ? ((AUX & 16) ? __hip_atomic_load(&norm[nidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : norm[nidx]) : 1.0f;
+    const __amdgpu_buffer_rsrc_t rs = planar_rsrc<short, NR>(base, stride);
+    const int off = x * 16;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, k * stride * 16, AUX);
+      w[4 * k] = t.x; w[4 * k + 1] = t.y; w[4 * k + 2] = t.z; w[4 * k + 3] = t.w;
+    }
+    if (TAIL == 4) {
+      const u32x2_t t = __builtin_amdgcn_raw_buffer_load_b64(rs, x * 8, NV * stride * 16, AUX);
+      w[4 * NV] = t.x; w[4 * NV + 1] = t.y;
+    } else if (TAIL == 2) {
+      w[4 * NV] = __builtin_amdgcn_raw_buffer_load_b32(rs, x * 4, NV * stride * 16, AUX);
+    }
+  }
+  // a 12-value block has its values 0..11 in the same dwords as the first 12 of a longer one (plane 0, then 4 values)
+  template <int AUX = 0> __device__ __forceinline__ void load12(const void *base, int stride, int x, const float *norm, int nidx) {
+    static_assert(NR >= 12, "half-spinor image needs 6 dwords");
+    nrm = norm ? ((AUX & 16) ? __hip_atomic_load(&norm[nidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : norm[nidx]) : 1.0f;
+    const __amdgpu_buffer_rsrc_t rs = planar_rsrc<short, 12>(base, stride);
+    const u32x4_t t = __builtin_amdgcn_raw_buffer_load_b128(rs, x * 16, 0, AUX);
+    w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
+    const u32x2_t u = __builtin_amdgcn_raw_buffer_load_b64(rs, x * 8, stride * 16, AUX);
+    w[4] = u.x; w[5] = u.y;
+  }
+  __device__ __forceinline__ void unpack(float *out) const {
+    const float s = nrm * kShortInv;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      out[2 * k] = (float)(short)(w[k] & 0xffffu) * s;
+      out[2 * k + 1] = (float)((int)w[k] >> 16) * s;
+    }
+  }
+  // the integers as they are stored; the caller applies scale() to the (fewer) results of its linear arithmetic
+  __device__ __forceinline__ void unpack_unscaled(float *out) const {
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      out[2 * k] = (float)(short)(w[k] & 0xffffu);
+      out[2 * k + 1] = (float)((int)w[k] >> 16);
+    }
+  }
+  __device__ __forceinline__ float scale() const { return nrm * kShortInv; }
+};
+
 // bytes of one planar block of NR reals x stride sites
 template <typename T> __host__ __device__ constexpr size_t storeSize() { return sizeof(T); }
 
@@ -160,6 +229,25 @@ template <typename T> __host__ __device__ constexpr size_t storeSize() { return 
 // tests/test_util.cpp:283-296 / lib/read_gauge.h) ----
 template <typename T, int R> struct Link {
   using real = typename Store<T>::real;
+  using Raw = RawBlock<T, R>;
+  // request / finish pair for the fenced stencil pipeline (RawBlock): finish converts and, for R = 12, rebuilds the third row
+  template <int AUX = 0> static __device__ __forceinline__ void request(Raw &raw, const void *blk, int stride, int x) { raw.template load<AUX>(blk, stride, x, nullptr, 0); }
+  static __device__ __forceinline__ void finish(real *U, const Raw &raw, real sign) {
+    raw.unpack(U);
+    if (R == 12) third_row(U, sign);
+  }
+  static __device__ __forceinline__ void third_row(real *U, real sign) {
+    // c = conj(a x b)
+#define QA_CROSS(i, j, k)                                                                               \
+  U[12 + 2 * i] = sign * ((U[2 * j] * U[6 + 2 * k] - U[2 * j + 1] * U[6 + 2 * k + 1]) -                \
+                          (U[2 * k] * U[6 + 2 * j] - U[2 * k + 1] * U[6 + 2 * j + 1]));                \
+  U[12 + 2 * i + 1] = -sign * ((U[2 * j] * U[6 + 2 * k + 1] + U[2 * j + 1] * U[6 + 2 * k]) -           \
+                               (U[2 * k] * U[6 + 2 * j + 1] + U[2 * k + 1] * U[6 + 2 * j]));
+    QA_CROSS(0, 1, 2)
+    QA_CROSS(1, 2, 0)
+    QA_CROSS(2, 0, 1)
+#undef QA_CROSS
+  }
   template <int AUX = 0> static __device__ __forceinline__ void load(real *U, const void *blk, int stride, int x, real sign) {
     Planar<T, R>::template load<AUX>(U, blk, stride, x, nullptr, 0);
     if (R == 12) {

@@ -141,6 +141,31 @@ template <int MU, typename real> __device__ __forceinline__ void spin_reconstruc
   }
 }
 
+// acc += w (reconstruction of g): the same 24 instructions as above (12 adds become multiply-adds) — how the 16-bit kernels apply the
+// scale of a neighbour's integers (site scale x link scale) for free, instead of to every one of the 24 + 18 converted operands
+template <int MU, typename real> __device__ __forceinline__ void spin_reconstruct_scaled(real *acc, const real *g, real s, real w) {
+  const real sw = s * w;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const real g0r = g[2 * c], g0i = g[2 * c + 1], g1r = g[6 + 2 * c], g1i = g[7 + 2 * c];
+    acc[0 + 2 * c] += w * g0r; acc[1 + 2 * c] += w * g0i;
+    acc[6 + 2 * c] += w * g1r; acc[7 + 2 * c] += w * g1i;
+    if (MU == 0) {
+      acc[12 + 2 * c] -= sw * g1i; acc[13 + 2 * c] += sw * g1r;
+      acc[18 + 2 * c] -= sw * g0i; acc[19 + 2 * c] += sw * g0r;
+    } else if (MU == 1) {
+      acc[12 + 2 * c] -= sw * g1r; acc[13 + 2 * c] -= sw * g1i;
+      acc[18 + 2 * c] += sw * g0r; acc[19 + 2 * c] += sw * g0i;
+    } else if (MU == 2) {
+      acc[12 + 2 * c] -= sw * g0i; acc[13 + 2 * c] += sw * g0r;
+      acc[18 + 2 * c] += sw * g1i; acc[19 + 2 * c] -= sw * g1r;
+    } else {
+      acc[12 + 2 * c] -= sw * g0r; acc[13 + 2 * c] -= sw * g0i;
+      acc[18 + 2 * c] -= sw * g1r; acc[19 + 2 * c] -= sw * g1i;
+    }
+  }
+}
+
 // (1 + i a g5) in place; g5 = diag(+,+,-,-)
 template <typename real> __device__ __forceinline__ void twist_inplace(real *p, real a) {
 #pragma unroll
@@ -260,8 +285,11 @@ __device__ __forceinline__ void ghost_ll_load(real *h, const void *zone, int fac
 // working set from L2 / Infinity Cache).
 // GH: 0 = every neighbour is local; 1 = off-node neighbours are read from the ghost zone (exterior pass); 2 = off-node hops are
 // skipped here and done by ghost_hop() once the faces have arrived (single-launch peer-store path)
+// hop_load only REQUESTS (raw register images, device_io.h RawBlock): the 16-bit -> fp32 conversion and the third row of a
+// 12-real link are arithmetic on the loaded data and belong to hop_compute, behind the fence — inside the request phase they made
+// the wave wait for the data of hop d + 1 before it started on hop d (16-bit and recon-12 kernels ran without any overlap).
 template <typename T, int R, int DIR, int GAUX, int GH = 0, typename real>
-__device__ __forceinline__ void hop_load(real *psi, real *U, const DslashArg<real> &arg, int idx, int nbr, real sign, bool off_node = false, int face = 0) {
+__device__ __forceinline__ void hop_load(RawBlock<T, 24> &psi, typename Link<T, R>::Raw &U, const DslashArg<real> &arg, int idx, int nbr, bool off_node = false, int face = 0) {
   constexpr int MU = DIR / 2;
   // GH == 2: the load is issued for every lane (the periodic wrap makes the index valid) and the contribution of an off-node
   // lane is zeroed in hop_compute: a per-lane branch here splits the 8-hop pipeline into many basic blocks and costs the
@@ -272,14 +300,15 @@ __device__ __forceinline__ void hop_load(real *psi, real *U, const DslashArg<rea
     // does not cost a dependent round trip in the compute phase.  sc0 sc1 (system-scope) loads: the zone may have been
     // written by another GPU while this kernel was running.
     const char *gb = arg.ghost[MU][(DIR & 1) ? 0 : 1];
-    Planar<T, 12>::template load<17>(psi, gb, arg.faceCB[MU], face, reinterpret_cast<const float *>(gb + arg.ghostNormOff[MU]), face);
+    psi.template load12<17>(gb, arg.faceCB[MU], face, reinterpret_cast<const float *>(gb + arg.ghostNormOff[MU]), face);
   } else {
-    Planar<T, 24>::load(psi, arg.in, arg.sp_stride, nbr, arg.inNorm, nbr);
+    psi.load(arg.in, arg.sp_stride, nbr, arg.inNorm, nbr);
   }
-  Link<T, R>::template load<GAUX>(U, arg.gauge + (size_t)DIR * arg.link_bytes, arg.g_stride, idx, sign);
+  Link<T, R>::template request<GAUX>(U, arg.gauge + (size_t)DIR * arg.link_bytes, arg.g_stride, idx);
 }
-template <typename T, int DIR, bool PRETWIST, int GH, typename real>
-__device__ __forceinline__ void hop_compute(real *acc, real *psi, const real *U, const DslashArg<real> &arg, bool off_node = false, int face = 0) {
+// project / multiply / reconstruct on unpacked operands
+template <int DIR, bool PRETWIST, int GH, bool SCALED = false, typename real>
+__device__ __forceinline__ void hop_arith(real *acc, real *psi, const real *U, const DslashArg<real> &arg, bool off_node = false, real w = 1) {
   constexpr int MU = DIR / 2;
   real h[12], g[12];
   const real s = (DIR & 1) ? -arg.sfwd : arg.sfwd;
@@ -296,7 +325,25 @@ __device__ __forceinline__ void hop_compute(real *acc, real *psi, const real *U,
   }
   su3_mv(g, U, h);
   su3_mv(g + 6, U, h + 6);
-  spin_reconstruct<MU>(acc, g, s);
+  if (SCALED) spin_reconstruct_scaled<MU>(acc, g, s, w);
+  else spin_reconstruct<MU>(acc, g, s);
+}
+template <typename T, int R, int DIR, bool PRETWIST, int GH, typename real>
+__device__ __forceinline__ void hop_compute(real *acc, const RawBlock<T, 24> &psiRaw, const typename Link<T, R>::Raw &URaw, const DslashArg<real> &arg, real sign, bool off_node = false,
+                                            int face = 0) {
+  real psi[24], U[18];
+  if constexpr (sizeof(T) == 2) {
+    // 16-bit: the hop is linear in the neighbour and in the link, so the integers go through it as they are and the product of
+    // the two scales is applied inside the reconstruction (conversion: one v_cvt per operand instead of v_cvt + v_mul)
+    psiRaw.unpack_unscaled(psi);
+    URaw.unpack_unscaled(U);
+    if (R == 12) Link<T, R>::third_row(U, sign * kShortInv);   // row 3 = conj(row 1 x row 2): back to the units of the stored rows
+    hop_arith<DIR, PRETWIST, GH, true>(acc, psi, U, arg, off_node, psiRaw.scale() * kShortInv);
+  } else {
+    psiRaw.unpack(psi);
+    Link<T, R>::finish(U, URaw, sign);
+    hop_arith<DIR, PRETWIST, GH>(acc, psi, U, arg, off_node);
+  }
 }
 
 // one off-node hop from the ghost zone (half spinor packed by the neighbour + this site's link), for the lanes that need it
@@ -313,12 +360,32 @@ __device__ __forceinline__ void ghost_hop(real *acc, const DslashArg<real> &arg,
   spin_reconstruct<MU>(acc, g, s);
 }
 
+// o = (chiral block held as a raw image) v.  16-bit: the block's integers go through the product unscaled and the 12 results take
+// the block's scale (12 multiplications instead of 36)
+template <typename T, typename real> __device__ __forceinline__ void clover_mv_raw(real *o, const RawBlock<T, 36> &raw, real *C, const real *v) {
+  if constexpr (sizeof(T) == 2) {
+    raw.unpack_unscaled(C);
+    clover_block_mv(o, C, v);
+    const real w = raw.scale();
+#pragma unroll
+    for (int k = 0; k < 12; k++) o[k] *= w;
+  } else {
+    raw.unpack(C);
+    clover_block_mv(o, C, v);
+  }
+}
+
 // fused epilogue of the stencil: twist / inverse twist / xpay / clover-twist (+ inverse), then the store of the site
 template <typename T, int VARIANT, int GAUX, int SAUX, typename real>
 __device__ __forceinline__ void dslash_epilogue(real *acc, const DslashArg<real> &arg, int idx) {
   constexpr bool CLOVER = VARIANT == 2;
   real xs[24];
-  if (arg.xpay) Planar<T, 24>::load(xs, arg.x, arg.sp_stride, idx, arg.xNorm, idx);
+  // (clover-twist inverse: x is only added at the very end; requested there, it does not sit in 24 registers through the four block products)
+  RawBlock<T, 24> xsRaw;
+  if (arg.xpay && !(CLOVER && arg.mode == DSLASH_CLOVER_TWIST_INV)) {
+    xsRaw.load(arg.x, arg.sp_stride, idx, arg.xNorm, idx);
+    if (!CLOVER) xsRaw.unpack(xs);
+  }
 
   if (arg.mode == DSLASH_PLAIN) {
     if (arg.xpay) {
@@ -341,46 +408,69 @@ __device__ __forceinline__ void dslash_epilogue(real *acc, const DslashArg<real>
   } else if (CLOVER) {
     real C[36], tmp[24];
     if (arg.mode == DSLASH_CLOVER_TWIST_INV) {
-      // tmp = (A + i a g5) acc ; res = Ainv tmp
+      // tmp = (A + i a g5) acc ; res = Ainv tmp, chirality by chirality (the two 6 x 6 blocks do not mix).  Four blocks of 36 reals
+      // are read; left to itself the compiler requests all four up front and converts them at once (144 live registers on top of
+      // acc: 176 VGPRs for the 16-bit kernel, 198 for fp32 — two waves per SIMD where the plain twisted-mass kernels run four).
+      // Two raw images (RawBlock: 19 registers each in 16-bit), the next block requested before the product with the current
+      // one, fenced like the hop pipeline.
+      // (fp64: two images are 144 registers; its blocks are requested and used one after the other)
+      if constexpr (sizeof(T) == 8) {
+        const real sa[2] = {arg.a, -arg.a};
 #pragma unroll
-      for (int chi = 0; chi < 2; chi++) {
-        Planar<T, 36>::template load<GAUX>(C, (const char *)arg.clA + (size_t)chi * 36 * sizeof(T) * arg.cl_stride, arg.cl_stride, idx, arg.clAn,
-                                           chi * arg.cl_stride + idx);
-        clover_block_mv(tmp + 12 * chi, C, acc + 12 * chi);
-      }
-      {
-        real t2[24];
+        for (int chi = 0; chi < 2; chi++) {
+          real *t = tmp + 12 * chi, *v = acc + 12 * chi;
+          Planar<T, 36>::template load<GAUX>(C, (const char *)arg.clA + (size_t)chi * 36 * sizeof(T) * arg.cl_stride, arg.cl_stride, idx, arg.clAn, chi * arg.cl_stride + idx);
+          clover_block_mv(t, C, v);
 #pragma unroll
-        for (int k = 0; k < 24; k++) t2[k] = acc[k];
-        // i a g5 acc
+          for (int k = 0; k < 6; k++) { t[2 * k] -= sa[chi] * v[2 * k + 1]; t[2 * k + 1] += sa[chi] * v[2 * k]; }
+        }
 #pragma unroll
-        for (int k = 0; k < 6; k++) { tmp[2 * k] -= arg.a * t2[2 * k + 1]; tmp[2 * k + 1] += arg.a * t2[2 * k]; }
+        for (int chi = 0; chi < 2; chi++) {
+          Planar<T, 36>::template load<GAUX>(C, (const char *)arg.clAinv + (size_t)chi * 36 * sizeof(T) * arg.cl_stride, arg.cl_stride, idx, arg.clAinvN, chi * arg.cl_stride + idx);
+          clover_block_mv(acc + 12 * chi, C, tmp + 12 * chi);
+        }
+      } else {
+        // one raw image at a time, each block requested after the product with the previous one (fenced): four exposed latencies,
+        // but the kernel keeps the register count of the plain twisted-mass stencil and other waves cover them
+        RawBlock<T, 36> Ca;
+        const real sa[2] = {arg.a, -arg.a};
 #pragma unroll
-        for (int k = 6; k < 12; k++) { tmp[2 * k] += arg.a * t2[2 * k + 1]; tmp[2 * k + 1] -= arg.a * t2[2 * k]; }
-      }
+        for (int chi = 0; chi < 2; chi++) {
+          real *t = tmp + 12 * chi, *v = acc + 12 * chi;
+          Ca.template load<GAUX>((const char *)arg.clA + (size_t)chi * 36 * sizeof(T) * arg.cl_stride, arg.cl_stride, idx, arg.clAn, chi * arg.cl_stride + idx);
+          __builtin_amdgcn_sched_barrier(0);
+          clover_mv_raw<T>(t, Ca, C, v);
 #pragma unroll
-      for (int chi = 0; chi < 2; chi++) {
-        Planar<T, 36>::template load<GAUX>(C, (const char *)arg.clAinv + (size_t)chi * 36 * sizeof(T) * arg.cl_stride, arg.cl_stride, idx,
-                                           arg.clAinvN, chi * arg.cl_stride + idx);
-        clover_block_mv(acc + 12 * chi, C, tmp + 12 * chi);
+          for (int k = 0; k < 6; k++) { t[2 * k] -= sa[chi] * v[2 * k + 1]; t[2 * k + 1] += sa[chi] * v[2 * k]; }
+          __builtin_amdgcn_sched_barrier(0);
+          Ca.template load<GAUX>((const char *)arg.clAinv + (size_t)chi * 36 * sizeof(T) * arg.cl_stride, arg.cl_stride, idx, arg.clAinvN, chi * arg.cl_stride + idx);
+          __builtin_amdgcn_sched_barrier(0);
+          clover_mv_raw<T>(v, Ca, C, t);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       if (arg.xpay) {
+        Planar<T, 24>::load(xs, arg.x, arg.sp_stride, idx, arg.xNorm, idx);
 #pragma unroll
         for (int k = 0; k < 24; k++) acc[k] = xs[k] + arg.k * acc[k];
       }
-    } else {  // DSLASH_CLOVER_TWIST_XPAY: out = k acc + (A + i a g5) x
+    } else {  // DSLASH_CLOVER_TWIST_XPAY: out = k acc + (A + i a g5) x, chirality by chirality
+      RawBlock<T, 36> Ca;
+      const real sa[2] = {arg.a, -arg.a};
 #pragma unroll
       for (int chi = 0; chi < 2; chi++) {
-        Planar<T, 36>::load(C, (const char *)arg.clA + (size_t)chi * 36 * sizeof(T) * arg.cl_stride, arg.cl_stride, idx, arg.clAn,
-                            chi * arg.cl_stride + idx);
-        clover_block_mv(tmp + 12 * chi, C, xs + 12 * chi);
+        real xv[24];
+        xsRaw.unpack(xv);   // only the 12 values of this chirality survive: x stays a raw image (13 registers in 16-bit) until here
+        real *t = tmp + 12 * chi, *v = xv + 12 * chi, *o = acc + 12 * chi;
+        Ca.load((const char *)arg.clA + (size_t)chi * 36 * sizeof(T) * arg.cl_stride, arg.cl_stride, idx, arg.clAn, chi * arg.cl_stride + idx);
+        __builtin_amdgcn_sched_barrier(0);
+        clover_mv_raw<T>(t, Ca, C, v);
+#pragma unroll
+        for (int k = 0; k < 6; k++) { t[2 * k] -= sa[chi] * v[2 * k + 1]; t[2 * k + 1] += sa[chi] * v[2 * k]; }
+#pragma unroll
+        for (int k = 0; k < 12; k++) o[k] = arg.k * o[k] + t[k];
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int k = 0; k < 6; k++) { tmp[2 * k] -= arg.a * xs[2 * k + 1]; tmp[2 * k + 1] += arg.a * xs[2 * k]; }
-#pragma unroll
-      for (int k = 6; k < 12; k++) { tmp[2 * k] += arg.a * xs[2 * k + 1]; tmp[2 * k + 1] -= arg.a * xs[2 * k]; }
-#pragma unroll
-      for (int k = 0; k < 24; k++) acc[k] = arg.k * acc[k] + tmp[k];
     }
   }
   Planar<T, 24>::template store<SAUX>(acc, arg.out, arg.sp_stride, idx, arg.outNorm, idx);
@@ -493,7 +583,8 @@ __device__ __forceinline__ void stencil_site(const DslashArg<real> &arg, const i
   const real one = 1;
   const real sg_tp = t == arg.T - 1 ? arg.tsign_fwd : one, sg_tm = t == 0 ? arg.tsign_bwd : one;
   // direction order: dir = 2 mu + (0 forward, 1 backward), as the reference (tests/dslash_util.h:131-140)
-  real pA[24], uA[18], pB[24], uB[18];
+  RawBlock<T, 24> pA, pB, pC;
+  typename Link<T, R>::Raw uA, uB, uC;
   // QA_FENCE: nothing may be scheduled across (machine scheduler).  QA_PIN: an empty volatile asm that "modifies" the
   // accumulators, so LLVM's IR-level sinking cannot push a hop's arithmetic past the following loads either (without it
   // all 8 hops' FMAs sink below the last fence and every loaded register stays live: 390-512 registers, scratch spills).
@@ -508,12 +599,18 @@ __device__ __forceinline__ void stencil_site(const DslashArg<real> &arg, const i
   const real sg[8] = {one, one, one, one, one, one, sg_tp, sg_tm};
   const bool of[8] = {o_xp, o_xm, o_yp, o_ym, o_zp, o_zm, o_tp, o_tm};
   const int fc[8] = {f_x, f_x, f_y, f_y, f_z, f_z, f_t, f_t};
-#define QA_LD(B, D) hop_load<T, R, D, GAUX, GH>(p##B, u##B, arg, idx, nb[D], sg[D], of[D], fc[D])
-#define QA_CP(B, D) QA_FENCE(); hop_compute<T, D, PT, GH>(acc, p##B, u##B, arg, of[D], fc[D]); QA_PIN(); QA_FENCE()
+#define QA_LD(B, D) hop_load<T, R, D, GAUX, GH>(p##B, u##B, arg, idx, nb[D], of[D], fc[D])
+#define QA_CP(B, D) QA_FENCE(); hop_compute<T, R, D, PT, GH>(acc, p##B, u##B, arg, sg[D], of[D], fc[D]); QA_PIN(); QA_FENCE()
 #define QA_PIPE(d0, d1, d2, d3, d4, d5, d6, d7)                                                      \
   QA_LD(A, d0); QA_LD(B, d1); QA_CP(A, d0); QA_LD(A, d2); QA_CP(B, d1); QA_LD(B, d3); QA_CP(A, d2);  \
   QA_LD(A, d4); QA_CP(B, d3); QA_LD(B, d5); QA_CP(A, d4); QA_LD(A, d6); QA_CP(B, d5); QA_LD(B, d7);  \
-  QA_CP(A, d6); QA_FENCE(); hop_compute<T, d7, PT, GH>(acc, pB, uB, arg, of[d7], fc[d7])
+  QA_CP(A, d6); QA_FENCE(); hop_compute<T, R, d7, PT, GH>(acc, pB, uB, arg, sg[d7], of[d7], fc[d7])
+  // 16-bit storage: a hop in flight is 22 registers (raw image) and ~1.4 KB per wave, half of what the fp32 kernel keeps in flight at
+  // the same depth — three hops deep instead of two
+#define QA_PIPE3()                                                                                                     \
+  QA_LD(A, 0); QA_LD(B, 1); QA_LD(C, 2); QA_CP(A, 0); QA_LD(A, 3); QA_CP(B, 1); QA_LD(B, 4); QA_CP(C, 2); QA_LD(C, 5); \
+  QA_CP(A, 3); QA_LD(A, 6); QA_CP(B, 4); QA_LD(B, 7); QA_CP(C, 5); QA_CP(A, 6); QA_FENCE();                            \
+  hop_compute<T, R, 7, PT, GH>(acc, pB, uB, arg, sg[7], of[7], fc[7])
 #if QA_P2P_FOLD
   if (KT == 3) {
     // Folded packing (launchDslash decides): thread `threadIdx.x` < packShare of one of the first packFoldBlocks blocks also packs one
@@ -537,14 +634,17 @@ __device__ __forceinline__ void stencil_site(const DslashArg<real> &arg, const i
     }
     QA_LD(B, 1); QA_CP(A, 0); QA_LD(A, 2); QA_CP(B, 1); QA_LD(B, 3); QA_CP(A, 2);
     QA_LD(A, 4); QA_CP(B, 3); QA_LD(B, 5); QA_CP(A, 4); QA_LD(A, 6); QA_CP(B, 5); QA_LD(B, 7);
-    QA_CP(A, 6); QA_FENCE(); hop_compute<T, 7, PT, GH>(acc, pB, uB, arg, of[7], fc[7]);
+    QA_CP(A, 6); QA_FENCE(); hop_compute<T, R, 7, PT, GH>(acc, pB, uB, arg, sg[7], of[7], fc[7]);
+  } else if (sizeof(T) == 2) {
+    QA_PIPE3();
   } else {
     QA_PIPE(0, 1, 2, 3, 4, 5, 6, 7);
   }
 #else
-  QA_PIPE(0, 1, 2, 3, 4, 5, 6, 7);
+  if (sizeof(T) == 2) { QA_PIPE3(); } else { QA_PIPE(0, 1, 2, 3, 4, 5, 6, 7); }
 #endif
 #undef QA_PIPE
+#undef QA_PIPE3
 #undef QA_LD
 #undef QA_CP
 #undef QA_FENCE
@@ -886,14 +986,14 @@ __global__ void __launch_bounds__(256) hop_dir_kernel(const DslashArg<typename S
     for (int sp = 0; sp < 4; sp++) su3_mv(acc + 6 * sp, U, psi + 6 * sp);
   } else
   switch (dir) {
-    case 0: hop_compute<T, 0, false, 0>(acc, psi, U, arg); break;
-    case 1: hop_compute<T, 1, false, 0>(acc, psi, U, arg); break;
-    case 2: hop_compute<T, 2, false, 0>(acc, psi, U, arg); break;
-    case 3: hop_compute<T, 3, false, 0>(acc, psi, U, arg); break;
-    case 4: hop_compute<T, 4, false, 0>(acc, psi, U, arg); break;
-    case 5: hop_compute<T, 5, false, 0>(acc, psi, U, arg); break;
-    case 6: hop_compute<T, 6, false, 0>(acc, psi, U, arg); break;
-    default: hop_compute<T, 7, false, 0>(acc, psi, U, arg); break;
+    case 0: hop_arith<0, false, 0>(acc, psi, U, arg); break;
+    case 1: hop_arith<1, false, 0>(acc, psi, U, arg); break;
+    case 2: hop_arith<2, false, 0>(acc, psi, U, arg); break;
+    case 3: hop_arith<3, false, 0>(acc, psi, U, arg); break;
+    case 4: hop_arith<4, false, 0>(acc, psi, U, arg); break;
+    case 5: hop_arith<5, false, 0>(acc, psi, U, arg); break;
+    case 6: hop_arith<6, false, 0>(acc, psi, U, arg); break;
+    default: hop_arith<7, false, 0>(acc, psi, U, arg); break;
   }
   if (arg.xpay) {   // out = k x + coef hop (x may be the output field itself: every thread reads its site before it writes it)
     real xs[24];
