@@ -45,6 +45,10 @@ void blockUnpack(const std::vector<ColorSpinorField *> &dst, const BlockField &s
 bool blockCoarseSupported(const CoarseGauge &G, int nrhs);
 void applyCoarseBlock(BlockField &out, const BlockField &in, const CoarseGauge &G);
 
+// [site][9] table of the full indices (parity * Vh + x_cb) of a site's 8 neighbours (order of the link matrices: 2 mu forward,
+// 2 mu + 1 backward) and of the site itself; device memory, built once per coarse lattice
+const int *coarseNeighbourTable(const int Xc[4]);
+
 // per-right-hand-side BLAS on block fields (coefficients indexed by right-hand side)
 namespace blockblas {
 void zero(BlockField &x);

@@ -89,6 +89,8 @@ void qudaAmdMultigridApply(void *mg_instance, int level, int op, float *h_out, c
  * qudaAmdMultigridTimeApply times the single-vector operator of a level the same way. */
 double qudaAmdMultigridApplyBlock(void *mg_instance, int level, int nrhs, float *h_out, const float *h_in, int niter);
 double qudaAmdMultigridTimeApply(void *mg_instance, int level, int niter);
+/* seconds per application of the restrictor (what = 0) or prolongator (what = 1) between `level` and `level + 1` */
+double qudaAmdMultigridTimeTransfer(void *mg_instance, int level, int what, int niter);
 
 /* ---- the solve loop of the QKXTM correlator drivers ----
  * calcMG_threepTwop_EvenOdd / calcMG_loop_wOneD_TSM_* (lib/interface_quda.cpp:6018-6531, :7093, :8535) open with the same

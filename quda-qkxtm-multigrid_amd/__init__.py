@@ -118,7 +118,7 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
                  "qudaAmdCommInit", "qudaAmdCommRank", "qudaAmdCommSize", "qudaAmdCommCoords", "qudaAmdCommBarrier", "qudaAmdCommAllreduce", "qudaAmdCommAllreduceMax",
                  "qudaAmdMultigridVerify", "qudaAmdMultigridCycle", "qudaAmdTimeAxpy", "qudaAmdMultigridLevels", "qudaAmdMultigridLevelInfo",
                  "qudaAmdMultigridSetHalfStorage", "qudaAmdMultigridGetNullVector", "qudaAmdMultigridGetV", "qudaAmdMultigridGetCoarseLinks", "qudaAmdMultigridApply", "qudaAmdMultigridApplyBlock",
-                 "qudaAmdMultigridTimeApply", "qudaAmdSpinorRawInfo", "qudaAmdGaugeRawInfo", "qudaAmdCloverRawInfo", "qudaAmdRawDeviceCopy",
+                 "qudaAmdMultigridTimeApply", "qudaAmdMultigridTimeTransfer", "qudaAmdSpinorRawInfo", "qudaAmdGaugeRawInfo", "qudaAmdCloverRawInfo", "qudaAmdRawDeviceCopy",
                  "qudaAmdSetSolutionSink"]
 
 _lib = None
@@ -202,6 +202,8 @@ def lib():
         L.qudaAmdMultigridApplyBlock.restype = _d
         L.qudaAmdMultigridTimeApply.argtypes = [_p, _i, _i]
         L.qudaAmdMultigridTimeApply.restype = _d
+        L.qudaAmdMultigridTimeTransfer.argtypes = [_p, _i, _i, _i]
+        L.qudaAmdMultigridTimeTransfer.restype = _d
         L.qudaAmdReadLimeGauge.argtypes = [C.POINTER(_p), C.c_char_p, C.POINTER(QudaGaugeParam), C.POINTER(QudaInvertParam), C.POINTER(_i)]
         L.qudaAmdWriteLimeGauge.argtypes = [C.POINTER(_p), C.c_char_p, C.POINTER(QudaGaugeParam), C.c_char_p]
         L.plaqQuda.argtypes = [C.POINTER(_d)]
@@ -580,6 +582,10 @@ class Multigrid:
 
     def time_apply(self, level, niter=20):
         return lib().qudaAmdMultigridTimeApply(self.h, int(level), int(niter))
+
+    def time_transfer(self, level, what, niter=20):
+        """seconds per restriction (what = 'R') or prolongation ('P') between level and level + 1"""
+        return lib().qudaAmdMultigridTimeTransfer(self.h, int(level), 1 if what == 'P' else 0, int(niter))
 
     def apply(self, level, op, h_in):
         """op 'R' (level -> level+1), 'P' (level+1 -> level), 'M' (operator of `level`); fields as (sites, spin, colour) complex64"""

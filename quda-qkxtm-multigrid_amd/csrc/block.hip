@@ -159,7 +159,7 @@ __global__ void neighbour_table_kernel(int *tab, int X0, int X1, int X2, int X3,
 }
 struct NbrTable { int Xc[4]; int *d; };
 static std::vector<NbrTable> g_nbrTables;
-static const int *neighbourTable(const int Xc[4]) {
+const int *coarseNeighbourTable(const int Xc[4]) {
   for (const NbrTable &t : g_nbrTables) if (t.Xc[0] == Xc[0] && t.Xc[1] == Xc[1] && t.Xc[2] == Xc[2] && t.Xc[3] == Xc[3]) return t.d;
   NbrTable t;
   for (int d = 0; d < 4; d++) t.Xc[d] = Xc[d];
@@ -363,7 +363,7 @@ void applyCoarseBlock(BlockField &out, const BlockField &in, const CoarseGauge &
     arg.spw = spw;
   }
   for (int d = 0; d < 4; d++) arg.Xc[d] = G.Xc[d];
-  arg.nbr = neighbourTable(G.Xc);
+  arg.nbr = coarseNeighbourTable(G.Xc);
 #define QA_CASE(NN, RR) if (G.n == NN && in.nrhs == RR) { launchCoarseBlock<NN, RR>(arg, G.nSites); return; }
   QA_CASE(48, 24) QA_CASE(48, 8) QA_CASE(48, 16) QA_CASE(48, 32)
   QA_CASE(16, 8) QA_CASE(16, 16) QA_CASE(16, 24) QA_CASE(16, 32)

@@ -5,6 +5,7 @@
 // broadcast from LDS; partial rows are combined through LDS.  Per site 9 (2Nc)^2 complex = 166 KB for Nc = 24 are read
 // exactly once: HBM-bound at ~1 flop/byte for a single right-hand side, so plain FMAs, not MFMA.
 #include "coarse.h"
+#include "block.h"
 #include "halo.h"
 
 #include "blas.h"
@@ -426,6 +427,67 @@ __global__ void insert_column_kernel(float *G, CVec c, int n, int m, int j, int 
   else { g[0] = p[0]; g[1] = p[1]; }
 }
 
+// ---- Galerkin construction from the forward hops only (reference: calculateY builds the backward links from the forward ones
+// unless bidirectional links are asked for, lib/coarse_op.cuh:1310-1420).  With the fine hop term gamma5-hermitian,
+// H_{-mu}(x + mu, x) = g5 H_{+mu}(x, x + mu)^dagger g5, and V made of vectors of definite chirality (g5 V_j = s_j V_j, s = +1 / -1
+// for the upper / lower coarse spin):
+//     Y_{2mu+1}(X + mu)[i][j] = s_i s_j conj( Y_{2mu}(X)[j][i] )
+//     X_hop(X)               = S(X) + G5 S(X)^dagger G5,   S = sum over the forward hops that stay inside the aggregate
+// so a probe needs the four forward hops and ONE pass over V (restrict4_kernel) instead of eight hops and three passes. ----
+// backward links from the forward links of the neighbour behind
+__global__ void galerkin_backward_kernel(float *G, const int *nbr, int n, int nvec, long total) {
+  const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;   // (site B, mu, column pair jp, row i)
+  if (t >= total) return;
+  const int i = (int)(t % n);
+  long r = t / n;
+  const int jp = (int)(r % (n / 2)); r /= (n / 2);
+  const int mu = (int)(r & 3);
+  const long B = r >> 2;
+  const long A = nbr[9 * B + 2 * mu + 1];   // B - mu
+  const float4 *src = reinterpret_cast<const float4 *>(G) + ((size_t)A * 9 + 2 * mu) * (n / 2) * n;
+  const float si = (i < nvec) ? 1.f : -1.f;
+  float o[4];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int j = 2 * jp + h;
+    const float sj = (j < nvec) ? 1.f : -1.f;
+    // Y_fwd(A)[j][i]: row j, column i -> float4 at (column pair i / 2, row j), component pair i & 1
+    const float4 v = src[(size_t)(i >> 1) * n + j];
+    const float re = (i & 1) ? v.z : v.x, im = (i & 1) ? v.w : v.y;
+    o[2 * h] = si * sj * re; o[2 * h + 1] = -si * sj * im;
+  }
+  reinterpret_cast<float4 *>(G)[(((size_t)B * 9 + 2 * mu + 1) * (n / 2) + jp) * n + i] = make_float4(o[0], o[1], o[2], o[3]);
+}
+// local matrix: X = S + G5 S^dagger G5 + diag(d_up, d_down)   (S read from a copy: the transpose reads what other threads write)
+__global__ void galerkin_local_kernel(float *G, const float4 *S, int n, int nvec, float2 dUp, float2 dDown, long total) {
+  const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;   // (site A, column pair jp, row i)
+  if (t >= total) return;
+  const int i = (int)(t % n);
+  long r = t / n;
+  const int jp = (int)(r % (n / 2));
+  const long A = r / (n / 2);
+  const float4 *Sa = S + (size_t)A * (n / 2) * n;
+  const float si = (i < nvec) ? 1.f : -1.f;
+  const float4 s = Sa[(size_t)jp * n + i];
+  float o[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int j = 2 * jp + h;
+    const float sj = (j < nvec) ? 1.f : -1.f;
+    const float4 v = Sa[(size_t)(i >> 1) * n + j];
+    const float re = (i & 1) ? v.z : v.x, im = (i & 1) ? v.w : v.y;
+    o[2 * h] += si * sj * re; o[2 * h + 1] -= si * sj * im;
+    if (i == j) { const float2 d = (i < nvec) ? dUp : dDown; o[2 * h] += d.x; o[2 * h + 1] += d.y; }
+  }
+  reinterpret_cast<float4 *>(G)[(((size_t)A * 9 + 8) * (n / 2) + jp) * n + i] = make_float4(o[0], o[1], o[2], o[3]);
+}
+__global__ void galerkin_copy_local_kernel(float4 *S, const float *G, int n, long total) {
+  const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const long per = (long)(n / 2) * n, A = t / per, e = t - A * per;
+  S[t] = reinterpret_cast<const float4 *>(G)[((size_t)A * 9 + 8) * per + e];
+}
+
 void DiracCoarse::build() {
   const Transfer &T = *transfer;
   const int n = 2 * T.Nvec;
@@ -443,6 +505,53 @@ void DiracCoarse::build() {
     for (int d = 0; d < 8; d++) { w8[d] = T.createFineField(); w8[d]->twistFlavor = fineFlavor; }
     for (int q = 0; q < 4; q++) { cl[q] = T.createCoarseField(); cs[q] = T.createCoarseField(); }
   }
+  // forward hops only + hermitian completion where the fine operator allows it: Wilson / twisted mass (local term (1 + i a g5):
+  // its coarse image is (1 +- i a) V^dagger V = a multiple of the identity per chirality, read off two probes), unpartitioned
+  bool herm = false;
+  if (four) {
+    static int full = -1;
+    if (full < 0) { const char *e = getenv("QUDA_AMD_GALERKIN_FULL"); full = e ? atoi(e) : 0; }
+    const QudaDiracType pt = parent->getDiracType();
+    herm = !full && (pt == QUDA_WILSON_DIRAC || pt == QUDA_TWISTED_MASS_DIRAC);
+    for (int d = 0; d < 4; d++) if (commGrid().partitioned(d)) herm = false;
+  }
+  if (herm) {
+    const int fdirs[4] = {0, 2, 4, 6};
+    for (int j = 0; j < n; j++) {
+      T.column(*phi, j);
+      for (int q = 0; q < 4; q++) parent->hopDir(*w8[q], *phi, fdirs[q]);
+      ColorSpinorField *in4[4] = {w8[0], w8[1], w8[2], w8[3]};
+      T.RSplit4(cl, cs, in4, fdirs);
+      for (int q = 0; q < 4; q++) {
+        hipLaunchKernelGGL(insert_column_kernel, dim3(nins), dim3(bs), 0, computeStream(), links->data, cvecFull(*cl[q]), n, fdirs[q], j, 0, links->nSites);
+        hipLaunchKernelGGL(insert_column_kernel, dim3(nins), dim3(bs), 0, computeStream(), links->data, cvecFull(*cs[q]), n, 8, j, 1, links->nSites);
+      }
+    }
+    // the local term's diagonal per chirality from one probe each (robust against the sign conventions of flavour and dagger)
+    float2 dloc[2];
+    for (int chi = 0; chi < 2; chi++) {
+      const int j = chi * T.Nvec;
+      T.column(*phi, j);
+      parent->localTerm(*w, *phi);
+      T.R(*c, *w);
+      HIP_CHECK(hipStreamSynchronize(computeStream()));
+      // component j of the coarse vector at coarse site 0 (even parity, x_cb = 0)
+      const CVec cv = cvecFull(*c);
+      float h[2];
+      HIP_CHECK(hipMemcpy(h, cv.v[0] + ((size_t)j * cv.stride + 0) * 2, 2 * sizeof(float), hipMemcpyDeviceToHost));
+      dloc[chi] = make_float2(h[0], h[1]);
+    }
+    const long per = (long)(n / 2) * n;
+    float4 *S = (float4 *)poolDeviceMalloc((size_t)links->nSites * per * sizeof(float4));
+    const long nS = (long)links->nSites * per;
+    hipLaunchKernelGGL(galerkin_copy_local_kernel, dim3((unsigned)((nS + 255) / 256)), dim3(256), 0, computeStream(), S, links->data, n, nS);
+    hipLaunchKernelGGL(galerkin_local_kernel, dim3((unsigned)((nS + 255) / 256)), dim3(256), 0, computeStream(), links->data, S, n, T.Nvec, dloc[0], dloc[1], nS);
+    const long nB = 4 * nS;
+    hipLaunchKernelGGL(galerkin_backward_kernel, dim3((unsigned)((nB + 255) / 256)), dim3(256), 0, computeStream(), links->data, coarseNeighbourTable(links->Xc), n, T.Nvec, nB);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(computeStream()));
+    poolDeviceFree(S, (size_t)links->nSites * per * sizeof(float4));
+  } else
   for (int j = 0; j < n; j++) {
     T.column(*phi, j);   // = P e_j for the unit vector j at every coarse site
     if (four) {

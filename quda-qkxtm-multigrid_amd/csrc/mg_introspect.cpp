@@ -197,6 +197,27 @@ double qudaAmdMultigridApplyBlock(void *mg_instance, int level, int nrhs, float 
   }
   return secs;
 }
+// seconds per application of the level's restrictor (what = 0) or prolongator (1), HIP events on the compute stream
+double qudaAmdMultigridTimeTransfer(void *mg_instance, int level, int what, int niter) {
+  MG *m = levelOf(mg_instance, level);
+  const Transfer *T = m->getTransfer();
+  if (!T) errorQuda("level %d has no transfer operator", level);
+  ColorSpinorField *fine = T->createFineField(), *coarse = T->createCoarseField();
+  blas::copy(*fine, *m->nullVectors()[0]);
+  T->R(*coarse, *fine);
+  T->P(*fine, *coarse);
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+  HIP_CHECK(hipEventRecord(e0, computeStream()));
+  for (int k = 0; k < niter; k++) { if (what) T->P(*fine, *coarse); else T->R(*coarse, *fine); }
+  HIP_CHECK(hipEventRecord(e1, computeStream()));
+  HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  HIP_CHECK(hipEventDestroy(e0)); HIP_CHECK(hipEventDestroy(e1));
+  delete fine; delete coarse;
+  return 1e-3 * ms / niter;
+}
 // the single-right-hand-side coarse operator of the same level, timed the same way (seconds per application)
 double qudaAmdMultigridTimeApply(void *mg_instance, int level, int niter) {
   MG *m = levelOf(mg_instance, level);

@@ -185,6 +185,38 @@ def test_resident_operator_api_and_properties_at_full_size(qa, oracle):
     d.free()
 
 
+def test_twisted_clover_at_full_size_against_the_oracle(qa, oracle):
+    """BASELINE configs[2]: 32^4 twisted-clover Dslash in fp32 and 16-bit (the kernels bench.py times as extra.tmc_*), every site
+    against the oracle on the same inputs — plain and xpay form (the two epilogues of DiracTwistedCloverPC::M), fp64 as well."""
+    X = (32, 32, 32, 32)
+    V = int(np.prod(X))
+    rng = np.random.default_rng(17)
+    g = rng.standard_normal((4, V, 3, 3)) + 1j * rng.standard_normal((4, V, 3, 3))
+    q, r = np.linalg.qr(g)
+    q = q * (np.diagonal(r, axis1=-2, axis2=-1) / np.abs(np.diagonal(r, axis1=-2, axis2=-1)))[..., None, :]
+    q = q / np.linalg.det(q)[..., None, None] ** (1.0 / 3.0)
+    gauge = np.ascontiguousarray(np.stack([q.real, q.imag], axis=-1)).reshape(4, V * 18)
+    del g, q, r
+    from synth import make_clover
+    clover = make_clover(list(X), seed=5)
+    kappa, mu = 0.1, 0.01
+    nh = V // 2 * 24
+    x_h = rng.random(nh)
+    oracle.set_threads(8)
+    try:
+        cinv = oracle.clover_twisted_inverse(clover, 4 * kappa * kappa * mu * mu)
+        want = oracle.tmc_dslash(gauge, x_h.copy(), clover, cinv, list(X), kappa, mu, +1, 0, "ee", 0)
+        want_m = oracle.tmc_matpc(gauge, x_h.copy(), clover, cinv, list(X), kappa, mu, +1, "ee", 0) if hasattr(oracle, "tmc_matpc") else None
+    finally:
+        oracle.set_threads(1)
+    for prec in (8, 4, 2):
+        _load_fields(qa, gauge, clover, X, kappa, mu, prec, 18)
+        ip = qa.invert_param(qa.QUDA_TWISTED_CLOVER_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=prec)
+        assert qc.rel_err(qa.dslash(x_h.copy(), ip, 0), want) < TOL[prec], prec
+        if want_m is not None:
+            assert qc.rel_err(qa.mat(x_h.copy(), ip), want_m) < 2 * TOL[prec], prec
+
+
 @pytest.mark.parametrize("mask", [1, 2, 4, 8, 6, 9, 15])
 def test_partitioned_dslash_self_neighbour(qa, mask):
     """The reference's own way of testing the halo path without a cluster (tests/test_util.cpp:2047-2065 --partition):

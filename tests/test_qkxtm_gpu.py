@@ -111,6 +111,8 @@ def test_propagators_plain_gcr(qa, oracle):
         ip.mass_normalization = norm
         ip.verbosity = qa.QUDA_SILENT
         worst = _check_propagators(qa, oracle, gauge, g_lex, X, kappa, mu, ip, (1, 2, 3, 5), 4, 0.6, norm == qa.QUDA_MASS_NORMALIZATION)
+        # the solver's own criterion is 1e-10 on the EVEN-ODD system (BASELINE's bar, met: QudaInvertParam.true_res); what is checked here
+        # is stricter in kind — the residual of the reconstructed FULL solution against the oracle's tm_mat on the host — hence the factor
         assert worst < 5e-10, (matpc, worst)
         assert ip.twist_flavor == qa.QUDA_TWIST_MINUS and 24 < ip.iter < 24 * 4000   # last solve was the down quark; iterations are summed
 
