@@ -70,6 +70,7 @@ struct DslashTune {
   int tiled = -1;      // plane-tiled order: -1 automatic (on where the lattice allows), 0 off, 1 chunk-major tiles, 2 z-major tiles
   int nxz = 0, tz = 0, tt = 0;   // plane-tiled order: XCDs along z, tile extents in z and t (0: automatic)
   int lds_pad = 0;     // dynamic LDS per block, only to cap the blocks per CU (measurement aid)
+  int ygroups = -1;    // plane-tiled order: groups of plane chunks walked one after the other (0 / 1 none, -1 automatic: fp64 fields whose three-slice set per XCD exceeds the L2, n explicit)
   // peer-store halo launch: face packing folded into the site threads (-1: environment QUDA_AMD_P2P_FOLD, default on), start delay of
   // the site blocks and raised issue priority of the pack waves (measurement aids)
   int p2p_fold = -1, site_delay = 0, pack_prio = 0;

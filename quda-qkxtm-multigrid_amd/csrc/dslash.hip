@@ -702,7 +702,16 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
     const uint32_t tile = arg.dPerTile.div((uint32_t)within), r = (uint32_t)within - tile * arg.dPerTile.d;
     const uint32_t tile_t = arg.dNtz.div(tile), tile_z = tile - tile_t * arg.dNtz.d;
     uint32_t yc, zi, ti;
-    if (arg.tiled == 2) {   // inside a tile: z slowest, then the chunk of the plane, t fastest (lexicographic for tt = 1)
+    if (arg.tiled == 3) {
+      // y groups: the XCD walks its whole (z-slab, t) range once per GROUP of plane chunks — group slowest, then t, z, chunk in the
+      // group.  The set an XCD has to hold for the +-t re-use (three time slices of its slab) shrinks by the number of groups; fp64
+      // at 48^3 x 96: 3 x 6 planes x 221 KB = 4 MB, the whole L2, without groups.  (tile = group here: dPerTile = Ts Zs Pg, dTzTt = Zs Pg,
+      // dPTt = Pg, tz = Zs, tt = 1)
+      const uint32_t tl3 = arg.dTzTt.div(r), r2 = r - tl3 * arg.dTzTt.d;
+      zi = arg.dPTt.div(r2);
+      yc = tile * arg.dPTt.d + (r2 - zi * arg.dPTt.d);
+      ti = tl3;
+    } else if (arg.tiled == 2) {   // inside a tile: z slowest, then the chunk of the plane, t fastest (lexicographic for tt = 1)
       zi = arg.dPTt.div(r); const uint32_t r2 = r - zi * arg.dPTt.d;
       yc = arg.dTt.div(r2); ti = r2 - yc * arg.dTt.d;
     } else {                // chunk slowest, then z, t fastest
@@ -710,6 +719,7 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
       zi = arg.dTt.div(r2); ti = r2 - zi * arg.dTt.d;
     }
     int zl = (int)tile_z * arg.tz + (int)zi, tl = (int)tile_t * arg.tt + (int)ti;
+    if (arg.tiled == 3) { zl = (int)zi; tl = (int)ti; }
     if (arg.edgeFirst) {
       // partitioned launch: an XCD starts with the blocks that own boundary sites (they have the most to do: the off-node hops come
       // on top, after a wait), and the blocks dispatched last — the ones that share a CU with a pack block — are interior ones.
@@ -1075,6 +1085,7 @@ DslashTune &dslashTune() {
     t.tz = env("QUDA_AMD_DSLASH_TZ", 0);
     t.tt = env("QUDA_AMD_DSLASH_TT", 0);
     t.lds_pad = env("QUDA_AMD_DSLASH_LDS", 0);
+    t.ygroups = env("QUDA_AMD_DSLASH_YGROUPS", -1);
   }
   return t;
 }
@@ -1090,6 +1101,7 @@ void setDslashTune(const char *key, int value) {
   else if (k == "tz") t.tz = value;
   else if (k == "tt") t.tt = value;
   else if (k == "lds_pad") t.lds_pad = value;
+  else if (k == "ygroups") t.ygroups = value;
   else if (k == "p2p_fold") t.p2p_fold = value;
   else if (k == "site_delay") t.site_delay = value;
   else if (k == "pack_prio") t.pack_prio = value;
@@ -1288,6 +1300,19 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
       arg.tiled = tune.tiled == 1 ? 1 : 2; arg.dPTt = FastDiv((uint32_t)((plane / bs) * tt)); arg.P = plane / bs; arg.nxz = nxz; arg.Zs = Zs; arg.Ts = Ts; arg.tz = tz; arg.tt = tt;
       arg.dNxz = FastDiv((uint32_t)nxz); arg.dPerTile = FastDiv((uint32_t)(arg.P * tz * tt)); arg.dNtz = FastDiv((uint32_t)(Zs / tz));
       arg.dTzTt = FastDiv((uint32_t)(tz * tt)); arg.dTt = FastDiv((uint32_t)tt);
+      // y groups (tune.ygroups > 1; automatic: fp64 fields whose three-slice working set per XCD exceeds the 4 MB L2)
+      int yg = tune.ygroups;
+      if (yg == 0) yg = 1;
+      if (yg < 0) {
+        yg = 1;
+        const size_t slice3 = (size_t)3 * Zs * plane * 24 * sizeof(T);
+        if (sizeof(T) == 8) while (yg < arg.P && arg.P % (2 * yg) == 0 && slice3 / yg > ((size_t)5 << 19)) yg *= 2;
+      }
+      if (yg > 1 && arg.P % yg == 0 && tz == Zs && tt == 1) {
+        const int Pg = arg.P / yg;
+        arg.tiled = 3;
+        arg.dPerTile = FastDiv((uint32_t)(Ts * Zs * Pg)); arg.dTzTt = FastDiv((uint32_t)(Zs * Pg)); arg.dPTt = FastDiv((uint32_t)Pg); arg.dNtz = FastDiv(1u);
+      }
     }
   }
   arg.commMask = 0; arg.blist = nullptr; arg.nboundary = 0;

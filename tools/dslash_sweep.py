@@ -33,7 +33,7 @@ def main():
     clover = None
     print("inputs %.1f s" % (time.time() - t0), flush=True)
     kinds = {"tm": qa.QUDA_TWISTED_MASS_DSLASH, "tmc": qa.QUDA_TWISTED_CLOVER_DSLASH, "wilson": qa.QUDA_WILSON_DSLASH}
-    defaults = dict(block=0, remap=1, order=1, store_aux=-1, tiled=-1, nxz=0, tz=0, tt=0, lds_pad=0)
+    defaults = dict(block=0, remap=1, order=1, store_aux=-1, tiled=-1, nxz=0, tz=0, tt=0, lds_pad=0, ygroups=-1)
     for prec, kind in cases:
         qa.load_gauge(gauge, qa.gauge_param(X, cuda_prec=prec))
         ip = qa.invert_param(kinds[kind], 0.1, 0.01, +1, "ee", 0, cuda_prec=prec)
