@@ -38,6 +38,100 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 from synth import make_clover, make_gauge, smooth_gauge, tiled_gauge  # noqa: E402
 
 
+class _LineGuard:
+    """Keeps the finished JSON line (rank 0) safe while an optional leg runs: a library error inside the leg writes it before the
+    process ends (qudaAmdSetExitLine; status 0 on every rank, so that the launcher does not tear the job down before rank 0 got
+    there), and a watchdog thread writes it if the leg does not come back within `timeout` seconds (ctypes calls release the GIL)."""
+
+    def __init__(self, qa, line, timeout):
+        import threading
+        self.qa, self.line, self.done = qa, line, False
+        text = None
+        if line is not None:
+            failed = dict(line)
+            failed["extra"] = dict(line.get("extra") or {}, mg_gcr=dict(failed="the library ended the process inside this leg (see stderr)"))
+            text = json.dumps(failed).encode()
+        qa.lib().qudaAmdSetExitLine(text if text is not None else b"", 0)
+        self._timer = threading.Timer(timeout, self._timeout, [timeout])
+        self._timer.daemon = True
+        self._timer.start()
+
+    def _timeout(self, timeout):
+        if self.done:
+            return
+        self.done = True
+        if self.line is not None:
+            self.line.setdefault("extra", {})["mg_gcr"] = dict(failed="no result after %.0f s" % timeout)
+            sys.stdout.write(json.dumps(self.line) + "\n")
+            sys.stdout.flush()
+        os._exit(0)
+
+    def disarm(self):
+        self.done = True
+        self._timer.cancel()
+        self.qa.lib().qudaAmdSetExitLine(None, 1)
+
+
+def run_mg_ranks(qa, dist, X, kappa=0.124, mu=0.005):
+    """MG-GCR to 1e-10 on the lattice decomposed over the ranks of `dist` (N > 1 leg of the metric): same field, source, solver and
+    hierarchy shape as run_mg at N = 1; seconds are the slowest rank's, the residual is the global |b - M x| / |b| from MatQuda."""
+    import ctypes as C
+    import multi_gpu as mgpu
+    hook = os.environ.get("QUDA_AMD_BENCH_MG_TEST")   # rehearsal of the line guard: a library error / a leg that never returns
+    if hook == "error" and dist.rank == dist.world - 1:
+        qa.lib().qudaAmdSetDslashTune(b"no-such-key", 0)
+    if hook == "hang":
+        time.sleep(1e6)
+    Xl = dist.local_dims
+    gauge = dist.scatter_gauge(smooth_gauge(tuple(X), 0.35))
+    qa.lib().freeCloverQuda()
+    qa.load_gauge(gauge, qa.gauge_param(Xl, cuda_prec=8, prec_sloppy=4, prec_precondition=4, t_boundary=qa.QUDA_PERIODIC_T))
+    del gauge
+    ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=8, prec_sloppy=4, prec_precondition=4, solution_type=qa.QUDA_MAT_SOLUTION)
+    ip.solve_type, ip.inv_type, ip.gcrNkrylov, ip.tol, ip.maxiter, ip.reliable_delta = qa.QUDA_DIRECT_SOLVE, qa.QUDA_GCR_INVERTER, 20, 1e-10, 5000, 1e-4
+    b = mgpu.scatter_field(np.random.default_rng(5).random(int(np.prod(X)) * 24), X, dist.grid, dist.coords, 24)
+
+    def global_res(x):
+        r = b - qa.mat(x, ip)
+        n2 = np.array([np.dot(r, r), np.dot(b, b)])
+        qa.lib().qudaAmdCommAllreduce(n2.ctypes.data_as(C.POINTER(C.c_double)), 2)
+        return float(np.sqrt(n2[0] / n2[1]))
+
+    def timed_solve():
+        qa.invert(b, ip)
+        best = None
+        for _ in range(2):
+            dist.barrier()
+            t0 = time.perf_counter()
+            x = qa.invert(b, ip)
+            wall = dist.max_over_ranks(time.perf_counter() - t0)
+            if best is None or wall < best[0]:
+                best = (wall, dist.max_over_ranks(ip.secs), ip.iter, x)
+        return best
+
+    ip.inv_type_precondition = qa.QUDA_INVALID_ENUM
+    wall, inner, iters, xp = timed_solve()
+    plain = dict(iters=iters, secs=round(wall, 4), solver_secs=round(inner, 4), true_res=global_res(xp))
+    # second-level aggregates by the reference's rule on the LOCAL coarse extents: the largest of 4 / 2 that leaves an even extent
+    lvl1 = [x // 4 for x in Xl]
+    b1 = tuple(2 if (x % 2 == 0 and (x // 2) % 2 == 0) else 1 for x in lvl1)
+    levels = 3 if all(x % 4 == 0 for x in Xl) and all(v == 2 for v in b1) else 2
+    dist.barrier()
+    t0 = time.perf_counter()
+    mp = qa.multigrid_param(ip, n_level=levels, geo_block=[(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)][:levels], n_vec=24, setup_maxiter=500, setup_tol=5e-6, smoother_pc=True)
+    mg = qa.Multigrid(mp)
+    setup = dist.max_over_ranks(time.perf_counter() - t0)
+    ip.inv_type_precondition = qa.QUDA_MG_INVERTER
+    ip.preconditioner = mg.h
+    ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
+    wall, inner, iters, x = timed_solve()
+    out = dict(lattice="x".join(map(str, X)), local_lattice="x".join(map(str, Xl)), process_grid=list(dist.grid), kappa=kappa, mu=mu, levels=levels, n_vec=24,
+               setup_secs=round(setup, 3), solve_secs=round(wall, 4), solver_secs=round(inner, 4), iters=iters, true_res=global_res(x), plain_gcr=plain,
+               timing="slowest rank, best of 2 after 1 warm-up solve; residual = global |b - M x| / |b| through MatQuda")
+    mg.free()
+    return out
+
+
 def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)), gauge=None, extras=True, kappa=0.124, mu=0.005, plain_maxiter=5000,
            coarse_bench=True, setup_repeats=1):
     """MG-preconditioned GCR to |r|/|b| <= 1e-10 (the second half of the metric) on one GPU: 3-level K-cycle, 24 null
@@ -155,6 +249,7 @@ def main():
     ap.add_argument("--fast-gauge", action="store_true", help="links = periodic repetition of 65536 random SU(3) matrices (profiling of big lattices)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the other-precision sweep")
+    ap.add_argument("--no-mg", action="store_true", help="N > 1: skip the MG-GCR leg on the decomposed lattice")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -388,7 +483,22 @@ def main():
             "cpu_baseline": cpu,
             "extra": extra,
         }
-        print(json.dumps(out))
+    if world > 1 and not args.no_mg and (X == [32, 32, 32, 32] or os.environ.get("QUDA_AMD_BENCH_MG_ANY")):
+        # The second half of the metric on the decomposed lattice: the same 32^4 MG-GCR problem as extra.mg_gcr at N = 1, the
+        # hierarchy built and the K-cycle run across the ranks (aggregates never straddle ranks, coarse halos through the same
+        # transport, global sums through the collective path).  The Dslash line above is complete at this point; a guard makes sure
+        # it is printed whatever happens in this leg — the library ends the process on an error (errorQuda -> exit, as the
+        # reference), and a collective that never returns would otherwise take the line with it.
+        guard = _LineGuard(qa, out if rank == 0 else None, float(os.environ.get("QUDA_AMD_BENCH_MG_TIMEOUT", "420")))
+        try:
+            res = run_mg_ranks(qa, dist, X)
+        except Exception as e:
+            res = dict(failed=str(e)[:300])
+        guard.disarm()
+        if rank == 0:
+            out["extra"]["mg_gcr"] = res
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.finalize()
     else:

@@ -88,6 +88,9 @@ void qudaAmdMultigridApply(void *mg_instance, int level, int op, float *h_out, c
  * back-to-back applications with device events and returns the seconds per application (0 otherwise).
  * qudaAmdMultigridTimeApply times the single-vector operator of a level the same way. */
 double qudaAmdMultigridApplyBlock(void *mg_instance, int level, int nrhs, float *h_out, const float *h_in, int niter);
+/* errorQuda ends the process (reference convention, include/util_quda.h:51-61).  A caller holding finished results can leave a text
+ * here that is written to stdout first, and the exit status to use; text = NULL restores the default (nothing, status 1). */
+void qudaAmdSetExitLine(const char *text, int status);
 double qudaAmdMultigridTimeApply(void *mg_instance, int level, int niter);
 /* seconds per application of the restrictor (what = 0) or prolongator (what = 1) between `level` and `level + 1` */
 double qudaAmdMultigridTimeTransfer(void *mg_instance, int level, int what, int niter);

@@ -602,6 +602,9 @@ void qudaAmdSetPartitionMask(int mask) {
 }
 void *qudaAmdComputeStream(void) { return (void *)computeStream(); }
 int qudaAmdHaloTransport(void) { return p2pTransport(); }
+// text written to stdout (and exit status used) if a library error ends the process; nullptr clears (quda_amd_ext.h)
+void qudaAmdSetExitLine(const char *text, int status) { setExitLine(text, status); }
+
 void qudaAmdSetDslashTune(const char *key, int value) { setDslashTune(key, value); }
 
 // ---- raw device images (layout contract checks, tests/test_layout_gpu.py) ----

@@ -1,6 +1,7 @@
 // qa_core.cpp — logging / error convention, streams, process-grid state.
 // Reference behaviour: include/util_quda.h:40-105 (printfQuda/warningQuda/errorQuda, verbosity),
 // lib/comm_common.cpp (topology), include/quda_internal.h:314-319 (streams).
+#include <string>
 #include "qa_core.h"
 
 #include <map>
@@ -61,6 +62,15 @@ void qa_warning(const char *fmt, ...) {
   fflush(f);
 }
 
+// A caller that has results to deliver (bench.py: its finished JSON line, while an optional leg is still running) can leave them
+// here: an error then writes the text to stdout before the process ends, with the status the caller asked for.
+static std::string g_exitLine;
+static int g_exitStatus = 1;
+void setExitLine(const char *text, int status) {
+  g_exitLine = text ? text : "";
+  g_exitStatus = text ? status : 1;
+}
+
 void qa_error(const char *file, int line, const char *func, const char *fmt, ...) {
   FILE *f = g_out ? g_out : stderr;
   fprintf(f, "%sERROR: ", g_prefix);
@@ -70,7 +80,8 @@ void qa_error(const char *file, int line, const char *func, const char *fmt, ...
   va_end(ap);
   fprintf(f, " (rank %d, %s:%d in %s())\n", commGrid().rank, file, line, func);
   fflush(f);
-  exit(1);  // comm_abort(1) of the reference, lib/comm_single.cpp:58-63
+  if (!g_exitLine.empty()) { fputs(g_exitLine.c_str(), stdout); fputc('\n', stdout); fflush(stdout); }
+  exit(g_exitStatus);  // comm_abort(1) of the reference, lib/comm_single.cpp:58-63
 }
 
 CommGrid &commGrid() {

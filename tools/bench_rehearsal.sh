@@ -6,7 +6,7 @@ export MASTER_ADDR=127.0.0.1 MASTER_PORT=$((20000 + $$ % 20000)) WORLD_SIZE=$N Q
 export QUDA_AMD_TRANSPORT=shm QUDA_AMD_SHM_DIR=$(mktemp -d /dev/shm/quda_amd_XXXXXX)
 pids=()
 for r in $(seq 0 $((N-1))); do
-  RANK=$r LOCAL_RANK=$r timeout -k 5 200 python3 bench.py --gpus $N --no-cpu --no-extra "$@" > ${LOG}.rank$r 2>&1 &
+  RANK=$r LOCAL_RANK=$r timeout -k 5 ${REH_TIMEOUT:-200} python3 bench.py --gpus $N --no-cpu --no-extra "$@" > ${LOG}.rank$r 2>&1 &
   pids+=($!)
 done
 rc=0
