@@ -43,6 +43,10 @@ void qudaAmdDiracM(void *dirac, void *out, const void *in);
 void qudaAmdDiracMdag(void *dirac, void *out, const void *in);
 void qudaAmdDiracMdagM(void *dirac, void *out, const void *in);
 unsigned long long qudaAmdDiracFlops(void *dirac);
+/* Dirac::prepare / reconstruct (include/dirac_quda.h:152-164) on resident FULL fields x, b: prepare leaves the source of the
+ * preconditioned system in src_out (a parity field; a full field for un-preconditioned operators), reconstruct completes x */
+void qudaAmdDiracPrepare(void *dirac, void *src_out, void *x, void *b, QudaSolutionType solution_type);
+void qudaAmdDiracReconstruct(void *dirac, void *x, const void *b, QudaSolutionType solution_type);
 
 /* niter back-to-back Dslash applications bracketed by device events on the compute stream;
  * returns seconds per application (reference tests/dslash_test.cpp:455-616). */

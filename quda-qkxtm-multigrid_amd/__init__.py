@@ -118,7 +118,7 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
                  "qudaAmdCommInit", "qudaAmdCommRank", "qudaAmdCommSize", "qudaAmdCommCoords", "qudaAmdCommBarrier", "qudaAmdCommAllreduce", "qudaAmdCommAllreduceMax",
                  "qudaAmdMultigridVerify", "qudaAmdMultigridCycle", "qudaAmdTimeAxpy", "qudaAmdMultigridLevels", "qudaAmdMultigridLevelInfo",
                  "qudaAmdMultigridSetHalfStorage", "qudaAmdMultigridGetNullVector", "qudaAmdMultigridGetV", "qudaAmdMultigridGetCoarseLinks", "qudaAmdMultigridApply", "qudaAmdMultigridApplyBlock",
-                 "qudaAmdMultigridTimeApply", "qudaAmdMultigridTimeTransfer", "qudaAmdSetExitLine", "qudaAmdSpinorRawInfo", "qudaAmdGaugeRawInfo", "qudaAmdCloverRawInfo", "qudaAmdRawDeviceCopy",
+                 "qudaAmdMultigridTimeApply", "qudaAmdMultigridTimeTransfer", "qudaAmdSetExitLine", "qudaAmdDiracPrepare", "qudaAmdDiracReconstruct", "qudaAmdSpinorRawInfo", "qudaAmdGaugeRawInfo", "qudaAmdCloverRawInfo", "qudaAmdRawDeviceCopy",
                  "qudaAmdSetSolutionSink"]
 
 _lib = None
@@ -206,6 +206,10 @@ def lib():
         L.qudaAmdMultigridTimeTransfer.restype = _d
         L.qudaAmdSetExitLine.argtypes = [C.c_char_p, _i]
         L.qudaAmdSetExitLine.restype = None
+        L.qudaAmdDiracPrepare.argtypes = [_p, _p, _p, _p, _i]
+        L.qudaAmdDiracPrepare.restype = None
+        L.qudaAmdDiracReconstruct.argtypes = [_p, _p, _p, _i]
+        L.qudaAmdDiracReconstruct.restype = None
         L.qudaAmdReadLimeGauge.argtypes = [C.POINTER(_p), C.c_char_p, C.POINTER(QudaGaugeParam), C.POINTER(QudaInvertParam), C.POINTER(_i)]
         L.qudaAmdWriteLimeGauge.argtypes = [C.POINTER(_p), C.c_char_p, C.POINTER(QudaGaugeParam), C.c_char_p]
         L.plaqQuda.argtypes = [C.POINTER(_d)]
@@ -478,6 +482,13 @@ class Dirac:
 
     def MdagM(self, out, inp):
         lib().qudaAmdDiracMdagM(self.h, out.h, inp.h)
+
+    def prepare(self, src_out, x, b, solution_type):
+        """Dirac::prepare on resident full fields; the source of the (preconditioned) system is copied into src_out"""
+        lib().qudaAmdDiracPrepare(self.h, src_out.h, x.h, b.h, int(solution_type))
+
+    def reconstruct(self, x, b, solution_type):
+        lib().qudaAmdDiracReconstruct(self.h, x.h, b.h, int(solution_type))
 
     def time_dslash(self, out, inp, parity, niter):
         return lib().qudaAmdTimeDslash(self.h, out.h, inp.h, int(parity), int(niter))

@@ -526,6 +526,17 @@ void qudaAmdDiracM(void *d, void *out, const void *in) { ((Dirac *)d)->M(*(Color
 void qudaAmdDiracMdag(void *d, void *out, const void *in) { ((Dirac *)d)->Mdag(*(ColorSpinorField *)out, *(const ColorSpinorField *)in); }
 void qudaAmdDiracMdagM(void *d, void *out, const void *in) { ((Dirac *)d)->MdagM(*(ColorSpinorField *)out, *(const ColorSpinorField *)in); }
 unsigned long long qudaAmdDiracFlops(void *d) { return ((Dirac *)d)->Flops(); }
+// Dirac::prepare / reconstruct on resident full fields (reference include/dirac_quda.h:152-164): prepare builds the source of the
+// (even-odd preconditioned) system from b — in the half of x the reference uses as scratch — and hands back a copy of it;
+// reconstruct completes x from the solved half and b
+void qudaAmdDiracPrepare(void *d, void *src_out, void *x, void *b, QudaSolutionType solution_type) {
+  ColorSpinorField *src = nullptr, *sol = nullptr;
+  ((Dirac *)d)->prepare(src, sol, *(ColorSpinorField *)x, *(ColorSpinorField *)b, solution_type);
+  blas::copy(*(ColorSpinorField *)src_out, *src);
+}
+void qudaAmdDiracReconstruct(void *d, void *x, const void *b, QudaSolutionType solution_type) {
+  ((Dirac *)d)->reconstruct(*(ColorSpinorField *)x, *(const ColorSpinorField *)b, solution_type);
+}
 
 double qudaAmdTimeDslash(void *d, void *out, const void *in, QudaParity parity, int niter) {
   hipEvent_t e0, e1;

@@ -185,6 +185,49 @@ def test_resident_operator_api_and_properties_at_full_size(qa, oracle):
     d.free()
 
 
+@pytest.mark.parametrize("matpc", ["ee", "oo", "eeasym", "ooasym"])
+def test_prepare_and_reconstruct_element_wise(qa, oracle, matpc):
+    """Dirac::prepare / reconstruct of the even-odd preconditioned twisted-mass operator (SURVEY 8 row a5; reference
+    lib/dirac_twisted_mass.cpp:526-586) against the oracle's building blocks on every site: with M = A - kappa D,
+    src = [A^-1] (b_p + kappa D A^-1 b_q) and x_q = A^-1 (b_q + kappa D x_p)."""
+    X = (8, 8, 8, 8)
+    gauge, spinor, _ = oracle.make_fields(list(X), clover=False)
+    nh = spinor.size // 2
+    kappa, mu = 0.1, 0.01
+    rng = np.random.default_rng(3)
+    b_h, x_h = spinor.copy(), rng.random(spinor.size)
+    Ainv = lambda v: oracle.twist_gamma5(v, kappa, mu, +1, 0, 1)
+    A = lambda v: oracle.twist_gamma5(v, kappa, mu, +1, 0, 0)
+    D = lambda v, parity: oracle.wil_dslash(gauge, v, list(X), parity, 0)
+    # conventions of the building blocks, pinned on the full operator: M x = A x - kappa D x
+    full = np.concatenate([A(x_h[:nh]) - kappa * D(x_h[nh:], 0), A(x_h[nh:]) - kappa * D(x_h[:nh], 1)])
+    assert qc.rel_err(full, oracle.tm_mat(gauge, x_h.copy(), list(X), kappa, mu, +1, 0)) < 1e-13
+    _load_fields(qa, gauge, None, X, kappa, mu, 8, 18)
+    ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, matpc, 0, cuda_prec=8, solution_type=qa.QUDA_MAT_SOLUTION)
+    ip.solve_type = qa.QUDA_DIRECT_PC_SOLVE
+    d = qa.Dirac(ip, pc=True)
+    x, b, src = qa.Spinor(8, qa.QUDA_FULL_SITE_SUBSET), qa.Spinor(8, qa.QUDA_FULL_SITE_SUBSET), qa.Spinor(8)
+    x.load(x_h, ip)
+    b.load(b_h, ip)
+    p = 0 if matpc.startswith("ee") else 1            # parity the system is solved on
+    half = lambda v, par: v[:nh] if par == 0 else v[nh:]
+    want = half(b_h, p) + kappa * D(Ainv(half(b_h, 1 - p)), p)
+    if not matpc.endswith("asym"):
+        want = Ainv(want)
+    d.prepare(src, x, b, qa.QUDA_MAT_SOLUTION)
+    assert qc.rel_err(src.save(ip, b_h[:nh]), want) < 1e-13
+    # reconstruct: the solved half of x stays, the other one is A^-1 (b_q + kappa D x_p)
+    x.load(x_h, ip)
+    b.load(b_h, ip)
+    d.reconstruct(x, b, qa.QUDA_MAT_SOLUTION)
+    got = x.save(ip, x_h)
+    assert np.array_equal(half(got, p), half(x_h, p))
+    assert qc.rel_err(half(got, 1 - p), Ainv(half(b_h, 1 - p) + kappa * D(half(x_h, p), 1 - p))) < 1e-13
+    for f in (x, b, src):
+        f.free()
+    d.free()
+
+
 def test_twisted_clover_at_full_size_against_the_oracle(qa, oracle):
     """BASELINE configs[2]: 32^4 twisted-clover Dslash in fp32 and 16-bit (the kernels bench.py times as extra.tmc_*), every site
     against the oracle on the same inputs — plain and xpay form (the two epilogues of DiracTwistedCloverPC::M), fp64 as well."""
