@@ -507,29 +507,41 @@ void DiracCoarse::build() {
   }
   // forward hops only + hermitian completion where the fine operator allows it: Wilson / twisted mass (local term (1 + i a g5):
   // its coarse image is (1 +- i a) V^dagger V = a multiple of the identity per chirality, read off two probes), unpartitioned
-  bool herm = false;
-  if (four) {
+  // A coarse parent (second coarsening) has the same structure in its hop part — its backward links ARE the g5-conjugates of its
+  // forward ones — but a dense local matrix: that one is probed as before, after the completion.
+  bool herm = false, analyticLocal = false;
+  {
     static int full = -1;
     if (full < 0) { const char *e = getenv("QUDA_AMD_GALERKIN_FULL"); full = e ? atoi(e) : 0; }
     const QudaDiracType pt = parent->getDiracType();
-    herm = !full && (pt == QUDA_WILSON_DIRAC || pt == QUDA_TWISTED_MASS_DIRAC);
+    analyticLocal = four && (pt == QUDA_WILSON_DIRAC || pt == QUDA_TWISTED_MASS_DIRAC);
+    herm = !full && (analyticLocal || (!four && pt == QUDA_COARSE_DIRAC));
     for (int d = 0; d < 4; d++) if (commGrid().partitioned(d)) herm = false;
   }
   if (herm) {
     const int fdirs[4] = {0, 2, 4, 6};
     for (int j = 0; j < n; j++) {
       T.column(*phi, j);
-      for (int q = 0; q < 4; q++) parent->hopDir(*w8[q], *phi, fdirs[q]);
-      ColorSpinorField *in4[4] = {w8[0], w8[1], w8[2], w8[3]};
-      T.RSplit4(cl, cs, in4, fdirs);
-      for (int q = 0; q < 4; q++) {
-        hipLaunchKernelGGL(insert_column_kernel, dim3(nins), dim3(bs), 0, computeStream(), links->data, cvecFull(*cl[q]), n, fdirs[q], j, 0, links->nSites);
-        hipLaunchKernelGGL(insert_column_kernel, dim3(nins), dim3(bs), 0, computeStream(), links->data, cvecFull(*cs[q]), n, 8, j, 1, links->nSites);
+      if (four) {
+        for (int q = 0; q < 4; q++) parent->hopDir(*w8[q], *phi, fdirs[q]);
+        ColorSpinorField *in4[4] = {w8[0], w8[1], w8[2], w8[3]};
+        T.RSplit4(cl, cs, in4, fdirs);
+        for (int q = 0; q < 4; q++) {
+          hipLaunchKernelGGL(insert_column_kernel, dim3(nins), dim3(bs), 0, computeStream(), links->data, cvecFull(*cl[q]), n, fdirs[q], j, 0, links->nSites);
+          hipLaunchKernelGGL(insert_column_kernel, dim3(nins), dim3(bs), 0, computeStream(), links->data, cvecFull(*cs[q]), n, 8, j, 1, links->nSites);
+        }
+      } else {
+        for (int q = 0; q < 4; q++) {
+          parent->hopDir(*w, *phi, fdirs[q]);
+          T.RSplit(*c, *c2, *w, fdirs[q]);
+          hipLaunchKernelGGL(insert_column_kernel, dim3(nins), dim3(bs), 0, computeStream(), links->data, cvecFull(*c), n, fdirs[q], j, 0, links->nSites);
+          hipLaunchKernelGGL(insert_column_kernel, dim3(nins), dim3(bs), 0, computeStream(), links->data, cvecFull(*c2), n, 8, j, 1, links->nSites);
+        }
       }
     }
     // the local term's diagonal per chirality from one probe each (robust against the sign conventions of flavour and dagger)
-    float2 dloc[2];
-    for (int chi = 0; chi < 2; chi++) {
+    float2 dloc[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+    for (int chi = 0; analyticLocal && chi < 2; chi++) {
       const int j = chi * T.Nvec;
       T.column(*phi, j);
       parent->localTerm(*w, *phi);
@@ -551,6 +563,13 @@ void DiracCoarse::build() {
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(computeStream()));
     poolDeviceFree(S, (size_t)links->nSites * per * sizeof(float4));
+    if (!analyticLocal)
+      for (int j = 0; j < n; j++) {   // the dense local matrix of a coarse parent, on top of the completed hop part
+        T.column(*phi, j);
+        parent->localTerm(*w, *phi);
+        T.R(*c, *w);
+        hipLaunchKernelGGL(insert_column_kernel, dim3(nins), dim3(bs), 0, computeStream(), links->data, cvecFull(*c), n, 8, j, 1, links->nSites);
+      }
   } else
   for (int j = 0; j < n; j++) {
     T.column(*phi, j);   // = P e_j for the unit vector j at every coarse site
