@@ -113,11 +113,33 @@ template <bool HALF> __device__ __forceinline__ float4 load_v(const void *V, siz
   return make_float4(t.x, t.y, t.z, t.w);
 }
 
+// work-group -> aggregate.  xgroup > 0: the four aggregates that are neighbours along x (xgroup = Xc[0] / 4 such groups per row) take
+// four consecutive slots of ONE XCD (work-groups b, b + 8, b + 16, b + 24).  An aggregate 4 sites wide covers 2 consecutive
+// checkerboard sites per row and parity, i.e. a 32-byte piece of every 128-byte line of the fine field; written a quarter at a
+// time by work-groups far apart in the grid (neighbours along x differ in coarse parity: half a grid apart) every line went to
+// memory in pieces once the field no longer fits the Infinity Cache — prolongator at 48^3 x 96: 0.56 of the HBM roofline against
+// 0.76 at 32^4.  With the four quarters written from one L2 within microseconds the line leaves it whole.  The restrictors READ the
+// fine vectors in the same 32-byte pieces (restrict4_kernel four of them at once): same order, so that three of the four pieces of a
+// line are L2 hits.
+struct AggMap { int xgroup, X0, X1, X2, Vh; };
+__device__ __forceinline__ int aggregate_of_block(const AggMap &m) {
+  const int b = blockIdx.x;
+  if (!m.xgroup) return b;
+  const int xcd = b & 7, within = b >> 3;
+  int g = xcd + 8 * (within >> 2);
+  const int r = within & 3;
+  const int xg = g % m.xgroup; g /= m.xgroup;
+  const int y = g % m.X1; g /= m.X1;
+  const int z = g % m.X2; const int t = g / m.X2;
+  const int x = 4 * xg + r;
+  return ((x + y + z + t) & 1) * m.Vh + ((((t * m.X2 + z) * m.X1 + y) * m.X0 + x) >> 1);
+}
+
 template <int NSF, int NCF, int NVEC, int NV, bool DUAL, bool HALF = false>
-__global__ void restrict_kernel(CoarseVec out, CoarseVec out2, FineVec in, const void *V, const int *block_to_fine, int blockVol, int spin_bs, MaskArg mask) {
+__global__ void restrict_kernel(CoarseVec out, CoarseVec out2, FineVec in, const void *V, const int *block_to_fine, int blockVol, int spin_bs, MaskArg mask, AggMap amap) {
   constexpr int K = NSF * NCF;
   __shared__ float4 lds[16];
-  const int A = blockIdx.x, b = threadIdx.x;
+  const int A = aggregate_of_block(amap), b = threadIdx.x;
   const bool active = b < blockVol && (DUAL || mask_keep(mask, b));
   const bool outside = DUAL && b < blockVol && mask_outside(mask, b);
   float2 r[K];
@@ -186,10 +208,10 @@ __device__ __forceinline__ bool mask_outside_dir(const MaskArg &m, int dir, int 
 // every wave keeps its partial sums of ALL (chirality, vector pair) steps in its own LDS rows, so the steps run back to back
 // without a barrier (24 steps x 2 barriers made this kernel 2.5x slower than the V stream); one barrier, then the block sum
 template <int NSF, int NCF, int NVEC, int NV>
-__global__ void __launch_bounds__(256) restrict4_kernel(Multi4 a, const float4 *V, const int *block_to_fine, int blockVol, int spin_bs, MaskArg mask) {
+__global__ void __launch_bounds__(256) restrict4_kernel(Multi4 a, const float4 *V, const int *block_to_fine, int blockVol, int spin_bs, MaskArg mask, AggMap amap) {
   constexpr int K = NSF * NCF, NIT = NVEC;   // steps = 2 chiralities x NVEC / 2 vector pairs
   __shared__ float4 part[4][NIT][8];          // [wave][step][rhs*2 + (0 leaving, 1 staying)]
-  const int A = blockIdx.x, b = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  const int A = aggregate_of_block(amap), b = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   const bool site = b < blockVol;
   float2 r[4][K];
   bool outside[4];
@@ -400,26 +422,6 @@ __global__ void __launch_bounds__(512) prolong_small_kernel(FineVec out, CoarseV
 }
 
 // ---- prolongator ----
-// work-group -> aggregate.  xgroup > 0: the four aggregates that are neighbours along x (xgroup = Xc[0] / 4 such groups per row) take
-// four consecutive slots of ONE XCD (work-groups b, b + 8, b + 16, b + 24).  An aggregate 4 sites wide covers 2 consecutive
-// checkerboard sites per row and parity, i.e. a 32-byte piece of every 128-byte line of the fine field; written a quarter at a
-// time by work-groups far apart in the grid (neighbours along x differ in coarse parity: half a grid apart) every line went to
-// memory in pieces once the field no longer fits the Infinity Cache — prolongator at 48^3 x 96: 0.56 of the HBM roofline against
-// 0.76 at 32^4.  With the four quarters written from one L2 within microseconds the line leaves it whole.
-struct AggMap { int xgroup, X0, X1, X2, Vh; };
-__device__ __forceinline__ int aggregate_of_block(const AggMap &m) {
-  const int b = blockIdx.x;
-  if (!m.xgroup) return b;
-  const int xcd = b & 7, within = b >> 3;
-  int g = xcd + 8 * (within >> 2);
-  const int r = within & 3;
-  const int xg = g % m.xgroup; g /= m.xgroup;
-  const int y = g % m.X1; g /= m.X1;
-  const int z = g % m.X2; const int t = g / m.X2;
-  const int x = 4 * xg + r;
-  return ((x + y + z + t) & 1) * m.Vh + ((((t * m.X2 + z) * m.X1 + y) * m.X0 + x) >> 1);
-}
-
 template <int NSF, int NCF, int NVEC, int NV, bool HALF = false>
 __global__ void prolong_kernel(FineVec out, CoarseVec in, const void *V, const int *block_to_fine, int blockVol, int spin_bs, AggMap amap) {
   constexpr int K = NSF * NCF;
@@ -880,6 +882,15 @@ void Transfer::setSiteSubset(QudaSiteSubset subset, QudaParity parity) {
   subset_parity = parity;
 }
 
+// the x-neighbour aggregate order (aggregate_of_block) where the blocking allows it; QUDA_AMD_PROLONG_XGROUP=0 switches it off
+static AggMap aggMapOf(const Transfer &T) {
+  AggMap amap = {0, T.Xc[0], T.Xc[1], T.Xc[2], T.nAgg / 2};
+  static int off = -1;
+  if (off < 0) { const char *e = getenv("QUDA_AMD_PROLONG_XGROUP"); off = (e && !atoi(e)) ? 1 : 0; }
+  if (!off && T.geo_bs[0] == 4 && T.Xc[0] % 4 == 0 && T.nAgg % 32 == 0) amap.xgroup = T.Xc[0] / 4;
+  return amap;
+}
+
 void Transfer::R(ColorSpinorField &coarse, const ColorSpinorField &fine, int dir, int boundary) const {
   const bool sub = fine.SiteSubset() == QUDA_PARITY_SITE_SUBSET;
   if (sub && site_subset != QUDA_PARITY_SITE_SUBSET) errorQuda("single-parity fine field but the transfer is set to full fields");
@@ -897,8 +908,8 @@ void Transfer::R(ColorSpinorField &coarse, const ColorSpinorField &fine, int dir
 #define QA_R(NSF, NCF, NVEC, NV) \
   if (small && half) hipLaunchKernelGGL((restrict_small_kernel<NSF, NCF, NVEC, NV, false, true>), dim3(nAgg), dim3(512), 0, computeStream(), out, out, in, (const void *)V_h, block_to_fine, blockVol, gs, spin_bs, m); \
   else if (small) hipLaunchKernelGGL((restrict_small_kernel<NSF, NCF, NVEC, NV, false, false>), dim3(nAgg), dim3(512), 0, computeStream(), out, out, in, (const void *)V, block_to_fine, blockVol, gs, spin_bs, m); \
-  else if (half) hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, false, true>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out, in, (const void *)V_h, block_to_fine, blockVol, spin_bs, m); \
-  else hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, false, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out, in, (const void *)V, block_to_fine, blockVol, spin_bs, m)
+  else if (half) hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, false, true>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out, in, (const void *)V_h, block_to_fine, blockVol, spin_bs, m, aggMapOf(*this)); \
+  else hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, false, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out, in, (const void *)V, block_to_fine, blockVol, spin_bs, m, aggMapOf(*this))
   QA_TRANSFER_DISPATCH(QA_R)
 #undef QA_R
   HIP_CHECK(hipGetLastError());
@@ -920,7 +931,7 @@ void Transfer::RSplit(ColorSpinorField &leaving, ColorSpinorField &staying, cons
   const bool small = blockVol <= 32;
 #define QA_R2(NSF, NCF, NVEC, NV) \
   if (small) hipLaunchKernelGGL((restrict_small_kernel<NSF, NCF, NVEC, NV, true, false>), dim3(nAgg), dim3(512), 0, computeStream(), out, out2, in, (const void *)V, block_to_fine, blockVol, gs, spin_bs, m); \
-  else hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, true, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out2, in, (const void *)V, block_to_fine, blockVol, spin_bs, m)
+  else hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, true, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out2, in, (const void *)V, block_to_fine, blockVol, spin_bs, m, aggMapOf(*this))
   QA_TRANSFER_DISPATCH(QA_R2)
 #undef QA_R2
   HIP_CHECK(hipGetLastError());
@@ -943,12 +954,7 @@ void Transfer::P(ColorSpinorField &fine, const ColorSpinorField &coarse) const {
   else if (small) hipLaunchKernelGGL((prolong_small_kernel<NSF, NCF, NVEC, NV, false>), dim3(nAgg), dim3(512), 0, computeStream(), out, in, (const void *)V, block_to_fine, blockVol, gs, spin_bs); \
   else if (half) hipLaunchKernelGGL((prolong_kernel<NSF, NCF, NVEC, NV, true>), dim3(nAgg), dim3(threads), 0, computeStream(), out, in, (const void *)V_h, block_to_fine, blockVol, spin_bs, amap); \
   else hipLaunchKernelGGL((prolong_kernel<NSF, NCF, NVEC, NV, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, in, (const void *)V, block_to_fine, blockVol, spin_bs, amap)
-  AggMap amap = {0, Xc[0], Xc[1], Xc[2], nAgg / 2};
-  {
-    static int off = -1;
-    if (off < 0) { const char *e = getenv("QUDA_AMD_PROLONG_XGROUP"); off = (e && !atoi(e)) ? 1 : 0; }
-    if (!off && geo_bs[0] == 4 && Xc[0] % 4 == 0 && nAgg % 32 == 0) amap.xgroup = Xc[0] / 4;
-  }
+  const AggMap amap = aggMapOf(*this);
   QA_TRANSFER_DISPATCH(QA_P)
 #undef QA_P
   HIP_CHECK(hipGetLastError());
@@ -988,10 +994,10 @@ void Transfer::RSplit4(ColorSpinorField *const leaving[4], ColorSpinorField *con
   for (int d = 0; d < 4; d++) { m.bs[d] = geo_bs[d]; m.single[d] = Xc[d] == 1; }
   const int threads = (blockVol + 63) / 64 * 64;
   switch (Nvec) {
-    case 4: hipLaunchKernelGGL((restrict4_kernel<4, 3, 4, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const float4 *)V, block_to_fine, blockVol, spin_bs, m); break;
-    case 8: hipLaunchKernelGGL((restrict4_kernel<4, 3, 8, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const float4 *)V, block_to_fine, blockVol, spin_bs, m); break;
-    case 24: hipLaunchKernelGGL((restrict4_kernel<4, 3, 24, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const float4 *)V, block_to_fine, blockVol, spin_bs, m); break;
-    case 32: hipLaunchKernelGGL((restrict4_kernel<4, 3, 32, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const float4 *)V, block_to_fine, blockVol, spin_bs, m); break;
+    case 4: hipLaunchKernelGGL((restrict4_kernel<4, 3, 4, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const float4 *)V, block_to_fine, blockVol, spin_bs, m, aggMapOf(*this)); break;
+    case 8: hipLaunchKernelGGL((restrict4_kernel<4, 3, 8, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const float4 *)V, block_to_fine, blockVol, spin_bs, m, aggMapOf(*this)); break;
+    case 24: hipLaunchKernelGGL((restrict4_kernel<4, 3, 24, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const float4 *)V, block_to_fine, blockVol, spin_bs, m, aggMapOf(*this)); break;
+    case 32: hipLaunchKernelGGL((restrict4_kernel<4, 3, 32, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const float4 *)V, block_to_fine, blockVol, spin_bs, m, aggMapOf(*this)); break;
     default: errorQuda("Nvec = %d not instantiated", Nvec);
   }
   HIP_CHECK(hipGetLastError());
