@@ -358,7 +358,7 @@ void applyCoarseBlock(BlockField &out, const BlockField &in, const CoarseGauge &
     // sites per work-group: enough work-groups left to fill 256 CUs x 3 several times over
     static int spwEnv = -1;
     if (spwEnv < 0) { const char *e = getenv("QUDA_AMD_BLOCK_COARSE_SPW"); spwEnv = e ? atoi(e) : 0; }
-    int spw = spwEnv > 0 ? spwEnv : 8;
+    int spw = spwEnv > 0 ? spwEnv : 4;   // measured at 12^3 x 24, n = 48: 4 sites 1066 / 1407 / 1834 us (8 / 16 / 24 right-hand sides), 8 sites 1084 / 1429 / 1864, 32 sites 1226 / 1520 / 1888
     while (spw > 1 && G.nSites / spw < 4 * 768) spw /= 2;
     arg.spw = spw;
   }
