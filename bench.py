@@ -7,8 +7,11 @@ reference's kernel-level flop count (1368 / checkerboard site, lib/dslash_twiste
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--prec 8|4|2] [--recon 18|12] [--dslash tm|tmc|wilson] [--lattice X,Y,Z,T]
 
-N > 1 (launched by torch.distributed.run): the global lattice is 4-D block-decomposed over the ranks and the
-halo exchange rides RCCL (strong scaling: the global volume is fixed).
+N > 1 (launched by torch.distributed.run): the global lattice is 4-D block-decomposed over the ranks (strong scaling: the
+global volume is fixed); the halo goes through direct peer stores over xGMI where the start-up probe and the first-use check
+allow it, else through grouped RCCL send/recv.  After the Dslash measurement the ranks run the MG-GCR half of the metric on the
+decomposed lattice (extra.mg_gcr; --no-mg skips it).  N = 1 adds the other precisions / actions, the 48^3 x 96 legs, the partitioned
+sub-lattice kernel of an 8-GPU split, the MG-GCR legs (32^4, its critical kappa, 16^4, 48^3 x 96) and the CPU baselines under `extra`.
 
 One JSON line on stdout; `roofline` is computed from the ALGORITHMIC bytes of the stencil kernel
 divided by its average duration measured with HIP events on the stream the kernel runs on; `cpu_baseline` is
