@@ -1,5 +1,6 @@
 // transfer.hip — restrictor / prolongator / block Gram-Schmidt kernels and the Transfer host class (see transfer.h).
 #include "transfer.h"
+#include "device_io.h"   // pk:: packed fp32 complex arithmetic
 
 #include <cstring>
 
@@ -593,13 +594,15 @@ template <int NVEC> __global__ void __launch_bounds__(256) block_cholqr_kernel(f
 #pragma unroll
       for (int q = 0; q < 3; q++) {
         if (pi[q] < 0) continue;
-        double re = 0, im = 0;
+        // fp32 inside a chunk (packed: conj(a) b = two v_pk_fma_f32), fp64 across the chunks: the per-term conversions and fp64
+        // multiply-adds made this loop the most expensive part of the kernel (59.5 ms per pass at 48^3 x 96); a chunk's 256-term
+        // sum is good to ~1e-6 relative, the second CholeskyQR round and the fp64 chunk sums keep the result at fp32 round-off
+        pkf2 part = {0.f, 0.f};
         for (int t = 0; t < kQrChunk; t++) {
           const float2 a = tile[t * tstride + pi[q]], b = tile[t * tstride + pj[q]];
-          re += (double)a.x * b.x + (double)a.y * b.y;
-          im += (double)a.x * b.y - (double)a.y * b.x;
+          part = pk::cmac_conj(part, (pkf2){a.x, a.y}, (pkf2){b.x, b.y});
         }
-        acc[q].x += re; acc[q].y += im;
+        acc[q].x += (double)part.x; acc[q].y += (double)part.y;
       }
     }
 #pragma unroll
@@ -661,10 +664,10 @@ template <int NVEC> __global__ void __launch_bounds__(256) block_cholqr_kernel(f
 #pragma unroll
         for (int h = 1; h >= 0; h--) {
           const int j = 2 * vp + h;
-          float re = 0.f, im = 0.f;
+          pkf2 a = {0.f, 0.f};
 #pragma unroll
-          for (int i = 0; i <= j; i++) { const float2 r = Rinv[i * nvec + j]; re += v[i].x * r.x - v[i].y * r.y; im += v[i].x * r.y + v[i].y * r.x; }
-          o[h] = make_float2(re, im);
+          for (int i = 0; i <= j; i++) { const float2 r = Rinv[i * nvec + j]; a = pk::cmac(a, (pkf2){v[i].x, v[i].y}, (pkf2){r.x, r.y}); }
+          o[h] = make_float2(a.x, a.y);
         }
         v[2 * vp] = o[0]; v[2 * vp + 1] = o[1];
         V4[addr4(e, vp)] = make_float4(o[0].x, o[0].y, o[1].x, o[1].y);
