@@ -478,6 +478,20 @@ template <int NV> __global__ void fillv_kernel(float *V, VecList B, int stride, 
   const int b = (int)(t - A * blockVol);
   const int f = block_to_fine[t];
   const int parity = f >= Vh, x = f - parity * Vh;
+  if (NV == 4 && K % 2 == 0) {
+    // 16-byte reads (two components of one vector share a plane entry) and 16-byte writes (the two vectors of a pair share a V entry)
+    float4 *V4 = reinterpret_cast<float4 *>(V);
+    for (int vp = 0; vp < nvec / 2; vp++) {
+      const float4 *b0 = reinterpret_cast<const float4 *>(parity ? B.od[2 * vp] : B.ev[2 * vp]);
+      const float4 *b1 = reinterpret_cast<const float4 *>(parity ? B.od[2 * vp + 1] : B.ev[2 * vp + 1]);
+      for (int m = 0; m < K / 2; m++) {
+        const float4 u = b0[(size_t)m * stride + x], w = b1[(size_t)m * stride + x];
+        V4[(((size_t)A * K + 2 * m) * (nvec / 2) + vp) * blockVol + b] = make_float4(u.x, u.y, w.x, w.y);
+        V4[(((size_t)A * K + 2 * m + 1) * (nvec / 2) + vp) * blockVol + b] = make_float4(u.z, u.w, w.z, w.w);
+      }
+    }
+    return;
+  }
   for (int v = 0; v < nvec; v++) {
     const float *base = parity ? B.od[v] : B.ev[v];
     for (int k = 0; k < K; k++) {
