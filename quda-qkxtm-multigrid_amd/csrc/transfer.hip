@@ -232,19 +232,31 @@ load_fine_site<NV, K>(r[q], base, a.in[q].stride, x);
   constexpr int KH = K / 2;
 #pragma unroll
   for (int chi = 0; chi < 2; chi++) {
-  float4 wn[KH];
+  // Three buffers of V entries, statically named and refilled in place right after their use, fenced against the scheduler (which
+  // would sink every request down to its use): three steps of requests in flight per thread
+  float4 w0[KH], w1[KH], w2[KH];
+  // unconditional loads (a thread beyond the aggregate reads entry 0 and its sums are masked out below): a load under a per-lane
+  // condition becomes its own basic block, and across blocks the wait-count bookkeeping falls back to vmcnt(0) again
+  const int bl = site ? b : 0;
+  auto vload = [&](float4 *dst, int vpl) {
+    if (vpl >= NVEC / 2) return;
 #pragma unroll
-  for (int kk = 0; kk < KH; kk++) wn[kk] = site ? V[(((size_t)A * K + chi * KH + kk) * (NVEC / 2) + 0) * blockVol + b] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 1
-  for (int vp = 0; vp < NVEC / 2; vp++) {
+    for (int kk = 0; kk < KH; kk++) dst[kk] = load_v<false>(V, (((size_t)A * K + chi * KH + kk) * (NVEC / 2) + vpl) * blockVol + bl);
+  };
+  vload(w0, 0); vload(w1, 1); vload(w2, 2);
+  __builtin_amdgcn_sched_barrier(0);
+  // fully unrolled: with a loop the wait-count bookkeeping of the compiler merges to s_waitcnt vmcnt(0) at the loop header and at
+  // every use — the three buffers were drained at each step, which is why neither they nor anything else moved this kernel
+#pragma unroll
+  for (int vp3 = 0; vp3 < NVEC / 2; vp3 += 3) {
+#pragma unroll
+  for (int ph = 0; ph < 3; ph++) {
+    const int vp = vp3 + ph;
+    if (vp >= NVEC / 2) break;
     const int it = chi * (NVEC / 2) + vp;
     float4 wc[KH];
 #pragma unroll
-    for (int kk = 0; kk < KH; kk++) wc[kk] = wn[kk];
-    if (vp + 1 < NVEC / 2) {
-#pragma unroll
-      for (int kk = 0; kk < KH; kk++) wn[kk] = site ? V[(((size_t)A * K + chi * KH + kk) * (NVEC / 2) + vp + 1) * blockVol + b] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int kk = 0; kk < KH; kk++) wc[kk] = ph == 0 ? w0[kk] : (ph == 1 ? w1[kk] : w2[kk]);
     float4 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -258,6 +270,10 @@ load_fine_site<NV, K>(r[q], base, a.in[q].stride, x);
         acc[q].z += w.z * r[q][k].x + w.w * r[q][k].y; acc[q].w += w.z * r[q][k].y - w.w * r[q][k].x;
       }
     }
+    // the buffer just used takes the entries of three steps ahead
+    __builtin_amdgcn_sched_barrier(0);
+    if (ph == 0) vload(w0, vp + 3); else if (ph == 1) vload(w1, vp + 3); else vload(w2, vp + 3);
+    __builtin_amdgcn_sched_barrier(0);
     // wave sum of the 32 partial reals (4 right-hand sides x {leaving, staying} x float4) by a reduce-scatter butterfly: at every
     // stage a lane keeps one half of its values and adds the partner's copy of that half, so the five xor stages move
     // 16 + 8 + 4 + 2 + 1 values instead of 32 each, one more adds the two half-waves: 32 cross-lane moves instead of 192
@@ -286,6 +302,8 @@ load_fine_site<NV, K>(r[q], base, a.in[q].stride, x);
       const int vi = ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
       reinterpret_cast<float *>(&part[wave][it][0])[vi] = w[0];
     }
+    __builtin_amdgcn_sched_barrier(0);
+  }
   }
   }
   __syncthreads();
