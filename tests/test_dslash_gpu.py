@@ -228,6 +228,42 @@ def test_prepare_and_reconstruct_element_wise(qa, oracle, matpc):
     d.free()
 
 
+@pytest.mark.parametrize("X", [(16, 16, 8, 24), (24, 16, 12, 8), (32, 8, 16, 16), (48, 12, 16, 8)])
+def test_block_orders_on_odd_shapes(qa, oracle, X):
+    """Every block order of the stencil is a re-numbering of the work-groups and must not change a single site: plane-tiled XCD
+    order, y groups (explicit counts and the automatic choice), the boundary-first order of partitioned launches and the legacy slab
+    order, on lattices whose planes / slabs divide differently (non-cubic, 3 x 2^k extents), against the oracle."""
+    gauge, spinor, _ = oracle.make_fields(list(X), clover=False)
+    nh = spinor.size // 2
+    kappa, mu = 0.1, 0.01
+    oracle.set_threads(8)
+    try:
+        want = oracle.tm_dslash(gauge, spinor[:nh].copy(), list(X), kappa, mu, +1, 0, "ee", 0)
+    finally:
+        oracle.set_threads(1)
+    L = qa.lib()
+    try:
+        for prec in (8, 2):
+            _load_fields(qa, gauge, None, X, kappa, mu, prec, 18)
+            ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=prec)
+            for setting in ({}, {"ygroups": 2}, {"ygroups": 3}, {"ygroups": 0}, {"tiled": 0}, {"tiled": 1, "tt": 2}, {"nxz": 4}, {"nxz": 2}, {"block": 64}, {"block": 128, "ygroups": 2}):
+                for k, v in dict(block=0, tiled=-1, nxz=0, tz=0, tt=0, ygroups=-1).items():
+                    L.qudaAmdSetDslashTune(k.encode(), v)
+                for k, v in setting.items():
+                    L.qudaAmdSetDslashTune(k.encode(), v)
+                assert qc.rel_err(qa.dslash(spinor[:nh].copy(), ip, 0), want) < TOL[prec], (prec, setting)
+                for mask in (14, 9):   # boundary-first order of the fused peer-store launch, self-neighbour emulation
+                    L.qudaAmdSetPartitionMask(mask)
+                    _load_fields(qa, gauge, None, X, kappa, mu, prec, 18)
+                    assert qc.rel_err(qa.dslash(spinor[:nh].copy(), ip, 0), want) < TOL[prec], (prec, setting, mask)
+                    L.qudaAmdSetPartitionMask(0)
+                _load_fields(qa, gauge, None, X, kappa, mu, prec, 18)
+    finally:
+        L.qudaAmdSetPartitionMask(0)
+        for k, v in dict(block=0, tiled=-1, nxz=0, tz=0, tt=0, ygroups=-1).items():
+            L.qudaAmdSetDslashTune(k.encode(), v)
+
+
 def test_twisted_clover_at_full_size_against_the_oracle(qa, oracle):
     """BASELINE configs[2]: 32^4 twisted-clover Dslash in fp32 and 16-bit (the kernels bench.py times as extra.tmc_*), every site
     against the oracle on the same inputs — plain and xpay form (the two epilogues of DiracTwistedCloverPC::M), fp64 as well."""
