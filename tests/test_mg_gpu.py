@@ -170,6 +170,38 @@ def test_hierarchy_against_oracle_restatement(qa, oracle, mask):
         qa.lib().qudaAmdSetPartitionMask(0)
 
 
+@pytest.mark.parametrize("X", [(16, 8, 8, 16), (32, 8, 8, 8), (16, 16, 8, 8)])
+def test_restrictor_and_prolongator_in_the_x_neighbour_order(qa, oracle, X):
+    """Lattices with four or more aggregates along x, where the transfer kernels walk the x-neighbour aggregates on one XCD
+    (transfer.hip aggregate_of_block) — a re-numbering of the work-groups that must not change R or P: element-wise against the
+    oracle with the device's own V, with the order switched on (default) — the hierarchy test above runs on 2 aggregates along x,
+    where it is off."""
+    kappa, mu = 0.124, 0.005
+    gauge, ip = _setup(qa, X, kappa, mu)
+    mp = qa.multigrid_param(ip, n_level=2, geo_block=(4, 4, 4, 4), n_vec=8, setup_maxiter=50, setup_tol=1e-3)
+    mg = qa.Multigrid(mp)
+    rng = np.random.default_rng(23)
+
+    def rel(a, b):
+        return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+    try:
+        i = mg.level_info(0)
+        Xf, Xc, bs, Ns, Nc, Nv, sbs = i["Xf"], i["Xc"], i["geo_bs"], i["fineSpin"], i["fineColor"], i["Nvec"], i["spin_bs"]
+        assert Xc[0] % 4 == 0 and int(np.prod(Xc)) % 32 == 0   # the condition under which the order is active
+        Vd = mg.V(0).astype(np.complex128)
+        phi = (rng.standard_normal((int(np.prod(Xf)), Ns, Nc)) + 1j * rng.standard_normal((int(np.prod(Xf)), Ns, Nc)))
+        eta = (rng.standard_normal((int(np.prod(Xc)), 2, Nv)) + 1j * rng.standard_normal((int(np.prod(Xc)), 2, Nv)))
+        assert rel(mg.apply(0, "R", phi), oracle.mg_restrict(phi, Vd, Xf, bs, Ns, Nc, Nv, sbs)) < 2e-5
+        assert rel(mg.apply(0, "P", eta), oracle.mg_prolongate(eta, Vd, Xf, bs, Ns, Nc, Nv, sbs)) < 2e-5
+        # Galerkin links from the forward hops + hermitian completion (restrict4 in the same order)
+        Yd, Xd = mg.coarse_links(0)
+        Yo, Xo = oracle.mg_coarse_op_fine(Vd, gauge, None, kappa, 2 * kappa * mu, Xf, bs, Nv)
+        assert rel(Xd, Xo) < 2e-5 and rel(Yd, -kappa * Yo) < 2e-5
+    finally:
+        mg.free()
+
+
 @pytest.mark.parametrize("nvec,nrhs_list", [(8, (8, 16, 24, 32)), (24, (24, 8))], ids=["n16", "n48"])
 def test_block_coarse_operator_on_mfma(qa, oracle, nvec, nrhs_list):
     """The multi-right-hand-side coarse operator on the matrix cores (csrc/block.hip, v_mfma_f32_16x16x4_f32; reference: the
