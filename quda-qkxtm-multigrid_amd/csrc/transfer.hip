@@ -334,15 +334,21 @@ __global__ void column_kernel(FineVec out, const float4 *V, const int *block_to_
   const int parity = f >= out.Vh, x = f - parity * out.Vh;
   float *base = out.v[parity];
   const int chi = j / NVEC, v = j - chi * NVEC;
+  float2 c[K];
 #pragma unroll
   for (int k = 0; k < K; k++) {
-    float re = 0.f, im = 0.f;
+    c[k] = make_float2(0.f, 0.f);
     if ((k / NCF) / spin_bs == chi) {
       const float4 w = V[(((size_t)A * K + k) * (NVEC / 2) + (v >> 1)) * blockVol + b];
-      re = (v & 1) ? w.z : w.x; im = (v & 1) ? w.w : w.y;
+      c[k] = (v & 1) ? make_float2(w.z, w.w) : make_float2(w.x, w.y);
     }
-    const size_t i = fidx<NV>(out.stride, x, k);
-    base[i] = re; base[i + 1] = im;
+  }
+  if (NV == 4 && K % 2 == 0) {   // two components per plane entry: one 16-byte store instead of four 4-byte ones
+#pragma unroll
+    for (int m = 0; m < K / 2; m++) reinterpret_cast<float4 *>(base)[(size_t)m * out.stride + x] = make_float4(c[2 * m].x, c[2 * m].y, c[2 * m + 1].x, c[2 * m + 1].y);
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; k++) { const size_t i = fidx<NV>(out.stride, x, k); base[i] = c[k].x; base[i + 1] = c[k].y; }
   }
 }
 
