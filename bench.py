@@ -301,9 +301,17 @@ def main():
         # untimed: bring the device to its steady clocks first — the driver's `--steps 20 --warmup 5` is a 3 ms measurement right after
         # the process started, and a GPU that idled through the host-side set-up needs tens of ms to ramp up.  Then the W warm-up
         # steps of the contract, then exactly K timed ones.
-        t_pre = time.perf_counter()
-        while prewarm > 0 and time.perf_counter() - t_pre < prewarm:
+        if prewarm > 0:
+            # the NUMBER of applications has to be the same on every rank (a partitioned application pairs with its neighbours'):
+            # time 100 of them, agree on the count through the slowest rank, then run that many
+            t_pre = time.perf_counter()
             d.time_dslash(dst, src, 0, 100)
+            t100 = time.perf_counter() - t_pre
+            n_pre = int(min(20000, max(0, (prewarm - t100) / max(t100, 1e-6) * 100)))
+            if dist is not None:
+                n_pre = int(dist.max_over_ranks(float(n_pre)))
+            if n_pre > 0:
+                d.time_dslash(dst, src, 0, n_pre)
         d.time_dslash(dst, src, 0, max(1, warmup))
         if dist is not None:
             dist.barrier()
