@@ -43,8 +43,9 @@ from synth import make_clover, make_gauge, smooth_gauge, tiled_gauge  # noqa: E4
 
 class _LineGuard:
     """Keeps the finished JSON line (rank 0) safe while an optional leg runs: a library error inside the leg writes it before the
-    process ends (qudaAmdSetExitLine; status 0 on every rank, so that the launcher does not tear the job down before rank 0 got
-    there), and a watchdog thread writes it if the leg does not come back within `timeout` seconds (ctypes calls release the GIL)."""
+    process ends (qudaAmdSetExitLine), and a watchdog thread writes it if the leg does not come back within `timeout` seconds (ctypes
+    calls release the GIL).  Either way the process ends with a NON-ZERO status (3): the line is delivered, but a failure inside a
+    process that has touched the GPU is never reported to the launcher as success."""
 
     def __init__(self, qa, line, timeout):
         import threading
@@ -54,7 +55,7 @@ class _LineGuard:
             failed = dict(line)
             failed["extra"] = dict(line.get("extra") or {}, mg_gcr=dict(failed="the library ended the process inside this leg (see stderr)"))
             text = json.dumps(failed).encode()
-        qa.lib().qudaAmdSetExitLine(text if text is not None else b"", 0)
+        qa.lib().qudaAmdSetExitLine(text if text is not None else b"", 3)
         self._timer = threading.Timer(timeout, self._timeout, [timeout])
         self._timer.daemon = True
         self._timer.start()
@@ -67,7 +68,7 @@ class _LineGuard:
             self.line.setdefault("extra", {})["mg_gcr"] = dict(failed="no result after %.0f s" % timeout)
             sys.stdout.write(json.dumps(self.line) + "\n")
             sys.stdout.flush()
-        os._exit(0)
+        os._exit(3)
 
     def disarm(self):
         self.done = True
@@ -240,6 +241,42 @@ def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2,
     return out
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` started plainly (no torch.distributed.run): this parent, which never touches the GPU, starts N
+    fresh children of this same script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (one process per GPU),
+    relays rank 0's stdout (the JSON line) and everybody's stderr, and returns the first non-zero status — after which the
+    remaining ranks are ended, since a partner that will never arrive only leaves them waiting in a collective."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    status, pending = 0, set(range(n))
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+                sys.stderr.write("bench.py: rank %d ended with status %d, ending the other ranks\n" % (r, rc))
+                deadline = time.time() + 20      # rank 0 may still be writing its guarded line
+                while time.time() < deadline and any(procs[q].poll() is None for q in pending):
+                    time.sleep(0.2)
+                for q in pending:
+                    if procs[q].poll() is None:
+                        procs[q].terminate()
+        time.sleep(0.1)
+    return status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -255,11 +292,13 @@ def main():
     ap.add_argument("--no-mg", action="store_true", help="N > 1: skip the MG-GCR leg on the decomposed lattice")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch plainly (python bench.py --gpus N) or with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
 
     qa = importlib.import_module("quda-qkxtm-multigrid_amd")
     X = [int(v) for v in args.lattice.split(",")]
@@ -301,6 +340,7 @@ def main():
         # untimed: bring the device to its steady clocks first — the driver's `--steps 20 --warmup 5` is a 3 ms measurement right after
         # the process started, and a GPU that idled through the host-side set-up needs tens of ms to ramp up.  Then the W warm-up
         # steps of the contract, then exactly K timed ones.
+        n_prewarm = 0
         if prewarm > 0:
             # the NUMBER of applications has to be the same on every rank (a partitioned application pairs with its neighbours'):
             # time 100 of them, agree on the count through the slowest rank, then run that many
@@ -312,6 +352,7 @@ def main():
                 n_pre = int(dist.max_over_ranks(float(n_pre)))
             if n_pre > 0:
                 d.time_dslash(dst, src, 0, n_pre)
+            n_prewarm = 100 + n_pre
         d.time_dslash(dst, src, 0, max(1, warmup))
         if dist is not None:
             dist.barrier()
@@ -333,7 +374,7 @@ def main():
         for f in (src, dst):
             f.free()
         d.free()
-        return dict(wall=wall, sec=sec_kernel, sec_min=sec_min, flops_site=flops_site, bytes_site=bytes_site, norm2=n2)
+        return dict(wall=wall, sec=sec_kernel, sec_min=sec_min, flops_site=flops_site, bytes_site=bytes_site, norm2=n2, prewarm=n_prewarm)
 
     r = run(args.prec, args.recon, args.dslash, args.steps, args.warmup, prewarm=float(os.environ.get("QUDA_AMD_BENCH_PREWARM", "0.3")))
     ms_per_step = 1e3 * r["wall"] / args.steps
@@ -488,6 +529,7 @@ def main():
         out = {
             "metric": "twisted-mass Dslash GFLOP/s (even-odd, 32^4)" if X == [32, 32, 32, 32] else "twisted-mass Dslash GFLOP/s",
             "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "prewarm_applications": r["prewarm"],   # untimed, in front of the W contract warm-ups: brings the device to steady clocks
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": dtype_name[args.prec], "data": "synthetic",
             "config": {"workload": "%s even-odd Dslash (DiracTwistedMassPC::Dslash, kappa=%g mu=%g), %s lattice, recon-%d, fields resident in HBM"

@@ -46,10 +46,15 @@ void applyShift(double *out, const double *in, const LatticeGeom &g, int stride,
 // multi-right-hand-side FULL operator on block fields ([parity * Vh + x][12 spin-colour][nrhs] float2, see block.h):
 // out = (1 + i a g5) in - kappa D in for nrhs vectors per link load (fp32, recon 18, unpartitioned lattice)
 bool fineBlockSupported(const GaugeField &U, int nrhs);
-void applyFineBlockM(float2 *out, const float2 *in, int nrhs, const GaugeField &U, double kappa, double a);
-// one parity of the generalised form: out = s0 (1 + i a0 g5) in_same + k1 (1 + i a1 g5) [8 hops of in_other], single-parity panels
+// tmat (twisted clover): per parity the dense site matrices A + i a g5 from cloverTwistDense(), which replace (1 + i a g5)
+void applyFineBlockM(float2 *out, const float2 *in, int nrhs, const GaugeField &U, double kappa, double a, const float *const tmat[2] = nullptr);
+// one parity of the generalised form: out = s0 (1 + i a0 g5) in_same + k1 (1 + i a1 g5) [8 hops of in_other], single-parity panels.
+// tmat != nullptr: dense site matrices [Vh][2 chiralities][6 x 6 complex] of the output parity in place of (1 + i a1 g5) on the hop
+// sum (tmode 1) or of (1 + i a0 g5) on in_same (tmode 2) — the twisted-clover operators (reference lib/dirac_twisted_clover.cpp:191-330)
 void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_other, int nrhs, const GaugeField &U, int parity, double s0, double a0, double k1,
-                          double a1);
+                          double a1, const float *tmat = nullptr, int tmode = 0);
+// out[site][chirality][6][6] complex fp32 = A + i a s (s = +-1 for the upper / lower chirality) of one parity, or its inverse
+void cloverTwistDense(float *out, const CloverField &C, int parity, double a, bool inverse);
 
 // site-local kernels
 enum SiteOp {

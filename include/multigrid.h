@@ -52,6 +52,11 @@ class MG : public Solver {
   DiracM *matCoarse, *matCoarseSmoother;
   bool pcSmooth;
   bool ownCoarseSolver;
+ public:
+  // how generateNullVectors produced this level's vectors: 0 loaded / restricted / sequential BiCGstab solves (the reference's loop),
+  // 1 lockstep block BiCGstab on the multi-right-hand-side fine stencil, 2 the same on the MFMA coarse operator; and the lockstep iteration count
+  int nullVectorMethod = 0, nullVectorIterations = 0;
+ private:
   void generateNullVectors(std::vector<ColorSpinorField *> &B);
   void cycleParity(ColorSpinorField &x, ColorSpinorField &b);
   void saveVectors(std::vector<ColorSpinorField *> &B);

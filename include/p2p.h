@@ -37,9 +37,21 @@ int p2pTransport();   // -1 not decided yet, 0 staged (RCCL send/recv), 1 direct
 void p2pDisable();    // fall back to the staged transport for the rest of the run (first-use verification failed)
 int p2pTakeError();   // value of the device error word, cleared
 
-// device word set by a wait that timed out (a neighbour never signalled); p2pCheck aborts with a message if it is set
+// Device error RECORD (kP2pErrInts ints) filled by the first wait that runs out — later waits see word 0 set and return at once:
+//   [0] code: 1 + hop direction (fine stencil: 2 mu forward, 2 mu + 1 backward hop), 17 + hop (coarse stencil)
+//   [1] face site (fine) / coarse site (coarse) whose data was missing        [2] flag / arrival count the wait expected
+//   [3], [4] what was last seen there (fine: the flags of the two 8-byte halves of the first vector that did not match;
+//            coarse: the arrival counter)                                       [5] exchange number of this rank's window
+//   [6] buffer (parity of the exchange number)                                  [7] index of that vector inside the face site
+// p2pCheck aborts with all of it spelled out; p2pDescribeError formats the same text (tools, tests).
+constexpr int kP2pErrInts = 16;
 int *p2pErrorWord();
 void p2pCheck(const char *where);
+bool p2pDescribeError(char *text, size_t n);   // false: no error recorded
+// counters of this process since initQuda: [0] fine-grid exchanges through peer stores, [1] through the staged (RCCL) transport,
+// [2] / [3] the same for the coarse grids, [4] global sums done inside the reduction kernel (peer windows), [5] through the
+// collective library, [6] fall-backs from peer stores to the staged transport, [7] multi-right-hand-side (block) exchanges
+long long *p2pStats();
 
 // 100 MHz constant-rate counter ticks a kernel waits for a neighbour before it gives up (QUDA_AMD_P2P_TIMEOUT_S, default 10 s)
 unsigned long long p2pTimeoutTicks();

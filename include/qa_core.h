@@ -21,6 +21,7 @@ void qa_warning(const char *fmt, ...);
 QudaVerbosity getVerbosity();
 
 void setExitLine(const char *text, int status);   // see qa_core.cpp
+[[noreturn]] void abortWithExitLine(int status);
 #define errorQuda(...) ::quda::qa_error(__FILE__, __LINE__, __func__, __VA_ARGS__)
 #define printfQuda(...) ::quda::qa_printf(__VA_ARGS__)
 #define warningQuda(...) ::quda::qa_warning(__VA_ARGS__)

@@ -80,7 +80,7 @@ void qudaAmdMultigridCycle(void *mg_instance, void *h_x, void *h_b, QudaInvertPa
  * does the same at newMultigridQuda. */
 void qudaAmdMultigridSetHalfStorage(void *mg_instance, int on);
 int qudaAmdMultigridLevels(void *mg_instance);
-void qudaAmdMultigridLevelInfo(void *mg_instance, int level, int info[18]); /* Xf[4] Xc[4] fineSpin fineColor Nvec geo_bs[4] spin_bs 0 0 */
+void qudaAmdMultigridLevelInfo(void *mg_instance, int level, int info[18]); /* Xf[4] Xc[4] fineSpin fineColor Nvec geo_bs[4] spin_bs null_vector_method (0 sequential solves / loaded, 1 lockstep on the multi-rhs fine stencil, 2 lockstep on the MFMA coarse operator) lockstep_iterations */
 void qudaAmdMultigridGetNullVector(void *mg_instance, int level, int k, float *h_out);
 void qudaAmdMultigridGetV(void *mg_instance, int level, float *h_out);
 void qudaAmdMultigridGetCoarseLinks(void *mg_instance, int level, float *h_Y, float *h_X);
@@ -94,6 +94,12 @@ void qudaAmdMultigridApply(void *mg_instance, int level, int op, float *h_out, c
 double qudaAmdMultigridApplyBlock(void *mg_instance, int level, int nrhs, float *h_out, const float *h_in, int niter);
 /* errorQuda ends the process (reference convention, include/util_quda.h:51-61).  A caller holding finished results can leave a text
  * here that is written to stdout first, and the exit status to use; text = NULL restores the default (nothing, status 1). */
+/* this process' transport counters since initQuda: fine-grid exchanges through peer stores / staged (RCCL), the same for the coarse
+ * grids, global sums inside the reduction kernel / through the collective library, fall-backs to the staged transport, block exchanges */
+void qudaAmdCommStats(long long out[8]);
+/* text of the device error record of a halo wait that ran out (dimension, direction, buffer, exchange number, expected and last-seen
+ * flag, interpretation); returns 0 if none is recorded */
+int qudaAmdDescribeHaloError(char *text, int n);
 void qudaAmdSetExitLine(const char *text, int status);
 double qudaAmdMultigridTimeApply(void *mg_instance, int level, int niter);
 /* seconds per application of the restrictor (what = 0) or prolongator (what = 1) between `level` and `level + 1` */

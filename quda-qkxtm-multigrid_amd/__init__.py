@@ -119,7 +119,7 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
                  "qudaAmdMultigridVerify", "qudaAmdMultigridCycle", "qudaAmdTimeAxpy", "qudaAmdMultigridLevels", "qudaAmdMultigridLevelInfo",
                  "qudaAmdMultigridSetHalfStorage", "qudaAmdMultigridGetNullVector", "qudaAmdMultigridGetV", "qudaAmdMultigridGetCoarseLinks", "qudaAmdMultigridApply", "qudaAmdMultigridApplyBlock",
                  "qudaAmdMultigridTimeApply", "qudaAmdMultigridTimeTransfer", "qudaAmdSetExitLine", "qudaAmdDiracPrepare", "qudaAmdDiracReconstruct", "qudaAmdSpinorRawInfo", "qudaAmdGaugeRawInfo", "qudaAmdCloverRawInfo", "qudaAmdRawDeviceCopy",
-                 "qudaAmdSetSolutionSink"]
+                 "qudaAmdSetSolutionSink", "qudaAmdCommStats", "qudaAmdDescribeHaloError"]
 
 _lib = None
 
@@ -289,6 +289,22 @@ def invert_param(dslash_type=QUDA_TWISTED_MASS_DSLASH, kappa=0.1, mu=0.01, flavo
     ip.preserve_source = QUDA_PRESERVE_SOURCE_YES
     ip.residual_type = QUDA_L2_RELATIVE_RESIDUAL
     return ip
+
+
+COMM_STATS_KEYS = ("fine_peer_store_exchanges", "fine_staged_exchanges", "coarse_peer_store_exchanges", "coarse_staged_exchanges",
+                   "in_kernel_allreduces", "collective_allreduces", "fallbacks_to_staged", "block_exchanges")
+
+
+def comm_stats():
+    """this process' transport counters since initQuda (include/quda_amd_ext.h qudaAmdCommStats)"""
+    a = (C.c_longlong * 8)()
+    lib().qudaAmdCommStats(a)
+    return dict(zip(COMM_STATS_KEYS, [int(v) for v in a]))
+
+
+def halo_error_text():
+    buf = C.create_string_buffer(1024)
+    return buf.value.decode() if lib().qudaAmdDescribeHaloError(buf, 1024) else None
 
 
 def init(device=0, verbosity=QUDA_SILENT):
@@ -563,7 +579,7 @@ class Multigrid:
         a = (_i * 18)()
         lib().qudaAmdMultigridLevelInfo(self.h, level, a)
         v = list(a)
-        return dict(Xf=v[0:4], Xc=v[4:8], fineSpin=v[8], fineColor=v[9], Nvec=v[10], geo_bs=v[11:15], spin_bs=v[15])
+        return dict(Xf=v[0:4], Xc=v[4:8], fineSpin=v[8], fineColor=v[9], Nvec=v[10], geo_bs=v[11:15], spin_bs=v[15], null_method=v[16], null_iters=v[17])
 
     def null_vector(self, level, k):
         i = self.level_info(level)
@@ -586,7 +602,8 @@ class Multigrid:
         return Y, X
 
     def apply_block(self, level, h_in, niter=0):
-        """M of coarse `level` on a batch (nrhs, sites, 2, Nc) complex64 through the multi-right-hand-side MFMA kernel;
+        """M of `level` on a batch (nrhs, sites, spin, colour) complex64 through the multi-right-hand-side kernels — the MFMA coarse
+        operator on a coarse level, the 8/16/24/32-right-hand-side stencil (Wilson / twisted mass / twisted clover) on level 0;
         returns (out, seconds per application if niter > 0)"""
         h_in = np.ascontiguousarray(h_in, dtype=np.complex64)
         out = np.zeros_like(h_in)

@@ -511,7 +511,8 @@ static void launch(const F &f, const ColorSpinorField &x, const ColorSpinorField
     arg.hred = h_red_dev;
     allreduce = false;
     peer = true;
-  }
+    p2pStats()[4]++;
+  } else if (allreduce) p2pStats()[5]++;
   hipStream_t s = computeStream();
   const long nreal = (long)x.Stride() * x.Nspin() * x.Ncolor() * 2;
   const int bs = 256;

@@ -66,7 +66,8 @@ struct CoarseArg {
   const unsigned *waitFlag[8];
   unsigned waitCount[8];
   unsigned long long waitTicks;
-  int *errWord;
+  int *errWord;              // error record (p2p.h kP2pErrInts)
+  unsigned exSeq; int exBuf; // exchange number / buffer of this launch, for that record
 };
 
 template <int NMAX, bool HALF>
@@ -95,7 +96,14 @@ __global__ void __launch_bounds__(256) coarse_apply_kernel(const CoarseArg arg) 
     if (need && !__hip_atomic_load(arg.errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
       const unsigned long long t0 = wall_clock64();
       while ((int)(__hip_atomic_load(arg.waitFlag[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - arg.waitCount[threadIdx.x]) < 0) {
-        if (wall_clock64() - t0 > arg.waitTicks) { __hip_atomic_store(arg.errWord, 17 + (int)threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (wall_clock64() - t0 > arg.waitTicks) {
+          if (atomicCAS(arg.errWord, 0, 17 + (int)threadIdx.x) == 0) {
+            const unsigned seen = __hip_atomic_load(arg.waitFlag[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            arg.errWord[1] = A; arg.errWord[2] = (int)arg.waitCount[threadIdx.x]; arg.errWord[3] = (int)seen; arg.errWord[4] = (int)seen;
+            arg.errWord[5] = (int)arg.exSeq; arg.errWord[6] = arg.exBuf; arg.errWord[7] = 0;
+          }
+          break;
+        }
         __builtin_amdgcn_s_sleep(1);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // once, after the poll: the face words read below are newer than the counter
@@ -298,7 +306,7 @@ __global__ void __launch_bounds__(256) coarse_pack_kernel(const CoarsePackArg ar
 // exchange the faces of `in` the masked hops need; fills arg.ghost / commMask
 static void exchangeCoarseGhost(CoarseArg &arg, const CoarseGauge &G, int single) {
   arg.commMask = 0; arg.ghostSingle = single >= 0;
-  arg.waitTicks = 0; arg.errWord = nullptr;
+  arg.waitTicks = 0; arg.errWord = nullptr; arg.exSeq = 0; arg.exBuf = 0;
   for (int m = 0; m < 8; m++) { arg.ghost[m] = nullptr; arg.waitFlag[m] = nullptr; arg.waitCount[m] = 0; }
   int mask = 0;
   for (int d = 0; d < 4; d++) if (commGrid().partitioned(d) && ((arg.mmask >> (2 * d)) & 3)) mask |= 1 << d;
@@ -312,6 +320,8 @@ static void exchangeCoarseGhost(CoarseArg &arg, const CoarseGauge &G, int single
   int nt = 0;
   std::vector<HaloMsg> msgs;
   const int buf = cg.p2p ? (int)(++cg.seq & 1) : 0;
+  arg.exSeq = cg.seq; arg.exBuf = buf;
+  p2pStats()[cg.p2p ? 2 : 3]++;
   for (int d = 0; d < 4; d++) {
     pa.Xc[d] = G.Xc[d]; pa.faceCB[d] = cg.faceCB[d];
     const size_t bytes = (size_t)nq * G.n * cg.faceCB[d] * sizeof(float2);

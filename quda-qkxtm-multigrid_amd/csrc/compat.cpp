@@ -151,6 +151,6 @@ void comm_broadcast(void *data, size_t nbytes) {
   memcpy(data, all.data(), nbytes);   // rank 0's block
 }
 void comm_barrier(void) { commBarrier(); }
-void comm_abort(int status) { exit(status); }
+void comm_abort(int status) { quda::abortWithExitLine(status ? status : 1); }   // through the same exit path as errorQuda (exit line of qa_core.cpp)
 
 }  // extern "C"

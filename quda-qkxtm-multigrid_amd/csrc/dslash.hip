@@ -85,7 +85,8 @@ template <typename real> struct DslashArg {
   unsigned waitCount[8];
   unsigned long long waitTicks;
   int siteDelay, packPrio;   // peer-store launch: site blocks start siteDelay x 64 x 8 cycles late; pack waves raise their issue priority
-  int *errWord;
+  int *errWord;              // error record (p2p.h kP2pErrInts)
+  unsigned exSeq; int exBuf; // exchange number / buffer of this launch, for that record
   // peer-store transport: the first packBlocks blocks of the interior launch pack the faces (pack_body) while the rest of
   // the grid does the interior stencil — one launch, the faces leave at time zero and travel during the interior pass
   int packBlocks, packChunk;
@@ -286,7 +287,7 @@ template <typename T, typename real> __device__ __forceinline__ void ghost_ll_st
 }
 // receiver: poll the site's own vectors (system-scope loads) until every half carries this exchange's flag; bounded by `ticks`
 template <typename T, typename real>
-__device__ __forceinline__ void ghost_ll_load(real *h, const void *zone, int faceCB, int f, unsigned flag, unsigned long long ticks, int *errWord, int code) {
+__device__ __forceinline__ void ghost_ll_load(real *h, const void *zone, int faceCB, int f, unsigned flag, unsigned long long ticks, int *errWord, int code, unsigned exSeq, int exBuf) {
   constexpr int NV = GhostLL<T>::NV;
   unsigned w[2 * NV];
   const __amdgpu_buffer_rsrc_t rs = ghost_ll_rsrc<T>(zone, faceCB);
@@ -301,8 +302,18 @@ __device__ __forceinline__ void ghost_ll_load(real *h, const void *zone, int fac
     }
     if (ok) break;
     if (!t0) t0 = wall_clock64();
-    else if (wall_clock64() - t0 > ticks || __hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-      __hip_atomic_store(errWord, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // give up: the host reports it (p2pCheck)
+    else if (__hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;   // another wait has given up already
+    else if (wall_clock64() - t0 > ticks) {
+      // give up: the host reports it (p2pCheck).  The first wait to get here claims the record and says what it was waiting for and
+      // what it last saw there (one more look at the vectors: nothing of this is kept live in the polling loop)
+      if (atomicCAS(errWord, 0, code) == 0) {
+        unsigned sy = flag, sw = flag; int sv = -1;
+        for (int v = NV - 1; v >= 0; v--) {
+          const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rs, f * 16, v * faceCB * 16, 17);
+          if (q.y != flag || q.w != flag) { sy = q.y; sw = q.w; sv = v; }
+        }
+        errWord[1] = f; errWord[2] = (int)flag; errWord[3] = (int)sy; errWord[4] = (int)sw; errWord[5] = (int)exSeq; errWord[6] = exBuf; errWord[7] = sv;
+      }
       break;
     }
     __builtin_amdgcn_s_sleep(2);
@@ -385,7 +396,7 @@ __device__ __forceinline__ void ghost_hop(real *acc, const DslashArg<real> &arg,
   if (!off_node) return;
   real h[12], g[12], U[18];
   Link<T, R>::template load<GAUX>(U, arg.gauge + (size_t)DIR * arg.link_bytes, arg.g_stride, idx, sign);
-  ghost_ll_load<T>(h, arg.ghost[MU][(DIR & 1) ? 0 : 1], arg.faceCB[MU], face, arg.waitCount[DIR], arg.waitTicks, arg.errWord, 1 + DIR);
+  ghost_ll_load<T>(h, arg.ghost[MU][(DIR & 1) ? 0 : 1], arg.faceCB[MU], face, arg.waitCount[DIR], arg.waitTicks, arg.errWord, 1 + DIR, arg.exSeq, arg.exBuf);
   const real s = (DIR & 1) ? -arg.sfwd : arg.sfwd;
   su3_mv(g, U, h);
   su3_mv(g + 6, U, h + 6);
@@ -835,16 +846,29 @@ struct FineBlockArg {
   FastDiv dXh, dY, dZ;
   // out = s0 (1 + i a0 g5) in_same + k1 (1 + i a1 g5) [sum of the 8 hops of in_other]; s0 = 0: in_same is not read
   float s0, a0, k1, a1;
+  // twisted clover (kernel template CL): a dense site matrix [site][chirality][6 x 6 complex] of the OUTPUT parity replaces the factor
+  // (1 + i a1 g5) of the hop sum (CL = 1: (A + i a g5)^-1 of the even-odd preconditioned operator) or (1 + i a0 g5) of in_same
+  // (CL = 2: A + i a g5 of the full operator)
+  const float *tmat;
   BlockOrder order;
 };
 
-template <int NRHS> __global__ void __launch_bounds__(256) fine_block_kernel(const FineBlockArg arg) {
+template <int NRHS, int CL = 0> __global__ void __launch_bounds__(256) fine_block_kernel(const FineBlockArg arg) {
   constexpr int SPB = NRHS == 24 ? 8 : 256 / NRHS;   // sites per work-group (192 threads for 24 right-hand sides, else 256)
   constexpr int USTR = 8 * 18 + 4;                    // floats per site of staged links: 148 = 20 mod 32, the up to 8 sites of a wave start on 8 different banks
+  constexpr int TSTR = 144 + 4;                       // the dense clover-twist matrices of a site: 2 x 36 complex, same bank spread
   __shared__ float ulds[SPB * USTR];
+  __shared__ __attribute__((aligned(16))) float tlds[CL ? SPB * TSTR : 4];
   const int lb = arg.order.map(blockIdx.x);
   const int s = threadIdx.x / NRHS, i = threadIdx.x - s * NRHS;
   const int idx0 = lb * SPB, idx = idx0 + s;
+  if (CL) {   // 36 float4 per site, contiguous in memory
+    for (int e = threadIdx.x; e < 36 * SPB; e += blockDim.x) {
+      const int ss = e / 36, q = e - ss * 36;
+      typedef float f32x4_t __attribute__((ext_vector_type(4)));
+      if (idx0 + ss < arg.Vh) *reinterpret_cast<f32x4_t *>(&tlds[ss * TSTR + 4 * q]) = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(arg.tmat) + (size_t)(idx0 + ss) * 36 + q);
+    }
+  }
   // ---- stage the links of the SPB sites: [site][dir][18]; planes 0..3 are float4, plane 4 the trailing float2 ----
   for (int e = threadIdx.x; e < 8 * 5 * SPB; e += blockDim.x) {
     const int ss = e % SPB, pl = (e / SPB) % 5, d = e / (5 * SPB);
@@ -919,6 +943,44 @@ template <int NRHS> __global__ void __launch_bounds__(256) fine_block_kernel(con
 #undef FB_LD
 #undef FB_CP
   float2 *o = arg.out + ((size_t)idx * 12) * NRHS + i;
+  if (CL) {
+    // dense 6 x 6 complex matrix per chirality on the hop sum (CL = 1) or on the site's own panel (CL = 2); rows read as three
+    // 16-byte LDS words, the same address for the NRHS lanes of a site
+    float *src = CL == 1 ? acc : pA;
+    float res[24];
+    const float *T0 = &tlds[s * TSTR];
+#pragma unroll
+    for (int chi = 0; chi < 2; chi++)
+#pragma unroll
+      for (int r = 0; r < 6; r++) {
+        float re = 0.f, im = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const float4 m = *reinterpret_cast<const float4 *>(&T0[(chi * 6 + r) * 12 + 4 * q]);
+          const float *v = &src[12 * chi + 4 * q];
+          re += m.x * v[0] - m.y * v[1] + m.z * v[2] - m.w * v[3];
+          im += m.x * v[1] + m.y * v[0] + m.z * v[3] + m.w * v[2];
+        }
+        res[12 * chi + 2 * r] = re; res[12 * chi + 2 * r + 1] = im;
+      }
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+      float re, im;
+      if (CL == 1) {
+        re = arg.k1 * res[2 * j]; im = arg.k1 * res[2 * j + 1];
+        if (arg.s0 != 0.f) {
+          const float a0 = (j < 6 ? 1.f : -1.f) * arg.a0;
+          re += arg.s0 * (pA[2 * j] - a0 * pA[2 * j + 1]); im += arg.s0 * (pA[2 * j + 1] + a0 * pA[2 * j]);
+        }
+      } else {
+        const float a1 = (j < 6 ? 1.f : -1.f) * arg.a1;
+        re = arg.k1 * (acc[2 * j] - a1 * acc[2 * j + 1]) + arg.s0 * res[2 * j];
+        im = arg.k1 * (acc[2 * j + 1] + a1 * acc[2 * j]) + arg.s0 * res[2 * j + 1];
+      }
+      o[j * NRHS] = make_float2(re, im);
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 12; j++) {
     const float sg = j < 6 ? 1.f : -1.f;   // g5 = diag(+,+,-,-): spins 0,1 are components 0..5
@@ -930,6 +992,66 @@ template <int NRHS> __global__ void __launch_bounds__(256) fine_block_kernel(con
     }
     o[j * NRHS] = make_float2(re, im);
   }
+}
+
+// Dense clover-twist matrices for fine_block_kernel: per site of one parity and chirality the 6 x 6 complex matrix
+//     A + i a s      (s = +1 upper, -1 lower chirality; inverse = false)      or its inverse      (inverse = true)
+// from the packed Hermitian clover blocks.  The inverse is a Gauss-Jordan elimination in fp64 on the matrix itself, not the
+// stored (A^2 + mu2)^-1 field (reference lib/clover_invert.cu:56-85), so it is exact for the a it is given — the multigrid setup may
+// run with a rescaled mu (delta_muPR, reference lib/interface_quda.cpp:2196-2211).  One thread per (site, chirality).
+__global__ void __launch_bounds__(128) clover_twist_dense_kernel(float *out, const void *clA, int cl_stride, int Vh, double a, int inverse) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * Vh) return;
+  const int idx = e >> 1, chi = e & 1;
+  float C[36];
+  Planar<float, 36>::load(C, (const char *)clA + (size_t)chi * 36 * sizeof(float) * cl_stride, cl_stride, idx, nullptr, 0);
+  double mr[6][6], mi[6][6];
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      if (i == j) { mr[i][j] = C[i]; mi[i][j] = chi ? -a : a; }
+      else if (j < i) { const int k = 15 - (6 - j) * (5 - j) / 2 + i - j - 1; mr[i][j] = C[6 + 2 * k]; mi[i][j] = C[6 + 2 * k + 1]; }
+      else { const int k = 15 - (6 - i) * (5 - i) / 2 + j - i - 1; mr[i][j] = C[6 + 2 * k]; mi[i][j] = -C[6 + 2 * k + 1]; }
+    }
+  float *o = out + ((size_t)idx * 2 + chi) * 72;
+  if (!inverse) {
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { o[(i * 6 + j) * 2] = (float)mr[i][j]; o[(i * 6 + j) * 2 + 1] = (float)mi[i][j]; }
+    return;
+  }
+  // the Hermitian part A is positive definite on any sensible field and i a s only adds to the diagonal: no pivoting needed, but
+  // the largest remaining diagonal element is taken anyway
+  double vr[6][6], vi[6][6];
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { vr[i][j] = i == j ? 1.0 : 0.0; vi[i][j] = 0.0; }
+  for (int c = 0; c < 6; c++) {
+    int p = c;
+    double best = mr[c][c] * mr[c][c] + mi[c][c] * mi[c][c];
+    for (int r = c + 1; r < 6; r++) { const double m2 = mr[r][c] * mr[r][c] + mi[r][c] * mi[r][c]; if (m2 > best) { best = m2; p = r; } }
+    if (p != c)
+      for (int j = 0; j < 6; j++) {
+        double t = mr[c][j]; mr[c][j] = mr[p][j]; mr[p][j] = t; t = mi[c][j]; mi[c][j] = mi[p][j]; mi[p][j] = t;
+        t = vr[c][j]; vr[c][j] = vr[p][j]; vr[p][j] = t; t = vi[c][j]; vi[c][j] = vi[p][j]; vi[p][j] = t;
+      }
+    const double dr = mr[c][c] / best, di = -mi[c][c] / best;   // 1 / pivot
+    for (int j = 0; j < 6; j++) {
+      double xr = mr[c][j] * dr - mi[c][j] * di, xi = mr[c][j] * di + mi[c][j] * dr; mr[c][j] = xr; mi[c][j] = xi;
+      xr = vr[c][j] * dr - vi[c][j] * di; xi = vr[c][j] * di + vi[c][j] * dr; vr[c][j] = xr; vi[c][j] = xi;
+    }
+    for (int r = 0; r < 6; r++) {
+      if (r == c) continue;
+      const double fr = mr[r][c], fi = mi[r][c];
+      for (int j = 0; j < 6; j++) {
+        mr[r][j] -= fr * mr[c][j] - fi * mi[c][j]; mi[r][j] -= fr * mi[c][j] + fi * mr[c][j];
+        vr[r][j] -= fr * vr[c][j] - fi * vi[c][j]; vi[r][j] -= fr * vi[c][j] + fi * vr[c][j];
+      }
+    }
+  }
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { o[(i * 6 + j) * 2] = (float)vr[i][j]; o[(i * 6 + j) * 2 + 1] = (float)vi[i][j]; }
+}
+
+void cloverTwistDense(float *out, const CloverField &C, int parity, double a, bool inverse) {
+  if (C.precision != QUDA_SINGLE_PRECISION) errorQuda("dense clover-twist matrices are built from an fp32 clover field (got precision %d)", C.precision);
+  const int Vh = C.geom.Vh;
+  hipLaunchKernelGGL(clover_twist_dense_kernel, dim3((2 * Vh + 127) / 128), dim3(128), 0, computeStream(), out, C.A(parity), C.stride, Vh, a, inverse ? 1 : 0);
+  HIP_CHECK(hipGetLastError());
 }
 
 bool fineBlockSupported(const GaugeField &U, int nrhs) {
@@ -945,9 +1067,11 @@ bool fineBlockSupported(const GaugeField &U, int nrhs) {
 //   out(x) = s0 (1 + i a0 g5) in_same(x) + k1 (1 + i a1 g5) sum_{8 hops} U P in_other(x + mu)       x of parity `parity`
 // all three fields are single-parity block panels [Vh][12][nrhs]; in_same may be nullptr when s0 = 0
 void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_other, int nrhs, const GaugeField &U, int parity, double s0, double a0, double k1,
-                          double a1) {
+                          double a1, const float *tmat, int tmode) {
   if (!fineBlockSupported(U, nrhs)) errorQuda("multi-right-hand-side fine operator: fp32 recon-18 links on an unpartitioned lattice, 8/16/24/32 right-hand sides");
   if (s0 != 0.0 && !in_same) errorQuda("same-parity input missing");
+  if (tmat && (tmode != 1 && tmode != 2)) errorQuda("site-matrix mode %d (1: on the hop sum, 2: on the same-parity input)", tmode);
+  if (tmat && tmode == 2 && s0 == 0.0) errorQuda("site matrix on the same-parity input, but that input is switched off");
   const LatticeGeom &g = U.geom;
   const int spb = nrhs == 24 ? 8 : 256 / nrhs, threads = spb * nrhs;
   FineBlockArg arg;
@@ -960,19 +1084,25 @@ void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_o
   arg.parity = parity;
   arg.out = out; arg.in_same = in_same ? in_same : in_other; arg.in_other = in_other;
   arg.gauge = (const char *)U.parityBase(parity);
+  arg.tmat = tmat;
+#define FB_LAUNCH(N) \
+  if (!tmat) hipLaunchKernelGGL((fine_block_kernel<N, 0>), dim3(nb), dim3(threads), 0, computeStream(), arg); \
+  else if (tmode == 1) hipLaunchKernelGGL((fine_block_kernel<N, 1>), dim3(nb), dim3(threads), 0, computeStream(), arg); \
+  else hipLaunchKernelGGL((fine_block_kernel<N, 2>), dim3(nb), dim3(threads), 0, computeStream(), arg)
   switch (nrhs) {
-    case 8: hipLaunchKernelGGL((fine_block_kernel<8>), dim3(nb), dim3(threads), 0, computeStream(), arg); break;
-    case 16: hipLaunchKernelGGL((fine_block_kernel<16>), dim3(nb), dim3(threads), 0, computeStream(), arg); break;
-    case 24: hipLaunchKernelGGL((fine_block_kernel<24>), dim3(nb), dim3(threads), 0, computeStream(), arg); break;
-    default: hipLaunchKernelGGL((fine_block_kernel<32>), dim3(nb), dim3(threads), 0, computeStream(), arg); break;
+    case 8: FB_LAUNCH(8); break;
+    case 16: FB_LAUNCH(16); break;
+    case 24: FB_LAUNCH(24); break;
+    default: FB_LAUNCH(32); break;
   }
+#undef FB_LAUNCH
   HIP_CHECK(hipGetLastError());
 }
 
 // out = (1 + i a g5) in - kappa D in on full block fields of 12 components (both parities, two launches)
-void applyFineBlockM(float2 *out, const float2 *in, int nrhs, const GaugeField &U, double kappa, double a) {
+void applyFineBlockM(float2 *out, const float2 *in, int nrhs, const GaugeField &U, double kappa, double a, const float *const tmat[2]) {
   const size_t par = (size_t)U.geom.Vh * 12 * nrhs;
-  for (int p = 0; p < 2; p++) applyFineBlockParity(out + p * par, in + p * par, in + (1 - p) * par, nrhs, U, p, 1.0, a, -kappa, 0.0);
+  for (int p = 0; p < 2; p++) applyFineBlockParity(out + p * par, in + p * par, in + (1 - p) * par, nrhs, U, p, 1.0, a, -kappa, 0.0, tmat ? tmat[p] : nullptr, 2);
 }
 
 // ---- single-direction hop (setup-time helper for the multigrid coarse-operator construction) ----
@@ -1348,6 +1478,7 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
     }
   }
   arg.commMask = 0; arg.blist = nullptr; arg.nboundary = 0;
+  arg.exSeq = 0; arg.exBuf = 0;
   arg.waitTicks = 0; arg.errWord = nullptr; arg.packBlocks = 0; arg.siteDelay = 0; arg.packPrio = 0; arg.packShare = 0; arg.packFoldBlocks = 0; arg.edgeFirst = 0;
   for (int k = 0; k < 8; k++) arg.waitCount[k] = 0;
   for (int d = 0; d < 4; d++) { arg.ghost[d][0] = arg.ghost[d][1] = nullptr; arg.faceCB[d] = g.faceCB[d]; arg.ghostNormOff[d] = 0; }
@@ -1424,6 +1555,8 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
     // the ones two exchanges old.
     const unsigned seq = ++hb.seq;
     const int buf = seq & 1;
+    arg.exSeq = seq; arg.exBuf = buf;
+    p2pStats()[0]++;
     int nt = 0;
     for (int d = 0; d < 4; d++) {
       pa.faceCB[d] = g.faceCB[d]; pa.normOff[d] = 0;
@@ -1517,6 +1650,7 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
   // staged transport: pack + ONE grouped RCCL send/recv on the comms stream, interior stencil on the compute stream meanwhile,
   // then the exterior pass over the boundary-site list
   if (!g_evIn) { HIP_CHECK(hipEventCreateWithFlags(&g_evIn, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&g_evHalo, hipEventDisableTiming)); }
+  p2pStats()[1]++;
   hipStream_t ms = commStream();
   HIP_CHECK(hipEventRecord(g_evIn, cs));            // `in` is complete and the previous exterior pass has released the ghost zone
   HIP_CHECK(hipStreamWaitEvent(ms, g_evIn, 0));

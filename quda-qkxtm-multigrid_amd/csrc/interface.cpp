@@ -613,6 +613,8 @@ void qudaAmdSetPartitionMask(int mask) {
 }
 void *qudaAmdComputeStream(void) { return (void *)computeStream(); }
 int qudaAmdHaloTransport(void) { return p2pTransport(); }
+void qudaAmdCommStats(long long out[8]) { for (int k = 0; k < 8; k++) out[k] = p2pStats()[k]; }
+int qudaAmdDescribeHaloError(char *text, int n) { return p2pDescribeError(text, (size_t)n) ? 1 : 0; }
 // text written to stdout (and exit status used) if a library error ends the process; nullptr clears (quda_amd_ext.h)
 void qudaAmdSetExitLine(const char *text, int status) { setExitLine(text, status); }
 

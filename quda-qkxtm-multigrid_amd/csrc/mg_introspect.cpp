@@ -11,6 +11,7 @@
 
 #include "interface_internal.h"
 #include "block.h"
+#include "dslash.h"
 #include "multigrid.h"
 #include "quda_amd_ext.h"
 
@@ -48,11 +49,13 @@ int qudaAmdMultigridLevels(void *mg_instance) {
 
 // info[18] = Xf[4], Xc[4], fineSpin, fineColor, Nvec, geo_bs[4], spin_bs, 0, 0  (of the transfer level -> level+1)
 void qudaAmdMultigridLevelInfo(void *mg_instance, int level, int info[18]) {
-  const Transfer *T = levelOf(mg_instance, level)->getTransfer();
+  const MG *lv = levelOf(mg_instance, level);
+  const Transfer *T = lv->getTransfer();
   if (!T) errorQuda("level %d is the coarsest level: no transfer", level);
   memset(info, 0, 18 * sizeof(int));
   for (int d = 0; d < 4; d++) { info[d] = T->Xf[d]; info[4 + d] = T->Xc[d]; info[11 + d] = T->geo_bs[d]; }
   info[8] = T->fineSpin; info[9] = T->fineColor; info[10] = T->Nvec; info[15] = T->spin_bs;
+  info[16] = lv->nullVectorMethod; info[17] = lv->nullVectorIterations;
 }
 
 void qudaAmdMultigridGetNullVector(void *mg_instance, int level, int k, float *h_out) {
@@ -161,9 +164,13 @@ void qudaAmdMultigridApply(void *mg_instance, int level, int op, float *h_out, c
 // niter times between device events on the compute stream and the seconds per application are returned (else 0).
 double qudaAmdMultigridApplyBlock(void *mg_instance, int level, int nrhs, float *h_out, const float *h_in, int niter) {
   MG *m = levelOf(mg_instance, level);
-  const DiracCoarse *dc = dynamic_cast<const DiracCoarse *>(m->residualMatrix().Expose());
-  if (!dc || dc->getDiracType() != QUDA_COARSE_DIRAC) errorQuda("level %d does not carry a (full) coarse operator", level);
-  if (!blockCoarseSupported(dc->Links(), nrhs)) errorQuda("block coarse operator not available for n = %d, nrhs = %d on this lattice", dc->Links().n, nrhs);
+  const Dirac *dg = m->residualMatrix().Expose();
+  const DiracCoarse *dc = dynamic_cast<const DiracCoarse *>(dg);
+  const QudaDiracType ty = dg->getDiracType();
+  const bool fine = ty == QUDA_WILSON_DIRAC || ty == QUDA_TWISTED_MASS_DIRAC || ty == QUDA_TWISTED_CLOVER_DIRAC;
+  if (!fine && (!dc || ty != QUDA_COARSE_DIRAC)) errorQuda("level %d does not carry a full fine or coarse operator", level);
+  if (!fine && !blockCoarseSupported(dc->Links(), nrhs)) errorQuda("block coarse operator not available for n = %d, nrhs = %d on this lattice", dc->Links().n, nrhs);
+  if (fine && !fineBlockSupported(*dg->Gauge(), nrhs)) errorQuda("block fine operator not available for nrhs = %d on this lattice", nrhs);
   const ColorSpinorField &proto = *m->nullVectors()[0];
   std::vector<ColorSpinorField *> f(nrhs);
   const size_t len = (size_t)proto.Volume() * proto.Nspin() * proto.Ncolor() * 2;
@@ -173,15 +180,30 @@ double qudaAmdMultigridApplyBlock(void *mg_instance, int level, int nrhs, float 
     ColorSpinorField hin = hostView(*f[i], const_cast<float *>(h_in) + i * len);
     *f[i] = hin;
   }
-  BlockField in(dc->Links().nSites, dc->Links().n, nrhs), out(dc->Links().nSites, dc->Links().n, nrhs);
+  const int nSites = fine ? proto.Volume() : dc->Links().nSites, ncomp = fine ? 12 : dc->Links().n;
+  BlockField in(nSites, ncomp, nrhs), out(nSites, ncomp, nrhs);
   blockPack(in, f);
-  applyCoarseBlock(out, in, dc->Links());
+  // level 0: the multi-right-hand-side stencil of the null-vector solves (dslash.h applyFineBlockM), twisted clover with its dense
+  // site matrices A + i a g5
+  float *tmat[2] = {nullptr, nullptr};
+  const size_t tmatBytes = (size_t)proto.VolumeCB() * 144 * sizeof(float);
+  double a = 0.0;
+  if (fine) {
+    a = ty == QUDA_WILSON_DIRAC ? 0.0 : 2.0 * dg->Kappa() * (double)proto.TwistFlavor() * dg->Mu();
+    if (ty == QUDA_TWISTED_CLOVER_DIRAC)
+      for (int p = 0; p < 2; p++) { tmat[p] = (float *)poolDeviceMalloc(tmatBytes); cloverTwistDense(tmat[p], *dg->Clover(), p, a, false); }
+  }
+  auto apply = [&]() {
+    if (fine) applyFineBlockM(out.v, in.v, nrhs, *dg->Gauge(), dg->Kappa(), a, tmat[0] ? tmat : nullptr);
+    else applyCoarseBlock(out, in, dc->Links());
+  };
+  apply();
   double secs = 0;
   if (niter > 0) {
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
     HIP_CHECK(hipEventRecord(e0, computeStream()));
-    for (int k = 0; k < niter; k++) applyCoarseBlock(out, in, dc->Links());
+    for (int k = 0; k < niter; k++) apply();
     HIP_CHECK(hipEventRecord(e1, computeStream()));
     HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0;
@@ -190,6 +212,8 @@ double qudaAmdMultigridApplyBlock(void *mg_instance, int level, int nrhs, float 
     secs = 1e-3 * ms / niter;
   }
   blockUnpack(f, out);
+  HIP_CHECK(hipStreamSynchronize(computeStream()));
+  for (int p = 0; p < 2; p++) if (tmat[p]) poolDeviceFree(tmat[p], tmatBytes);
   for (int i = 0; i < nrhs; i++) {
     ColorSpinorField hout = hostView(*f[i], h_out + i * len);
     hout = *f[i];

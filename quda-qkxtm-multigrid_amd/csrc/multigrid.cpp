@@ -260,6 +260,7 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
     const int kmax = blockBiCGstabNull(X, [](BlockField &out, const BlockField &in, void *c) { Ctx *x = (Ctx *)c; applyCoarseBlock(out, in, *x->G); x->applies++; }, &ctx, sp.tol, sp.maxiter, iters);
     blockUnpack(Bv, X);
     orthonormaliseNullVectors(B, mgp.Nvec);
+    nullVectorMethod = 2; nullVectorIterations = kmax;
     if (getVerbosity() >= QUDA_SUMMARIZE || mgProfiling()) {
       int imin = iters[0], imax = iters[0];
       for (int i = 1; i < mgp.Nvec; i++) { imin = iters[i] < imin ? iters[i] : imin; imax = iters[i] > imax ? iters[i] : imax; }
@@ -276,23 +277,34 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
     static int nbEnv = -1;
     if (nbEnv < 0) { const char *e = getenv("QUDA_AMD_BLOCK_FINE_NRHS"); nbEnv = e ? atoi(e) : 8; if (nbEnv != 8 && nbEnv != 16 && nbEnv != 24 && nbEnv != 32) nbEnv = 8; }
     const int nb = nbEnv;
-    if (df && (ty == QUDA_TWISTED_MASS_DIRAC || ty == QUDA_WILSON_DIRAC) && B[0]->Nspin() == 4 && B[0]->Precision() == QUDA_SINGLE_PRECISION &&
+    const bool tmc = ty == QUDA_TWISTED_CLOVER_DIRAC && df->Clover() && df->Clover()->precision == QUDA_SINGLE_PRECISION;
+    if (df && (ty == QUDA_TWISTED_MASS_DIRAC || ty == QUDA_WILSON_DIRAC || tmc) && B[0]->Nspin() == 4 && B[0]->Precision() == QUDA_SINGLE_PRECISION &&
         mgp.Nvec % nb == 0 && df->Gauge() && fineBlockSupported(*df->Gauge(), nb)) {
       const double t0 = now();
-      const double a = ty == QUDA_TWISTED_MASS_DIRAC ? 2.0 * df->Kappa() * (double)mgp.fineFlavor * df->Mu() : 0.0;
+      const double a = ty == QUDA_WILSON_DIRAC ? 0.0 : 2.0 * df->Kappa() * (double)mgp.fineFlavor * df->Mu();
       // The solves run on the EVEN-ODD PRECONDITIONED system: M x = 0 with x = (x_e, x_o) is  Mhat x_e = 0,  x_o = kappa A^-1 D_oe x_e
       // (Mhat = 1 - kappa^2 A^-1 D_eo A^-1 D_oe, A = 1 + i a g5: reference DiracTwistedMassPC::M / reconstruct with b = 0,
       // lib/dirac_twisted_mass.cpp:340-393, :526-548) — the same null space, but the BiCGstab vectors are half as long (its 21
       // field passes per iteration, not the links, bound the stage) and the Schur complement is better conditioned.
+      // Twisted clover: the same with A = clover + i a g5 (reference DiracTwistedCloverPC::M / reconstruct,
+      // lib/dirac_twisted_clover.cpp:296-330, :400-421); A^-1 resp. A enter the stencil's epilogue as dense 6 x 6 site matrices
+      // per chirality (cloverTwistDense), built once per setup.
       // QUDA_AMD_NULL_FULL=1 keeps the solves on the full operator as the reference has them.
       static int fullOp = -1;
       if (fullOp < 0) { const char *e = getenv("QUDA_AMD_NULL_FULL"); fullOp = e ? atoi(e) : 0; }
       const double kappa = df->Kappa(), binv = 1.0 / (1.0 + a * a);
-      struct Ctx { const GaugeField *U; double kappa, a, binv; BlockField *tmp; long applies; } ctx = {df->Gauge(), kappa, a, binv, nullptr, 0};
+      const int Vh = B[0]->VolumeCB();
+      float *tmat[2] = {nullptr, nullptr};
+      const size_t tmatBytes = (size_t)Vh * 144 * sizeof(float);
+      if (tmc)
+        for (int p = 0; p < 2; p++) {
+          tmat[p] = (float *)poolDeviceMalloc(tmatBytes);
+          cloverTwistDense(tmat[p], *df->Clover(), p, a, !fullOp);
+        }
+      struct Ctx { const GaugeField *U; double kappa, a, binv; BlockField *tmp; long applies; const float *tmat[2]; } ctx = {df->Gauge(), kappa, a, binv, nullptr, 0, {tmat[0], tmat[1]}};
       int kmaxAll = 0, imin = 1 << 30, imax = 0;
       for (int i = 0; i < mgp.Nvec; i++) { B[i]->twistFlavor = mgp.fineFlavor; spinorRandom(*B[i], 0x5eedULL + 7919ULL * (mgp.level * 131 + i)); }
       double tPack = 0, tSolve = 0;
-      const int Vh = B[0]->VolumeCB();
       for (int g0 = 0; g0 < mgp.Nvec; g0 += nb) {
         std::vector<ColorSpinorField *> Bv(B.begin() + g0, B.begin() + g0 + nb);
         double tp = now();
@@ -301,7 +313,8 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
           BlockField X(B[0]->Volume(), 12, nb);
           blockPack(X, Bv);
           if (mgProfiling()) { HIP_CHECK(hipStreamSynchronize(computeStream())); tPack += now() - tp; tp = now(); }
-          kmax = blockBiCGstabNull(X, [](BlockField &out, const BlockField &in, void *c) { Ctx *x = (Ctx *)c; applyFineBlockM(out.v, in.v, in.nrhs, *x->U, x->kappa, x->a); x->applies++; },
+          kmax = blockBiCGstabNull(X, [](BlockField &out, const BlockField &in, void *c) {
+            Ctx *x = (Ctx *)c; applyFineBlockM(out.v, in.v, in.nrhs, *x->U, x->kappa, x->a, x->tmat[0] ? x->tmat : nullptr); x->applies++; },
                                    &ctx, sp.tol, sp.maxiter, iters);
           if (mgProfiling()) { HIP_CHECK(hipStreamSynchronize(computeStream())); tSolve += now() - tp; tp = now(); }
           blockUnpack(Bv, X);
@@ -312,13 +325,19 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
           if (mgProfiling()) { HIP_CHECK(hipStreamSynchronize(computeStream())); tPack += now() - tp; tp = now(); }
           kmax = blockBiCGstabNull(Xe, [](BlockField &out, const BlockField &in, void *c) {
             Ctx *x = (Ctx *)c;
-            // tmp_o = A^-1 D_oe in_e ;  out_e = in_e - kappa^2 A^-1 D_eo tmp_o          (A^-1 = binv (1 - i a g5))
-            applyFineBlockParity(x->tmp->v, nullptr, in.v, in.nrhs, *x->U, 1, 0.0, 0.0, x->binv, -x->a);
-            applyFineBlockParity(out.v, in.v, x->tmp->v, in.nrhs, *x->U, 0, 1.0, 0.0, -x->kappa * x->kappa * x->binv, -x->a);
+            // tmp_o = A^-1 D_oe in_e ;  out_e = in_e - kappa^2 A^-1 D_eo tmp_o          (twisted mass: A^-1 = binv (1 - i a g5))
+            if (x->tmat[0]) {
+              applyFineBlockParity(x->tmp->v, nullptr, in.v, in.nrhs, *x->U, 1, 0.0, 0.0, 1.0, 0.0, x->tmat[1], 1);
+              applyFineBlockParity(out.v, in.v, x->tmp->v, in.nrhs, *x->U, 0, 1.0, 0.0, -x->kappa * x->kappa, 0.0, x->tmat[0], 1);
+            } else {
+              applyFineBlockParity(x->tmp->v, nullptr, in.v, in.nrhs, *x->U, 1, 0.0, 0.0, x->binv, -x->a);
+              applyFineBlockParity(out.v, in.v, x->tmp->v, in.nrhs, *x->U, 0, 1.0, 0.0, -x->kappa * x->kappa * x->binv, -x->a);
+            }
             x->applies++;
           }, &ctx, sp.tol, sp.maxiter, iters);
           // x_o = kappa A^-1 D_oe x_e
-          applyFineBlockParity(Xo.v, nullptr, Xe.v, nb, *df->Gauge(), 1, 0.0, 0.0, kappa * binv, -a);
+          if (tmc) applyFineBlockParity(Xo.v, nullptr, Xe.v, nb, *df->Gauge(), 1, 0.0, 0.0, kappa, 0.0, tmat[1], 1);
+          else applyFineBlockParity(Xo.v, nullptr, Xe.v, nb, *df->Gauge(), 1, 0.0, 0.0, kappa * binv, -a);
           if (mgProfiling()) { HIP_CHECK(hipStreamSynchronize(computeStream())); tSolve += now() - tp; tp = now(); }
           blockUnpack(Bv, Xe, 0);
           blockUnpack(Bv, Xo, 1);
@@ -327,11 +346,16 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
         kmaxAll = kmax > kmaxAll ? kmax : kmaxAll;
         for (int i = 0; i < nb; i++) { imin = iters[i] < imin ? iters[i] : imin; imax = iters[i] > imax ? iters[i] : imax; }
       }
+      if (tmc) {
+        HIP_CHECK(hipStreamSynchronize(computeStream()));
+        for (int p = 0; p < 2; p++) poolDeviceFree(tmat[p], tmatBytes);
+      }
       orthonormaliseNullVectors(B, mgp.Nvec);
+      nullVectorMethod = 1; nullVectorIterations = kmaxAll;
       if (mgProfiling()) printfQuda("MG level %d: block null-vector stage: pack/unpack + field allocation %.3f s, lockstep solves %.3f s, orthonormalisation %.3f s\n", mgp.level + 1, tPack, tSolve, now() - t0 - tPack - tSolve);
       if (getVerbosity() >= QUDA_SUMMARIZE || mgProfiling())
-        printfQuda("MG level %d: %d null vectors by block BiCGstab on the %d-right-hand-side stencil: up to %d lockstep iterations (per vector %d..%d), %ld block applications, %.3f s\n",
-                   mgp.level + 1, mgp.Nvec, nb, kmaxAll, imin, imax, ctx.applies, now() - t0);
+        printfQuda("MG level %d: %d null vectors by block BiCGstab on the %d-right-hand-side %s stencil: up to %d lockstep iterations (per vector %d..%d), %ld block applications, %.3f s\n",
+                   mgp.level + 1, mgp.Nvec, nb, tmc ? "twisted-clover" : "twisted-mass / Wilson", kmaxAll, imin, imax, ctx.applies, now() - t0);
       return;
     }
   }

@@ -89,20 +89,45 @@ unsigned long long p2pTimeoutTicks() {
   return t;
 }
 
-static int *g_err = nullptr;   // device word: 0, or 1 + slot of the first wait that timed out (later waits then return at once)
+static int *g_err = nullptr;   // device record (p2p.h): word 0 = 0, or the code of the first wait that timed out (later waits then return at once)
 int *p2pErrorWord() {
   if (!g_err) {
-    HIP_CHECK(hipMalloc((void **)&g_err, sizeof(int)));
-    HIP_CHECK(hipMemset(g_err, 0, sizeof(int)));
+    HIP_CHECK(hipMalloc((void **)&g_err, kP2pErrInts * sizeof(int)));
+    HIP_CHECK(hipMemset(g_err, 0, kP2pErrInts * sizeof(int)));
     HIP_CHECK(hipDeviceSynchronize());
   }
   return g_err;
 }
+// What the record says about the three ways an exchange can fail: the expected flag of a (dimension, buffer) zone is this rank's use
+// count of the zone, the sender writes ITS use count of the same zone; a word that still carries the flag of the zone's previous use
+// (expected - 1; 0 on the first use) was simply never written in this exchange — the sender is late or starved; any other value is
+// a sender whose counters disagree with this rank's (different number of exchanges on the two sides, or the other buffer).
+static bool describe(const int *h, char *text, size_t n) {
+  if (!h[0]) return false;
+  const CommGrid &g = commGrid();
+  const bool coarse = h[0] >= 17;
+  const int hop = coarse ? h[0] - 17 : h[0] - 1, mu = hop >> 1, bwd = hop & 1;
+  const unsigned expect = (unsigned)h[2], s0 = (unsigned)h[3], s1 = (unsigned)h[4];
+  const int from = commNeighborRank(mu, bwd ? -1 : +1);
+  const char *verdict;
+  if (coarse) verdict = (int)(s0 - expect) < 0 ? "the arrival counter is short: the neighbour's pack kernel has not (fully) delivered this exchange" : "counter reached after the bound";
+  else if ((s0 == expect - 1 || s0 == 0) && (s1 == expect - 1 || s1 == 0)) verdict = "the words still carry the zone's previous use: this exchange's face was never written (sender late, starved or gone)";
+  else if (s0 == expect || s1 == expect) verdict = "one half of the vector arrived, the other did not: a store of this exchange is still in flight or was lost";
+  else verdict = "the words carry a flag of neither this exchange nor the previous one: the two ranks disagree about the exchange count of this zone (or about the buffer)";
+  snprintf(text, n, "%s-grid halo wait ran out on rank %d: %s hop in dimension %d (face from rank %d), %s %d, vector %d, exchange %u of this rank's window, buffer %d: expected %s %u, last seen %u / %u — %s",
+           coarse ? "coarse" : "fine", g.rank, bwd ? "backward" : "forward", mu, from, coarse ? "coarse site" : "face site", h[1], h[7], (unsigned)h[5], h[6], coarse ? "arrival count" : "flag",
+           expect, s0, s1, verdict);
+  return true;
+}
+bool p2pDescribeError(char *text, size_t n) {
+  if (!g_err) return false;
+  int h[kP2pErrInts];
+  HIP_CHECK(hipMemcpy(h, g_err, sizeof(h), hipMemcpyDeviceToHost));
+  return describe(h, text, n);
+}
 void p2pCheck(const char *where) {
-  if (!g_err) return;
-  int h = 0;
-  HIP_CHECK(hipMemcpy(&h, g_err, sizeof(int), hipMemcpyDeviceToHost));
-  if (h) errorQuda("%s: a halo wait timed out (a neighbour rank never delivered its face; error word %d)", where, h);
+  char text[768];
+  if (p2pDescribeError(text, sizeof(text))) errorQuda("%s: %s (QUDA_AMD_P2P_TIMEOUT_S bounds the wait; QUDA_AMD_HALO=rccl selects the staged transport)", where, text);
 }
 
 // ---- token round trips through the mapped windows, with the same access types as the production protocols: system-scope
@@ -192,15 +217,21 @@ void p2pReset() {
   g_p2p = -1;
   if (g_err) { (void)hipFree(g_err); g_err = nullptr; }
 }
+static long long g_stats[8];
+long long *p2pStats() { return g_stats; }
 int p2pTransport() { return g_p2p; }
 // the production kernel disagreed with the staged transport on its first use (halo.h, verifyPeerStores): staged from now on
-void p2pDisable() { g_p2p = 0; }
-int p2pTakeError() {   // read and clear the device error word
+void p2pDisable() { g_p2p = 0; g_stats[6]++; }
+int p2pTakeError() {   // read and clear the device error record
   if (!g_err) return 0;
-  int h = 0;
-  HIP_CHECK(hipMemcpy(&h, g_err, sizeof(int), hipMemcpyDeviceToHost));
-  if (h) { HIP_CHECK(hipMemset(g_err, 0, sizeof(int))); HIP_CHECK(hipDeviceSynchronize()); }
-  return h;
+  int h[kP2pErrInts];
+  HIP_CHECK(hipMemcpy(h, g_err, sizeof(h), hipMemcpyDeviceToHost));
+  if (h[0]) {
+    char text[768];
+    if (describe(h, text, sizeof(text)) && getVerbosity() >= QUDA_SUMMARIZE) warningQuda("%s", text);
+    HIP_CHECK(hipMemset(g_err, 0, sizeof(h))); HIP_CHECK(hipDeviceSynchronize());
+  }
+  return h[0];
 }
 
 bool p2pHaloEnabled() {

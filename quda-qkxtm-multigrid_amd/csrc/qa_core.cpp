@@ -64,11 +64,17 @@ void qa_warning(const char *fmt, ...) {
 
 // A caller that has results to deliver (bench.py: its finished JSON line, while an optional leg is still running) can leave them
 // here: an error then writes the text to stdout before the process ends, with the status the caller asked for.
+// The status is never 0: a failure must reach the launcher as a failure (a status of 0 is replaced by 1).
 static std::string g_exitLine;
 static int g_exitStatus = 1;
 void setExitLine(const char *text, int status) {
   g_exitLine = text ? text : "";
-  g_exitStatus = text ? status : 1;
+  g_exitStatus = (text && status != 0) ? status : 1;
+}
+// the one way out after an error: errorQuda, the util_quda.h errorQuda of linked callers (compat.cpp qudaLogError) and comm_abort
+void abortWithExitLine(int status) {
+  if (!g_exitLine.empty()) { fputs(g_exitLine.c_str(), stdout); fputc('\n', stdout); fflush(stdout); }
+  exit(status != 0 ? status : g_exitStatus);
 }
 
 void qa_error(const char *file, int line, const char *func, const char *fmt, ...) {
@@ -80,8 +86,7 @@ void qa_error(const char *file, int line, const char *func, const char *fmt, ...
   va_end(ap);
   fprintf(f, " (rank %d, %s:%d in %s())\n", commGrid().rank, file, line, func);
   fflush(f);
-  if (!g_exitLine.empty()) { fputs(g_exitLine.c_str(), stdout); fputc('\n', stdout); fflush(stdout); }
-  exit(g_exitStatus);  // comm_abort(1) of the reference, lib/comm_single.cpp:58-63
+  abortWithExitLine(g_exitStatus);  // comm_abort(1) of the reference, lib/comm_single.cpp:58-63
 }
 
 CommGrid &commGrid() {

@@ -229,3 +229,72 @@ def test_matdagmat_through_the_c_abi(qa, oracle, dslash):
             else:
                 want = oracle.tmc_matpc(gauge, oracle.tmc_matpc(gauge, spinor[:nh].copy(), clover, cinv, list(X), kappa, mu, flavor, matpc, 0), clover, cinv, list(X), kappa, mu, flavor, matpc, 1)
             assert _rel(got, want) < 1e-12, (dslash, flavor, matpc)
+
+
+@pytest.mark.parametrize("dslash", ["tm", "tmc"])
+def test_multi_rhs_fine_stencil_against_the_oracle(qa, oracle, dslash):
+    """The 8/16/24/32-right-hand-side stencil of the lockstep null-vector solves (csrc/dslash.hip fine_block_kernel; twisted clover:
+    the dense A + i a g5 site matrices of cloverTwistDense in its epilogue) applied to a batch, every right-hand side against the
+    host tm_mat / tmc_mat (fp32 device arithmetic: 2e-5 of the largest element); and the hierarchy's own record that the level-0 null
+    vectors came from the lockstep solve on that stencil (null_method 1), the coarse ones from the MFMA operator (2)."""
+    X, kappa, mu = (8, 8, 8, 16), 0.124, 0.005
+    if dslash == "tmc":
+        gauge, clover, ip = _setup(qa, oracle, X, kappa, mu)
+    else:
+        gauge, clover, ip = _setup(qa, oracle, X, kappa, mu)
+        ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=8, prec_sloppy=4, prec_precondition=4, solution_type=qa.QUDA_MAT_SOLUTION)
+        ip.solve_type, ip.inv_type, ip.verbosity = qa.QUDA_DIRECT_SOLVE, qa.QUDA_GCR_INVERTER, qa.QUDA_SILENT
+    mp = qa.multigrid_param(ip, n_level=3, geo_block=[(4, 4, 4, 4), (1, 1, 1, 2), (2, 2, 2, 2)], n_vec=8, setup_maxiter=100, setup_tol=1e-4)
+    mg = qa.Multigrid(mp)
+    rng = np.random.default_rng(31)
+    V = int(np.prod(X))
+    try:
+        assert mg.level_info(0)["null_method"] == 1 and mg.level_info(0)["null_iters"] > 0
+        assert mg.level_info(1)["null_method"] == 2
+        for nrhs in (8, 16, 24, 32):
+            phi = (rng.standard_normal((nrhs, V, 4, 3)) + 1j * rng.standard_normal((nrhs, V, 4, 3))).astype(np.complex64)
+            phi *= (10.0 ** rng.integers(-2, 3, size=nrhs)).astype(np.float32)[:, None, None, None]
+            got, _ = mg.apply_block(0, phi)
+            oracle.set_threads(8)
+            try:
+                for k in range(nrhs):
+                    v = np.ascontiguousarray(phi[k].astype(np.complex128)).view(np.float64).reshape(-1)
+                    if dslash == "tmc":
+                        want = oracle.tmc_mat(gauge, clover, v, list(X), kappa, mu, +1, 0)
+                    else:
+                        want = oracle.tm_mat(gauge, v, list(X), kappa, mu, +1, 0)
+                    assert _rel(got[k], want.view(np.complex128).reshape(-1, 4, 3)) < 2e-5, (nrhs, k)
+            finally:
+                oracle.set_threads(1)
+    finally:
+        mg.free()
+
+
+def test_dense_clover_twist_inverse_in_the_lockstep_solve(qa, oracle):
+    """The even-odd preconditioned lockstep solve uses (A + i a g5)^-1 as a dense site matrix (Gauss-Jordan on the device) and
+    reconstructs x_o = kappa (A + i a g5)^-1 D_oe x_e (reference DiracTwistedCloverPC::reconstruct with b = 0,
+    lib/dirac_twisted_clover.cpp:400-421).  Sharp consequence, checked with the HOST operator: the odd half of tmc_mat v vanishes to
+    fp32 round-off for every null vector v — (M v)_o = (A + i a g5) x_o - kappa D_oe x_e — which it only does if the dense inverse
+    really is the inverse of the host's clover-twist term; and the vectors are rich in low modes (|M v| / |v| well below a random
+    vector's)."""
+    X, kappa, mu = (8, 8, 8, 16), 0.124, 0.005
+    gauge, clover, ip = _setup(qa, oracle, X, kappa, mu)
+    mp = qa.multigrid_param(ip, n_level=2, geo_block=(4, 4, 4, 4), n_vec=8, setup_maxiter=300, setup_tol=1e-5)
+    mg = qa.Multigrid(mp)
+    try:
+        assert mg.level_info(0)["null_method"] == 1
+        rng = np.random.default_rng(1)
+        r = rng.standard_normal(int(np.prod(X)) * 24)
+        scale = np.linalg.norm(oracle.tmc_mat(gauge, clover, r, list(X), kappa, mu, +1, 0)) / np.linalg.norm(r)
+        worst, worst_odd = 0.0, 0.0
+        nh = r.size // 2
+        for k in range(8):
+            v = np.ascontiguousarray(mg.null_vector(0, k).astype(np.complex128)).view(np.float64).reshape(-1)
+            mv = oracle.tmc_mat(gauge, clover, v, list(X), kappa, mu, +1, 0)
+            worst = max(worst, np.linalg.norm(mv) / np.linalg.norm(v))
+            worst_odd = max(worst_odd, np.linalg.norm(mv[nh:]) / np.linalg.norm(v))
+        print("twisted-clover null vectors: worst |M v| / |v| = %.3e (random vector %.3e), odd half %.3e" % (worst, scale, worst_odd))
+        assert worst_odd < 2e-6, worst_odd
+        assert worst < 0.5 * scale, (worst, scale)
+    finally:
+        mg.free()
