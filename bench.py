@@ -137,7 +137,7 @@ def run_mg_ranks(qa, dist, X, kappa=0.124, mu=0.005):
 
 
 def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)), gauge=None, extras=True, kappa=0.124, mu=0.005, plain_maxiter=5000,
-           coarse_bench=True, setup_repeats=1):
+           coarse_bench=True, setup_repeats=1, dslash="tm", csw=1.57551):
     """MG-preconditioned GCR to |r|/|b| <= 1e-10 (the second half of the metric) on one GPU: 3-level K-cycle, 24 null
     vectors, 4^4 then 2^4 aggregates, even-odd preconditioned MR smoother — the reference harness' default shape
     (tests/multigrid_invert_test.cpp:224-286) on a smooth synthetic gauge field (synth.smooth_gauge: far easier than a production
@@ -149,13 +149,18 @@ def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2,
     gp = qa.gauge_param(X, cuda_prec=8, prec_sloppy=4, prec_precondition=4, t_boundary=qa.QUDA_PERIODIC_T)
     qa.load_gauge(gauge, gp)
     del gauge
-    ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=8, prec_sloppy=4, prec_precondition=4,
-                         solution_type=qa.QUDA_MAT_SOLUTION)
+    ip = qa.invert_param(qa.QUDA_TWISTED_CLOVER_DSLASH if dslash == "tmc" else qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=8, prec_sloppy=4,
+                         prec_precondition=4, solution_type=qa.QUDA_MAT_SOLUTION)
     ip.solve_type = qa.QUDA_DIRECT_SOLVE
     ip.inv_type = qa.QUDA_GCR_INVERTER
     ip.gcrNkrylov = 20
     ip.tol = 1e-10
     ip.maxiter = plain_maxiter
+    if dslash == "tmc":
+        # the production ETMC action the way the QKXTM drivers set it up (reference qkxtm/CalcMG_2pt3pt_EvenOdd.cpp:222-240): the clover
+        # term is built on the device from the resident links, loadCloverQuda(NULL, NULL), clover_coeff = kappa csw
+        ip.clover_coeff = kappa * csw
+        qa.load_clover(None, None, ip)
     b = np.random.default_rng(5).random(int(np.prod(X)) * 24)
 
     def timed_solve():
@@ -196,7 +201,12 @@ def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2,
     res = float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b))
     # solve_secs: wall clock of invertQuda (host source in, host solution out, as SURVEY 8d defines it: includes the two
     # PCIe transfers and the operator / field set-up); solver_secs: the GCR loop alone (QudaInvertParam.secs)
-    out = dict(lattice="x".join(map(str, X)), kappa=kappa, mu=mu, levels=3, n_vec=24, blocks=[list(bk) for bk in blocks[:2]], setup_secs=min(setups), setup_secs_all=setups, solve_secs=round(wall, 4),
+    lv0, lv1 = mg.level_info(0), mg.level_info(1)
+    out = dict(lattice="x".join(map(str, X)), action={"tm": "twisted mass", "tmc": "twisted clover (device-built clover, csw %g)" % csw}[dslash], kappa=kappa, mu=mu, levels=3, n_vec=24, blocks=[list(bk) for bk in blocks[:2]],
+               null_vectors=dict(level0={0: "sequential BiCGstab solves", 1: "lockstep block BiCGstab on the multi-rhs stencil", 2: "lockstep block BiCGstab on the MFMA coarse operator"}[lv0["null_method"]],
+                                 level0_lockstep_iters=lv0["null_iters"], level1={0: "sequential BiCGstab solves", 1: "lockstep (fine stencil)", 2: "lockstep block BiCGstab on the MFMA coarse operator"}[lv1["null_method"]],
+                                 level1_lockstep_iters=lv1["null_iters"]),
+               setup_secs=min(setups), setup_secs_all=setups, solve_secs=round(wall, 4),
                solver_secs=round(inner, 4), iters=iters, true_res=res, plain_gcr=plain, timing="best of 3 after 1 warm-up solve")
     # the multi-right-hand-side coarse operator on the matrix cores (level 1: 2 Nvec = 48 rows, 9 dense matrices per site) against
     # the single-vector kernel: seconds per application, HBM rate on the ALGORITHMIC bytes (links once + in/out panels) and MFMA rate
@@ -433,6 +443,8 @@ def main():
     if not args.no_extra and rank == 0 and world == 1:
         g32 = smooth_gauge((32, 32, 32, 32), 0.35)
         extra["mg_gcr"] = run_mg(qa, (32, 32, 32, 32), gauge=g32)
+        # the same problem with the production action (twisted CLOVER): lockstep set-up on the clover variant of the multi-rhs stencil
+        extra["mg_gcr_tmc"] = run_mg(qa, (32, 32, 32, 32), gauge=g32, dslash="tmc", coarse_bench=False)
         # where multigrid matters: the same field at its critical kappa (tools/mg_kappa_scan.py, profiles/r02_mg_kappa_scan_32x4_c.json:
         # plain GCR(20) needs > 10^4 iterations there and stagnates beyond it; the twisted mass keeps the operator regular)
         extra["mg_gcr_critical"] = run_mg(qa, (32, 32, 32, 32), gauge=g32, extras=False, kappa=0.147, mu=0.001, plain_maxiter=30000, coarse_bench=False)
@@ -525,6 +537,23 @@ def main():
                         traffic, traffic_source = round(v["hbm_bytes_per_launch"]), os.path.basename(path)
             except Exception:
                 pass
+    def per_rank_report():
+        """every rank's transport and exchange counters (a rank that fell back to the staged transport, or global sums that went through
+        the collective library, are visible in the line): gathered with one sum all-reduce into rank-indexed slots"""
+        stats = qa.comm_stats()
+        mine = [float(qa.lib().qudaAmdHaloTransport())] + [float(stats[k]) for k in qa.COMM_STATS_KEYS]
+        if dist is None:
+            rows = [mine]
+        else:
+            import ctypes as C
+            buf = np.zeros(world * len(mine))
+            buf[rank * len(mine):(rank + 1) * len(mine)] = mine
+            qa.lib().qudaAmdCommAllreduce(buf.ctypes.data_as(C.POINTER(C.c_double)), buf.size)
+            rows = buf.reshape(world, len(mine)).tolist()
+        names = {1: "peer stores", 0: "RCCL send/recv", -1: "none"}
+        return [dict(rank=i, halo_transport=names.get(int(row[0]), "?"), **{k: int(v) for k, v in zip(qa.COMM_STATS_KEYS, row[1:])}) for i, row in enumerate(rows)]
+
+    ranks_dslash = per_rank_report() if world > 1 else None
     if rank == 0:
         out = {
             "metric": "twisted-mass Dslash GFLOP/s (even-odd, 32^4)" if X == [32, 32, 32, 32] else "twisted-mass Dslash GFLOP/s",
@@ -536,6 +565,7 @@ def main():
                        % ({"tm": "twisted-mass", "tmc": "twisted-clover", "wilson": "Wilson"}[args.dslash], kappa, mu, "x".join(map(str, X)), args.recon),
                        "local_lattice": Xl, "halo_transport": {1: "direct peer stores (IPC-mapped ghost zones over xGMI)", 0: "RCCL send/recv", -1: "none (single rank)"}[int(qa.lib().qudaAmdHaloTransport())], "process_grid": dist.grid if dist else [1, 1, 1, 1], "flops_per_site": r["flops_site"],
                        "ranks_in_communicator": int(qa.lib().qudaAmdCommSize()), "per_rank_kernel_us": {"slowest": round(1e6 * r["sec"], 2), "fastest": round(1e6 * r["sec_min"], 2)},
+                       "per_rank": ranks_dslash,   # transport + exchange / global-sum counters of every rank after the Dslash measurement
                        "other_configs": "BASELINE configs[3] (32^3 x 64 over 8 GPUs): --lattice 32,32,32,64 (grid 1x2x2x2, local 32x16x16x32)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "traffic_unit": "B/launch", "traffic_source": traffic_source, "bytes_per_site": r["bytes_site"], "kernel_us": round(1e6 * r["sec"], 3)},
@@ -554,7 +584,10 @@ def main():
         except Exception as e:
             res = dict(failed=str(e)[:300])
         guard.disarm()
+        ranks_mg = per_rank_report()
         if rank == 0:
+            if isinstance(res, dict):
+                res["per_rank"] = ranks_mg   # counters now include the hierarchy set-up and the solves
             out["extra"]["mg_gcr"] = res
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -80,6 +80,7 @@ void qudaAmdMultigridCycle(void *mg_instance, void *h_x, void *h_b, QudaInvertPa
  * does the same at newMultigridQuda. */
 void qudaAmdMultigridSetHalfStorage(void *mg_instance, int on);
 int qudaAmdMultigridLevels(void *mg_instance);
+int qudaAmdMultigridOrthoFallbackBlocks(void *mg_instance, int level); /* blocks the fp32 CholeskyQR2 block orthonormalisation handed to Gram-Schmidt (ill-conditioned) */
 void qudaAmdMultigridLevelInfo(void *mg_instance, int level, int info[18]); /* Xf[4] Xc[4] fineSpin fineColor Nvec geo_bs[4] spin_bs null_vector_method (0 sequential solves / loaded, 1 lockstep on the multi-rhs fine stencil, 2 lockstep on the MFMA coarse operator) lockstep_iterations */
 void qudaAmdMultigridGetNullVector(void *mg_instance, int level, int k, float *h_out);
 void qudaAmdMultigridGetV(void *mg_instance, int level, float *h_out);

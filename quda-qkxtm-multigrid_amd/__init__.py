@@ -119,7 +119,7 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
                  "qudaAmdMultigridVerify", "qudaAmdMultigridCycle", "qudaAmdTimeAxpy", "qudaAmdMultigridLevels", "qudaAmdMultigridLevelInfo",
                  "qudaAmdMultigridSetHalfStorage", "qudaAmdMultigridGetNullVector", "qudaAmdMultigridGetV", "qudaAmdMultigridGetCoarseLinks", "qudaAmdMultigridApply", "qudaAmdMultigridApplyBlock",
                  "qudaAmdMultigridTimeApply", "qudaAmdMultigridTimeTransfer", "qudaAmdSetExitLine", "qudaAmdDiracPrepare", "qudaAmdDiracReconstruct", "qudaAmdSpinorRawInfo", "qudaAmdGaugeRawInfo", "qudaAmdCloverRawInfo", "qudaAmdRawDeviceCopy",
-                 "qudaAmdSetSolutionSink", "qudaAmdCommStats", "qudaAmdDescribeHaloError"]
+                 "qudaAmdSetSolutionSink", "qudaAmdCommStats", "qudaAmdDescribeHaloError", "qudaAmdMultigridOrthoFallbackBlocks"]
 
 _lib = None
 
@@ -193,6 +193,9 @@ def lib():
         L.qudaAmdTimeAxpy.restype = _d
         L.qudaAmdMultigridSetHalfStorage.argtypes = [_p, _i]
         L.qudaAmdMultigridLevels.argtypes = [_p]
+        L.qudaAmdMultigridOrthoFallbackBlocks.argtypes = [_p, _i]
+        L.qudaAmdCommStats.argtypes = [C.POINTER(C.c_longlong)]
+        L.qudaAmdDescribeHaloError.argtypes = [C.c_char_p, _i]
         L.qudaAmdMultigridLevelInfo.argtypes = [_p, _i, C.POINTER(_i)]
         L.qudaAmdMultigridGetNullVector.argtypes = [_p, _i, _i, _p]
         L.qudaAmdMultigridGetV.argtypes = [_p, _i, _p]
@@ -580,6 +583,9 @@ class Multigrid:
         lib().qudaAmdMultigridLevelInfo(self.h, level, a)
         v = list(a)
         return dict(Xf=v[0:4], Xc=v[4:8], fineSpin=v[8], fineColor=v[9], Nvec=v[10], geo_bs=v[11:15], spin_bs=v[15], null_method=v[16], null_iters=v[17])
+
+    def ortho_fallback_blocks(self, level):
+        return int(lib().qudaAmdMultigridOrthoFallbackBlocks(self.h, int(level)))
 
     def null_vector(self, level, k):
         i = self.level_info(level)

@@ -58,6 +58,13 @@ void qudaAmdMultigridLevelInfo(void *mg_instance, int level, int info[18]) {
   info[16] = lv->nullVectorMethod; info[17] = lv->nullVectorIterations;
 }
 
+// (aggregate, chirality) blocks of the level's transfer operator that the fp32 CholeskyQR2 orthonormalisation handed to Gram-Schmidt
+int qudaAmdMultigridOrthoFallbackBlocks(void *mg_instance, int level) {
+  const Transfer *T = levelOf(mg_instance, level)->getTransfer();
+  if (!T) errorQuda("level %d is the coarsest level: no transfer", level);
+  return T->lastGsFallbackBlocks;
+}
+
 void qudaAmdMultigridGetNullVector(void *mg_instance, int level, int k, float *h_out) {
   const std::vector<ColorSpinorField *> &B = levelOf(mg_instance, level)->nullVectors();
   if (k < 0 || k >= (int)B.size()) errorQuda("null vector %d of %zu", k, B.size());

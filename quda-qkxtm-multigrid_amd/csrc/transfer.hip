@@ -539,7 +539,8 @@ __device__ __forceinline__ double2 block_sum2d(double2 v, double2 *lds) {
 
 // modified Gram-Schmidt over the nvec vectors of one (aggregate, chirality) block, sums in fp64
 // (reference blockGramSchmidt, lib/transfer_util.cu:328-363)
-__global__ void block_gs_kernel(float *V, int blockVol, int K, int ncf, int spin_bs, int nvec) {
+__global__ void block_gs_kernel(float *V, int blockVol, int K, int ncf, int spin_bs, int nvec, const int *only) {
+  if (only && !only[blockIdx.x]) return;   // fall-back of the CholeskyQR kernel: just the blocks it flagged
   __shared__ double2 lds[16];
   const int A = blockIdx.x >> 1, chi = blockIdx.x & 1;
   const int Kc = K / 2, n = Kc * blockVol;
@@ -582,11 +583,16 @@ __global__ void block_gs_kernel(float *V, int blockVol, int K, int ncf, int spin
 // Gram matrix G = V^dagger V (= R^dagger R) IS the Gram-Schmidt result — but G needs one sweep over the block (all 300 inner
 // products of 24 vectors at once, fp64 sums, the block staged through LDS in chunks of 256 elements) and V R^-1 a second one,
 // where modified Gram-Schmidt makes 276 dependent sweeps with two block reductions each (0.44 - 0.6 s at 48^3 x 96).  Run twice
-// (CholeskyQR2): the second round removes the orthogonality the first one loses to the conditioning of the block.  A block whose
-// Gram matrix is not numerically positive definite is left to the Gram-Schmidt kernel (fail flag).
+// (CholeskyQR2): the second round removes the orthogonality the first one loses to the conditioning of the block — as long as
+// eps cond(V)^2 < 1 with the eps of the Gram matrix, which is fp32 here (V is fp32 and a chunk's 256-term sum is fp32: ~1e-6
+// relative).  Two guards, both matched to that precision: a Cholesky pivot below kQrPivot x G_jj is round-off, not data, and a
+// first-round result whose Gram matrix is further than kQrRound2 from the identity is beyond what the second round repairs.  A block
+// that trips either one is flagged and goes to the Gram-Schmidt kernel — that block only; what the first round may already have
+// written is V T with T upper triangular with a positive diagonal, which has the same Q.
 // Reference semantics: blockGramSchmidt, lib/transfer_util.cu:328-363.
 constexpr int kQrChunk = 256;
-template <int NVEC> __global__ void __launch_bounds__(256) block_cholqr_kernel(float *V, int blockVol, int K, int ncf, int spin_bs, int *failed) {
+constexpr double kQrPivot = 1e-5, kQrRound2 = 5e-2;
+template <int NVEC> __global__ void __launch_bounds__(256) block_cholqr_kernel(float *V, int blockVol, int K, int ncf, int spin_bs, int *failed, int *failedBlock) {
   constexpr int nvec = NVEC;
   extern __shared__ double smem[];
   // layout: tile [kQrChunk][nvec + 1] float2 | G / L [nvec][nvec] double2 | Rinv [nvec][nvec] float2 | flag
@@ -645,14 +651,19 @@ template <int NVEC> __global__ void __launch_bounds__(256) block_cholqr_kernel(f
     }
 #pragma unroll
     for (int q = 0; q < 3; q++)
-      if (pi[q] >= 0) { G[pi[q] * nvec + pj[q]] = acc[q]; G[pj[q] * nvec + pi[q]] = make_double2(acc[q].x, -acc[q].y); }
+      if (pi[q] >= 0) {
+        G[pi[q] * nvec + pj[q]] = acc[q]; G[pj[q] * nvec + pi[q]] = make_double2(acc[q].x, -acc[q].y);
+        // second round: the first one must have left something close to orthonormal
+        if (round == 1 && (fabs(acc[q].x - (pi[q] == pj[q] ? 1.0 : 0.0)) > kQrRound2 || fabs(acc[q].y) > kQrRound2)) *bad = 1;
+      }
     __syncthreads();
+    if (*bad) break;
     // ---- Cholesky G = L L^dagger in place (lower triangle), column by column; thread i owns row i ----
     for (int j = 0; j < nvec; j++) {
       if ((int)threadIdx.x == j) {
         double d = G[j * nvec + j].x;
         for (int k = 0; k < j; k++) { const double2 l = G[j * nvec + k]; d -= l.x * l.x + l.y * l.y; }
-        if (!(d > 1e-12 * G[j * nvec + j].x) || !(d > 0.0)) { *bad = 1; d = 1.0; }
+        if (!(d > kQrPivot * G[j * nvec + j].x) || !(d > 0.0)) { *bad = 1; d = 1.0; }
         G[j * nvec + j] = make_double2(sqrt(d), 0.0);
       }
       __syncthreads();
@@ -713,7 +724,7 @@ template <int NVEC> __global__ void __launch_bounds__(256) block_cholqr_kernel(f
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0 && *bad) atomicAdd(failed, 1);
+  if (threadIdx.x == 0 && *bad) { atomicAdd(failed, 1); failedBlock[blockIdx.x] = 1; }
 }
 
 // ---- random source ----
@@ -837,16 +848,18 @@ void Transfer::fillAndOrthonormalise(const std::vector<ColorSpinorField *> &B) {
   static int useQr = -1;
   if (useQr < 0) { const char *e = getenv("QUDA_AMD_BLOCK_ORTHO"); useQr = (e && !strcmp(e, "gs")) ? 0 : 1; }
   int nfail = useQr ? 0 : 1;
+  lastGsFallbackBlocks = 0;
   if (useQr) {
-    int *d_fail = nullptr;
-    HIP_CHECK(hipMalloc((void **)&d_fail, sizeof(int)));
-    HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(int), computeStream()));
+    int *d_fail = nullptr;   // [0] number of flagged blocks, [1 + b] flag of (aggregate, chirality) block b
+    const size_t failBytes = (1 + 2 * (size_t)nAgg) * sizeof(int);
+    HIP_CHECK(hipMalloc((void **)&d_fail, failBytes));
+    HIP_CHECK(hipMemsetAsync(d_fail, 0, failBytes, computeStream()));
     const size_t tileFloats2 = (size_t)kQrChunk * (Nvec + 1) + 1;
     const size_t lds = tileFloats2 * sizeof(float2) + (size_t)Nvec * Nvec * (sizeof(double2) + sizeof(float2)) + 64;
 #define QA_QR(NV)                                                                                                                  \
   {                                                                                                                                \
     HIP_CHECK(hipFuncSetAttribute((const void *)block_cholqr_kernel<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
-    hipLaunchKernelGGL((block_cholqr_kernel<NV>), dim3(2 * nAgg), dim3(256), lds, computeStream(), V, blockVol, K, fineColor, spin_bs, d_fail); \
+    hipLaunchKernelGGL((block_cholqr_kernel<NV>), dim3(2 * nAgg), dim3(256), lds, computeStream(), V, blockVol, K, fineColor, spin_bs, d_fail, d_fail + 1); \
   }
     switch (Nvec) {
       case 4: QA_QR(4) break;
@@ -859,15 +872,19 @@ void Transfer::fillAndOrthonormalise(const std::vector<ColorSpinorField *> &B) {
     HIP_CHECK(hipGetLastError());
     if (!nfail) HIP_CHECK(hipMemcpyAsync(&nfail, d_fail, sizeof(int), hipMemcpyDeviceToHost, computeStream()));
     HIP_CHECK(hipStreamSynchronize(computeStream()));
-    HIP_CHECK(hipFree(d_fail));
     if (nfail && (Nvec == 4 || Nvec == 8 || Nvec == 24 || Nvec == 32)) {
-      warningQuda("block orthonormalisation: %d blocks with a numerically singular Gram matrix, falling back to Gram-Schmidt", nfail);
-      // the failed blocks left V untouched or partially updated: refill and run the sequential kernel on everything
-      if (fineSpin == 4) hipLaunchKernelGGL((fillv_kernel<4>), dim3((total + 255) / 256), dim3(256), 0, computeStream(), V, vl, f0.stride, f0.Vh, block_to_fine, blockVol, K, Nvec, total);
-      else hipLaunchKernelGGL((fillv_kernel<2>), dim3((total + 255) / 256), dim3(256), 0, computeStream(), V, vl, f0.stride, f0.Vh, block_to_fine, blockVol, K, Nvec, total);
+      // flagged blocks hold their original vectors or those times an upper-triangular matrix with a positive diagonal (first round done,
+      // second refused): the same Q either way, so the sequential kernel runs on exactly those blocks, in place
+      if (getVerbosity() >= QUDA_SUMMARIZE) printfQuda("block orthonormalisation: %d of %ld blocks too ill-conditioned for CholeskyQR2 in fp32, Gram-Schmidt on those\n", nfail, 2 * (long)nAgg);
+      hipLaunchKernelGGL(block_gs_kernel, dim3(2 * nAgg), dim3(256), 0, computeStream(), V, blockVol, K, fineColor, spin_bs, Nvec, (const int *)(d_fail + 1));
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(computeStream()));
+      lastGsFallbackBlocks = nfail;
+      nfail = 0;
     }
+    HIP_CHECK(hipFree(d_fail));
   }
-  if (nfail) hipLaunchKernelGGL(block_gs_kernel, dim3(2 * nAgg), dim3(256), 0, computeStream(), V, blockVol, K, fineColor, spin_bs, Nvec);
+  if (nfail) hipLaunchKernelGGL(block_gs_kernel, dim3(2 * nAgg), dim3(256), 0, computeStream(), V, blockVol, K, fineColor, spin_bs, Nvec, (const int *)nullptr);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(computeStream()));
 }

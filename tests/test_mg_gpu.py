@@ -434,3 +434,68 @@ def test_c5_full_size_on_one_gpu(qa, oracle):
         assert res < 1e-10 and ip.iter < 40, (res, ip.iter)
     finally:
         mg.free()
+
+
+def _write_null_vectors(path, X, B):
+    """a null-vector file of this library (csrc/multigrid.cpp NullVecHeader: 64-byte header + Nvec site-major fp32 vectors), so a test can
+    hand the hierarchy the vectors it wants through vec_infile / compute_null_vector = NO (reference MG::loadVectors, lib/multigrid.cpp:639-691)"""
+    import struct
+    with open(path, "wb") as f:
+        f.write(struct.pack("<8s4i4i4i2i", b"QAMDNV02", *X, 4, 3, len(B), 4, 1, 1, 1, 1, 0, 0x01020304))
+        for v in B:
+            f.write(np.ascontiguousarray(v, dtype=np.complex64).tobytes())
+
+
+@pytest.mark.parametrize("eps,expect_fallback", [(3e-2, False), (1e-3, True), ("mixed", True)], ids=["cond-1e2", "cond-1e3", "ill-conditioned-in-some-blocks"])
+def test_block_orthonormalisation_of_nearly_dependent_vectors(qa, oracle, tmp_path, eps, expect_fallback):
+    """ADVICE r2 (transfer.hip pivot test): locally coherent near-null vectors make the block Gram matrices ill-conditioned.  The fp32
+    CholeskyQR2 kernel has to notice what is beyond it — pivots at the round-off level of an fp32 Gram matrix, a first round that is
+    not close to orthonormal — and hand exactly those blocks to Gram-Schmidt.  Vectors v_k = v_0 + eps r_k go in through vec_infile;
+    checked: P^dag P = 1 per block to fp32 level (|V^dag V - 1| element-wise), the span (identity (1) of MG::verify), agreement with
+    the oracle's fp64 Gram-Schmidt (lib/transfer_util.cu:328-363) at the accuracy the conditioning allows, and whether the fall-back ran."""
+    X, kappa, mu = (8, 8, 8, 8), 0.124, 0.005
+    _, ip = _setup(qa, X, kappa, mu)
+    V4, nvec = int(np.prod(X)), 8
+    rng = np.random.default_rng(77)
+    v0 = (rng.standard_normal((V4, 4, 3)) + 1j * rng.standard_normal((V4, 4, 3))).astype(np.complex64)
+    amp = np.full(V4, 0.3 if eps == "mixed" else eps)
+    if eps == "mixed":
+        amp[: V4 // 4] = 1e-3       # the first quarter of the even sites: low t, i.e. a few aggregates only
+    B = [v0] + [(v0 + amp[:, None, None] * (rng.standard_normal((V4, 4, 3)) + 1j * rng.standard_normal((V4, 4, 3)))).astype(np.complex64) for _ in range(nvec - 1)]
+    base = str(tmp_path / "nv")
+    _write_null_vectors(base + "_level_0", X, B)
+    mp = qa.multigrid_param(ip, n_level=2, geo_block=(4, 4, 4, 4), n_vec=nvec)
+    mp.compute_null_vector = qa.QUDA_COMPUTE_NULL_VECTOR_NO
+    mp.vec_infile = base.encode()
+    mg = qa.Multigrid(mp)
+    try:
+        i = mg.level_info(0)
+        Xf, bs = i["Xf"], i["geo_bs"]
+        nfb = mg.ortho_fallback_blocks(0)
+        assert (nfb > 0) == expect_fallback, nfb
+        if eps == "mixed":
+            assert nfb < 2 * int(np.prod(i["Xc"])), nfb     # only the ill-conditioned blocks
+        Vd = mg.V(0).astype(np.complex128)
+        # per (aggregate, chirality) Gram matrix of the device's V
+        c = np.indices(X[::-1]).reshape(4, -1)[::-1]                       # x, y, z, t of lexicographic sites
+        lex = ((c[3] * X[2] + c[2]) * X[1] + c[1]) * X[0] + c[0]
+        par = (c[0] + c[1] + c[2] + c[3]) & 1
+        eo = par * (V4 // 2) + lex // 2
+        agg = (((c[3] // bs[3]) * (X[2] // bs[2]) + c[2] // bs[2]) * (X[1] // bs[1]) + c[1] // bs[1]) * (X[0] // bs[0]) + c[0] // bs[0]
+        worst = 0.0
+        for a in range(int(agg.max()) + 1):
+            sites = eo[agg == a]
+            for chi in range(2):
+                M = Vd[sites][:, 2 * chi:2 * chi + 2].reshape(-1, nvec)
+                worst = max(worst, float(np.max(np.abs(M.conj().T @ M - np.eye(nvec)))))
+        bound = 5e-4 if expect_fallback else 1e-5     # modified Gram-Schmidt in fp32 loses eps x cond; CholeskyQR2 ends at round-off
+        print("block orthonormalisation eps=%s: %d blocks to Gram-Schmidt, max |V^dag V - 1| = %.2e" % (eps, nfb, worst))
+        assert worst < bound, worst
+        dev = mg.verify()
+        assert dev[0] < (2e-3 if expect_fallback else 1e-4) and dev[1] < bound * 10, dev
+        Bd = np.stack([mg.null_vector(0, k) for k in range(nvec)], axis=-1)
+        Vo = oracle.mg_block_orthogonalize(Bd, Xf, bs, 4, 3, nvec, 2)
+        cond = 1.0 / (1e-3 if expect_fallback else 3e-2)
+        assert float(np.max(np.abs(Vd - Vo)) / np.max(np.abs(Vo))) < 2e-6 * cond * 10
+    finally:
+        mg.free()
