@@ -25,9 +25,12 @@ constexpr int kMaxBlockRhs = 32;
 struct BlockField {
   float2 *v = nullptr;
   int nSites = 0, Vh = 0, ncomp = 0, nrhs = 0;
+  // grid-decomposed lattices: nGhost further panels behind the nSites local ones, the faces of the neighbour ranks (BlockGhost below);
+  // BLAS and pack / unpack never touch them
+  int nGhost = 0;
   size_t bytes = 0;
   BlockField() {}
-  BlockField(int nSites, int ncomp, int nrhs);
+  BlockField(int nSites, int ncomp, int nrhs, int nGhost = 0);
   BlockField(const BlockField &) = delete;
   BlockField &operator=(const BlockField &) = delete;
   ~BlockField();
@@ -39,14 +42,36 @@ struct BlockField {
 void blockPack(BlockField &dst, const std::vector<ColorSpinorField *> &src, int parity = -1);
 void blockUnpack(const std::vector<ColorSpinorField *> &dst, const BlockField &src, int parity = -1);
 
-// out = M in for every right-hand side: X in + sum_d H_d in(x + dhat(d)) with the links read ONCE per site for all of them,
-// on v_mfma_f32_16x16x4_f32 (exact fp32).  Needs n = 2 Nc a multiple of 16, nrhs a multiple of 8 (<= 32), an unpartitioned
-// lattice and fp32 links; blockCoarseSupported() says whether a given operator / batch qualifies.
-bool blockCoarseSupported(const CoarseGauge &G, int nrhs);
-void applyCoarseBlock(BlockField &out, const BlockField &in, const CoarseGauge &G);
+// Ghost zone of a block field on a grid-decomposed lattice (reference: the ghost of a multi-source coarse field is a full coarse
+// spinor per face site and source, lib/dslash_coarse.cu:68-137; here the same for the multi-right-hand-side fine stencil): per
+// partitioned dimension d two zones of faceSites[d] panels, [d][0] the x_d = L - 1 face of the -d neighbour (read by backward hops
+// from x_d = 0), [d][1] the x_d = 0 face of the +d neighbour (read by forward hops from x_d = L - 1), at panel index
+// nSites + offset[d][k] + face index.  Face index: full fields (coarse levels) the lexicographic index of the other three coordinates;
+// single-parity fields (fine level) that index halved, as the reference numbers its face sites.
+struct BlockGhost {
+  int X[4] = {0, 0, 0, 0};     // local lattice (full extents)
+  bool parityField = false;    // the field holds one parity of it (nSites = V / 2)
+  int mask = 0;                // bit d: dimension d is partitioned
+  int faceSites[4] = {0, 0, 0, 0};
+  int offset[4][2] = {};
+  int nGhost = 0;
+};
+BlockGhost blockGhost(const int X[4], bool parityField);
+// fills the ghost zone of f: one pack launch, one grouped exchange (commExchange: RCCL send / recv, or a copy where the process is its
+// own neighbour) on the compute stream.  parity: the parity f holds (parityField), else ignored.
+void blockExchangeGhost(BlockField &f, const BlockGhost &gh, int parity);
+void blockExchangeGhostRaw(const float2 *field, float2 *ghostZone, int ncomp, int nrhs, const BlockGhost &gh, int parity);
 
-// [site][9] table of the full indices (parity * Vh + x_cb) of a site's 8 neighbours (order of the link matrices: 2 mu forward,
-// 2 mu + 1 backward) and of the site itself; device memory, built once per coarse lattice
+// out = M in for every right-hand side: X in + sum_d H_d in(x + dhat(d)) with the links read ONCE per site for all of them,
+// on v_mfma_f32_16x16x4_f32 (exact fp32).  Needs n = 2 Nc a multiple of 16, nrhs a multiple of 8 (<= 32) and fp32 links;
+// blockCoarseSupported() says whether a given operator / batch qualifies.  On a grid-decomposed lattice `in` must carry the ghost zone
+// of blockGhost(G.Xc, false) (it is filled here); `in` is therefore not const.
+bool blockCoarseSupported(const CoarseGauge &G, int nrhs);
+void applyCoarseBlock(BlockField &out, BlockField &in, const CoarseGauge &G);
+
+// [site][9] table of the panel indices of a site's 8 neighbours (order of the link matrices: 2 mu forward, 2 mu + 1 backward) and of
+// the site itself: parity * Vh + x_cb, or — across a partitioned face — the ghost panel nSites + offset + face index; device memory,
+// built once per coarse lattice and partition mask
 const int *coarseNeighbourTable(const int Xc[4]);
 
 // per-right-hand-side BLAS on block fields (coefficients indexed by right-hand side)
@@ -69,7 +94,7 @@ void negate(BlockField &x);                                                     
 // Nvec BiCGstab solves of M x_i = 0 in lockstep (null-vector mode of the reference's BiCGstab, lib/inv_bicgstab_quda.cpp:96-127:
 // b = 0, x_i the initial guesses, b2_i := |M x_i|^2, shadow residual r0 = r), each stopping at |r_i|^2 <= tol^2 b2_i or maxiter.
 // Returns the number of iterations of the slowest right-hand side; iters[i] per right-hand side if not null.
-typedef void (*BlockMatVec)(BlockField &out, const BlockField &in, void *ctx);
+typedef void (*BlockMatVec)(BlockField &out, BlockField &in, void *ctx);   // `in` not const: its ghost zone is filled by the operator
 int blockBiCGstabNull(BlockField &x, BlockMatVec mat, void *ctx, double tol, int maxiter, int *iters);
 
 }  // namespace quda

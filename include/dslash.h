@@ -47,13 +47,17 @@ void applyShift(double *out, const double *in, const LatticeGeom &g, int stride,
 // out = (1 + i a g5) in - kappa D in for nrhs vectors per link load (fp32, recon 18, unpartitioned lattice)
 bool fineBlockSupported(const GaugeField &U, int nrhs);
 // tmat (twisted clover): per parity the dense site matrices A + i a g5 from cloverTwistDense(), which replace (1 + i a g5)
-void applyFineBlockM(float2 *out, const float2 *in, int nrhs, const GaugeField &U, double kappa, double a, const float *const tmat[2] = nullptr);
+// grid-decomposed lattice: `in` carries the ghost zones of its two halves behind the local panels (2 x blockGhost(X, true).nGhost) and is written there
+void applyFineBlockM(float2 *out, float2 *in, int nrhs, const GaugeField &U, double kappa, double a, const float *const tmat[2] = nullptr);
 // one parity of the generalised form: out = s0 (1 + i a0 g5) in_same + k1 (1 + i a1 g5) [8 hops of in_other], single-parity panels.
 // tmat != nullptr: dense site matrices [Vh][2 chiralities][6 x 6 complex] of the output parity in place of (1 + i a1 g5) on the hop
 // sum (tmode 1) or of (1 + i a0 g5) on in_same (tmode 2) — the twisted-clover operators (reference lib/dirac_twisted_clover.cpp:191-330)
 void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_other, int nrhs, const GaugeField &U, int parity, double s0, double a0, double k1,
-                          double a1, const float *tmat = nullptr, int tmode = 0);
+                          double a1, const float *tmat = nullptr, int tmode = 0, float2 *ghost = nullptr);
+// ghost: on a grid-decomposed lattice the ghost zone of in_other (blockGhost(X, true).nGhost panels, a whole number of panels away from
+// in_other); it is filled here (pack + grouped exchange) before the launch
 // out[site][chirality][6][6] complex fp32 = A + i a s (s = +-1 for the upper / lower chirality) of one parity, or its inverse
+int haloWireFormat();
 void cloverTwistDense(float *out, const CloverField &C, int parity, double a, bool inverse);
 
 // site-local kernels
@@ -76,9 +80,12 @@ struct DslashTune {
   int nxz = 0, tz = 0, tt = 0;   // plane-tiled order: XCDs along z, tile extents in z and t (0: automatic)
   int lds_pad = 0;     // dynamic LDS per block, only to cap the blocks per CU (measurement aid)
   int ygroups = -1;    // plane-tiled order: groups of plane chunks walked one after the other (0 / 1 none, -1 automatic: fp64 fields whose three-slice set per XCD exceeds the L2, n explicit)
-  // peer-store halo launch: face packing folded into the site threads (-1: environment QUDA_AMD_P2P_FOLD, default on), start delay of
+  // peer-store halo launch: face packing folded into the site threads (-1: environment QUDA_AMD_P2P_FOLD, default OFF; the path is compiled out unless dslash.hip is built with -DQA_P2P_FOLD=1: it measured slower than pack blocks), start delay of
   // the site blocks and raised issue priority of the pack waves (measurement aids)
   int p2p_fold = -1, site_delay = 0, pack_prio = 0;
+  // wire format of the peer-store ghost zones: 0 flag-in-data 16-byte vectors (default), 1 32-byte sectors = one 128-byte line per fp64
+  // face site (QUDA_AMD_HALO_FORMAT=sector); must be the same on every rank
+  int halo_format = 0;
   int edge_first = 1;  // peer-store launch, plane-tiled order: every XCD starts with its boundary planes
 };
 DslashTune &dslashTune();

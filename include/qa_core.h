@@ -94,8 +94,11 @@ CommGrid &commGrid();
 // Blocks return to the cache on free and are handed out again to the next request of the same size — safe because every user
 // works in compute-stream order.  Emptied by endQuda.
 void *poolDeviceMalloc(size_t bytes);
+// hipMalloc that hands the parked pool buffers back and tries once more when the device is out of memory
+hipError_t qaMallocRaw(void **p, size_t bytes);
+template <typename T> inline hipError_t qaMalloc(T **p, size_t bytes) { return qaMallocRaw((void **)p, bytes); }
 void poolDeviceFree(void *ptr, size_t bytes);
-void poolDeviceFlush();
+void poolDeviceFlush(size_t atLeast = 0);   // returns the parked buffers of at least that many bytes to the runtime (0: all)
 
 void setLastKernel(const char *kernel, const int X[4], int prec, int recon, int block);
 

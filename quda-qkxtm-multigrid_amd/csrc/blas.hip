@@ -133,8 +133,8 @@ static bool reduceWindowActive() {
   std::vector<double *> hs(g.size);
   std::vector<unsigned *> hc(g.size);
   for (int r = 0; r < g.size; r++) { hs[r] = (double *)byRank[r]; hc[r] = (unsigned *)((char *)byRank[r] + slotBytes); }
-  HIP_CHECK(hipMalloc((void **)&g_rw.d_slots, g.size * sizeof(double *)));
-  HIP_CHECK(hipMalloc((void **)&g_rw.d_counts, g.size * sizeof(unsigned *)));
+  HIP_CHECK(qaMalloc((void **)&g_rw.d_slots, g.size * sizeof(double *)));
+  HIP_CHECK(qaMalloc((void **)&g_rw.d_counts, g.size * sizeof(unsigned *)));
   HIP_CHECK(hipMemcpy(g_rw.d_slots, hs.data(), g.size * sizeof(double *), hipMemcpyHostToDevice));
   HIP_CHECK(hipMemcpy(g_rw.d_counts, hc.data(), g.size * sizeof(unsigned *), hipMemcpyHostToDevice));
   HIP_CHECK(hipDeviceSynchronize());
@@ -142,7 +142,7 @@ static bool reduceWindowActive() {
   // probe: three all-reduces of known values with the production kernel code; any rank that sees a wrong sum or a
   // timeout vetoes, and then every rank drops back to the RCCL all-reduce
   int *d_res = nullptr;
-  HIP_CHECK(hipMalloc((void **)&d_res, sizeof(int)));
+  HIP_CHECK(qaMalloc((void **)&d_res, sizeof(int)));
   double fail = 0;
   for (int round = 0; round < 3; round++) {
     const int buf = (int)(++g_rw.seq & 1);
@@ -195,14 +195,14 @@ static void finishAllreduceOnHost(int buf, unsigned expect, int nred, double *ou
 static bool g_global_reduction = true;
 
 void init() {
-  if (!d_red) HIP_CHECK(hipMalloc((void **)&d_red, kMaxRed * sizeof(double)));
+  if (!d_red) HIP_CHECK(qaMalloc((void **)&d_red, kMaxRed * sizeof(double)));
   if (!h_red) {
     HIP_CHECK(hipHostMalloc((void **)&h_red, kMaxRed * sizeof(double), hipHostMallocMapped));
     HIP_CHECK(hipHostGetDevicePointer((void **)&h_red_dev, h_red, 0));
   }
-  if (!d_part) HIP_CHECK(hipMalloc((void **)&d_part, (size_t)kMaxBlocks * 4 * sizeof(double)));
+  if (!d_part) HIP_CHECK(qaMalloc((void **)&d_part, (size_t)kMaxBlocks * 4 * sizeof(double)));
   if (!d_count) {
-    HIP_CHECK(hipMalloc((void **)&d_count, sizeof(unsigned)));
+    HIP_CHECK(qaMalloc((void **)&d_count, sizeof(unsigned)));
     HIP_CHECK(hipMemset(d_count, 0, sizeof(unsigned)));
     HIP_CHECK(hipDeviceSynchronize());
   }

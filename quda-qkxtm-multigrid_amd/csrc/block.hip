@@ -29,13 +29,17 @@
 #include <cmath>
 #include <cstring>
 
+#include <algorithm>
+
 #include "blas.h"
+#include "halo.h"
+#include "p2p.h"
 
 namespace quda {
 
-BlockField::BlockField(int nSites_, int ncomp_, int nrhs_) : nSites(nSites_), Vh(nSites_ / 2), ncomp(ncomp_), nrhs(nrhs_) {
+BlockField::BlockField(int nSites_, int ncomp_, int nrhs_, int nGhost_) : nSites(nSites_), Vh(nSites_ / 2), ncomp(ncomp_), nrhs(nrhs_), nGhost(nGhost_) {
   if (nrhs < 1 || nrhs > kMaxBlockRhs) errorQuda("block field with %d right-hand sides (1..%d supported)", nrhs, kMaxBlockRhs);
-  bytes = elems() * sizeof(float2);
+  bytes = (elems() + (size_t)nGhost * ncomp * nrhs) * sizeof(float2);
   // From the size-bucketed pool (qa_core.h): the solver's six work fields have the same size in every batch of right-hand sides and
   // in every hierarchy (up / down flavour), so they are allocated once per process.  Allocating and releasing them per batch was
   // measured at 48^3 x 96: 5 of the 8 s of the null-vector stage went into hipMalloc / hipFree of ~150 GB (the runtime unmaps
@@ -93,6 +97,100 @@ void blockUnpack(const std::vector<ColorSpinorField *> &dst, const BlockField &s
 }
 
 // ================================================================================================
+// ghost zone of a block field (block.h BlockGhost)
+// ================================================================================================
+BlockGhost blockGhost(const int X[4], bool parityField) {
+  BlockGhost g;
+  long V = 1;
+  for (int d = 0; d < 4; d++) { g.X[d] = X[d]; V *= X[d]; }
+  g.parityField = parityField;
+  const long n = parityField ? V / 2 : V;
+  for (int d = 0; d < 4; d++) {
+    g.faceSites[d] = (int)(n / X[d]);
+    if (!commGrid().partitioned(d)) continue;
+    g.mask |= 1 << d;
+    for (int k = 0; k < 2; k++) { g.offset[d][k] = g.nGhost; g.nGhost += g.faceSites[d]; }
+  }
+  return g;
+}
+
+// panel index (inside the local field) of face site fs of the face x_d = c; full field: fs = lexicographic index of the other three
+// coordinates; parity field: fs = that index halved, among the sites of parity q
+__device__ __forceinline__ int face_site_to_panel(int fs, int d, int c, const int *X, bool parityField, int q) {
+  int o[3], L[3], k = 0;
+  for (int e = 0; e < 4; e++) if (e != d) { L[k] = X[e]; o[k] = e; k++; }
+  int lex = parityField ? 2 * fs : fs;
+  int cc[4];
+  cc[d] = c;
+  const int c0 = lex % L[0]; lex /= L[0];
+  const int c1 = lex % L[1]; const int c2 = lex / L[1];
+  cc[o[0]] = c0; cc[o[1]] = c1; cc[o[2]] = c2;
+  if (parityField) cc[o[0]] += (q + cc[0] + cc[1] + cc[2] + cc[3]) & 1;   // the fastest face coordinate carries the parity bit
+  const int par = (cc[0] + cc[1] + cc[2] + cc[3]) & 1;
+  const int cb = (((cc[3] * X[2] + cc[2]) * X[1] + cc[1]) * X[0] + cc[0]) >> 1;
+  const int Vh = (X[0] * X[1] * X[2] * X[3]) >> 1;
+  return parityField ? cb : par * Vh + cb;
+}
+struct BlockFaceArg {
+  const float4 *in; float4 *send[8];   // [2 d + k]: k = 0 the x_d = 0 face (goes backward), k = 1 the x_d = L - 1 face (goes forward)
+  long start[9];                       // first float4 of every message in the launch's flat index
+  int X[4], faceSites[4], parityField, parity, panel4;
+};
+__global__ void __launch_bounds__(256) block_face_pack_kernel(const BlockFaceArg arg) {
+  const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (t >= arg.start[8]) return;
+  int m = 0;
+  while (m < 7 && t >= arg.start[m + 1]) m++;
+  const long r = t - arg.start[m];
+  const int fs = (int)(r / arg.panel4), w = (int)(r - (long)fs * arg.panel4);
+  const int d = m >> 1, c = (m & 1) ? arg.X[d] - 1 : 0;
+  const int site = face_site_to_panel(fs, d, c, arg.X, arg.parityField != 0, arg.parity);
+  arg.send[m][(size_t)fs * arg.panel4 + w] = arg.in[(size_t)site * arg.panel4 + w];
+}
+static float4 *g_blockSend = nullptr;
+static size_t g_blockSendBytes = 0;
+void blockExchangeGhost(BlockField &f, const BlockGhost &gh, int parity) {
+  if (!gh.mask) return;
+  if (f.nGhost < gh.nGhost) errorQuda("block field without room for its ghost zone (%d panels, %d needed)", f.nGhost, gh.nGhost);
+  blockExchangeGhostRaw(f.v, f.v + (size_t)f.nSites * f.ncomp * f.nrhs, f.ncomp, f.nrhs, gh, parity);
+}
+void blockExchangeGhostRaw(const float2 *field, float2 *ghostZone, int ncomp, int nrhs, const BlockGhost &gh, int parity) {
+  if (!gh.mask) return;
+  if ((ncomp * nrhs) % 2) errorQuda("block panels of %d x %d complex numbers are not a whole number of 16-byte words", ncomp, nrhs);
+  const int panel4 = ncomp * nrhs / 2;
+  size_t need = 0;
+  for (int d = 0; d < 4; d++) if ((gh.mask >> d) & 1) need += 2 * (size_t)gh.faceSites[d] * panel4 * sizeof(float4);
+  if (need > g_blockSendBytes) {
+    if (g_blockSend) poolDeviceFree(g_blockSend, g_blockSendBytes);
+    g_blockSend = (float4 *)poolDeviceMalloc(need);
+    g_blockSendBytes = need;
+  }
+  BlockFaceArg a;
+  a.in = (const float4 *)field; a.parityField = gh.parityField ? 1 : 0; a.parity = parity; a.panel4 = panel4;
+  std::vector<HaloMsg> msgs;
+  long nt = 0;
+  float4 *sp = g_blockSend;
+  float4 *ghost0 = (float4 *)ghostZone;
+  for (int d = 0; d < 4; d++) {
+    a.X[d] = gh.X[d]; a.faceSites[d] = gh.faceSites[d];
+    for (int k = 0; k < 2; k++) {
+      a.start[2 * d + k] = nt; a.send[2 * d + k] = sp;
+      if (!((gh.mask >> d) & 1)) continue;
+      const long n4 = (long)gh.faceSites[d] * panel4;
+      // my x_d = 0 face travels backward and lands in the -d neighbour's zone [d][1] ("from ahead"); what arrives from my +d neighbour
+      // in the same message slot is ITS x_d = 0 face -> my zone [d][1].  Likewise forward / zone [d][0].
+      msgs.push_back({d, k ? +1 : -1, sp, ghost0 + (size_t)gh.offset[d][k ? 0 : 1] * panel4, (size_t)n4 * sizeof(float4)});
+      nt += n4; sp += n4;
+    }
+  }
+  a.start[8] = nt;
+  hipLaunchKernelGGL(block_face_pack_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, computeStream(), a);
+  HIP_CHECK(hipGetLastError());
+  commExchange(msgs, computeStream());
+  p2pStats()[7]++;
+}
+
+// ================================================================================================
 // coarse operator on v_mfma_f32_16x16x4_f32
 // ================================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -138,7 +236,8 @@ template <int N, int NRHS, int NT> __device__ __forceinline__ void load_bfrag(fl
 // index table of the 9 input panels of every site (8 neighbours in the order of the link matrices, then the site itself): read
 // by the MFMA kernel with SCALAR loads — its waves must not spend vector registers, vector memory requests or barriers on the
 // lattice arithmetic (see the request ring below).  Built once per coarse lattice.
-__global__ void neighbour_table_kernel(int *tab, int X0, int X1, int X2, int X3, int Vh) {
+struct NbrGhost { int mask, faceSites[4], offset[4][2]; };
+__global__ void neighbour_table_kernel(int *tab, int X0, int X1, int X2, int X3, int Vh, NbrGhost gh) {
   const int t9 = blockIdx.x * blockDim.x + threadIdx.x;
   if (t9 >= 2 * Vh * 9) return;
   const int A = t9 / 9, m = t9 - 9 * A;
@@ -152,24 +251,42 @@ __global__ void neighbour_table_kernel(int *tab, int X0, int X1, int X2, int X3,
   const int L[4] = {X0, X1, X2, X3};
   if (m < 8) {
     const int mu = m >> 1;
+    const bool off = (m & 1) ? cn[mu] == 0 : cn[mu] == L[mu] - 1;
+    if (off && ((gh.mask >> mu) & 1)) {
+      // across a partitioned face: the ghost panel of the neighbour rank's face site with the same other three coordinates
+      int lex = 0, mul = 1;
+      for (int e = 0; e < 4; e++) if (e != mu) { lex += cn[e] * mul; mul *= L[e]; }
+      tab[t9] = 2 * Vh + gh.offset[mu][(m & 1) ? 0 : 1] + lex;
+      return;
+    }
     cn[mu] = (m & 1) ? (cn[mu] == 0 ? L[mu] - 1 : cn[mu] - 1) : (cn[mu] == L[mu] - 1 ? 0 : cn[mu] + 1);
   }
   const int npar = (cn[0] + cn[1] + cn[2] + cn[3]) & 1;
   tab[t9] = npar * Vh + ((((cn[3] * X2 + cn[2]) * X1 + cn[1]) * X0 + cn[0]) >> 1);
 }
-struct NbrTable { int Xc[4]; int *d; };
+struct NbrTable { int Xc[4]; int mask; int *d; };
 static std::vector<NbrTable> g_nbrTables;
 const int *coarseNeighbourTable(const int Xc[4]) {
-  for (const NbrTable &t : g_nbrTables) if (t.Xc[0] == Xc[0] && t.Xc[1] == Xc[1] && t.Xc[2] == Xc[2] && t.Xc[3] == Xc[3]) return t.d;
+  const BlockGhost bg = blockGhost(Xc, false);
+  for (const NbrTable &t : g_nbrTables) if (t.Xc[0] == Xc[0] && t.Xc[1] == Xc[1] && t.Xc[2] == Xc[2] && t.Xc[3] == Xc[3] && t.mask == bg.mask) return t.d;
   NbrTable t;
   for (int d = 0; d < 4; d++) t.Xc[d] = Xc[d];
+  t.mask = bg.mask;
+  NbrGhost gh;
+  gh.mask = bg.mask;
+  for (int d = 0; d < 4; d++) { gh.faceSites[d] = bg.faceSites[d]; gh.offset[d][0] = bg.offset[d][0]; gh.offset[d][1] = bg.offset[d][1]; }
   const int nSites = Xc[0] * Xc[1] * Xc[2] * Xc[3];
-  HIP_CHECK(hipMalloc((void **)&t.d, (size_t)(nSites + 1) * 9 * sizeof(int)));   // + one row: the table is read one site ahead
+  HIP_CHECK(qaMalloc((void **)&t.d, (size_t)(nSites + 1) * 9 * sizeof(int)));   // + one row: the table is read one site ahead
   HIP_CHECK(hipMemsetAsync(t.d, 0, (size_t)(nSites + 1) * 9 * sizeof(int), computeStream()));
-  hipLaunchKernelGGL(neighbour_table_kernel, dim3((nSites * 9 + 255) / 256), dim3(256), 0, computeStream(), t.d, Xc[0], Xc[1], Xc[2], Xc[3], nSites / 2);
+  hipLaunchKernelGGL(neighbour_table_kernel, dim3((nSites * 9 + 255) / 256), dim3(256), 0, computeStream(), t.d, Xc[0], Xc[1], Xc[2], Xc[3], nSites / 2, gh);
   HIP_CHECK(hipGetLastError());
   g_nbrTables.push_back(t);
   return t.d;
+}
+void freeBlockTables() {   // endQuda
+  for (NbrTable &t : g_nbrTables) (void)hipFree(t.d);
+  g_nbrTables.clear();
+  if (g_blockSend) { poolDeviceFree(g_blockSend, g_blockSendBytes); g_blockSend = nullptr; g_blockSendBytes = 0; }
 }
 
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
@@ -340,16 +457,19 @@ template <int N, int NRHS> static void launchCoarseBlock(const BlockCoarseArg &a
 bool blockCoarseSupported(const CoarseGauge &G, int nrhs) {
   if (G.n != 16 && G.n != 32 && G.n != 48 && G.n != 64) return false;
   if (nrhs != 8 && nrhs != 16 && nrhs != 24 && nrhs != 32) return false;
-  for (int d = 0; d < 4; d++) if (commGrid().partitioned(d)) return false;
   static int off = -1;
   if (off < 0) { const char *e = getenv("QUDA_AMD_BLOCK_COARSE"); off = (e && !atoi(e)) ? 1 : 0; }
   return !off;
 }
 
-void applyCoarseBlock(BlockField &out, const BlockField &in, const CoarseGauge &G) {
+void applyCoarseBlock(BlockField &out, BlockField &in, const CoarseGauge &G) {
   if (!blockCoarseSupported(G, in.nrhs)) errorQuda("block coarse operator: n = %d, nrhs = %d not supported", G.n, in.nrhs);
   if (in.ncomp != G.n || out.ncomp != G.n || in.nSites != G.nSites || out.nSites != G.nSites || in.nrhs != out.nrhs) errorQuda("block fields do not match the coarse operator");
   if (in.v == out.v) errorQuda("in and out must not alias");
+  // grid-decomposed lattice: the neighbour ranks' face panels (full coarse vectors for every right-hand side, reference
+  // lib/dslash_coarse.cu:68-137) behind the local ones; the kernel reaches them through the neighbour table like any other panel
+  const BlockGhost gh = blockGhost(G.Xc, false);
+  blockExchangeGhost(in, gh, 0);
   BlockCoarseArg arg;
   arg.out = out.v; arg.in = in.v; arg.G = G.data; arg.Vh = G.nSites / 2;
   if (in.bytes >= ((size_t)1 << 32)) errorQuda("block field of %zu bytes exceeds the 4 GiB a buffer descriptor addresses", in.bytes);
@@ -387,7 +507,7 @@ static double *h_res_dev = nullptr;
 
 static void ensureBuffers() {
   if (d_part) return;
-  HIP_CHECK(hipMalloc((void **)&d_part, (size_t)kMaxBlocks * 3 * kMaxBlockRhs * sizeof(double)));
+  HIP_CHECK(qaMalloc((void **)&d_part, (size_t)kMaxBlocks * 3 * kMaxBlockRhs * sizeof(double)));
   HIP_CHECK(hipHostMalloc((void **)&h_res, 3 * kMaxBlockRhs * sizeof(double), hipHostMallocMapped));
   HIP_CHECK(hipHostGetDevicePointer((void **)&h_res_dev, h_res, 0));
 }
@@ -501,14 +621,17 @@ template <int OP, int NSUM> static void run(BArg &arg, const BlockField &shape) 
   if (NSUM > 0) {
     hipLaunchKernelGGL(block_blas_finish, dim3(NSUM * shape.nrhs), dim3(64), 0, computeStream(), (const double *)d_part, h_res_dev, nb, NSUM * shape.nrhs);
     HIP_CHECK(hipStreamSynchronize(computeStream()));
+    // grid-decomposed lattice: the per-right-hand-side sums are global sums (reference: every reduction of a solver ends in an
+    // all-reduce, lib/reduce_quda.cu); the host collective takes 64 doubles at a time
+    if (commReductionsNeeded()) for (int o = 0; o < NSUM * shape.nrhs; o += 64) comm_allreduce(h_res + o, std::min(64, NSUM * shape.nrhs - o));
   }
   HIP_CHECK(hipGetLastError());
 }
 
-void zero(BlockField &x) { HIP_CHECK(hipMemsetAsync(x.v, 0, x.bytes, computeStream())); }
+void zero(BlockField &x) { HIP_CHECK(hipMemsetAsync(x.v, 0, x.elems() * sizeof(float2), computeStream())); }
 void copy(BlockField &dst, const BlockField &src) {
   check(dst, src);
-  HIP_CHECK(hipMemcpyAsync(dst.v, src.v, src.bytes, hipMemcpyDeviceToDevice, computeStream()));
+  HIP_CHECK(hipMemcpyAsync(dst.v, src.v, src.elems() * sizeof(float2), hipMemcpyDeviceToDevice, computeStream()));
 }
 void norm2(double *out, const BlockField &x) {
   BArg a = {};
@@ -569,7 +692,8 @@ void negate(BlockField &x) {
 // ================================================================================================
 int blockBiCGstabNull(BlockField &x, BlockMatVec mat, void *ctx, double tol, int maxiter, int *iters) {
   const int n = x.nrhs;
-  BlockField r(x.nSites, x.ncomp, n), p(x.nSites, x.ncomp, n), v(x.nSites, x.ncomp, n), t(x.nSites, x.ncomp, n), r0(x.nSites, x.ncomp, n);
+  // p and r are operator inputs: they carry the ghost zone of x
+  BlockField r(x.nSites, x.ncomp, n, x.nGhost), p(x.nSites, x.ncomp, n, x.nGhost), v(x.nSites, x.ncomp, n), t(x.nSites, x.ncomp, n), r0(x.nSites, x.ncomp, n);
   double b2[kMaxBlockRhs], r2[kMaxBlockRhs], stop[kMaxBlockRhs], tn[kMaxBlockRhs];
   Complex rho[kMaxBlockRhs], rho0[kMaxBlockRhs], alpha[kMaxBlockRhs], omega[kMaxBlockRhs], beta[kMaxBlockRhs], r0v[kMaxBlockRhs], tr[kMaxBlockRhs], ca[kMaxBlockRhs], cb[kMaxBlockRhs];
   bool done[kMaxBlockRhs];

@@ -18,7 +18,7 @@ CoarseGauge::CoarseGauge(const int xc[4], int n_) : n(n_), data(nullptr), data_h
   nSites = 1;
   for (int d = 0; d < 4; d++) { Xc[d] = xc[d]; nSites *= xc[d]; }
   bytes = (size_t)nSites * 9 * n * n * 2 * sizeof(float);
-  HIP_CHECK(hipMalloc((void **)&data, bytes));
+  HIP_CHECK(qaMalloc((void **)&data, bytes));
   HIP_CHECK(hipMemsetAsync(data, 0, bytes, computeStream()));
 }
 CoarseGauge::~CoarseGauge() { if (data) (void)hipFree(data); if (data_h) (void)hipFree(data_h); }
@@ -35,7 +35,7 @@ __global__ void to_half_kernel(half4_t *out, const float4 *in, size_t n) {
 void CoarseGauge::makeHalf() const {
   if (data_h) return;
   const size_t n4 = bytes / sizeof(float4);
-  HIP_CHECK(hipMalloc(&data_h, n4 * sizeof(half4_t)));
+  HIP_CHECK(qaMalloc(&data_h, n4 * sizeof(half4_t)));
   hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, computeStream(), (half4_t *)data_h, (const float4 *)data, n4);
   HIP_CHECK(hipGetLastError());
 }
@@ -214,7 +214,7 @@ static CoarseGhost &coarseGhost(const int Xc[4], int n) {
   size_t total = 0;
   const int Vh = Xc[0] * Xc[1] * Xc[2] * Xc[3] / 2;
   for (int d = 0; d < 4; d++) { c.Xc[d] = Xc[d]; c.faceCB[d] = Vh / Xc[d]; total += (size_t)4 * 2 * n * c.faceCB[d]; }
-  HIP_CHECK(hipMalloc((void **)&c.pool, total * sizeof(float2)));
+  HIP_CHECK(qaMalloc((void **)&c.pool, total * sizeof(float2)));
   HIP_CHECK(hipMemsetAsync(c.pool, 0, total * sizeof(float2), computeStream()));
   float2 *p = c.pool;
   for (int d = 0; d < 4; d++)
@@ -700,7 +700,7 @@ const CoarseGauge &DiracCoarse::HatLinks() const {
   hat = new CoarseGauge(links->Xc, n);
   ownHat = true;
   int *d_fail = nullptr, h_fail = 0;
-  HIP_CHECK(hipMalloc((void **)&d_fail, sizeof(int)));
+  HIP_CHECK(qaMalloc((void **)&d_fail, sizeof(int)));
   HIP_CHECK(hipMemsetAsync(d_fail, 0, sizeof(int), computeStream()));
   HIP_CHECK(hipFuncSetAttribute((const void *)coarse_invert_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
   HIP_CHECK(hipFuncSetAttribute((const void *)coarse_hat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));

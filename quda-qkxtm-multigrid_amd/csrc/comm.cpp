@@ -124,7 +124,7 @@ void commFinalize() {
 static double *d_scratch = nullptr;
 static double *h_scratch = nullptr;
 static void ensureScratch() {
-  if (!d_scratch) HIP_CHECK(hipMalloc((void **)&d_scratch, 64 * sizeof(double)));
+  if (!d_scratch) HIP_CHECK(qaMalloc((void **)&d_scratch, 64 * sizeof(double)));
   if (!h_scratch) HIP_CHECK(hipHostMalloc((void **)&h_scratch, 64 * sizeof(double), hipHostMallocDefault));
 }
 
@@ -187,7 +187,7 @@ void commAllgatherBytes(const void *mine, void *all, size_t n) {
     return;
   }
   char *d = nullptr;
-  HIP_CHECK(hipMalloc((void **)&d, n * (g.size + 1)));
+  HIP_CHECK(qaMalloc((void **)&d, n * (g.size + 1)));
   hipStream_t s = computeStream();
   HIP_CHECK(hipMemcpyAsync(d, mine, n, hipMemcpyHostToDevice, s));
   NCCL_CHECK(ncclAllGather(d, d + n, n, ncclChar, g_nccl, s));

@@ -28,6 +28,7 @@
 #include "blas.h"
 #include "device_io.h"
 #include "halo.h"
+#include "block.h"
 
 namespace quda {
 
@@ -46,6 +47,7 @@ template <typename real> struct PackArg {
   int start[9];     // prefix offsets of the 8 (dim, dir) thread ranges
   // peer-store transport: send[][] point into the NEIGHBOURS' ghost zones; the last block to finish raises the flags there
   unsigned llFlag[4];      // flag-in-data value of this exchange per dimension (use count of the (dimension, buffer) zone)
+  int llFormat;            // wire format of the peer-store ghost zones: 0 flag-in-data 16-byte vectors (GhostLL), 1 32-byte sectors (GhostSector)
   unsigned long long *timeline;
 };
 
@@ -226,11 +228,13 @@ template <typename real> __device__ __forceinline__ void twist_inplace(real *p, 
 #define QA_LL_STORE_AUX 17   // sc0 sc1: system scope, write-through
 #endif
 #ifndef QA_P2P_FOLD
-#define QA_P2P_FOLD 1   // face packing inside the site threads compiled in (stencil_site); used with QUDA_AMD_P2P_FOLD=1 / "p2p_fold", measured slower than pack blocks
+#define QA_P2P_FOLD 0   // 1 compiles the folded face packing (inside the site threads, stencil_site) into the peer-store kernels; it then runs with
+                        // QUDA_AMD_P2P_FOLD=1 / tune key "p2p_fold".  Measured slower than pack blocks in round 2 (27.3 against 24.0 us), so it is
+                        // compiled OUT by default: the kernels lose a ballot, a branch and the registers of a second basic-block structure
 #endif
 template <typename T> struct GhostLL;
 template <> struct GhostLL<double> {
-  static constexpr int NV = 12;
+  static constexpr int NV = 12, NS = 4;
   static __device__ __forceinline__ void encode(unsigned *w, const double *h) {
 #pragma unroll
     for (int k = 0; k < 12; k++) { const unsigned long long b = __builtin_bit_cast(unsigned long long, h[k]); w[2 * k] = (unsigned)b; w[2 * k + 1] = (unsigned)(b >> 32); }
@@ -241,7 +245,7 @@ template <> struct GhostLL<double> {
   }
 };
 template <> struct GhostLL<float> {
-  static constexpr int NV = 6;
+  static constexpr int NV = 6, NS = 2;
   static __device__ __forceinline__ void encode(unsigned *w, const float *h) {
 #pragma unroll
     for (int k = 0; k < 12; k++) w[k] = __builtin_bit_cast(unsigned, h[k]);
@@ -252,7 +256,7 @@ template <> struct GhostLL<float> {
   }
 };
 template <> struct GhostLL<short> {   // 12 int16 + the fp32 scale of the site (same quantisation as Planar<short>::store)
-  static constexpr int NV = 4;
+  static constexpr int NV = 4, NS = 1;
   static __device__ __forceinline__ void encode(unsigned *w, const float *h) {
     float m = 0.f;
 #pragma unroll
@@ -286,10 +290,62 @@ template <typename T, typename real> __device__ __forceinline__ void ghost_ll_st
   }
 }
 // receiver: poll the site's own vectors (system-scope loads) until every half carries this exchange's flag; bounded by `ticks`
+// ---- the 32-byte-sector wire format (selectable next to flag-in-data: QUDA_AMD_HALO_FORMAT=sector, tune key "halo_format") ----
+// The flag-in-data vectors spend half of every byte on the wire on flags (786 KB per fp64 face of the 8-GPU split of 32^3 x 64, two
+// such faces sharing one xGMI link where a dimension has only two ranks).  Here a face site travels as NS sectors of 32 bytes =
+// 24 bytes of payload + the exchange's flag in the last 8 (16-bit storage: 24 + the 4-byte scale + a 4-byte flag) — fp64 4 sectors =
+// ONE 128-byte line per site (96 B payload + 4 x 8 B flags: the line of the collective libraries' 128-byte protocol, with its spare 32
+// bytes spent on a flag per sector instead of one per line), fp32 half a line, 16-bit a quarter: 128 / 64 / 32 bytes per site against
+// 192 / 96 / 64.  Plane-major [sector][faceCB].  What it assumes, and the 16-byte format does not: that a 32-byte sector written by ONE
+// store instruction (two adjacent lanes, 16 bytes each — the pack block transposes its sites through LDS for that, pack_body_sector)
+// becomes visible as a whole, i.e. that the flag in its second half never overtakes its first half.  True on every path of this
+// device a 1-GPU box can exercise; across xGMI it is what the first multi-GPU run has to show (the start-up probe and the first-use
+// comparison with the staged transport run in the selected format), which is why flag-in-data stays the default.
+template <typename T> __device__ __forceinline__ __amdgpu_buffer_rsrc_t ghost_sector_rsrc(const void *base, int faceCB) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)((unsigned)faceCB * (unsigned)(GhostLL<T>::NS * 32)), 0x00020000);
+}
+template <typename T> __device__ __forceinline__ bool ghost_sector_read(unsigned *w, const __amdgpu_buffer_rsrc_t &rs, int faceCB, int f, unsigned flag, unsigned &sy, unsigned &sw, int &sv) {
+  constexpr int NS = GhostLL<T>::NS;
+  bool ok = true;
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    const u32x4_t q0 = __builtin_amdgcn_raw_buffer_load_b128(rs, f * 32, s * faceCB * 32, 17);
+    const u32x4_t q1 = __builtin_amdgcn_raw_buffer_load_b128(rs, f * 32 + 16, s * faceCB * 32, 17);
+    bool good;
+    if (sizeof(T) == 2) {
+      w[0] = q0.x; w[1] = q0.y; w[2] = q0.z; w[3] = q0.w; w[4] = q1.x; w[5] = q1.y; w[6] = q1.z; w[7] = 0u;
+      good = q1.w == flag;
+    } else {
+      w[6 * s] = q0.x; w[6 * s + 1] = q0.y; w[6 * s + 2] = q0.z; w[6 * s + 3] = q0.w; w[6 * s + 4] = q1.x; w[6 * s + 5] = q1.y;
+      good = q1.z == flag && q1.w == flag;
+    }
+    if (!good && ok) { sy = sizeof(T) == 2 ? q1.w : q1.z; sw = q1.w; sv = s; }
+    ok = ok && good;
+  }
+  return ok;
+}
 template <typename T, typename real>
-__device__ __forceinline__ void ghost_ll_load(real *h, const void *zone, int faceCB, int f, unsigned flag, unsigned long long ticks, int *errWord, int code, unsigned exSeq, int exBuf) {
+__device__ __forceinline__ void ghost_ll_load(real *h, const void *zone, int faceCB, int f, unsigned flag, unsigned long long ticks, int *errWord, int code, unsigned exSeq, int exBuf,
+                                              int fmt) {
   constexpr int NV = GhostLL<T>::NV;
   unsigned w[2 * NV];
+  if (fmt) {
+    const __amdgpu_buffer_rsrc_t rs = ghost_sector_rsrc<T>(zone, faceCB);
+    unsigned long long t0 = 0;
+    for (;;) {
+      unsigned sy = flag, sw = flag; int sv = -1;
+      if (ghost_sector_read<T>(w, rs, faceCB, f, flag, sy, sw, sv)) break;
+      if (!t0) t0 = wall_clock64();
+      else if (__hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      else if (wall_clock64() - t0 > ticks) {
+        if (atomicCAS(errWord, 0, code) == 0) { errWord[1] = f; errWord[2] = (int)flag; errWord[3] = (int)sy; errWord[4] = (int)sw; errWord[5] = (int)exSeq; errWord[6] = exBuf; errWord[7] = sv; }
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    GhostLL<T>::decode(h, w);
+    return;
+  }
   const __amdgpu_buffer_rsrc_t rs = ghost_ll_rsrc<T>(zone, faceCB);
   unsigned long long t0 = 0;
   for (;;) {
@@ -396,7 +452,7 @@ __device__ __forceinline__ void ghost_hop(real *acc, const DslashArg<real> &arg,
   if (!off_node) return;
   real h[12], g[12], U[18];
   Link<T, R>::template load<GAUX>(U, arg.gauge + (size_t)DIR * arg.link_bytes, arg.g_stride, idx, sign);
-  ghost_ll_load<T>(h, arg.ghost[MU][(DIR & 1) ? 0 : 1], arg.faceCB[MU], face, arg.waitCount[DIR], arg.waitTicks, arg.errWord, 1 + DIR, arg.exSeq, arg.exBuf);
+  ghost_ll_load<T>(h, arg.ghost[MU][(DIR & 1) ? 0 : 1], arg.faceCB[MU], face, arg.waitCount[DIR], arg.waitTicks, arg.errWord, 1 + DIR, arg.exSeq, arg.exBuf, arg.pack.llFormat);
   const real s = (DIR & 1) ? -arg.sfwd : arg.sfwd;
   su3_mv(g, U, h);
   su3_mv(g + 6, U, h + 6);
@@ -580,6 +636,57 @@ template <typename T, bool PRETWIST, bool P2P, typename real> __device__ __force
   if (P2P && arg.timeline && threadIdx.x == 0) arg.timeline[1024 + bid] = wall_clock64();
 }
 
+// The pack block of the 32-byte-sector format (ghost_sector_read above): every thread builds the sectors of its face site in LDS —
+// [sector][site of the block][8 words] — and the block then copies them out with 16 bytes per lane, consecutive lanes on consecutive
+// addresses: lanes 2 i and 2 i + 1 of ONE store instruction write the two halves of one sector, and a wave instruction covers 32 whole
+// sectors of consecutive face sites.  Needs chunk * (NS * 32 + 8) bytes of dynamic LDS (launchDslash).
+template <typename T, bool PRETWIST, typename real> __device__ __forceinline__ void pack_body_sector(const PackArg<real> &arg, int bid, int chunk) {
+  constexpr int NV = GhostLL<T>::NV, NS = GhostLL<T>::NS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char pack_lds[];
+  u32x4_t *sec = reinterpret_cast<u32x4_t *>(pack_lds);                                  // [NS][chunk][2]
+  int2 *meta = reinterpret_cast<int2 *>(pack_lds + (size_t)NS * chunk * 32);            // (slot, face index) per site, slot < 0: none
+  const int t = (int)threadIdx.x;
+  const int tid = t < chunk ? bid * chunk + t : arg.start[8];
+  if (t < chunk) meta[t] = make_int2(-1, 0);
+  if (tid < arg.start[8]) {
+    int slot, f;
+    const int idx = pack_locate(arg, tid, slot, f);
+    real psi[24], h[12];
+    Planar<T, 24>::load(psi, arg.in, arg.sp_stride, idx, arg.inNorm, idx);
+    const int d = slot >> 1, to_fwd = slot & 1;
+    if (PRETWIST) twist_inplace(psi, arg.a);
+    const real sgn = to_fwd ? -arg.sfwd : arg.sfwd;
+    switch (d) {
+      case 0: spin_project<0>(h, psi, sgn); break;
+      case 1: spin_project<1>(h, psi, sgn); break;
+      case 2: spin_project<2>(h, psi, sgn); break;
+      default: spin_project<3>(h, psi, sgn); break;
+    }
+    unsigned w[2 * NV];
+    GhostLL<T>::encode(w, h);
+    const unsigned flag = arg.llFlag[d];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      u32x4_t q0, q1;
+      if (sizeof(T) == 2) { q0.x = w[0]; q0.y = w[1]; q0.z = w[2]; q0.w = w[3]; q1.x = w[4]; q1.y = w[5]; q1.z = w[6]; q1.w = flag; }
+      else { q0.x = w[6 * s]; q0.y = w[6 * s + 1]; q0.z = w[6 * s + 2]; q0.w = w[6 * s + 3]; q1.x = w[6 * s + 4]; q1.y = w[6 * s + 5]; q1.z = flag; q1.w = flag; }
+      sec[((size_t)s * chunk + t) * 2] = q0;
+      sec[((size_t)s * chunk + t) * 2 + 1] = q1;
+    }
+    meta[t] = make_int2(slot, f);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NS; s++)
+    for (int j = t; j < 2 * chunk; j += (int)blockDim.x) {
+      const int2 m = meta[j >> 1];
+      if (m.x < 0) continue;
+      const int d = m.x >> 1;
+      const __amdgpu_buffer_rsrc_t rs = ghost_sector_rsrc<T>(arg.send[d][m.x & 1], arg.faceCB[d]);
+      __builtin_amdgcn_raw_buffer_store_b128(sec[(size_t)s * chunk * 2 + j], rs, m.y * 32 + (j & 1) * 16, s * arg.faceCB[d] * 32, QA_LL_STORE_AUX);
+    }
+}
+
 // VARIANT: 0 = Wilson / twist epilogues, 1 = twist applied to the neighbours first (TWIST_INV_DSLASH), 2 = clover epilogues.
 // Compile-time so the 8-hop pipeline below is one straight-line basic block (a wave-uniform runtime branch per hop
 // made hipcc split it into ~80 blocks and shuttle the double buffers through AGPRs).
@@ -728,7 +835,8 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
     // ghost words they need and add the off-node hops (stencil_site, KT == 3)
     if (b < arg.packBlocks) {
       if (arg.packPrio) __builtin_amdgcn_s_setprio(3);
-      pack_body<T, VARIANT == 1, true>(arg.pack, b, arg.packChunk);
+      if (arg.pack.llFormat) pack_body_sector<T, VARIANT == 1>(arg.pack, b, arg.packChunk);
+      else pack_body<T, VARIANT == 1, true>(arg.pack, b, arg.packChunk);
       return;
     }
     b -= arg.packBlocks;
@@ -850,6 +958,10 @@ struct FineBlockArg {
   // (1 + i a1 g5) of the hop sum (CL = 1: (A + i a g5)^-1 of the even-odd preconditioned operator) or (1 + i a0 g5) of in_same
   // (CL = 2: A + i a g5 of the full operator)
   const float *tmat;
+  // grid-decomposed lattice: a hop across a partitioned face reads the neighbour rank's panel from the ghost zone of in_other (block.h
+  // BlockGhost, parity field): ghostBase[d][k] = panel index, RELATIVE to in_other, of zone [d][k]
+  int commMask;
+  int ghostBase[4][2];
   BlockOrder order;
 };
 
@@ -904,6 +1016,28 @@ template <int NRHS, int CL = 0> __global__ void __launch_bounds__(256) fine_bloc
   nb[5] = z == 0 ? idx + (arg.Z - 1) * sz : idx - sz;
   nb[6] = t == arg.T - 1 ? idx - (arg.T - 1) * st : idx + st;
   nb[7] = t == 0 ? idx + (arg.T - 1) * st : idx - st;
+  if (arg.commMask) {   // face index: the other three coordinates, lexicographic, halved (block.hip face_site_to_panel packs in this order)
+    if (arg.commMask & 1) {
+      const int f = ((t * arg.Z + z) * arg.Y + y) >> 1;
+      if (xodd && xh == Xh - 1) nb[0] = arg.ghostBase[0][1] + f;
+      if (!xodd && xh == 0) nb[1] = arg.ghostBase[0][0] + f;
+    }
+    if (arg.commMask & 2) {
+      const int f = (t * arg.Z + z) * Xh + xh;
+      if (y == arg.Y - 1) nb[2] = arg.ghostBase[1][1] + f;
+      if (y == 0) nb[3] = arg.ghostBase[1][0] + f;
+    }
+    if (arg.commMask & 4) {
+      const int f = (t * arg.Y + y) * Xh + xh;
+      if (z == arg.Z - 1) nb[4] = arg.ghostBase[2][1] + f;
+      if (z == 0) nb[5] = arg.ghostBase[2][0] + f;
+    }
+    if (arg.commMask & 8) {
+      const int f = (z * arg.Y + y) * Xh + xh;
+      if (t == arg.T - 1) nb[6] = arg.ghostBase[3][1] + f;
+      if (t == 0) nb[7] = arg.ghostBase[3][0] + f;
+    }
+  }
 
   float acc[24];
 #pragma unroll
@@ -914,7 +1048,7 @@ template <int NRHS, int CL = 0> __global__ void __launch_bounds__(256) fine_bloc
   // 48^3 x 96, four times the bandwidth bound) nor serialises them.
   float pA[24], pB[24];
   auto load_panel = [&](float *psi, const float2 *base, int site) {
-    const float2 *p = base + ((size_t)site * 12) * NRHS + i;
+    const float2 *p = base + ((long)site * 12) * NRHS + i;
 #pragma unroll
     for (int j = 0; j < 12; j++) { const float2 v = p[j * NRHS]; psi[2 * j] = v.x; psi[2 * j + 1] = v.y; }
   };
@@ -1057,7 +1191,6 @@ void cloverTwistDense(float *out, const CloverField &C, int parity, double a, bo
 bool fineBlockSupported(const GaugeField &U, int nrhs) {
   if (U.precision != QUDA_SINGLE_PRECISION || U.reconstruct != QUDA_RECONSTRUCT_NO) return false;
   if (nrhs != 8 && nrhs != 16 && nrhs != 24 && nrhs != 32) return false;
-  for (int d = 0; d < 4; d++) if (commGrid().partitioned(d)) return false;
   static int off = -1;
   if (off < 0) { const char *e = getenv("QUDA_AMD_BLOCK_FINE"); off = (e && !atoi(e)) ? 1 : 0; }
   return !off;
@@ -1067,8 +1200,8 @@ bool fineBlockSupported(const GaugeField &U, int nrhs) {
 //   out(x) = s0 (1 + i a0 g5) in_same(x) + k1 (1 + i a1 g5) sum_{8 hops} U P in_other(x + mu)       x of parity `parity`
 // all three fields are single-parity block panels [Vh][12][nrhs]; in_same may be nullptr when s0 = 0
 void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_other, int nrhs, const GaugeField &U, int parity, double s0, double a0, double k1,
-                          double a1, const float *tmat, int tmode) {
-  if (!fineBlockSupported(U, nrhs)) errorQuda("multi-right-hand-side fine operator: fp32 recon-18 links on an unpartitioned lattice, 8/16/24/32 right-hand sides");
+                          double a1, const float *tmat, int tmode, float2 *ghost) {
+  if (!fineBlockSupported(U, nrhs)) errorQuda("multi-right-hand-side fine operator: fp32 recon-18 links, 8/16/24/32 right-hand sides");
   if (s0 != 0.0 && !in_same) errorQuda("same-parity input missing");
   if (tmat && (tmode != 1 && tmode != 2)) errorQuda("site-matrix mode %d (1: on the hop sum, 2: on the same-parity input)", tmode);
   if (tmat && tmode == 2 && s0 == 0.0) errorQuda("site matrix on the same-parity input, but that input is switched off");
@@ -1085,6 +1218,21 @@ void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_o
   arg.out = out; arg.in_same = in_same ? in_same : in_other; arg.in_other = in_other;
   arg.gauge = (const char *)U.parityBase(parity);
   arg.tmat = tmat;
+  // grid-decomposed lattice: the faces of in_other (parity 1 - parity) go to the neighbours' ghost zones first — one pack launch and one
+  // grouped exchange on the compute stream (setup-time traffic; the solve-time stencil has its own overlapped transports, halo.h)
+  arg.commMask = 0;
+  for (int d = 0; d < 4; d++) arg.ghostBase[d][0] = arg.ghostBase[d][1] = 0;
+  {
+    const BlockGhost gh = blockGhost(g.X, true);
+    if (gh.mask) {
+      if (!ghost) errorQuda("multi-right-hand-side stencil on a grid-decomposed lattice: the input needs a ghost zone (block.h BlockGhost)");
+      blockExchangeGhostRaw(in_other, ghost, 12, nrhs, gh, 1 - parity);
+      const long panel = 12l * nrhs, rel = ghost - in_other;
+      if (rel % panel) errorQuda("ghost zone not aligned with the panels of its field");
+      arg.commMask = gh.mask;
+      for (int d = 0; d < 4; d++) for (int k = 0; k < 2; k++) arg.ghostBase[d][k] = (int)(rel / panel) + gh.offset[d][k];
+    }
+  }
 #define FB_LAUNCH(N) \
   if (!tmat) hipLaunchKernelGGL((fine_block_kernel<N, 0>), dim3(nb), dim3(threads), 0, computeStream(), arg); \
   else if (tmode == 1) hipLaunchKernelGGL((fine_block_kernel<N, 1>), dim3(nb), dim3(threads), 0, computeStream(), arg); \
@@ -1100,9 +1248,14 @@ void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_o
 }
 
 // out = (1 + i a g5) in - kappa D in on full block fields of 12 components (both parities, two launches)
-void applyFineBlockM(float2 *out, const float2 *in, int nrhs, const GaugeField &U, double kappa, double a, const float *const tmat[2]) {
+// grid-decomposed lattice: `in` carries 2 x blockGhost(X, true).nGhost panels behind its V local ones — the ghost zone of the even
+// half, then that of the odd half
+void applyFineBlockM(float2 *out, float2 *in, int nrhs, const GaugeField &U, double kappa, double a, const float *const tmat[2]) {
   const size_t par = (size_t)U.geom.Vh * 12 * nrhs;
-  for (int p = 0; p < 2; p++) applyFineBlockParity(out + p * par, in + p * par, in + (1 - p) * par, nrhs, U, p, 1.0, a, -kappa, 0.0, tmat ? tmat[p] : nullptr, 2);
+  const BlockGhost gh = blockGhost(U.geom.X, true);
+  for (int p = 0; p < 2; p++)
+    applyFineBlockParity(out + p * par, in + p * par, in + (1 - p) * par, nrhs, U, p, 1.0, a, -kappa, 0.0, tmat ? tmat[p] : nullptr, 2,
+                         gh.mask ? in + 2 * par + (size_t)(1 - p) * gh.nGhost * 12 * nrhs : nullptr);
 }
 
 // ---- single-direction hop (setup-time helper for the multigrid coarse-operator construction) ----
@@ -1248,9 +1401,11 @@ DslashTune &dslashTune() {
     t.tt = env("QUDA_AMD_DSLASH_TT", 0);
     t.lds_pad = env("QUDA_AMD_DSLASH_LDS", 0);
     t.ygroups = env("QUDA_AMD_DSLASH_YGROUPS", -1);
+    { const char *e = getenv("QUDA_AMD_HALO_FORMAT"); t.halo_format = (e && (!strcmp(e, "sector") || !strcmp(e, "line128") || !strcmp(e, "1"))) ? 1 : 0; }
   }
   return t;
 }
+int haloWireFormat() { return dslashTune().halo_format ? 1 : 0; }
 void setDslashTune(const char *key, int value) {
   DslashTune &t = dslashTune();
   const std::string k(key);
@@ -1264,10 +1419,11 @@ void setDslashTune(const char *key, int value) {
   else if (k == "tt") t.tt = value;
   else if (k == "lds_pad") t.lds_pad = value;
   else if (k == "ygroups") t.ygroups = value;
-  else if (k == "p2p_fold") t.p2p_fold = value;
+  else if (k == "p2p_fold") { t.p2p_fold = value; if (value > 0 && !QA_P2P_FOLD) warningQuda("folded face packing is compiled out (QA_P2P_FOLD = 0 in dslash.hip): pack blocks are used"); }
   else if (k == "site_delay") t.site_delay = value;
   else if (k == "pack_prio") t.pack_prio = value;
   else if (k == "edge_first") t.edge_first = value;
+  else if (k == "halo_format") t.halo_format = value;
   else errorQuda("unknown stencil tuning key '%s'", key);
 }
 
@@ -1307,7 +1463,7 @@ HaloBuffers &haloBuffers(const LatticeGeom &g, QudaPrecision prec) {
     h.face_bytes[d] = payload + (prec == QUDA_HALF_PRECISION ? ((size_t)g.faceCB[d] * sizeof(float) + 255) / 256 * 256 : 0);
     total += 4 * h.face_bytes[d];
   }
-  HIP_CHECK(hipMalloc((void **)&h.pool, total));
+  HIP_CHECK(qaMalloc((void **)&h.pool, total));
   // hipMemset on the null stream may still be in flight when it returns and does not order against the non-blocking
   // compute/comm streams: a late memset would wipe a freshly packed send buffer, so zero on the compute stream and drain
   HIP_CHECK(hipMemsetAsync(h.pool, 0, total, computeStream()));
@@ -1373,7 +1529,7 @@ const BoundaryList &boundaryList(const LatticeGeom &g, int mask) {
     }
     b.count[parity] = (int)list.size();
     if (!list.empty()) {
-      HIP_CHECK(hipMalloc((void **)&b.d_idx[parity], list.size() * sizeof(int)));
+      HIP_CHECK(qaMalloc((void **)&b.d_idx[parity], list.size() * sizeof(int)));
       HIP_CHECK(hipMemcpy(b.d_idx[parity], list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice));
     }
   }
@@ -1510,6 +1666,7 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
   pa.timeline = nullptr; arg.timeline = nullptr;
   for (int k = 0; k < 8; k++) arg.waitCount[k] = 0;
   for (int d = 0; d < 4; d++) pa.llFlag[d] = 0;
+  pa.llFormat = 0;
   arg.waitTicks = 0; arg.errWord = nullptr;
   arg.commMask = mask;
   arg.blist = bl.d_idx[p.parity]; arg.nboundary = bl.count[p.parity];
@@ -1587,11 +1744,12 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
     // before any block that could wait for them, so the faces always get out): no pack blocks at all, see stencil_site.
     // Measured on the 8-GPU sub-lattice 32 x 16 x 16 x 16 (y, z, t partitioned, self-neighbour emulation): the pack blocks need
     // 11 us (up to 18) next to the stencil traffic against 3 us on an idle device (tools/ubench_ll_store.hip) and the site block
-    // that shares their CU ends 4-6 us late.  QUDA_AMD_P2P_FOLD=0 keeps the pack blocks.
+    // that shares their CU ends 4-6 us late.  Off by default and compiled out (QA_P2P_FOLD above); with -DQA_P2P_FOLD=1, QUDA_AMD_P2P_FOLD=1 selects it.
     {
       static int foldEnv = -1;
       if (foldEnv < 0) { const char *e = getenv("QUDA_AMD_P2P_FOLD"); foldEnv = e ? atoi(e) : 0; }
-      const int fold = tune.p2p_fold >= 0 ? tune.p2p_fold : foldEnv;
+      pa.llFormat = haloWireFormat();
+      const int fold = pa.llFormat ? 0 : (tune.p2p_fold >= 0 ? tune.p2p_fold : foldEnv);   // the sector format packs in whole blocks (LDS transpose)
       const int nbp = nb < 256 ? nb : 256;
       const int share = (nt + nbp - 1) / nbp;
       arg.packShare = 0; arg.packFoldBlocks = 0;
@@ -1606,7 +1764,7 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
         HIP_CHECK(hipStreamSynchronize(cs));
         memset(tl, 0, 16384 * sizeof(unsigned long long));
         pa.timeline = tl; arg.timeline = tl; arg.pack = pa;
-        hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 3>), dim3(arg.packBlocks + nb), dim3(bs), 0, cs, arg);
+        hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 3>), dim3(arg.packBlocks + nb), dim3(bs), pa.llFormat ? (size_t)bs * (GhostLL<T>::NS * 32 + 8) : 0, cs, arg);
         HIP_CHECK(hipStreamSynchronize(cs));
         unsigned long long t0 = ~0ull;
         for (int i = 0; i < 16384; i++) if ((i < 3072 || i >= 4096) && tl[i] && tl[i] < t0) t0 = tl[i];   // 3072..4095 hold placement words
@@ -1642,7 +1800,8 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
     }
     pa.timeline = nullptr; arg.timeline = nullptr;
     arg.pack = pa;
-    hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 3>), dim3(arg.packBlocks + nb), dim3(bs), 0, cs, arg);
+    const size_t packLds = pa.llFormat ? (size_t)bs * (GhostLL<T>::NS * 32 + 8) : 0;   // LDS transpose of the sector pack blocks
+    hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 3>), dim3(arg.packBlocks + nb), dim3(bs), packLds, cs, arg);
     HIP_CHECK(hipGetLastError());
     return;
   }
@@ -1773,8 +1932,8 @@ template <typename T, int R> static void launchHopDir(ColorSpinorField &out, con
     const size_t bytes = (size_t)g.faceCB[mu] * 24 * sizeof(real);
     if (bytes > g_ffBytes) {
       freeFullFaceBuffers();
-      HIP_CHECK(hipMalloc((void **)&g_ffSend, bytes));
-      HIP_CHECK(hipMalloc((void **)&g_ffGhost, bytes));
+      HIP_CHECK(qaMalloc((void **)&g_ffSend, bytes));
+      HIP_CHECK(qaMalloc((void **)&g_ffGhost, bytes));
       g_ffBytes = bytes;
     }
     const bool fwd = !(dir & 1);
@@ -1855,8 +2014,8 @@ void applyShift(double *out, const double *in, const LatticeGeom &g, int stride,
     const size_t bytes = (size_t)g.faceCB[mu] * 24 * sizeof(double);
     if (bytes > g_ffBytes) {
       freeFullFaceBuffers();
-      HIP_CHECK(hipMalloc((void **)&g_ffSend, bytes));
-      HIP_CHECK(hipMalloc((void **)&g_ffGhost, bytes));
+      HIP_CHECK(qaMalloc((void **)&g_ffSend, bytes));
+      HIP_CHECK(qaMalloc((void **)&g_ffGhost, bytes));
       g_ffBytes = bytes;
     }
     const bool fwd = !(dir & 1);

@@ -233,7 +233,7 @@ static size_t g_stage_bytes = 0;
 void *stagingBuffer(size_t bytes) {
   if (bytes > g_stage_bytes) {
     if (g_stage) HIP_CHECK(hipFree(g_stage));
-    HIP_CHECK(hipMalloc(&g_stage, bytes));
+    HIP_CHECK(qaMalloc(&g_stage, bytes));
     g_stage_bytes = bytes;
   }
   return g_stage;
@@ -365,7 +365,7 @@ GaugeField::GaugeField(const LatticeGeom &g, QudaPrecision prec, QudaReconstruct
   if (prec == QUDA_HALF_PRECISION && aniso != 1.0) errorQuda("16-bit links need anisotropy 1 (fixed-point range)");
   link_bytes = alignUp((size_t)stride * (int)recon * (int)prec, 1024);
   bytes = 16 * link_bytes;
-  HIP_CHECK(hipMalloc(&data, bytes));
+  HIP_CHECK(qaMalloc(&data, bytes));
 }
 GaugeField::~GaugeField() { if (data) (void)hipFree(data); }
 
@@ -518,13 +518,13 @@ CloverField::CloverField(const LatticeGeom &g, QudaPrecision prec)
     : geom(g), precision(prec), stride(g.Vh), clover(nullptr), cloverInv(nullptr), norm(nullptr), invNorm(nullptr), twisted(false), mu2(0) {
   parity_bytes = alignUp((size_t)stride * 72 * (int)prec, 1024);
   bytes = 2 * parity_bytes;
-  HIP_CHECK(hipMalloc(&clover, bytes));
-  HIP_CHECK(hipMalloc(&cloverInv, bytes));
+  HIP_CHECK(qaMalloc(&clover, bytes));
+  HIP_CHECK(qaMalloc(&cloverInv, bytes));
   parity_norm_bytes = 0;
   if (prec == QUDA_HALF_PRECISION) {
     parity_norm_bytes = (size_t)2 * stride * sizeof(float);
-    HIP_CHECK(hipMalloc((void **)&norm, 2 * parity_norm_bytes));
-    HIP_CHECK(hipMalloc((void **)&invNorm, 2 * parity_norm_bytes));
+    HIP_CHECK(qaMalloc((void **)&norm, 2 * parity_norm_bytes));
+    HIP_CHECK(qaMalloc((void **)&invNorm, 2 * parity_norm_bytes));
   }
   trlog[0] = trlog[1] = 0;
 }
@@ -904,7 +904,7 @@ template <typename T, int R> static void cloverFromGaugeDecomposed(double *stage
   const int Vh = geom.Vh, bs = 128, nb = (2 * Vh + bs - 1) / bs;
   const size_t fieldDoubles = (size_t)2 * 24 * Vh;
   double *pool = nullptr;
-  HIP_CHECK(hipMalloc((void **)&pool, 9 * fieldDoubles * sizeof(double)));
+  HIP_CHECK(qaMalloc((void **)&pool, 9 * fieldDoubles * sizeof(double)));
   MatField W[5], b1[2], b2[2];
   for (int i = 0; i < 5; i++) W[i] = {pool + i * fieldDoubles, Vh};
   b1[0] = {pool + 5 * fieldDoubles, Vh}; b1[1] = {pool + 6 * fieldDoubles, Vh};
@@ -1014,7 +1014,7 @@ void CloverField::computeInverse(double mu2_) {
   mu2 = mu2_;
   twisted = mu2_ != 0.0;
   double *d_trlog = nullptr;
-  HIP_CHECK(hipMalloc((void **)&d_trlog, 2 * sizeof(double)));
+  HIP_CHECK(qaMalloc((void **)&d_trlog, 2 * sizeof(double)));
   HIP_CHECK(hipMemsetAsync(d_trlog, 0, 2 * sizeof(double), computeStream()));
   const int bs = 128, nb = (2 * geom.Vh + bs - 1) / bs;
   QA_DISPATCH_DEV(precision, (launchCloverInvert<TD>(*this, nb, bs, mu2_, d_trlog)));
@@ -1231,7 +1231,7 @@ GaugeField *apeSmear(const GaugeField &U, unsigned nSteps, double alpha) {
   const int Vh = geom.Vh, bs = 128, nb = (2 * Vh + bs - 1) / bs;
   const size_t fieldDoubles = (size_t)2 * 24 * Vh;
   double *pool = nullptr;
-  HIP_CHECK(hipMalloc((void **)&pool, 13 * fieldDoubles * sizeof(double)));
+  HIP_CHECK(qaMalloc((void **)&pool, 13 * fieldDoubles * sizeof(double)));
   MatField F[4], G[3], S, W1, W2, T1, T2;
   for (int i = 0; i < 4; i++) F[i] = {pool + i * fieldDoubles, Vh};
   for (int i = 0; i < 3; i++) G[i] = {pool + (4 + i) * fieldDoubles, Vh};
@@ -1286,7 +1286,7 @@ void saveGaugeQDP(const GaugeField &U, void *const h_gauge[4], QudaPrecision cpu
   const LatticeGeom &geom = U.geom;
   const int Vh = geom.Vh, bs = 128, nb = (2 * Vh + bs - 1) / bs;
   double *pool = nullptr;
-  HIP_CHECK(hipMalloc((void **)&pool, (size_t)2 * 24 * Vh * sizeof(double)));
+  HIP_CHECK(qaMalloc((void **)&pool, (size_t)2 * 24 * Vh * sizeof(double)));
   MatField F = {pool, Vh};
   double *stage = (double *)stagingBuffer((size_t)geom.V * 18 * sizeof(double));
   for (int mu = 0; mu < 4; mu++) {
@@ -1305,8 +1305,8 @@ void plaquette(const GaugeField &U, double plq[3]) {
   const int Vh = geom.Vh, nb = (2 * Vh + 255) / 256;
   const size_t fieldDoubles = (size_t)2 * 24 * Vh;
   double *pool = nullptr, *d_acc = nullptr;
-  HIP_CHECK(hipMalloc((void **)&pool, 6 * fieldDoubles * sizeof(double)));
-  HIP_CHECK(hipMalloc((void **)&d_acc, 2 * sizeof(double)));
+  HIP_CHECK(qaMalloc((void **)&pool, 6 * fieldDoubles * sizeof(double)));
+  HIP_CHECK(qaMalloc((void **)&d_acc, 2 * sizeof(double)));
   HIP_CHECK(hipMemsetAsync(d_acc, 0, 2 * sizeof(double), computeStream()));
   MatField F[4], W1, W2;
   for (int i = 0; i < 4; i++) F[i] = {pool + i * fieldDoubles, Vh};

@@ -19,6 +19,7 @@ void setVerbosityInternal(QudaVerbosity v, const char *prefix, FILE *f);
 void createStreams();
 void destroyStreams();
 void freeStagingBuffer();
+void freeBlockTables();
 
 // resident fields (reference lib/interface_quda.cpp:119-145)
 GaugeField *gaugePrecise = nullptr, *gaugeSloppy = nullptr, *gaugePrecondition = nullptr, *gaugeSmeared = nullptr;
@@ -146,6 +147,7 @@ void endQuda(void) {
   freeGaugeQuda();
   freeCloverQuda();
   freeStagingBuffer();
+  freeBlockTables();
   poolDeviceFlush();
   blas::end();
   commFinalize();

@@ -188,7 +188,8 @@ double qudaAmdMultigridApplyBlock(void *mg_instance, int level, int nrhs, float 
     *f[i] = hin;
   }
   const int nSites = fine ? proto.Volume() : dc->Links().nSites, ncomp = fine ? 12 : dc->Links().n;
-  BlockField in(nSites, ncomp, nrhs), out(nSites, ncomp, nrhs);
+  const int nGhost = fine ? 2 * blockGhost(dg->Gauge()->geom.X, true).nGhost : blockGhost(dc->Links().Xc, false).nGhost;
+  BlockField in(nSites, ncomp, nrhs, nGhost), out(nSites, ncomp, nrhs);
   blockPack(in, f);
   // level 0: the multi-right-hand-side stencil of the null-vector solves (dslash.h applyFineBlockM), twisted clover with its dense
   // site matrices A + i a g5

@@ -252,12 +252,12 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
   if (dc && dc->getDiracType() == QUDA_COARSE_DIRAC && blockCoarseSupported(dc->Links(), mgp.Nvec) && !coarseHalfStorage()) {
     const double t0 = now();
     for (int i = 0; i < mgp.Nvec; i++) { B[i]->twistFlavor = mgp.fineFlavor; spinorRandom(*B[i], 0x5eedULL + 7919ULL * (mgp.level * 131 + i)); }
-    BlockField X(dc->Links().nSites, dc->Links().n, mgp.Nvec);
+    BlockField X(dc->Links().nSites, dc->Links().n, mgp.Nvec, blockGhost(dc->Links().Xc, false).nGhost);
     std::vector<ColorSpinorField *> Bv(B.begin(), B.begin() + mgp.Nvec);
     blockPack(X, Bv);
     struct Ctx { const CoarseGauge *G; long applies; } ctx = {&dc->Links(), 0};
     int iters[kMaxBlockRhs];
-    const int kmax = blockBiCGstabNull(X, [](BlockField &out, const BlockField &in, void *c) { Ctx *x = (Ctx *)c; applyCoarseBlock(out, in, *x->G); x->applies++; }, &ctx, sp.tol, sp.maxiter, iters);
+    const int kmax = blockBiCGstabNull(X, [](BlockField &out, BlockField &in, void *c) { Ctx *x = (Ctx *)c; applyCoarseBlock(out, in, *x->G); x->applies++; }, &ctx, sp.tol, sp.maxiter, iters);
     blockUnpack(Bv, X);
     orthonormaliseNullVectors(B, mgp.Nvec);
     nullVectorMethod = 2; nullVectorIterations = kmax;
@@ -294,6 +294,8 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
       if (fullOp < 0) { const char *e = getenv("QUDA_AMD_NULL_FULL"); fullOp = e ? atoi(e) : 0; }
       const double kappa = df->Kappa(), binv = 1.0 / (1.0 + a * a);
       const int Vh = B[0]->VolumeCB();
+      // grid-decomposed lattice: every operator input carries the faces of the neighbour ranks behind its local panels (block.h BlockGhost)
+      const int nGhostPar = blockGhost(df->Gauge()->geom.X, true).nGhost;
       float *tmat[2] = {nullptr, nullptr};
       const size_t tmatBytes = (size_t)Vh * 144 * sizeof(float);
       if (tmc)
@@ -310,34 +312,36 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
         double tp = now();
         int iters[kMaxBlockRhs], kmax;
         if (fullOp) {
-          BlockField X(B[0]->Volume(), 12, nb);
+          BlockField X(B[0]->Volume(), 12, nb, 2 * nGhostPar);
           blockPack(X, Bv);
           if (mgProfiling()) { HIP_CHECK(hipStreamSynchronize(computeStream())); tPack += now() - tp; tp = now(); }
-          kmax = blockBiCGstabNull(X, [](BlockField &out, const BlockField &in, void *c) {
+          kmax = blockBiCGstabNull(X, [](BlockField &out, BlockField &in, void *c) {
             Ctx *x = (Ctx *)c; applyFineBlockM(out.v, in.v, in.nrhs, *x->U, x->kappa, x->a, x->tmat[0] ? x->tmat : nullptr); x->applies++; },
                                    &ctx, sp.tol, sp.maxiter, iters);
           if (mgProfiling()) { HIP_CHECK(hipStreamSynchronize(computeStream())); tSolve += now() - tp; tp = now(); }
           blockUnpack(Bv, X);
         } else {
-          BlockField Xe(Vh, 12, nb), Xo(Vh, 12, nb);
+          BlockField Xe(Vh, 12, nb, nGhostPar), Xo(Vh, 12, nb, nGhostPar);
           blockPack(Xe, Bv, 0);
           ctx.tmp = &Xo;
           if (mgProfiling()) { HIP_CHECK(hipStreamSynchronize(computeStream())); tPack += now() - tp; tp = now(); }
-          kmax = blockBiCGstabNull(Xe, [](BlockField &out, const BlockField &in, void *c) {
+          auto ghostOf = [](BlockField &f) { return f.nGhost ? f.v + f.elems() : nullptr; };
+          kmax = blockBiCGstabNull(Xe, [](BlockField &out, BlockField &in, void *c) {
             Ctx *x = (Ctx *)c;
+            float2 *gin = in.nGhost ? in.v + in.elems() : nullptr, *gtmp = x->tmp->nGhost ? x->tmp->v + x->tmp->elems() : nullptr;
             // tmp_o = A^-1 D_oe in_e ;  out_e = in_e - kappa^2 A^-1 D_eo tmp_o          (twisted mass: A^-1 = binv (1 - i a g5))
             if (x->tmat[0]) {
-              applyFineBlockParity(x->tmp->v, nullptr, in.v, in.nrhs, *x->U, 1, 0.0, 0.0, 1.0, 0.0, x->tmat[1], 1);
-              applyFineBlockParity(out.v, in.v, x->tmp->v, in.nrhs, *x->U, 0, 1.0, 0.0, -x->kappa * x->kappa, 0.0, x->tmat[0], 1);
+              applyFineBlockParity(x->tmp->v, nullptr, in.v, in.nrhs, *x->U, 1, 0.0, 0.0, 1.0, 0.0, x->tmat[1], 1, gin);
+              applyFineBlockParity(out.v, in.v, x->tmp->v, in.nrhs, *x->U, 0, 1.0, 0.0, -x->kappa * x->kappa, 0.0, x->tmat[0], 1, gtmp);
             } else {
-              applyFineBlockParity(x->tmp->v, nullptr, in.v, in.nrhs, *x->U, 1, 0.0, 0.0, x->binv, -x->a);
-              applyFineBlockParity(out.v, in.v, x->tmp->v, in.nrhs, *x->U, 0, 1.0, 0.0, -x->kappa * x->kappa * x->binv, -x->a);
+              applyFineBlockParity(x->tmp->v, nullptr, in.v, in.nrhs, *x->U, 1, 0.0, 0.0, x->binv, -x->a, nullptr, 0, gin);
+              applyFineBlockParity(out.v, in.v, x->tmp->v, in.nrhs, *x->U, 0, 1.0, 0.0, -x->kappa * x->kappa * x->binv, -x->a, nullptr, 0, gtmp);
             }
             x->applies++;
           }, &ctx, sp.tol, sp.maxiter, iters);
           // x_o = kappa A^-1 D_oe x_e
-          if (tmc) applyFineBlockParity(Xo.v, nullptr, Xe.v, nb, *df->Gauge(), 1, 0.0, 0.0, kappa, 0.0, tmat[1], 1);
-          else applyFineBlockParity(Xo.v, nullptr, Xe.v, nb, *df->Gauge(), 1, 0.0, 0.0, kappa * binv, -a);
+          if (tmc) applyFineBlockParity(Xo.v, nullptr, Xe.v, nb, *df->Gauge(), 1, 0.0, 0.0, kappa, 0.0, tmat[1], 1, ghostOf(Xe));
+          else applyFineBlockParity(Xo.v, nullptr, Xe.v, nb, *df->Gauge(), 1, 0.0, 0.0, kappa * binv, -a, nullptr, 0, ghostOf(Xe));
           if (mgProfiling()) { HIP_CHECK(hipStreamSynchronize(computeStream())); tSolve += now() - tp; tp = now(); }
           blockUnpack(Bv, Xe, 0);
           blockUnpack(Bv, Xo, 1);
@@ -703,6 +707,9 @@ multigrid_solver::multigrid_solver(QudaMultigridParam &mg_param)
   inv_param_copy = *param;
   { const char *e = getenv("QUDA_AMD_MG_HALF"); if (e && atoi(e)) multigridSetHalfStorage(*this, true); }
   mg_param.secs = now() - t0;
+  // the block work fields of the lockstep solves (7 x 4 GB at 48^3 x 96) stay parked in the pool for the next hierarchy (the down-flavour
+  // one of the QKXTM drivers is built right after this one); QUDA_AMD_POOL_KEEP=0 hands everything of 256 MB and more back now
+  { const char *e = getenv("QUDA_AMD_POOL_KEEP"); if (e && !atoi(e)) { HIP_CHECK(hipStreamSynchronize(computeStream())); poolDeviceFlush((size_t)256 << 20); } }
 }
 
 void multigridSetHalfStorage(multigrid_solver &mgs, bool on) {

@@ -92,7 +92,7 @@ unsigned long long p2pTimeoutTicks() {
 static int *g_err = nullptr;   // device record (p2p.h): word 0 = 0, or the code of the first wait that timed out (later waits then return at once)
 int *p2pErrorWord() {
   if (!g_err) {
-    HIP_CHECK(hipMalloc((void **)&g_err, kP2pErrInts * sizeof(int)));
+    HIP_CHECK(qaMalloc((void **)&g_err, kP2pErrInts * sizeof(int)));
     HIP_CHECK(hipMemset(g_err, 0, kP2pErrInts * sizeof(int)));
     HIP_CHECK(hipDeviceSynchronize());
   }
@@ -135,7 +135,7 @@ void p2pCheck(const char *where) {
 // (coarse-grid halo, all-reduce), and 16-byte flag-in-data buffer stores / polling buffer loads (fine-grid halo).
 // Several rounds over the SAME addresses, so a receiver that could serve a later round from a stale cache line fails here
 // and not in production. ----
-struct ProbeWindow { unsigned data[8][16]; unsigned flag[8]; unsigned pad[8]; unsigned ll[8][32][4]; };   // ll: 16-byte aligned
+struct ProbeWindow { unsigned data[8][16]; unsigned flag[8]; unsigned pad[8]; unsigned ll[8][32][4]; unsigned sec[8][32][8]; };   // ll, sec: 16-byte aligned
 typedef unsigned int probe_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned probe_token(int rank, int s, int k, int round) { return 0x5eed0000u + (unsigned)round * 4096u + (unsigned)rank * 128u + s * 16u + k; }
@@ -153,6 +153,17 @@ __global__ void p2p_probe_send(ProbeWindow *const *peer, int rank, int round) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)w->ll[s], 0, (int)sizeof(w->ll[s]), 0x00020000);
     probe_u32x4 q; q.x = probe_token(rank, s, v, round); q.y = 0xf1a60000u + round; q.z = ~probe_token(rank, s, v, round); q.w = 0xf1a60000u + round;
     __builtin_amdgcn_raw_buffer_store_b128(q, rs, v * 16, 0, 17);
+  }
+  // the 32-byte-sector format (dslash.hip ghost_sector_read): 6 payload words + the flag twice, the two 16-byte halves of a sector
+  // written by two ADJACENT lanes of one store instruction (16 lanes of slot s = 8 sectors per instruction, 4 instructions)
+  for (int v4 = 0; v4 < 4; v4++) {
+    const int sct = v4 * 8 + (k >> 1), half = k & 1;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)w->sec[s], 0, (int)sizeof(w->sec[s]), 0x00020000);
+    const unsigned tk = probe_token(rank, s, sct, round);
+    probe_u32x4 q;
+    if (!half) { q.x = tk; q.y = ~tk; q.z = tk + 1u; q.w = tk + 2u; }
+    else { q.x = tk + 3u; q.y = tk + 4u; q.z = 0x5ec70000u + round; q.w = 0x5ec70000u + round; }
+    __builtin_amdgcn_raw_buffer_store_b128(q, rs, sct * 32 + half * 16, 0, 17);
   }
 }
 __global__ void p2p_probe_recv(ProbeWindow *mine, const int *fromRank, unsigned long long ticks, int *result, int round) {
@@ -173,6 +184,16 @@ __global__ void p2p_probe_recv(ProbeWindow *mine, const int *fromRank, unsigned 
     for (;;) {
       const probe_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, v * 16, 0, 17);
       if (q.y == flag && q.w == flag) { ok = q.x == probe_token(fromRank[s], s, v, round) && q.z == ~probe_token(fromRank[s], s, v, round); break; }
+      if (wall_clock64() - t0 > ticks) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rsec = __builtin_amdgcn_make_buffer_rsrc((void *)mine->sec[s], 0, (int)sizeof(mine->sec[s]), 0x00020000);
+  for (int v = 0; v < 32 && ok; v++) {
+    const unsigned flag = 0x5ec70000u + round, tk = probe_token(fromRank[s], s, v, round);
+    for (;;) {
+      const probe_u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rsec, v * 32, 0, 17), q1 = __builtin_amdgcn_raw_buffer_load_b128(rsec, v * 32 + 16, 0, 17);
+      if (q1.z == flag && q1.w == flag) { ok = q0.x == tk && q0.y == ~tk && q0.z == tk + 1u && q0.w == tk + 2u && q1.x == tk + 3u && q1.y == tk + 4u; break; }
       if (wall_clock64() - t0 > ticks) { ok = false; break; }
       __builtin_amdgcn_s_sleep(1);
     }
@@ -249,9 +270,9 @@ bool p2pHaloEnabled() {
     int *d_from = nullptr, *d_res = nullptr, h_from[8], h_res = 0;
     // window s is written by the rank that has me as its slot-s neighbour: its +dim neighbour (s odd) is me -> it is my -dim neighbour
     for (int s = 0; s < 8; s++) h_from[s] = commNeighborRank(s >> 1, (s & 1) ? -1 : +1);
-    HIP_CHECK(hipMalloc((void **)&d_peer, 8 * sizeof(void *)));
-    HIP_CHECK(hipMalloc((void **)&d_from, 8 * sizeof(int)));
-    HIP_CHECK(hipMalloc((void **)&d_res, sizeof(int)));
+    HIP_CHECK(qaMalloc((void **)&d_peer, 8 * sizeof(void *)));
+    HIP_CHECK(qaMalloc((void **)&d_from, 8 * sizeof(int)));
+    HIP_CHECK(qaMalloc((void **)&d_res, sizeof(int)));
     HIP_CHECK(hipMemcpy(d_peer, pm.peer, 8 * sizeof(void *), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemcpy(d_from, h_from, 8 * sizeof(int), hipMemcpyHostToDevice));
     HIP_CHECK(hipMemset(d_res, 0, sizeof(int)));

@@ -117,16 +117,28 @@ void *poolDeviceMalloc(size_t bytes) {
     return p;
   }
   void *p = nullptr;
-  HIP_CHECK(hipMalloc(&p, bytes));
+  HIP_CHECK(qaMallocRaw(&p, bytes));
   return p;
+}
+hipError_t qaMallocRaw(void **p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipErrorOutOfMemory) {   // memory parked in the pool (tens of GB after a 48^3 x 96 set-up) is given back before giving up
+    (void)hipGetLastError();
+    poolDeviceFlush();
+    e = hipMalloc(p, bytes);
+  }
+  return e;
 }
 void poolDeviceFree(void *ptr, size_t bytes) {
   if (ptr) g_pool[bytes].push_back(ptr);
 }
-void poolDeviceFlush() {
-  for (auto &kv : g_pool)
-    for (void *p : kv.second) (void)hipFree(p);
-  g_pool.clear();
+void poolDeviceFlush(size_t atLeast) {
+  for (auto it = g_pool.begin(); it != g_pool.end();) {
+    if (it->first >= atLeast) {
+      for (void *p : it->second) (void)hipFree(p);
+      it = g_pool.erase(it);
+    } else ++it;
+  }
 }
 
 }  // namespace quda

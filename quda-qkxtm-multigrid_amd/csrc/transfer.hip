@@ -782,7 +782,7 @@ Transfer::Transfer(const std::vector<ColorSpinorField *> &B, int Nvec_, int *gbs
   if (blockVol > 1024) errorQuda("aggregate of %d sites exceeds one work-group", blockVol);
   if (getVerbosity() >= QUDA_VERBOSE) printfQuda("Transfer: using block size %d x %d x %d x %d\n", geo_bs[0], geo_bs[1], geo_bs[2], geo_bs[3]);
   createGeoMap();
-  HIP_CHECK(hipMalloc((void **)&V, vBytes()));
+  HIP_CHECK(qaMalloc((void **)&V, vBytes()));
   fillAndOrthonormalise(B);
 }
 
@@ -797,7 +797,7 @@ __global__ void v_to_half_kernel(vhalf4_t *out, const float4 *in, size_t n) {
 void Transfer::makeHalf() const {
   if (V_h) return;
   const size_t n4 = vBytes() / sizeof(float4);
-  HIP_CHECK(hipMalloc(&V_h, n4 * sizeof(vhalf4_t)));
+  HIP_CHECK(qaMalloc(&V_h, n4 * sizeof(vhalf4_t)));
   hipLaunchKernelGGL(v_to_half_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, computeStream(), (vhalf4_t *)V_h, (const float4 *)V, n4);
   HIP_CHECK(hipGetLastError());
 }
@@ -829,8 +829,8 @@ void Transfer::createGeoMap() {
       b2f[A * blockVol + b] = (int)f;
       f2b[f] = (int)(A * blockVol + b);
     }
-  HIP_CHECK(hipMalloc((void **)&block_to_fine, fineVol * sizeof(int)));
-  HIP_CHECK(hipMalloc((void **)&fine_to_block, fineVol * sizeof(int)));
+  HIP_CHECK(qaMalloc((void **)&block_to_fine, fineVol * sizeof(int)));
+  HIP_CHECK(qaMalloc((void **)&fine_to_block, fineVol * sizeof(int)));
   HIP_CHECK(hipMemcpy(block_to_fine, b2f.data(), fineVol * sizeof(int), hipMemcpyHostToDevice));
   HIP_CHECK(hipMemcpy(fine_to_block, f2b.data(), fineVol * sizeof(int), hipMemcpyHostToDevice));
 }
@@ -852,7 +852,7 @@ void Transfer::fillAndOrthonormalise(const std::vector<ColorSpinorField *> &B) {
   if (useQr) {
     int *d_fail = nullptr;   // [0] number of flagged blocks, [1 + b] flag of (aggregate, chirality) block b
     const size_t failBytes = (1 + 2 * (size_t)nAgg) * sizeof(int);
-    HIP_CHECK(hipMalloc((void **)&d_fail, failBytes));
+    HIP_CHECK(qaMalloc((void **)&d_fail, failBytes));
     HIP_CHECK(hipMemsetAsync(d_fail, 0, failBytes, computeStream()));
     const size_t tileFloats2 = (size_t)kQrChunk * (Nvec + 1) + 1;
     const size_t lds = tileFloats2 * sizeof(float2) + (size_t)Nvec * Nvec * (sizeof(double2) + sizeof(float2)) + 64;

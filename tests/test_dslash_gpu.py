@@ -296,11 +296,15 @@ def test_twisted_clover_at_full_size_against_the_oracle(qa, oracle):
             assert qc.rel_err(qa.mat(x_h.copy(), ip), want_m) < 2 * TOL[prec], prec
 
 
+@pytest.mark.parametrize("fmt", [0, 1], ids=["flag-in-data", "sectors-128B-line"])
 @pytest.mark.parametrize("mask", [1, 2, 4, 8, 6, 9, 15])
-def test_partitioned_dslash_self_neighbour(qa, mask):
+def test_partitioned_dslash_self_neighbour(qa, mask, fmt):
     """The reference's own way of testing the halo path without a cluster (tests/test_util.cpp:2047-2065 --partition):
     a single process treats dimension d as partitioned and talks to itself — pack kernel, ghost-zone exchange,
-    interior + exterior kernels — and must reproduce the golden vectors exactly like the unpartitioned kernel."""
+    interior + exterior kernels — and must reproduce the golden vectors exactly like the unpartitioned kernel.
+    fmt: wire format of the peer-store ghost zones — flag-in-data 16-byte vectors, or 32-byte sectors with a flag each (one 128-byte
+    line per fp64 face site), selected at run time through the tune key the environment variable sets."""
+    qa.lib().qudaAmdSetDslashTune(b"halo_format", fmt)
     z, X, kappa, mu, gauge = qc.load(qc.FILES[1])  # 6x4x2x8: includes an extent-2 dimension
     names = ["wil_dslash_p0_d0", "wil_dslash_p1_d1", "tm_dslash_fp_ee_d0_p0", "tm_dslash_fm_oo_d1_p0", "tm_dslash_fp_ee_d1_p0",
              "tmc_dslash_fp_ee_d0_p0", "tmc_dslash_fm_ooasym_d1_p0", "tm_matpc_fp_ee_d0", "tm_matpc_fp_oo_d1", "tm_mat_fp_d0", "tmc_matpc_fm_eeasym_d1", "tmc_matpc_fm_ee_d1"]
@@ -313,8 +317,39 @@ def test_partitioned_dslash_self_neighbour(qa, mask):
                 got = qc.run_abi(qa, name, z["spinor"], X, kappa, mu, prec)
                 assert qc.rel_err(got, z[name]) < TOL[prec], (name, prec, mask)
             qa.lib().qudaAmdSetPartitionMask(0)
+        assert int(qa.lib().qudaAmdHaloTransport()) == 1 and qa.comm_stats()["fine_peer_store_exchanges"] > 0
     finally:
         qa.lib().qudaAmdSetPartitionMask(0)
+        qa.lib().qudaAmdSetDslashTune(b"halo_format", 0)
+
+
+@pytest.mark.parametrize("fmt", [0, 1], ids=["flag-in-data", "sectors-128B-line"])
+def test_partitioned_dslash_at_the_8gpu_sublattice(qa, oracle, fmt):
+    """the local lattice of an 8-GPU split of 32^4 (32 x 16 x 16 x 16, y z t partitioned): many pack blocks, faces of different sizes,
+    pack blocks that straddle two (dimension, direction) ranges; all three precisions against the oracle, both wire formats"""
+    X, kappa, mu = (32, 16, 16, 16), 0.1, 0.01
+    gauge, spinor, _ = oracle.make_fields(list(X), clover=False)
+    nh = spinor.size // 2
+    oracle.set_threads(8)
+    try:
+        want = oracle.tm_dslash(gauge, spinor[:nh].copy(), list(X), kappa, mu, +1, 0, "ee", 0)
+        want_m = oracle.tm_matpc(gauge, spinor[:nh].copy(), list(X), kappa, mu, +1, "ee", 0)
+    finally:
+        oracle.set_threads(1)
+    qa.lib().qudaAmdSetDslashTune(b"halo_format", fmt)
+    qa.lib().qudaAmdSetPartitionMask(0b1110)
+    try:
+        for prec in (8, 4, 2):
+            qa.load_gauge(gauge, qa.gauge_param(X, cuda_prec=prec))
+            ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=prec)
+            for _ in range(3):   # first use (verification against the staged transport), then both buffers of the steady state
+                got = qa.dslash(spinor[:nh].copy(), ip, 0)
+                assert qc.rel_err(got, want) < TOL[prec], (prec, fmt)
+            assert qc.rel_err(qa.mat(spinor[:nh].copy(), ip), want_m) < 2 * TOL[prec], (prec, fmt)
+        assert int(qa.lib().qudaAmdHaloTransport()) == 1
+    finally:
+        qa.lib().qudaAmdSetPartitionMask(0)
+        qa.lib().qudaAmdSetDslashTune(b"halo_format", 0)
 
 
 def test_rccl_call_sequence_self_loop():
@@ -438,7 +473,11 @@ def test_missing_neighbour_face_is_an_error_not_a_hang():
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
         outs = [p.communicate(timeout=120)[0] for p in procs]
     assert "transport 1" in outs[0], outs[0][-1500:]
-    assert procs[0].returncode == 1 and "a halo wait timed out" in outs[0] and "NOT REACHED" not in outs[0], outs[0][-1500:]
+    assert procs[0].returncode == 1 and "halo wait ran out" in outs[0] and "NOT REACHED" not in outs[0], outs[0][-1500:]
+    # the record says where and why: t is the partitioned dimension, the face comes from rank 1, and the words still
+    # carry the zone's previous use — the face of this exchange was never written
+    assert "in dimension 3" in outs[0] and "face from rank 1" in outs[0] and "expected flag" in outs[0], outs[0][-1500:]
+    assert "never written" in outs[0], outs[0][-1500:]
 
 
 @pytest.mark.parametrize("forced_failure", [False, True])

@@ -125,6 +125,8 @@ def test_hierarchy_against_oracle_restatement(qa, oracle, mask):
 
     try:
         assert mg.levels() == 3
+        # lockstep set-up on every level, partitioned or not
+        assert mg.level_info(0)["null_method"] == 1 and mg.level_info(1)["null_method"] == 2
         Yprev = Xprev = None
         for level in range(2):
             i = mg.level_info(level)
@@ -202,14 +204,20 @@ def test_restrictor_and_prolongator_in_the_x_neighbour_order(qa, oracle, X):
         mg.free()
 
 
+@pytest.mark.parametrize("mask", [0, 15, 9], ids=["unpartitioned", "self-neighbour-xyzt", "self-neighbour-xt"])
 @pytest.mark.parametrize("nvec,nrhs_list", [(8, (8, 16, 24, 32)), (24, (24, 8))], ids=["n16", "n48"])
-def test_block_coarse_operator_on_mfma(qa, oracle, nvec, nrhs_list):
+def test_block_coarse_operator_on_mfma(qa, oracle, nvec, nrhs_list, mask):
     """The multi-right-hand-side coarse operator on the matrix cores (csrc/block.hip, v_mfma_f32_16x16x4_f32; reference: the
     multi-source 5th dimension of coarseDslashKernel, lib/dslash_coarse.cu:294-333) against the oracle's restatement of the
     reference's CPU coarse operator (lib/dslash_coarse.cu:50-290) applied to every right-hand side separately, with the device's
     own links, and against the single-vector device kernel.  fp32 MFMA is exact fp32 arithmetic: same 2e-5 bar as the
-    single-vector kernel.  n = 2 Nvec = 16 and the production 48 x 24 shape."""
+    single-vector kernel.  n = 2 Nvec = 16 and the production 48 x 24 shape.
+    mask != 0: the dimensions in the mask are grid-decomposed with the process as its own neighbour — the panels
+    of the face sites travel through the pack kernel and the exchange into the ghost zone behind the field and the MFMA kernel reaches
+    them through the neighbour table (reference: ghost of the multi-source coarse field, lib/dslash_coarse.cu:68-137); the result must
+    not change."""
     X, kappa, mu = (8, 8, 8, 16), 0.124, 0.005
+    qa.lib().qudaAmdSetPartitionMask(mask)
     gauge, ip = _setup(qa, X, kappa, mu)
     mp = qa.multigrid_param(ip, n_level=2, geo_block=[(4, 4, 4, 4), (2, 2, 2, 2)], n_vec=nvec, setup_maxiter=50, setup_tol=1e-3)
     mg = qa.Multigrid(mp)
@@ -234,8 +242,13 @@ def test_block_coarse_operator_on_mfma(qa, oracle, nvec, nrhs_list):
                 assert rel(got[k], want) < 2e-5, (nrhs, k, rel(got[k], want))
                 if k in (0, nrhs - 1):
                     assert rel(got[k], mg.apply(1, "M", eta[k])) < 2e-5
+        if mask:
+            assert qa.comm_stats()["block_exchanges"] > 0
+            # and the set-up itself went through the lockstep solves on the partitioned lattice
+            assert mg.level_info(0)["null_method"] == 1
     finally:
         mg.free()
+        qa.lib().qudaAmdSetPartitionMask(0)
 
 
 def test_block_bicgstab_null_vectors_give_the_same_hierarchy_quality(qa, oracle):
@@ -458,9 +471,12 @@ def test_block_orthonormalisation_of_nearly_dependent_vectors(qa, oracle, tmp_pa
     V4, nvec = int(np.prod(X)), 8
     rng = np.random.default_rng(77)
     v0 = (rng.standard_normal((V4, 4, 3)) + 1j * rng.standard_normal((V4, 4, 3))).astype(np.complex64)
+    c = np.indices(X[::-1]).reshape(4, -1)[::-1]                       # x, y, z, t of the lexicographic sites
+    lex = ((c[3] * X[2] + c[2]) * X[1] + c[1]) * X[0] + c[0]
+    eo = ((c[0] + c[1] + c[2] + c[3]) & 1) * (V4 // 2) + lex // 2      # their place in the even-odd host order
     amp = np.full(V4, 0.3 if eps == "mixed" else eps)
     if eps == "mixed":
-        amp[: V4 // 4] = 1e-3       # the first quarter of the even sites: low t, i.e. a few aggregates only
+        amp[eo[c[3] < 4]] = 1e-3       # nearly dependent on the time slices 0..3 only: half of the aggregates
     B = [v0] + [(v0 + amp[:, None, None] * (rng.standard_normal((V4, 4, 3)) + 1j * rng.standard_normal((V4, 4, 3)))).astype(np.complex64) for _ in range(nvec - 1)]
     base = str(tmp_path / "nv")
     _write_null_vectors(base + "_level_0", X, B)
@@ -477,10 +493,6 @@ def test_block_orthonormalisation_of_nearly_dependent_vectors(qa, oracle, tmp_pa
             assert nfb < 2 * int(np.prod(i["Xc"])), nfb     # only the ill-conditioned blocks
         Vd = mg.V(0).astype(np.complex128)
         # per (aggregate, chirality) Gram matrix of the device's V
-        c = np.indices(X[::-1]).reshape(4, -1)[::-1]                       # x, y, z, t of lexicographic sites
-        lex = ((c[3] * X[2] + c[2]) * X[1] + c[1]) * X[0] + c[0]
-        par = (c[0] + c[1] + c[2] + c[3]) & 1
-        eo = par * (V4 // 2) + lex // 2
         agg = (((c[3] // bs[3]) * (X[2] // bs[2]) + c[2] // bs[2]) * (X[1] // bs[1]) + c[1] // bs[1]) * (X[0] // bs[0]) + c[0] // bs[0]
         worst = 0.0
         for a in range(int(agg.max()) + 1):
@@ -495,7 +507,7 @@ def test_block_orthonormalisation_of_nearly_dependent_vectors(qa, oracle, tmp_pa
         assert dev[0] < (2e-3 if expect_fallback else 1e-4) and dev[1] < bound * 10, dev
         Bd = np.stack([mg.null_vector(0, k) for k in range(nvec)], axis=-1)
         Vo = oracle.mg_block_orthogonalize(Bd, Xf, bs, 4, 3, nvec, 2)
-        cond = 1.0 / (1e-3 if expect_fallback else 3e-2)
+        cond = 1.0 / (1e-3 if expect_fallback else 3e-2)   # fp32 input rounding is amplified by the conditioning in either algorithm
         assert float(np.max(np.abs(Vd - Vo)) / np.max(np.abs(Vo))) < 2e-6 * cond * 10
     finally:
         mg.free()

@@ -231,13 +231,17 @@ def test_matdagmat_through_the_c_abi(qa, oracle, dslash):
             assert _rel(got, want) < 1e-12, (dslash, flavor, matpc)
 
 
+@pytest.mark.parametrize("mask", [0, 15, 6], ids=["unpartitioned", "self-neighbour-xyzt", "self-neighbour-yz"])
 @pytest.mark.parametrize("dslash", ["tm", "tmc"])
-def test_multi_rhs_fine_stencil_against_the_oracle(qa, oracle, dslash):
+def test_multi_rhs_fine_stencil_against_the_oracle(qa, oracle, dslash, mask):
     """The 8/16/24/32-right-hand-side stencil of the lockstep null-vector solves (csrc/dslash.hip fine_block_kernel; twisted clover:
     the dense A + i a g5 site matrices of cloverTwistDense in its epilogue) applied to a batch, every right-hand side against the
     host tm_mat / tmc_mat (fp32 device arithmetic: 2e-5 of the largest element); and the hierarchy's own record that the level-0 null
-    vectors came from the lockstep solve on that stencil (null_method 1), the coarse ones from the MFMA operator (2)."""
+    vectors came from the lockstep solve on that stencil (null_method 1), the coarse ones from the MFMA operator (2).
+    mask != 0: grid-decomposed lattice with the process as its own neighbour — the hops across a partitioned face read the neighbour's
+    panel from the ghost zone behind the block field (block.h BlockGhost), filled by one pack launch + one grouped exchange."""
     X, kappa, mu = (8, 8, 8, 16), 0.124, 0.005
+    qa.lib().qudaAmdSetPartitionMask(mask)
     if dslash == "tmc":
         gauge, clover, ip = _setup(qa, oracle, X, kappa, mu)
     else:
@@ -266,8 +270,11 @@ def test_multi_rhs_fine_stencil_against_the_oracle(qa, oracle, dslash):
                     assert _rel(got[k], want.view(np.complex128).reshape(-1, 4, 3)) < 2e-5, (nrhs, k)
             finally:
                 oracle.set_threads(1)
+        if mask:
+            assert qa.comm_stats()["block_exchanges"] > 0
     finally:
         mg.free()
+        qa.lib().qudaAmdSetPartitionMask(0)
 
 
 def test_dense_clover_twist_inverse_in_the_lockstep_solve(qa, oracle):

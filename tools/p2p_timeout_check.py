@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A neighbour that never delivers its face must produce an error, not a hang: rank 1 sets up the decomposition and then
-leaves without applying the operator; rank 0 applies it and has to come back with `a halo wait timed out` after
+leaves without applying the operator; rank 0 applies it and has to come back with `halo wait ran out` (and the record of what it waited for) after
 QUDA_AMD_P2P_TIMEOUT_S.  Started once per rank (env RANK / WORLD_SIZE = 2 / file transport) by the GPU test."""
 import importlib
 import os
