@@ -416,8 +416,11 @@ def main():
             halo = dict(local_lattice="x".join(map(str, Xs)), partitioned="y,z,t (self-neighbour emulation)")
             for prec in (8, 4, 2):
                 row = {}
-                for mask, name in ((0, "unpartitioned_us"), (0b1110, "partitioned_us")):
+                # the partitioned kernel in both wire formats of the peer-store ghost zones: flag-in-data 16-byte vectors (default) and
+                # 32-byte sectors = one 128-byte line per fp64 face site (QUDA_AMD_HALO_FORMAT=sector): 2/3 of the bytes on the links
+                for mask, fmt, name in ((0, 0, "unpartitioned_us"), (0b1110, 0, "partitioned_us"), (0b1110, 1, "partitioned_sector_format_us")):
                     qa.lib().qudaAmdSetPartitionMask(mask)
+                    qa.lib().qudaAmdSetDslashTune(b"halo_format", fmt)
                     qa.load_gauge(gs, qa.gauge_param(Xs, cuda_prec=prec))
                     ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=prec)
                     src, dst = qa.Spinor(prec), qa.Spinor(prec)
@@ -425,9 +428,13 @@ def main():
                     d = qa.Dirac(ip, pc=True)
                     d.time_dslash(dst, src, 0, 50)
                     row[name] = round(1e6 * min(d.time_dslash(dst, src, 0, 500) for _ in range(3)), 2)
-                    if mask:
+                    if mask and not fmt:
                         row["transport"] = {1: "direct peer stores", 0: "RCCL send/recv", -1: "none"}[int(qa.lib().qudaAmdHaloTransport())]
                     src.free(); dst.free(); d.free()
+                qa.lib().qudaAmdSetDslashTune(b"halo_format", 0)
+                site_bytes = {8: (192, 128), 4: (96, 64), 2: (64, 32)}[prec]
+                row["wire_bytes_per_face_site"] = {"flag_in_data": site_bytes[0], "sector_format": site_bytes[1], "payload": {8: 96, 4: 48, 2: 28}[prec]}
+                row["y_face_bytes"] = {"flag_in_data": site_bytes[0] * 32 * 16 * 16 // 2, "sector_format": site_bytes[1] * 32 * 16 * 16 // 2}
                 # what an 8-GPU strong-scaling run would make of it if xGMI behaved like the emulation: the 32^4 kernel of this precision on
                 # one GPU over the partitioned sub-lattice kernel (8 = ideal)
                 one = {8: 1e6 * r["sec"] if (args.prec, args.recon, args.dslash) == (8, 18, "tm") else None,
@@ -435,6 +442,7 @@ def main():
                 if one:
                     row["one_gpu_32x4_us"] = round(one, 2)
                     row["projected_speedup_8_gpus"] = round(one / row["partitioned_us"], 2)
+                    row["projected_speedup_8_gpus_sector_format"] = round(one / row["partitioned_sector_format_us"], 2)
                 halo[dtype_name[prec].split("+")[0]] = row
             qa.lib().qudaAmdSetPartitionMask(0)
             extra["halo_8gpu_sublattice"] = halo

@@ -1401,6 +1401,7 @@ DslashTune &dslashTune() {
     t.tt = env("QUDA_AMD_DSLASH_TT", 0);
     t.lds_pad = env("QUDA_AMD_DSLASH_LDS", 0);
     t.ygroups = env("QUDA_AMD_DSLASH_YGROUPS", -1);
+    t.edge_first = env("QUDA_AMD_EDGE_FIRST", 1);
     { const char *e = getenv("QUDA_AMD_HALO_FORMAT"); t.halo_format = (e && (!strcmp(e, "sector") || !strcmp(e, "line128") || !strcmp(e, "1"))) ? 1 : 0; }
   }
   return t;
