@@ -54,6 +54,15 @@ Complex caxpyDotzy(const Complex &a, const ColorSpinorField &x, ColorSpinorField
 void caxpbypzYmbw(const Complex &a, const ColorSpinorField &x, const Complex &b, ColorSpinorField &y, ColorSpinorField &z,
                   const ColorSpinorField &w);                                         // z += a x + b y ; y -= b w
 double3_t HeavyQuarkResidualNorm(const ColorSpinorField &x, const ColorSpinorField &r);
+// multi-field forms for the blocked orthogonalisation of GCR (reference lib/inv_gcr_quda.cpp:53-84, :103-121: N dots / N caxpys per pass),
+// k <= 20 fields of fp64 / fp32 (multiSupported):
+//   multiDot:            beta[i] = (f_i, y) for i < k, yr = (y, r), ynorm = |y|^2                       — one sweep
+//   multiCaxpyResidual:  y <- scale (y + sum_i c_i f_i) ; r <- r - a y ; r2 = |r|^2, y2 = |y|^2        — one sweep
+//   multiCaxpy:          y <- y + sum_i c_i f_i
+bool multiSupported(const ColorSpinorField &x, int k);
+void multiDot(Complex *beta, Complex &yr, double &ynorm, const std::vector<ColorSpinorField *> &f, int k, const ColorSpinorField &y, const ColorSpinorField &r);
+void multiCaxpyResidual(double &r2, double &y2, const Complex *c, const std::vector<ColorSpinorField *> &f, int k, double scale, ColorSpinorField &y, const Complex &a, ColorSpinorField &r);
+void multiCaxpy(const Complex *c, const std::vector<ColorSpinorField *> &f, int k, ColorSpinorField &y);
 
 // vectorised forms used by GCR's orthogonalisation / solution update
 void caxpy(const Complex *a, std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorField *> &y);

@@ -48,6 +48,12 @@ constexpr int kP2pErrInts = 16;
 int *p2pErrorWord();
 void p2pCheck(const char *where);
 bool p2pDescribeError(char *text, size_t n);   // false: no error recorded
+// Several ranks of this run sit on ONE device (rehearsals of N ranks on a 1-GPU box).  Their kernels then compete for the same CU slots,
+// and the boundary-first block order of the fused peer-store launch can fill the device with blocks that spin on faces whose senders
+// cannot get a slot any more (4 ranks on one MI355X: reproduced twice, r3_reh4c3_default.log — every record says "previous use", i.e.
+// never written, none shows a foreign flag — while the interior-first order passes, r3_reh4c3_interior_first.log).  launchDslash
+// therefore starts with the interior blocks when this is true.  One process per GPU, the production shape, is not affected.
+bool p2pDeviceShared();
 // counters of this process since initQuda: [0] fine-grid exchanges through peer stores, [1] through the staged (RCCL) transport,
 // [2] / [3] the same for the coarse grids, [4] global sums done inside the reduction kernel (peer windows), [5] through the
 // collective library, [6] fall-backs from peer stores to the staged transport, [7] multi-right-hand-side (block) exchanges

@@ -32,7 +32,7 @@ static double *d_part = nullptr;  // per-block partial sums
 static unsigned *d_count = nullptr;  // completion counter (zero between launches)
 constexpr int kMaxBlocks = 4096;
 constexpr int kMaxRed = 64;
-constexpr int kSlotDoubles = 8;   // doubles per (buffer, rank) slot of the all-reduce window
+constexpr int kSlotDoubles = 48;  // doubles per (buffer, rank) slot of the all-reduce window (the blocked GCR orthogonalisation reduces 2 k + 3 <= 43 sums at once)
 
 // Block-level all-reduce over ranks through the peer windows (called by ONE block per rank, all threads of it).  Thread r
 // delivers this rank's nred sums to rank r with system-scope write-through stores followed by a fire-and-forget counter
@@ -200,7 +200,7 @@ void init() {
     HIP_CHECK(hipHostMalloc((void **)&h_red, kMaxRed * sizeof(double), hipHostMallocMapped));
     HIP_CHECK(hipHostGetDevicePointer((void **)&h_red_dev, h_red, 0));
   }
-  if (!d_part) HIP_CHECK(qaMalloc((void **)&d_part, (size_t)kMaxBlocks * 4 * sizeof(double)));
+  if (!d_part) HIP_CHECK(qaMalloc((void **)&d_part, (size_t)kMaxBlocks * kSlotDoubles * sizeof(double)));
   if (!d_count) {
     HIP_CHECK(qaMalloc((void **)&d_count, sizeof(unsigned)));
     HIP_CHECK(hipMemset(d_count, 0, sizeof(unsigned)));
@@ -355,6 +355,81 @@ struct CaxpbypzYmbwF { double ar, ai, br, bi; QA_FLAGS(1, 1, 1, 1, 0, 1, 1, 0, 0
     }
   } };
 
+// ---- the tail of every reducing kernel: wave shuffles -> LDS -> per-block partial -> the LAST block (completion counter) adds the
+// partials in block order (bit-reproducible), optionally does the all-reduce over ranks through the peer windows, and writes the
+// sums to device and pinned host memory.  NRED sums per thread come in, every thread of the block must call it. ----
+struct RedCtl {
+  double *red, *hred, *part;
+  unsigned *count;
+  double *const *peerSlots;
+  unsigned *const *peerCount;
+  int nranks, rank, buf;
+  unsigned expect;
+  unsigned long long waitTicks;
+};
+template <int NRED> __device__ __forceinline__ void finish_reduction(const double *red, const RedCtl &arg) {
+  __shared__ double lds[4][NRED];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NRED; k++) {
+    double v = red[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) lds[wave][k] = v;
+  }
+  __syncthreads();
+  // block partial -> memory (agent-scope write-through stores: no L2 write-back needed before the counter is bumped)
+  if (threadIdx.x < NRED) {
+    double v = 0;
+    for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) v += lds[wv][threadIdx.x];
+    __hip_atomic_store(&arg.part[(size_t)blockIdx.x * NRED + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __shared__ int isLast;
+  // the partials are sc1 (write-through) stores; the storing wave waits for their acknowledgement BEFORE the barrier, so the
+  // counter bump below cannot overtake them on their way to memory (the last block may sit on another XCD with its own L2);
+  // it then reads them with sc1 loads behind its own barrier — the drained-sc1 hand-off of MI355X_MICROARCH.md
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) isLast = __hip_atomic_fetch_add(arg.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (isLast) {
+    // the last block adds the partials in a fixed order: thread t takes blocks t, t + blockDim, ...; then the block tree
+#pragma unroll 1
+    for (int k = 0; k < NRED; k++) {
+      double v = 0;
+      for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) v += __hip_atomic_load(&arg.part[(size_t)b * NRED + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      __syncthreads();
+      if (lane == 0) lds[wave][k] = v;
+    }
+    __syncthreads();
+    if (arg.peerSlots) {
+      __shared__ double mine[NRED];
+      if (threadIdx.x < NRED) {
+        double v = 0;
+        for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) v += lds[wv][threadIdx.x];
+        mine[threadIdx.x] = v;
+      }
+      __syncthreads();
+      __shared__ int done;
+      const double v = peer_allreduce<NRED>(mine, arg.peerSlots, arg.peerCount, arg.nranks, arg.rank, arg.buf, arg.expect, arg.waitTicks, &done);
+      if (threadIdx.x < NRED) {
+        arg.red[threadIdx.x] = v;
+        __hip_atomic_store(&arg.hred[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      // last word of the host buffer: 1 = the sums above are the global ones, 0 = the host has to finish the reduction
+      if (threadIdx.x == 0) __hip_atomic_store(&arg.hred[kMaxRed - 1], done ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else if (threadIdx.x < NRED) {
+      double v = 0;
+      for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) v += lds[wv][threadIdx.x];
+      arg.red[threadIdx.x] = v;
+      if (arg.hred) __hip_atomic_store(&arg.hred[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(arg.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ---- kernel ----
 template <typename T, int M, bool SITE, typename F>
 __global__ void __launch_bounds__(256) blas_kernel(BlasArg<F> arg) {
@@ -397,68 +472,113 @@ __global__ void __launch_bounds__(256) blas_kernel(BlasArg<F> arg) {
     }
   }
   if (F::nred > 0) {
-    __shared__ double lds[4][F::nred > 0 ? F::nred : 1];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    RedCtl c;
+    c.red = arg.red; c.hred = arg.hred; c.part = arg.part; c.count = arg.count; c.peerSlots = arg.peerSlots; c.peerCount = arg.peerCount;
+    c.nranks = arg.nranks; c.rank = arg.rank; c.buf = arg.buf; c.expect = arg.expect; c.waitTicks = arg.waitTicks;
+    finish_reduction<(F::nred > 0 ? F::nred : 1)>(red, c);
+  }
+}
+
+// ================================================================================================
+// Blocked orthogonalisation of GCR (reference lib/inv_gcr_quda.cpp:53-84, :103-121: its pipelined forms compute N dots in one pass
+// and apply N caxpys in one pass).  Iteration k of GCR has to orthogonalise Ap_k against the k normalised directions before it,
+// normalise it and update the residual.  One direction after the other (modified Gram-Schmidt, solver.cpp orthoDir) that is
+// 4 (k - 1) + 9 field passes; here it is TWO kernels:
+//   multi_dot_kernel      beta_i = (Ap_i, Ap_k) for all i < k, (Ap_k, r) and |Ap_k|^2 in one sweep           (k + 2 reads)
+//   multi_caxpy_kernel    Ap_k <- (Ap_k - sum_i beta_i Ap_i) / gamma ; r <- r - alpha Ap_k ; |r|^2, |Ap_k|^2   (k + 2 reads, 2 writes)
+// with gamma^2 = |Ap_k|^2 - sum |beta_i|^2 and alpha = (Ap_k, r) / gamma between them on the host (classical Gram-Schmidt; the caller
+// falls back to the sequential form when gamma^2 is a small difference of large numbers).  The same second kernel, without the
+// residual part, adds the k search directions to the solution at a restart (updateSolution).  k <= kMaxDirs, fp64 / fp32 fields.
+// ================================================================================================
+constexpr int kMaxDirs = 20;
+struct MultiArg {
+  const void *f[kMaxDirs][2];   // the k fields [i][segment]
+  void *y[2];                   // Ap_k (dots: read; caxpy: read-modify-write) or the solution
+  void *r[2];                   // residual (may be null for the plain multi-caxpy)
+  double cr[kMaxDirs], ci[kMaxDirs];   // coefficients of the fields
+  double scale, ar, ai;         // y <- scale (y + sum c_i f_i) ; r <- r - (ar + i ai) y
+  int k, nseg;
+  long n;
+  RedCtl c;
+};
+template <typename real, int M> __global__ void __launch_bounds__(256) multi_dot_kernel(const MultiArg arg) {
+  constexpr int NRED = 2 * kMaxDirs + 3;
+  double red[NRED];
 #pragma unroll
-    for (int k = 0; k < F::nred; k++) {
-      double v = red[k];
+  for (int q = 0; q < NRED; q++) red[q] = 0.0;
+  using V = Chunk<real, M>;
+  const long total = arg.n * arg.nseg;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int seg = i >= arg.n ? 1 : 0;
+    const long j = i - seg * arg.n;
+    alignas(16) real y[M];
+    alignas(16) real r[M];
+    *reinterpret_cast<V *>(y) = reinterpret_cast<const V *>(arg.y[seg])[j];
+    *reinterpret_cast<V *>(r) = reinterpret_cast<const V *>(arg.r[seg])[j];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-      if (lane == 0) lds[wave][k] = v;
+    for (int e = 0; e < M; e += 2) {
+      const double yr = y[e], yi = y[e + 1], rr = r[e], ri = r[e + 1];
+      red[2 * kMaxDirs] += yr * rr + yi * ri;        // conj(y) r
+      red[2 * kMaxDirs + 1] += yr * ri - yi * rr;
+      red[2 * kMaxDirs + 2] += yr * yr + yi * yi;
     }
-    __syncthreads();
-    // block partial -> memory (agent-scope write-through stores: no L2 write-back needed before the counter is bumped)
-    if (threadIdx.x < F::nred) {
-      double v = 0;
-      for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) v += lds[wv][threadIdx.x];
-      __hip_atomic_store(&arg.part[(size_t)blockIdx.x * F::nred + threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __shared__ int isLast;
-    // the partials are sc1 (write-through) stores; the storing wave waits for their acknowledgement BEFORE the barrier, so the
-    // counter bump below cannot overtake them on their way to memory (the last block may sit on another XCD with its own L2);
-    // it then reads them with sc1 loads behind its own barrier — the drained-sc1 hand-off of MI355X_MICROARCH.md
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) isLast = __hip_atomic_fetch_add(arg.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-    __syncthreads();
-    if (isLast) {
-      // the last block adds the partials in a fixed order: thread t takes blocks t, t + blockDim, ...; then the block tree
 #pragma unroll
-      for (int k = 0; k < F::nred; k++) {
-        double v = 0;
-        for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) v += __hip_atomic_load(&arg.part[(size_t)b * F::nred + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int d = 0; d < kMaxDirs; d++) {
+      if (d < arg.k) {   // uniform
+        alignas(16) real f[M];
+        *reinterpret_cast<V *>(f) = reinterpret_cast<const V *>(arg.f[d][seg])[j];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        __syncthreads();
-        if (lane == 0) lds[wave][k] = v;
-      }
-      __syncthreads();
-      if (arg.peerSlots) {
-        constexpr int NR = F::nred > 0 ? F::nred : 1;
-        __shared__ double mine[NR];
-        if (threadIdx.x < F::nred) {
-          double v = 0;
-          for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) v += lds[wv][threadIdx.x];
-          mine[threadIdx.x] = v;
+        for (int e = 0; e < M; e += 2) {
+          const double fr = f[e], fi = f[e + 1], yr = y[e], yi = y[e + 1];
+          red[2 * d] += fr * yr + fi * yi;             // conj(f) y
+          red[2 * d + 1] += fr * yi - fi * yr;
         }
-        __syncthreads();
-        __shared__ int done;
-        const double v = peer_allreduce<F::nred>(mine, arg.peerSlots, arg.peerCount, arg.nranks, arg.rank, arg.buf, arg.expect, arg.waitTicks, &done);
-        if (threadIdx.x < F::nred) {
-          arg.red[threadIdx.x] = v;
-          __hip_atomic_store(&arg.hred[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        // last word of the host buffer: 1 = the sums above are the global ones, 0 = the host has to finish the reduction
-        if (threadIdx.x == 0) __hip_atomic_store(&arg.hred[kMaxRed - 1], done ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      } else if (threadIdx.x < F::nred) {
-        double v = 0;
-        for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) v += lds[wv][threadIdx.x];
-        arg.red[threadIdx.x] = v;
-        if (arg.hred) __hip_atomic_store(&arg.hred[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
-      if (threadIdx.x == 0) __hip_atomic_store(arg.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  finish_reduction<NRED>(red, arg.c);
+}
+template <typename real, int M, bool RES> __global__ void __launch_bounds__(256) multi_caxpy_kernel(const MultiArg arg) {
+  double red[2] = {0.0, 0.0};
+  using V = Chunk<real, M>;
+  const long total = arg.n * arg.nseg;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int seg = i >= arg.n ? 1 : 0;
+    const long j = i - seg * arg.n;
+    alignas(16) real y[M];
+    *reinterpret_cast<V *>(y) = reinterpret_cast<const V *>(arg.y[seg])[j];
+    // the sum in the field's own precision, as the one-at-a-time caxpys have it
+#pragma unroll
+    for (int d = 0; d < kMaxDirs; d++) {
+      if (d < arg.k) {
+        alignas(16) real f[M];
+        *reinterpret_cast<V *>(f) = reinterpret_cast<const V *>(arg.f[d][seg])[j];
+        const real cr = (real)arg.cr[d], ci = (real)arg.ci[d];
+#pragma unroll
+        for (int e = 0; e < M; e += 2) {
+          y[e] += cr * f[e] - ci * f[e + 1];
+          y[e + 1] += cr * f[e + 1] + ci * f[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < M; e++) y[e] *= (real)arg.scale;
+    reinterpret_cast<V *>(arg.y[seg])[j] = *reinterpret_cast<V *>(y);
+    if (RES) {
+      alignas(16) real r[M];
+      *reinterpret_cast<V *>(r) = reinterpret_cast<const V *>(arg.r[seg])[j];
+      const real ar = (real)arg.ar, ai = (real)arg.ai;
+#pragma unroll
+      for (int e = 0; e < M; e += 2) {
+        r[e] -= ar * y[e] - ai * y[e + 1];
+        r[e + 1] -= ar * y[e + 1] + ai * y[e];
+        red[0] += (double)r[e] * (double)r[e] + (double)r[e + 1] * (double)r[e + 1];
+        red[1] += (double)y[e] * (double)y[e] + (double)y[e + 1] * (double)y[e + 1];
+      }
+      reinterpret_cast<V *>(arg.r[seg])[j] = *reinterpret_cast<V *>(r);
+    }
+  }
+  if (RES) finish_reduction<2>(red, arg.c);
 }
 
 static Seg segOf(const ColorSpinorField &f) {
@@ -551,6 +671,109 @@ static void launch(const F &f, const ColorSpinorField &x, const ColorSpinorField
   const int nrd = F::rx + F::ry + F::rz + F::rw, nwr = F::wx + F::wy + F::wz + F::ww;
   bytes += (unsigned long long)(nrd + nwr) * x.RealLength() * x.Precision();
   flops += (unsigned long long)2 * x.RealLength() * (nrd + nwr);
+}
+
+// ---- host side of the multi-field kernels ----
+bool multiSupported(const ColorSpinorField &x, int k) {
+  static int off = -1;
+  if (off < 0) { const char *e = getenv("QUDA_AMD_GCR_BLOCK_ORTHO"); off = (e && !atoi(e)) ? 1 : 0; }
+  return !off && k >= 0 && k <= kMaxDirs && (x.Precision() == QUDA_DOUBLE_PRECISION || x.Precision() == QUDA_SINGLE_PRECISION) && x.Location() == QUDA_CUDA_FIELD_LOCATION;
+}
+struct RedPlan { bool allreduce, peer; };
+static RedPlan planReduction(RedCtl &c, int nred) {
+  if (!d_red) init();
+  RedPlan p;
+  p.allreduce = g_global_reduction && commReductionsNeeded(); p.peer = false;
+  c.red = d_red; c.part = d_part; c.count = d_count;
+  c.hred = p.allreduce ? nullptr : h_red_dev;
+  c.peerSlots = nullptr; c.peerCount = nullptr; c.nranks = 1; c.rank = 0; c.buf = 0; c.expect = 0; c.waitTicks = 0;
+  if (p.allreduce && nred <= kSlotDoubles && reduceWindowActive()) {
+    const CommGrid &cg = commGrid();
+    c.peerSlots = g_rw.d_slots; c.peerCount = g_rw.d_counts;
+    c.nranks = cg.size; c.rank = cg.rank;
+    c.buf = (int)(++g_rw.seq & 1);
+    c.expect = (g_rw.uses[c.buf] += (unsigned)cg.size);
+    c.waitTicks = 2000000ull;
+    c.hred = h_red_dev;
+    p.allreduce = false; p.peer = true;
+    p2pStats()[4]++;
+  } else if (p.allreduce) p2pStats()[5]++;
+  return p;
+}
+static void finishPlan(const RedPlan &p, const RedCtl &c, int nred, double *out, hipStream_t s) {
+  if (p.allreduce) {
+    commAllreduceDevice(d_red, nred, s);
+    HIP_CHECK(hipMemcpyAsync(h_red, d_red, nred * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  HIP_CHECK(hipStreamSynchronize(s));
+  if (p.peer && h_red[kMaxRed - 1] == 0.0) finishAllreduceOnHost(c.buf, c.expect, nred, h_red);
+  for (int k = 0; k < nred; k++) out[k] = h_red[k];
+}
+static int multiGrid(long chunks) {
+  static int cap = 0;
+  if (!cap) { const char *e = getenv("QUDA_AMD_BLAS_BLOCKS"); cap = e ? atoi(e) : 512; if (cap < 1 || cap > kMaxBlocks) cap = 512; }
+  const long b = (chunks + 255) / 256;
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+static void fillMulti(MultiArg &a, const std::vector<ColorSpinorField *> &f, int k, const ColorSpinorField &y, const ColorSpinorField *r) {
+  if (!multiSupported(y, k)) errorQuda("multi-field blas: %d fields of precision %d not supported", k, y.Precision());
+  if ((int)f.size() < k) errorQuda("multi-field blas: %zu fields given, %d wanted", f.size(), k);
+  const Seg sy = segOf(y);
+  a.y[0] = sy.v[0]; a.y[1] = sy.v[1];
+  a.r[0] = a.r[1] = nullptr;
+  if (r) { checkSame(y, *r); const Seg sr = segOf(*r); a.r[0] = sr.v[0]; a.r[1] = sr.v[1]; }
+  for (int i = 0; i < kMaxDirs; i++) { a.f[i][0] = a.f[i][1] = nullptr; a.cr[i] = a.ci[i] = 0.0; }
+  for (int i = 0; i < k; i++) { checkSame(y, *f[i]); const Seg sf = segOf(*f[i]); a.f[i][0] = sf.v[0]; a.f[i][1] = sf.v[1]; }
+  a.k = k; a.nseg = y.SiteSubset() == QUDA_FULL_SITE_SUBSET ? 2 : 1;
+  const long nreal = (long)y.Stride() * y.Nspin() * y.Ncolor() * 2;
+  a.n = y.Precision() == QUDA_DOUBLE_PRECISION ? nreal / 2 : nreal / 4;
+  if (y.Precision() == QUDA_SINGLE_PRECISION && nreal % 4) errorQuda("field length %ld not a multiple of 4", nreal);
+  a.scale = 1.0; a.ar = a.ai = 0.0;
+}
+void multiDot(Complex *beta, Complex &yr, double &ynorm, const std::vector<ColorSpinorField *> &f, int k, const ColorSpinorField &y, const ColorSpinorField &r) {
+  constexpr int NRED = 2 * kMaxDirs + 3;
+  MultiArg a;
+  fillMulti(a, f, k, y, &r);
+  const RedPlan p = planReduction(a.c, NRED);
+  hipStream_t s = computeStream();
+  if (y.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((multi_dot_kernel<double, 2>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((multi_dot_kernel<float, 4>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a);
+  HIP_CHECK(hipGetLastError());
+  double out[NRED];
+  finishPlan(p, a.c, NRED, out, s);
+  for (int i = 0; i < k; i++) beta[i] = Complex(out[2 * i], out[2 * i + 1]);
+  yr = Complex(out[2 * kMaxDirs], out[2 * kMaxDirs + 1]);
+  ynorm = out[2 * kMaxDirs + 2];
+  bytes += (unsigned long long)(k + 2) * y.RealLength() * y.Precision();
+  flops += (unsigned long long)(8 * k + 12) * (y.RealLength() / 2);
+}
+void multiCaxpyResidual(double &r2, double &y2, const Complex *c, const std::vector<ColorSpinorField *> &f, int k, double scale, ColorSpinorField &y, const Complex &a_, ColorSpinorField &r) {
+  MultiArg a;
+  fillMulti(a, f, k, y, &r);
+  for (int i = 0; i < k; i++) { a.cr[i] = c[i].real(); a.ci[i] = c[i].imag(); }
+  a.scale = scale; a.ar = a_.real(); a.ai = a_.imag();
+  const RedPlan p = planReduction(a.c, 2);
+  hipStream_t s = computeStream();
+  if (y.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((multi_caxpy_kernel<double, 2, true>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((multi_caxpy_kernel<float, 4, true>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a);
+  HIP_CHECK(hipGetLastError());
+  double out[2];
+  finishPlan(p, a.c, 2, out, s);
+  r2 = out[0]; y2 = out[1];
+  bytes += (unsigned long long)(k + 4) * y.RealLength() * y.Precision();
+  flops += (unsigned long long)(8 * k + 16) * (y.RealLength() / 2);
+}
+void multiCaxpy(const Complex *c, const std::vector<ColorSpinorField *> &f, int k, ColorSpinorField &y) {
+  MultiArg a;
+  fillMulti(a, f, k, y, nullptr);
+  for (int i = 0; i < k; i++) { a.cr[i] = c[i].real(); a.ci[i] = c[i].imag(); }
+  memset(&a.c, 0, sizeof(a.c));
+  hipStream_t s = computeStream();
+  if (y.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((multi_caxpy_kernel<double, 2, false>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((multi_caxpy_kernel<float, 4, false>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a);
+  HIP_CHECK(hipGetLastError());
+  bytes += (unsigned long long)(k + 2) * y.RealLength() * y.Precision();
+  flops += (unsigned long long)(8 * k) * (y.RealLength() / 2);
 }
 
 void zero(ColorSpinorField &a) { a.zero(); }

@@ -1733,7 +1733,7 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
     }
     pa.start[8] = nt;
     arg.waitTicks = p2pTimeoutTicks(); arg.errWord = p2pErrorWord();
-    arg.siteDelay = tune.site_delay; arg.packPrio = tune.pack_prio; arg.edgeFirst = tune.edge_first;
+    arg.siteDelay = tune.site_delay; arg.packPrio = tune.pack_prio; arg.edgeFirst = p2pDeviceShared() ? 0 : tune.edge_first;   // ranks sharing a device: interior blocks first (p2p.h)
     // Full pack blocks (256 face sites each) in front of the grid.  They share CUs with site blocks, and the placement statistics of
     // the timeline show what that costs on the 8-GPU sub-lattice: a site block next to a pack block ends 4.3 us later than one
     // that has its CU to itself.  Spreading the packing thinly (one 96-thread pack block on EVERY CU) is far worse — 46 us

@@ -205,8 +205,11 @@ __global__ void p2p_probe_recv(ProbeWindow *mine, const int *fromRank, unsigned 
 // across processes with different visibility masks); a peer that is visible here must be peer-accessible, and access is switched on
 // up front rather than left to the lazy path of hipIpcOpenMemHandle — a kernel touching a window that is not reachable would
 // fault, and a fault cannot be caught and turned into a fall-back.  Ranks on the same device (rehearsals) need nothing.
+static bool g_deviceShared = false;
+bool p2pDeviceShared() { return g_deviceShared; }
 static bool peersReachable() {
   const CommGrid &g = commGrid();
+  g_deviceShared = false;
   if (g.size == 1) return true;
   int dev = 0;
   HIP_CHECK(hipGetDevice(&dev));
@@ -221,7 +224,7 @@ static bool peersReachable() {
     const char *bus = &all[(size_t)r * 64];
     int peer = -1;
     if (!bus[0] || hipDeviceGetByPCIBusId(&peer, bus) != hipSuccess) { (void)hipGetLastError(); continue; }   // not visible here: leave it to the IPC mapping
-    if (peer == dev) continue;
+    if (peer == dev) { g_deviceShared = true; continue; }   // another rank on this very device (rehearsals): see p2pDeviceShared
     int can = 0;
     if (hipDeviceCanAccessPeer(&can, dev, peer) != hipSuccess) { (void)hipGetLastError(); can = 0; }
     if (!can) { fail = 1; break; }
@@ -230,6 +233,7 @@ static bool peersReachable() {
     (void)hipGetLastError();
   }
   comm_allreduce(&fail, 1);
+  { double sh = g_deviceShared ? 1.0 : 0.0; comm_allreduce_max(&sh, 1); g_deviceShared = sh != 0.0; }   // the same answer on every rank
   return fail == 0;
 }
 
