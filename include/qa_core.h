@@ -93,6 +93,14 @@ CommGrid &commGrid();
 // trim its memory pool (measured inside invertQuda); the reference has the same kind of pool (lib/malloc.cpp pool_device_malloc).
 // Blocks return to the cache on free and are handed out again to the next request of the same size — safe because every user
 // works in compute-stream order.  Emptied by endQuda.
+// Launch accounting for profile post-processing (tools/mg_solve_profile.py): while switched on, every instrumented launch site appends
+// (kernel base name as rocprofv3 prints it, ALGORITHMIC bytes of this launch, a tag: level / precision) to a list; the i-th record of a
+// name belongs to the i-th dispatch of that name in the kernel trace.  Off by default (one branch per launch).
+extern bool g_acctOn;
+void acctRecord(const char *kernel, double bytes, const char *tag);
+inline void acct(const char *kernel, double bytes, const char *tag = "") { if (g_acctOn) acctRecord(kernel, bytes, tag); }
+void acctStart();
+void acctDump(const char *path);   // JSON: [{"kernel":..., "bytes":..., "tag":...}, ...] in launch order; switches the accounting off
 void *poolDeviceMalloc(size_t bytes);
 // hipMalloc that hands the parked pool buffers back and tries once more when the device is out of memory
 hipError_t qaMallocRaw(void **p, size_t bytes);

@@ -101,6 +101,11 @@ void qudaAmdCommStats(long long out[8]);
 /* text of the device error record of a halo wait that ran out (dimension, direction, buffer, exchange number, expected and last-seen
  * flag, interpretation); returns 0 if none is recorded */
 int qudaAmdDescribeHaloError(char *text, int n);
+/* profile post-processing: a one-wave marker dispatch (kernel qa_profile_marker_kernel) that brackets a region of the rocprofv3 kernel
+ * trace, and the launch accounting — between Start and Dump every instrumented launch is recorded with its ALGORITHMIC bytes */
+void qudaAmdProfileMarker(int id);
+void qudaAmdAccountStart(void);
+void qudaAmdAccountDump(const char *path);
 void qudaAmdSetExitLine(const char *text, int status);
 double qudaAmdMultigridTimeApply(void *mg_instance, int level, int niter);
 /* seconds per application of the restrictor (what = 0) or prolongator (what = 1) between `level` and `level + 1` */

@@ -119,7 +119,7 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
                  "qudaAmdMultigridVerify", "qudaAmdMultigridCycle", "qudaAmdTimeAxpy", "qudaAmdMultigridLevels", "qudaAmdMultigridLevelInfo",
                  "qudaAmdMultigridSetHalfStorage", "qudaAmdMultigridGetNullVector", "qudaAmdMultigridGetV", "qudaAmdMultigridGetCoarseLinks", "qudaAmdMultigridApply", "qudaAmdMultigridApplyBlock",
                  "qudaAmdMultigridTimeApply", "qudaAmdMultigridTimeTransfer", "qudaAmdSetExitLine", "qudaAmdDiracPrepare", "qudaAmdDiracReconstruct", "qudaAmdSpinorRawInfo", "qudaAmdGaugeRawInfo", "qudaAmdCloverRawInfo", "qudaAmdRawDeviceCopy",
-                 "qudaAmdSetSolutionSink", "qudaAmdCommStats", "qudaAmdDescribeHaloError", "qudaAmdMultigridOrthoFallbackBlocks"]
+                 "qudaAmdSetSolutionSink", "qudaAmdCommStats", "qudaAmdDescribeHaloError", "qudaAmdMultigridOrthoFallbackBlocks", "qudaAmdProfileMarker", "qudaAmdAccountStart", "qudaAmdAccountDump"]
 
 _lib = None
 
@@ -194,6 +194,8 @@ def lib():
         L.qudaAmdMultigridSetHalfStorage.argtypes = [_p, _i]
         L.qudaAmdMultigridLevels.argtypes = [_p]
         L.qudaAmdMultigridOrthoFallbackBlocks.argtypes = [_p, _i]
+        L.qudaAmdProfileMarker.argtypes = [_i]
+        L.qudaAmdAccountDump.argtypes = [C.c_char_p]
         L.qudaAmdCommStats.argtypes = [C.POINTER(C.c_longlong)]
         L.qudaAmdDescribeHaloError.argtypes = [C.c_char_p, _i]
         L.qudaAmdMultigridLevelInfo.argtypes = [_p, _i, C.POINTER(_i)]

@@ -501,81 +501,82 @@ struct MultiArg {
   long n;
   RedCtl c;
 };
-template <typename real, int M> __global__ void __launch_bounds__(256) multi_dot_kernel(const MultiArg arg) {
+// KB: compile-time bucket >= k (4, 8, 12, 16, 20): the loads of all KB fields of a chunk are issued back to back, without a branch between
+// them (a per-field `if (d < k)` made every load its own basic block: load, wait, use — twenty dependent latencies per chunk); the
+// surplus slots point at field 0 again and carry a zero coefficient / an ignored sum
+template <typename real, int M, int KB> __global__ void __launch_bounds__(256) multi_dot_kernel(const MultiArg arg) {
   constexpr int NRED = 2 * kMaxDirs + 3;
-  double red[NRED];
+  double red[2 * KB + 3];
 #pragma unroll
-  for (int q = 0; q < NRED; q++) red[q] = 0.0;
+  for (int q = 0; q < 2 * KB + 3; q++) red[q] = 0.0;
   using V = Chunk<real, M>;
   const long total = arg.n * arg.nseg;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int seg = i >= arg.n ? 1 : 0;
     const long j = i - seg * arg.n;
-    alignas(16) real y[M];
-    alignas(16) real r[M];
-    *reinterpret_cast<V *>(y) = reinterpret_cast<const V *>(arg.y[seg])[j];
-    *reinterpret_cast<V *>(r) = reinterpret_cast<const V *>(arg.r[seg])[j];
+    V y, r, f[KB];
+    y = reinterpret_cast<const V *>(arg.y[seg])[j];
+    r = reinterpret_cast<const V *>(arg.r[seg])[j];
+#pragma unroll
+    for (int d = 0; d < KB; d++) f[d] = reinterpret_cast<const V *>(arg.f[d][seg])[j];
 #pragma unroll
     for (int e = 0; e < M; e += 2) {
-      const double yr = y[e], yi = y[e + 1], rr = r[e], ri = r[e + 1];
-      red[2 * kMaxDirs] += yr * rr + yi * ri;        // conj(y) r
-      red[2 * kMaxDirs + 1] += yr * ri - yi * rr;
-      red[2 * kMaxDirs + 2] += yr * yr + yi * yi;
-    }
+      const double yr = y.v[e], yi = y.v[e + 1], rr = r.v[e], ri = r.v[e + 1];
+      red[2 * KB] += yr * rr + yi * ri;        // conj(y) r
+      red[2 * KB + 1] += yr * ri - yi * rr;
+      red[2 * KB + 2] += yr * yr + yi * yi;
 #pragma unroll
-    for (int d = 0; d < kMaxDirs; d++) {
-      if (d < arg.k) {   // uniform
-        alignas(16) real f[M];
-        *reinterpret_cast<V *>(f) = reinterpret_cast<const V *>(arg.f[d][seg])[j];
-#pragma unroll
-        for (int e = 0; e < M; e += 2) {
-          const double fr = f[e], fi = f[e + 1], yr = y[e], yi = y[e + 1];
-          red[2 * d] += fr * yr + fi * yi;             // conj(f) y
-          red[2 * d + 1] += fr * yi - fi * yr;
-        }
+      for (int d = 0; d < KB; d++) {
+        const double fr = f[d].v[e], fi = f[d].v[e + 1];
+        red[2 * d] += fr * yr + fi * yi;             // conj(f) y
+        red[2 * d + 1] += fr * yi - fi * yr;
       }
     }
   }
-  finish_reduction<NRED>(red, arg.c);
+  double full[NRED];
+#pragma unroll
+  for (int q = 0; q < NRED; q++) full[q] = 0.0;
+#pragma unroll
+  for (int q = 0; q < 2 * KB; q++) full[q] = red[q];
+  full[2 * kMaxDirs] = red[2 * KB]; full[2 * kMaxDirs + 1] = red[2 * KB + 1]; full[2 * kMaxDirs + 2] = red[2 * KB + 2];
+  finish_reduction<NRED>(full, arg.c);
 }
-template <typename real, int M, bool RES> __global__ void __launch_bounds__(256) multi_caxpy_kernel(const MultiArg arg) {
+template <typename real, int M, bool RES, int KB> __global__ void __launch_bounds__(256) multi_caxpy_kernel(const MultiArg arg) {
   double red[2] = {0.0, 0.0};
   using V = Chunk<real, M>;
   const long total = arg.n * arg.nseg;
+  real cr[KB], ci[KB];
+#pragma unroll
+  for (int d = 0; d < KB; d++) { cr[d] = (real)arg.cr[d]; ci[d] = (real)arg.ci[d]; }
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int seg = i >= arg.n ? 1 : 0;
     const long j = i - seg * arg.n;
-    alignas(16) real y[M];
-    *reinterpret_cast<V *>(y) = reinterpret_cast<const V *>(arg.y[seg])[j];
+    V y, r, f[KB];
+    y = reinterpret_cast<const V *>(arg.y[seg])[j];
+    if (RES) r = reinterpret_cast<const V *>(arg.r[seg])[j];
+#pragma unroll
+    for (int d = 0; d < KB; d++) f[d] = reinterpret_cast<const V *>(arg.f[d][seg])[j];
     // the sum in the field's own precision, as the one-at-a-time caxpys have it
 #pragma unroll
-    for (int d = 0; d < kMaxDirs; d++) {
-      if (d < arg.k) {
-        alignas(16) real f[M];
-        *reinterpret_cast<V *>(f) = reinterpret_cast<const V *>(arg.f[d][seg])[j];
-        const real cr = (real)arg.cr[d], ci = (real)arg.ci[d];
+    for (int d = 0; d < KB; d++)
 #pragma unroll
-        for (int e = 0; e < M; e += 2) {
-          y[e] += cr * f[e] - ci * f[e + 1];
-          y[e + 1] += cr * f[e + 1] + ci * f[e];
-        }
+      for (int e = 0; e < M; e += 2) {
+        y.v[e] += cr[d] * f[d].v[e] - ci[d] * f[d].v[e + 1];
+        y.v[e + 1] += cr[d] * f[d].v[e + 1] + ci[d] * f[d].v[e];
       }
-    }
 #pragma unroll
-    for (int e = 0; e < M; e++) y[e] *= (real)arg.scale;
-    reinterpret_cast<V *>(arg.y[seg])[j] = *reinterpret_cast<V *>(y);
+    for (int e = 0; e < M; e++) y.v[e] *= (real)arg.scale;
+    reinterpret_cast<V *>(arg.y[seg])[j] = y;
     if (RES) {
-      alignas(16) real r[M];
-      *reinterpret_cast<V *>(r) = reinterpret_cast<const V *>(arg.r[seg])[j];
       const real ar = (real)arg.ar, ai = (real)arg.ai;
 #pragma unroll
       for (int e = 0; e < M; e += 2) {
-        r[e] -= ar * y[e] - ai * y[e + 1];
-        r[e + 1] -= ar * y[e + 1] + ai * y[e];
-        red[0] += (double)r[e] * (double)r[e] + (double)r[e + 1] * (double)r[e + 1];
-        red[1] += (double)y[e] * (double)y[e] + (double)y[e + 1] * (double)y[e + 1];
+        r.v[e] -= ar * y.v[e] - ai * y.v[e + 1];
+        r.v[e + 1] -= ar * y.v[e + 1] + ai * y.v[e];
+        red[0] += (double)r.v[e] * (double)r.v[e] + (double)r.v[e + 1] * (double)r.v[e + 1];
+        red[1] += (double)y.v[e] * (double)y.v[e] + (double)y.v[e + 1] * (double)y.v[e + 1];
       }
-      reinterpret_cast<V *>(arg.r[seg])[j] = *reinterpret_cast<V *>(r);
+      reinterpret_cast<V *>(arg.r[seg])[j] = r;
     }
   }
   if (RES) finish_reduction<2>(red, arg.c);
@@ -669,6 +670,7 @@ static void launch(const F &f, const ColorSpinorField &x, const ColorSpinorField
     for (int k = 0; k < F::nred; k++) out[k] = h_red[k];
   }
   const int nrd = F::rx + F::ry + F::rz + F::rw, nwr = F::wx + F::wy + F::wz + F::ww;
+  if (g_acctOn) { char tag[48]; snprintf(tag, sizeof(tag), "%s prec %d", x.Nspin() == 4 ? "level 0" : "coarse", (int)x.Precision()); acct("blas_kernel", (double)(nrd + nwr) * x.RealLength() * x.Precision(), tag); }
   bytes += (unsigned long long)(nrd + nwr) * x.RealLength() * x.Precision();
   flops += (unsigned long long)2 * x.RealLength() * (nrd + nwr);
 }
@@ -724,6 +726,9 @@ static void fillMulti(MultiArg &a, const std::vector<ColorSpinorField *> &f, int
   if (r) { checkSame(y, *r); const Seg sr = segOf(*r); a.r[0] = sr.v[0]; a.r[1] = sr.v[1]; }
   for (int i = 0; i < kMaxDirs; i++) { a.f[i][0] = a.f[i][1] = nullptr; a.cr[i] = a.ci[i] = 0.0; }
   for (int i = 0; i < k; i++) { checkSame(y, *f[i]); const Seg sf = segOf(*f[i]); a.f[i][0] = sf.v[0]; a.f[i][1] = sf.v[1]; }
+  // surplus slots of the kernel's bucket (multiple of 4 >= k): a valid field again — y itself where there is none — with a zero
+  // coefficient / an ignored sum
+  for (int i = k; i < kMaxDirs; i++) { a.f[i][0] = k ? a.f[0][0] : a.y[0]; a.f[i][1] = k ? a.f[0][1] : a.y[1]; }
   a.k = k; a.nseg = y.SiteSubset() == QUDA_FULL_SITE_SUBSET ? 2 : 1;
   const long nreal = (long)y.Stride() * y.Nspin() * y.Ncolor() * 2;
   a.n = y.Precision() == QUDA_DOUBLE_PRECISION ? nreal / 2 : nreal / 4;
@@ -736,14 +741,17 @@ void multiDot(Complex *beta, Complex &yr, double &ynorm, const std::vector<Color
   fillMulti(a, f, k, y, &r);
   const RedPlan p = planReduction(a.c, NRED);
   hipStream_t s = computeStream();
-  if (y.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((multi_dot_kernel<double, 2>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((multi_dot_kernel<float, 4>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a);
+#define QA_MD(KB) { if (y.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((multi_dot_kernel<double, 2, KB>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a); \
+                   else hipLaunchKernelGGL((multi_dot_kernel<float, 4, KB>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a); }
+  if (k <= 4) QA_MD(4) else if (k <= 8) QA_MD(8) else if (k <= 12) QA_MD(12) else if (k <= 16) QA_MD(16) else QA_MD(20)
+#undef QA_MD
   HIP_CHECK(hipGetLastError());
   double out[NRED];
   finishPlan(p, a.c, NRED, out, s);
   for (int i = 0; i < k; i++) beta[i] = Complex(out[2 * i], out[2 * i + 1]);
   yr = Complex(out[2 * kMaxDirs], out[2 * kMaxDirs + 1]);
   ynorm = out[2 * kMaxDirs + 2];
+  acct("multi_dot_kernel", (double)(k + 2) * y.RealLength() * y.Precision(), y.Nspin() == 4 ? "level 0" : "coarse");
   bytes += (unsigned long long)(k + 2) * y.RealLength() * y.Precision();
   flops += (unsigned long long)(8 * k + 12) * (y.RealLength() / 2);
 }
@@ -754,12 +762,15 @@ void multiCaxpyResidual(double &r2, double &y2, const Complex *c, const std::vec
   a.scale = scale; a.ar = a_.real(); a.ai = a_.imag();
   const RedPlan p = planReduction(a.c, 2);
   hipStream_t s = computeStream();
-  if (y.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((multi_caxpy_kernel<double, 2, true>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((multi_caxpy_kernel<float, 4, true>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a);
+#define QA_MC(KB) { if (y.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((multi_caxpy_kernel<double, 2, true, KB>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a); \
+                   else hipLaunchKernelGGL((multi_caxpy_kernel<float, 4, true, KB>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a); }
+  if (k <= 4) QA_MC(4) else if (k <= 8) QA_MC(8) else if (k <= 12) QA_MC(12) else if (k <= 16) QA_MC(16) else QA_MC(20)
+#undef QA_MC
   HIP_CHECK(hipGetLastError());
   double out[2];
   finishPlan(p, a.c, 2, out, s);
   r2 = out[0]; y2 = out[1];
+  acct("multi_caxpy_kernel", (double)(k + 4) * y.RealLength() * y.Precision(), y.Nspin() == 4 ? "level 0" : "coarse");
   bytes += (unsigned long long)(k + 4) * y.RealLength() * y.Precision();
   flops += (unsigned long long)(8 * k + 16) * (y.RealLength() / 2);
 }
@@ -769,9 +780,12 @@ void multiCaxpy(const Complex *c, const std::vector<ColorSpinorField *> &f, int 
   for (int i = 0; i < k; i++) { a.cr[i] = c[i].real(); a.ci[i] = c[i].imag(); }
   memset(&a.c, 0, sizeof(a.c));
   hipStream_t s = computeStream();
-  if (y.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((multi_caxpy_kernel<double, 2, false>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((multi_caxpy_kernel<float, 4, false>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a);
+#define QA_MC(KB) { if (y.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((multi_caxpy_kernel<double, 2, false, KB>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a); \
+                   else hipLaunchKernelGGL((multi_caxpy_kernel<float, 4, false, KB>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a); }
+  if (k <= 4) QA_MC(4) else if (k <= 8) QA_MC(8) else if (k <= 12) QA_MC(12) else if (k <= 16) QA_MC(16) else QA_MC(20)
+#undef QA_MC
   HIP_CHECK(hipGetLastError());
+  acct("multi_caxpy_kernel", (double)(k + 2) * y.RealLength() * y.Precision(), y.Nspin() == 4 ? "level 0" : "coarse");
   bytes += (unsigned long long)(k + 2) * y.RealLength() * y.Precision();
   flops += (unsigned long long)(8 * k) * (y.RealLength() / 2);
 }

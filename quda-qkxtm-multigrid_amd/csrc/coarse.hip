@@ -418,6 +418,14 @@ void applyCoarse(ColorSpinorField &out, const ColorSpinorField &in, const Coarse
   arg.G = half ? (const void *)G.data_h : (const void *)G.data;
   for (int d = 0; d < 4; d++) arg.Xc[d] = G.Xc[d];
   arg.n = G.n; arg.mmask = mmask; arg.parity = parity;
+  if (g_acctOn) {
+    // links of the matrices in the mask (once per work site) + one input vector per matrix (ideal re-use: each vector once) + output
+    int nm = 0;
+    for (int m = 0; m < 9; m++) nm += (mmask >> m) & 1;
+    char tag[64];
+    snprintf(tag, sizeof(tag), "coarse %dx%dx%dx%d n %d mask 0x%x%s", G.Xc[0], G.Xc[1], G.Xc[2], G.Xc[3], G.n, mmask, half ? " fp16 links" : "");
+    acct("coarse_apply_kernel", (double)arg.nwork * ((double)nm * G.n * G.n * (half ? 4 : 8) + 2.0 * G.n * 8), tag);
+  }
   exchangeCoarseGhost(arg, G, parity < 0 ? -1 : 1 - parity);
   if (half) hipLaunchKernelGGL((coarse_apply_kernel<64, true>), dim3(arg.nwork), dim3(256), 0, computeStream(), arg);
   else hipLaunchKernelGGL((coarse_apply_kernel<64, false>), dim3(arg.nwork), dim3(256), 0, computeStream(), arg);

@@ -1869,6 +1869,11 @@ void applyDslash(ColorSpinorField &out, const ColorSpinorField &in, const GaugeF
   if (in.V() == out.V()) errorQuda("in and out must not alias");
   if (in.Nspin() != 4 || in.Ncolor() != 3) errorQuda("fine-grid dslash needs nSpin=4 nColor=3");
   if (p.clover && p.clover->precision != in.Precision()) errorQuda("clover precision mismatch");
+  if (g_acctOn) {   // one dslash_kernel launch on an unpartitioned lattice (the case the profile tool measures)
+    char tag[48];
+    snprintf(tag, sizeof(tag), "level 0 prec %d mode %d%s", (int)in.Precision(), (int)p.mode, p.x ? " xpay" : "");
+    acct("dslash_kernel", (double)dslashBytesPerSite(in.Precision(), (int)U.reconstruct, p.mode, p.x != nullptr) * in.VolumeCB(), tag);
+  }
   switch (in.Precision()) {
     case QUDA_DOUBLE_PRECISION: dispatchRecon<double>(out, in, U, p); break;
     case QUDA_SINGLE_PRECISION: dispatchRecon<float>(out, in, U, p); break;
@@ -2061,6 +2066,10 @@ void applySite(ColorSpinorField &out, const ColorSpinorField &in, SiteOp op, dou
   if (in.Precision() != out.Precision()) errorQuda("precision mismatch");
   if (in.SiteSubset() != QUDA_PARITY_SITE_SUBSET) errorQuda("parity fields required");
   if (clover && clover->precision != in.Precision()) errorQuda("clover precision mismatch");
+  if (g_acctOn) {
+    const double P = in.Precision();
+    acct("site_kernel", (48 * P + (op == SITE_TWIST ? 0 : (op == SITE_CLOVER_TWIST_INV ? 144 : 72) * P)) * in.VolumeCB(), "level 0");
+  }
   switch (in.Precision()) {
     case QUDA_DOUBLE_PRECISION: launchSite<double>(out, in, op, a, b, clover, parity, inverse); break;
     case QUDA_SINGLE_PRECISION: launchSite<float>(out, in, op, a, b, clover, parity, inverse); break;

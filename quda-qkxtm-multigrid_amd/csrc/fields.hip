@@ -294,6 +294,7 @@ template <typename TDev, typename THost> static void d2hParity(ColorSpinorField 
 
 template <typename TOut, typename TIn> static void d2dParity(ColorSpinorField &dst, const ColorSpinorField &src) {
   const int Vh = src.VolumeCB(), bs = 256, nb = (Vh + bs - 1) / bs;
+  acct(src.nSpin == 4 && src.nColor == 3 ? "spinor_d2d_kernel" : "generic_d2d_kernel", (double)Vh * src.nSpin * src.nColor * 2 * (sizeof(TOut) + sizeof(TIn)), src.nSpin == 4 ? "level 0" : "coarse");
   if (src.nSpin == 4 && src.nColor == 3) {
     hipLaunchKernelGGL((spinor_d2d_kernel<TOut, TIn>), dim3(nb), dim3(bs), 0, computeStream(), dst.V(), (float *)dst.Norm(), dst.Stride(), src.V(),
                        (const float *)src.Norm(), src.Stride(), Vh);

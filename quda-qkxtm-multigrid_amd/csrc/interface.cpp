@@ -615,6 +615,12 @@ void qudaAmdSetPartitionMask(int mask) {
 }
 void *qudaAmdComputeStream(void) { return (void *)computeStream(); }
 int qudaAmdHaloTransport(void) { return p2pTransport(); }
+// profile post-processing (tools/mg_solve_profile.py): a marker dispatch that brackets a region in the rocprofv3 kernel trace, and the
+// launch accounting of qa_core.h
+__global__ void qa_profile_marker_kernel(int id, int *sink) { if (sink && id < 0) *sink = id; }
+void qudaAmdProfileMarker(int id) { hipLaunchKernelGGL(qa_profile_marker_kernel, dim3(1), dim3(64), 0, computeStream(), id, (int *)nullptr); HIP_CHECK(hipGetLastError()); }
+void qudaAmdAccountStart(void) { acctStart(); }
+void qudaAmdAccountDump(const char *path) { acctDump(path); }
 void qudaAmdCommStats(long long out[8]) { for (int k = 0; k < 8; k++) out[k] = p2pStats()[k]; }
 int qudaAmdDescribeHaloError(char *text, int n) { return p2pDescribeError(text, (size_t)n) ? 1 : 0; }
 // text written to stdout (and exit status used) if a library error ends the process; nullptr clears (quda_amd_ext.h)

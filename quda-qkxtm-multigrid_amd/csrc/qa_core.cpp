@@ -107,6 +107,23 @@ void destroyStreams() {
 hipStream_t computeStream() { return g_compute; }
 hipStream_t commStream() { return g_comm; }
 
+bool g_acctOn = false;
+struct AcctRec { std::string kernel, tag; double bytes; };
+static std::vector<AcctRec> g_acct;
+void acctRecord(const char *kernel, double bytes, const char *tag) { g_acct.push_back({kernel, tag ? tag : "", bytes}); }
+void acctStart() { g_acct.clear(); g_acctOn = true; }
+void acctDump(const char *path) {
+  g_acctOn = false;
+  FILE *f = fopen(path, "w");
+  if (!f) errorQuda("cannot write %s", path);
+  fprintf(f, "[\n");
+  for (size_t i = 0; i < g_acct.size(); i++)
+    fprintf(f, " {\"kernel\": \"%s\", \"bytes\": %.0f, \"tag\": \"%s\"}%s\n", g_acct[i].kernel.c_str(), g_acct[i].bytes, g_acct[i].tag.c_str(), i + 1 < g_acct.size() ? "," : "");
+  fprintf(f, "]\n");
+  fclose(f);
+  g_acct.clear();
+}
+
 static std::map<size_t, std::vector<void *>> g_pool;
 
 void *poolDeviceMalloc(size_t bytes) {

@@ -968,6 +968,11 @@ void Transfer::R(ColorSpinorField &coarse, const ColorSpinorField &fine, int dir
   else if (small) hipLaunchKernelGGL((restrict_small_kernel<NSF, NCF, NVEC, NV, false, false>), dim3(nAgg), dim3(512), 0, computeStream(), out, out, in, (const void *)V, block_to_fine, blockVol, gs, spin_bs, m); \
   else if (half) hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, false, true>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out, in, (const void *)V_h, block_to_fine, blockVol, spin_bs, m, aggMapOf(*this)); \
   else hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, false, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out, in, (const void *)V, block_to_fine, blockVol, spin_bs, m, aggMapOf(*this))
+  if (g_acctOn) {   // V once (fp32 or its fp16 mirror; a single-parity source touches half of it) + fine vector + coarse vector
+    const double frac = sub ? 0.5 : 1.0;
+    char tag[48]; snprintf(tag, sizeof(tag), "level %s -> coarse%s", fineSpin == 4 ? "0" : "c", half ? " fp16 V" : "");
+    acct(small ? "restrict_small_kernel" : "restrict_kernel", frac * fineVol * ((double)fineSpin * fineColor * Nvec * (half ? 4 : 8) + fineSpin * fineColor * 8.0) + (double)nAgg * 2 * Nvec * 8, tag);
+  }
   QA_TRANSFER_DISPATCH(QA_R)
 #undef QA_R
   HIP_CHECK(hipGetLastError());
@@ -1013,6 +1018,11 @@ void Transfer::P(ColorSpinorField &fine, const ColorSpinorField &coarse) const {
   else if (half) hipLaunchKernelGGL((prolong_kernel<NSF, NCF, NVEC, NV, true>), dim3(nAgg), dim3(threads), 0, computeStream(), out, in, (const void *)V_h, block_to_fine, blockVol, spin_bs, amap); \
   else hipLaunchKernelGGL((prolong_kernel<NSF, NCF, NVEC, NV, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, in, (const void *)V, block_to_fine, blockVol, spin_bs, amap)
   const AggMap amap = aggMapOf(*this);
+  if (g_acctOn) {
+    const double frac = sub ? 0.5 : 1.0;
+    char tag[48]; snprintf(tag, sizeof(tag), "coarse -> level %s%s", fineSpin == 4 ? "0" : "c", half ? " fp16 V" : "");
+    acct(small ? "prolong_small_kernel" : "prolong_kernel", frac * fineVol * ((double)fineSpin * fineColor * Nvec * (half ? 4 : 8) + fineSpin * fineColor * 8.0) + (double)nAgg * 2 * Nvec * 8, tag);
+  }
   QA_TRANSFER_DISPATCH(QA_P)
 #undef QA_P
   HIP_CHECK(hipGetLastError());

@@ -40,15 +40,21 @@ for name, sloppy in (("gcr_fp64", 8), ("gcr_mixed", 4)):
     else:
         qa.load_gauge(gauge, qa.gauge_param(X, cuda_prec=8, prec_sloppy=4, prec_precondition=4, t_boundary=qa.QUDA_PERIODIC_T))
     qa.invert(b, ip)
-    x = qa.invert(b, ip)
-    out[name] = dict(iters=ip.iter, secs=ip.secs, res=host_res(x))
+    secs = []
+    for _ in range(3):      # best of three: single calls on a shared test box occasionally stall on the host side
+        x = qa.invert(b, ip)
+        secs.append(ip.secs)
+    out[name] = dict(iters=ip.iter, secs=min(secs), res=host_res(x))
 mp = qa.multigrid_param(ip, n_level=3, geo_block=[(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)], n_vec=24, setup_maxiter=500, setup_tol=5e-6, smoother_pc=True)
 mg = qa.Multigrid(mp)
 ip.inv_type_precondition, ip.preconditioner = qa.QUDA_MG_INVERTER, mg.h
 ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
 qa.invert(b, ip)
-x = qa.invert(b, ip)
-out["mg_gcr"] = dict(iters=ip.iter, secs=ip.secs, res=host_res(x))
+secs = []
+for _ in range(3):
+    x = qa.invert(b, ip)
+    secs.append(ip.secs)
+out["mg_gcr"] = dict(iters=ip.iter, secs=min(secs), res=host_res(x))
 mg.free()
 qa.end()
 print("RESULT " + json.dumps(out), flush=True)
