@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "quda.h"
 
@@ -101,6 +102,11 @@ void acctRecord(const char *kernel, double bytes, const char *tag);
 inline void acct(const char *kernel, double bytes, const char *tag = "") { if (g_acctOn) acctRecord(kernel, bytes, tag); }
 void acctStart();
 void acctDump(const char *path);   // JSON: [{"kernel":..., "bytes":..., "tag":...}, ...] in launch order; switches the accounting off
+// SciDAC / QIO single-file container of Nvec colour-spinor fields (csrc/lime_io.cpp): fp32 host fields of the local lattice in even-odd
+// site order; every rank writes / reads its own rows of the one file
+bool scidacIsContainer(const char *fname);
+void scidacWriteSpinors(const char *fname, const std::vector<const float *> &vecs, const int X[4], int nSpin, int nColor);
+void scidacReadSpinors(const char *fname, const std::vector<float *> &vecs, const int X[4], int nSpin, int nColor);
 void *poolDeviceMalloc(size_t bytes);
 // hipMalloc that hands the parked pool buffers back and tries once more when the device is out of memory
 hipError_t qaMallocRaw(void **p, size_t bytes);

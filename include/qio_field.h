@@ -2,8 +2,8 @@
  * qio_field.h — file I/O helpers under the names the reference's tests use (include/qio_field.h: read_gauge_field,
  * read_spinor_field, write_spinor_field; QIO-backed there, lib/qio_field.cpp).  QIO is not a dependency of this library:
  * gauge configurations are read from ILDG / LIME containers by the library's own reader (qudaAmdReadLimeGauge,
- * csrc/lime_io.cpp), null vectors are persisted by the multigrid object itself (QudaMultigridParam::vec_infile / vec_outfile),
- * so the two spinor functions only report that.
+ * csrc/lime_io.cpp), and vector files are the SciDAC records QIO writes, restated from the published format in the same file
+ * (qudaAmdReadSpinorFields / qudaAmdWriteSpinorFields) — what the multigrid object uses for vec_infile / vec_outfile too.
  */
 #ifndef _GAUGE_QIO_H
 #define _GAUGE_QIO_H
@@ -35,15 +35,15 @@ inline void read_gauge_field(const char *filename, void *gauge[], QudaPrecision 
   for (int d = 0; d < 4; d++)
     if (p.X[d] != X[d]) { fprintf(stderr, "read_gauge_field: %s holds a %dx%dx%dx%d lattice\n", filename, p.X[0], p.X[1], p.X[2], p.X[3]); exit(1); }
 }
+/* V[Nvec]: host fields of the LOCAL lattice X[4] in even-odd site order, 2 nSpin nColor reals per site in `precision`; the file is the
+ * SciDAC / QIO single-file container of the reference (lib/qio_field.cpp:198-328), written and read by the library's own code */
 inline void read_spinor_field(const char *filename, void *V[], QudaPrecision precision, const int *X, int nColor, int nSpin, int Nvec, int argc, char *argv[]) {
-  (void)filename; (void)V; (void)precision; (void)X; (void)nColor; (void)nSpin; (void)Nvec; (void)argc; (void)argv;
-  fprintf(stderr, "read_spinor_field: null vectors are loaded by newMultigridQuda itself (QudaMultigridParam::vec_infile)\n");
-  exit(1);
+  (void)argc; (void)argv;
+  qudaAmdReadSpinorFields(filename, V, precision, X, nColor, nSpin, Nvec);
 }
 inline void write_spinor_field(const char *filename, void *V[], QudaPrecision precision, const int *X, int nColor, int nSpin, int Nvec, int argc, char *argv[]) {
-  (void)filename; (void)V; (void)precision; (void)X; (void)nColor; (void)nSpin; (void)Nvec; (void)argc; (void)argv;
-  fprintf(stderr, "write_spinor_field: null vectors are saved by newMultigridQuda itself (QudaMultigridParam::vec_outfile)\n");
-  exit(1);
+  (void)argc; (void)argv;
+  qudaAmdWriteSpinorFields(filename, V, precision, X, nColor, nSpin, Nvec);
 }
 
 #endif /* _GAUGE_QIO_H */

@@ -106,6 +106,11 @@ int qudaAmdDescribeHaloError(char *text, int n);
 void qudaAmdProfileMarker(int id);
 void qudaAmdAccountStart(void);
 void qudaAmdAccountDump(const char *path);
+/* Nvec colour-spinor fields in the SciDAC / QIO single-file container the reference's read_spinor_field / write_spinor_field use
+ * (lib/qio_field.cpp:198-328; LIME records scidac-private-file-xml ... scidac-binary-data, scidac-checksum).  V[i]: host field of the local
+ * lattice X[4], even-odd site order, 2 nSpin nColor reals per site in `precision`; the file holds fp32.  Every rank moves its own rows. */
+void qudaAmdWriteSpinorFields(const char *filename, void *V[], QudaPrecision precision, const int *X, int nColor, int nSpin, int Nvec);
+void qudaAmdReadSpinorFields(const char *filename, void *V[], QudaPrecision precision, const int *X, int nColor, int nSpin, int Nvec);
 void qudaAmdSetExitLine(const char *text, int status);
 double qudaAmdMultigridTimeApply(void *mg_instance, int level, int niter);
 /* seconds per application of the restrictor (what = 0) or prolongator (what = 1) between `level` and `level + 1` */

@@ -119,7 +119,7 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
                  "qudaAmdMultigridVerify", "qudaAmdMultigridCycle", "qudaAmdTimeAxpy", "qudaAmdMultigridLevels", "qudaAmdMultigridLevelInfo",
                  "qudaAmdMultigridSetHalfStorage", "qudaAmdMultigridGetNullVector", "qudaAmdMultigridGetV", "qudaAmdMultigridGetCoarseLinks", "qudaAmdMultigridApply", "qudaAmdMultigridApplyBlock",
                  "qudaAmdMultigridTimeApply", "qudaAmdMultigridTimeTransfer", "qudaAmdSetExitLine", "qudaAmdDiracPrepare", "qudaAmdDiracReconstruct", "qudaAmdSpinorRawInfo", "qudaAmdGaugeRawInfo", "qudaAmdCloverRawInfo", "qudaAmdRawDeviceCopy",
-                 "qudaAmdSetSolutionSink", "qudaAmdCommStats", "qudaAmdDescribeHaloError", "qudaAmdMultigridOrthoFallbackBlocks", "qudaAmdProfileMarker", "qudaAmdAccountStart", "qudaAmdAccountDump"]
+                 "qudaAmdSetSolutionSink", "qudaAmdCommStats", "qudaAmdDescribeHaloError", "qudaAmdMultigridOrthoFallbackBlocks", "qudaAmdProfileMarker", "qudaAmdAccountStart", "qudaAmdAccountDump", "qudaAmdWriteSpinorFields", "qudaAmdReadSpinorFields"]
 
 _lib = None
 

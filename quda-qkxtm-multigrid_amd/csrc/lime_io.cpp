@@ -22,6 +22,8 @@
 #include <vector>
 
 #include "qa_core.h"
+#include "blas.h"
+#include "halo.h"
 #include "quda_amd_ext.h"
 
 namespace quda {
@@ -61,11 +63,246 @@ static void swap8(double *d, size_t n) {
 }
 static bool hostIsBigEndian() { const uint16_t v = 1; return *(const unsigned char *)&v == 0; }
 
+// ================================================================================================
+// SciDAC / QIO "single file" container of colour-spinor fields — the container the reference hands its null vectors to
+// (MG::saveVectors / loadVectors -> write_spinor_field / read_spinor_field, lib/multigrid.cpp:607-691, lib/qio_field.cpp:198-328:
+// QIO_write of ONE field record with datacount = Nvec, QIO_SINGLEFILE, QIO_PARALLEL).  QIO and c-lime are not in the reference tree nor
+// in this image; the layout is restated from the published QIO 2.x file format: LIME records
+//   scidac-private-file-xml   <scidacFile><version>1.1</version><spacetime>4</spacetime><dims>X Y Z T </dims><volfmt>0</volfmt></scidacFile>
+//   scidac-file-xml           the user file string ("Dummy user file XML", lib/qio_field.cpp:38)
+//   scidac-private-record-xml <scidacRecord>... <datatype>QUDA_FNs4Nc3_ColorSpinorField</datatype><precision>F</precision><colors>3</colors>
+//                             <spins>4</spins><typesize>96</typesize><datacount>Nvec</datacount></scidacRecord>   (lib/qio_field.cpp:243-245, :314)
+//   scidac-record-xml         the user record string ("Dummy user record XML for SU(N) field", :219)
+//   scidac-binary-data        for every GLOBAL site in lexicographic order (x fastest): datacount x typesize bytes, big-endian — the 24
+//                             (2 nSpin nColor) reals of the site in vector 0, then vector 1, ... (vgetM, lib/qio_field.cpp)
+//   scidac-checksum           <scidacChecksum><version>1.0</version><suma>%x</suma><sumb>%x</sumb></scidacChecksum>: the CRC-32 of every site's
+//                             bytes, rotated left by (site rank mod 29) resp. (mod 31), XORed over the sites (QIO DML_checksum_accum)
+// The fields are the level's vectors in the host order the reference holds them in: even-odd site order locally (node_index,
+// lib/layout_hyper.c:215-230), (spin, colour, re/im) per site.  "PARITY UNPINNED" against QIO itself (it cannot be built here): pinned
+// by a record-by-record check of the bytes in tests/test_lime_io.py and by the round trip.  Every rank writes / reads the rows of
+// its own sub-lattice of the one file (plain seeks; QIO_PARALLEL in the reference).
+// ================================================================================================
+static uint32_t crc32_bytes(const unsigned char *p, size_t n) {
+  static uint32_t table[256];
+  static bool init = false;
+  if (!init) {
+    for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; }
+    init = true;
+  }
+  uint32_t c = 0xFFFFFFFFu;
+  for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xff] ^ (c >> 8);
+  return c ^ 0xFFFFFFFFu;
+}
+static void limeWriteHeader(FILE *f, const char *type, uint64_t bytes, bool mb, bool me) {
+  unsigned char h[144];
+  memset(h, 0, sizeof(h));
+  put_be(h, 0x456789abu, 4); put_be(h + 4, 1, 2); put_be(h + 6, (mb ? 0x8000u : 0u) | (me ? 0x4000u : 0u), 2); put_be(h + 8, bytes, 8);
+  strncpy((char *)h + 16, type, 127);
+  if (fwrite(h, 1, 144, f) != 144) errorQuda("short write of a LIME header");
+}
+static void limeWriteRecord(FILE *f, const char *type, const void *data, uint64_t bytes, bool mb, bool me) {
+  limeWriteHeader(f, type, bytes, mb, me);
+  if (fwrite(data, 1, bytes, f) != bytes) errorQuda("short write of a %s record", type);
+  const unsigned char zero[8] = {0};
+  if (bytes % 8 && fwrite(zero, 1, 8 - bytes % 8, f) != 8 - bytes % 8) errorQuda("short write");
+}
+static void swap4(float *d, size_t n) {
+  unsigned char *p = (unsigned char *)d;
+  for (size_t i = 0; i < n; i++, p += 4) { unsigned char t = p[0]; p[0] = p[3]; p[3] = t; t = p[1]; p[1] = p[2]; p[2] = t; }
+}
+// global checksum from the per-rank partial XORs (an XOR all-reduce through a sum over rank-indexed slots)
+static void xorAllreduce(uint32_t &a, uint32_t &b) {
+  const CommGrid &g = commGrid();
+  if (g.size == 1) return;
+  if (2 * g.size > 64) errorQuda("checksum reduction over %d ranks exceeds the host collective's buffer", g.size);
+  std::vector<double> v(2 * (size_t)g.size, 0.0);
+  v[2 * g.rank] = (double)a; v[2 * g.rank + 1] = (double)b;
+  comm_allreduce(v.data(), 2 * g.size);
+  a = b = 0;
+  for (int r = 0; r < g.size; r++) { a ^= (uint32_t)v[2 * r]; b ^= (uint32_t)v[2 * r + 1]; }
+}
+
+bool scidacIsContainer(const char *fname) {
+  FILE *f = fopen(fname, "rb");
+  if (!f) return false;
+  unsigned char h[4];
+  const bool ok = fread(h, 1, 4, f) == 4 && be32(h) == 0x456789abu;
+  fclose(f);
+  return ok;
+}
+
+// vecs[i]: fp32 host field of the LOCAL lattice X, even-odd site order, nReal = 2 nSpin nColor reals per site
+void scidacWriteSpinors(const char *fname, const std::vector<const float *> &vecs, const int X[4], int nSpin, int nColor) {
+  const CommGrid &g = commGrid();
+  const int nvec = (int)vecs.size(), nReal = 2 * nSpin * nColor;
+  int G[4], off[4];
+  for (int d = 0; d < 4; d++) { G[d] = X[d] * g.dims[d]; off[d] = X[d] * g.coords[d]; }
+  const uint64_t gvol = (uint64_t)G[0] * G[1] * G[2] * G[3], siteBytes = (uint64_t)nvec * nReal * sizeof(float);
+  long dataOffset = 0;
+  if (g.rank == 0) {
+    FILE *f = fopen(fname, "wb");
+    if (!f) errorQuda("cannot open %s for writing", fname);
+    char xml[1024];
+    snprintf(xml, sizeof(xml), "<?xml version=\"1.0\" encoding=\"UTF-8\"?><scidacFile><version>1.1</version><spacetime>4</spacetime><dims>%d %d %d %d </dims><volfmt>0</volfmt></scidacFile>", G[0], G[1], G[2], G[3]);
+    limeWriteRecord(f, "scidac-private-file-xml", xml, strlen(xml) + 1, true, false);
+    const char *userFile = "Dummy user file XML";
+    limeWriteRecord(f, "scidac-file-xml", userFile, strlen(userFile) + 1, false, true);
+    snprintf(xml, sizeof(xml), "<?xml version=\"1.0\" encoding=\"UTF-8\"?><scidacRecord><version>1.1</version><date>unknown</date><recordtype>0</recordtype>"
+             "<datatype>QUDA_FNs%dNc%d_ColorSpinorField</datatype><precision>F</precision><colors>%d</colors><spins>%d</spins><typesize>%d</typesize><datacount>%d</datacount></scidacRecord>",
+             nSpin, nColor, nColor, nSpin, (int)(nReal * sizeof(float)), nvec);
+    limeWriteRecord(f, "scidac-private-record-xml", xml, strlen(xml) + 1, true, false);
+    const char *userRec = "Dummy user record XML for SU(N) field";
+    limeWriteRecord(f, "scidac-record-xml", userRec, strlen(userRec) + 1, false, false);
+    limeWriteHeader(f, "scidac-binary-data", gvol * siteBytes, false, false);
+    dataOffset = ftell(f);
+    // the payload area exists before any rank seeks into it
+    const uint64_t padded = (gvol * siteBytes + 7) / 8 * 8;
+    if (fseek(f, dataOffset + (long)padded - 1, SEEK_SET) != 0 || fputc(0, f) == EOF) errorQuda("cannot extend %s to %llu payload bytes", fname, (unsigned long long)padded);
+    fclose(f);
+  }
+  { double o = (double)dataOffset; comm_allreduce(&o, 1); dataOffset = (long)o; }   // rank 0's value (the others contribute 0); also a barrier
+  FILE *f = fopen(fname, "r+b");
+  if (!f) errorQuda("cannot reopen %s", fname);
+  const long Vh = (long)X[0] * X[1] * X[2] * X[3] / 2;
+  std::vector<float> row((size_t)X[0] * nvec * nReal);
+  const bool swap = !hostIsBigEndian();
+  uint32_t suma = 0, sumb = 0;
+  for (int t = 0; t < X[3]; t++)
+    for (int z = 0; z < X[2]; z++)
+      for (int y = 0; y < X[1]; y++) {
+        for (int x = 0; x < X[0]; x++) {
+          const int par = (x + y + z + t) & 1;   // local parity (local extents are even, so it equals the global one)
+          const long cb = ((((long)t * X[2] + z) * X[1] + y) * X[0] + x) >> 1;
+          for (int v = 0; v < nvec; v++) memcpy(&row[((size_t)x * nvec + v) * nReal], vecs[v] + ((size_t)par * Vh + cb) * nReal, nReal * sizeof(float));
+        }
+        if (swap) swap4(row.data(), row.size());
+        const uint64_t rank0 = (((uint64_t)(t + off[3]) * G[2] + (z + off[2])) * G[1] + (y + off[1])) * G[0] + off[0];
+        for (int x = 0; x < X[0]; x++) {
+          const uint32_t c = crc32_bytes((const unsigned char *)&row[(size_t)x * nvec * nReal], siteBytes);
+          const unsigned r29 = (unsigned)((rank0 + x) % 29), r31 = (unsigned)((rank0 + x) % 31);
+          suma ^= (c << r29) | (r29 ? c >> (32 - r29) : 0u);
+          sumb ^= (c << r31) | (r31 ? c >> (32 - r31) : 0u);
+        }
+        if (fseek(f, dataOffset + (long)(rank0 * siteBytes), SEEK_SET) != 0 || fwrite(row.data(), sizeof(float), row.size(), f) != row.size()) errorQuda("short write on %s", fname);
+      }
+  fclose(f);
+  xorAllreduce(suma, sumb);
+  if (g.rank == 0) {
+    f = fopen(fname, "r+b");
+    if (!f) errorQuda("cannot reopen %s", fname);
+    fseek(f, 0, SEEK_END);
+    char xml[512];
+    snprintf(xml, sizeof(xml), "<?xml version=\"1.0\" encoding=\"UTF-8\"?><scidacChecksum><version>1.0</version><suma>%x</suma><sumb>%x</sumb></scidacChecksum>", suma, sumb);
+    limeWriteRecord(f, "scidac-checksum", xml, strlen(xml) + 1, false, true);
+    fclose(f);
+  }
+  commBarrier();
+}
+
+// fills vecs[0 .. n-1] (n <= datacount of the file) with this rank's sub-lattice; the file's lattice, site size and checksum are checked
+void scidacReadSpinors(const char *fname, const std::vector<float *> &vecs, const int X[4], int nSpin, int nColor) {
+  const CommGrid &g = commGrid();
+  const int nvec = (int)vecs.size(), nReal = 2 * nSpin * nColor;
+  int G[4], off[4];
+  for (int d = 0; d < 4; d++) { G[d] = X[d] * g.dims[d]; off[d] = X[d] * g.coords[d]; }
+  FILE *f = fopen(fname, "rb");
+  if (!f) errorQuda("cannot open %s", fname);
+  LimeRecord r;
+  long payload = -1;
+  int fileCount = 0, typesize = 0, fd[4] = {0, 0, 0, 0};
+  uint32_t wantA = 0, wantB = 0;
+  bool haveSum = false;
+  char prec = 0;
+  while (limeNext(f, r, fname)) {
+    if (r.type == "scidac-private-file-xml" || r.type == "scidac-private-record-xml" || r.type == "scidac-checksum") {
+      std::string data(r.bytes, 0);
+      if (fread(&data[0], 1, r.bytes, f) != r.bytes) errorQuda("%s: truncated %s record", fname, r.type.c_str());
+      if (r.type == "scidac-private-file-xml") {
+        const size_t p = data.find("<dims>");
+        if (p == std::string::npos || sscanf(data.c_str() + p + 6, "%d %d %d %d", &fd[0], &fd[1], &fd[2], &fd[3]) != 4) errorQuda("%s: no <dims> in the file record", fname);
+      } else if (r.type == "scidac-private-record-xml") {
+        if (!xmlInt(data, "<typesize>", typesize) || !xmlInt(data, "<datacount>", fileCount)) errorQuda("%s: no typesize / datacount in the record description", fname);
+        const size_t p = data.find("<precision>");
+        if (p != std::string::npos) prec = data[p + 11];
+      } else {
+        const size_t pa = data.find("<suma>"), pb = data.find("<sumb>");
+        if (pa != std::string::npos && pb != std::string::npos && sscanf(data.c_str() + pa + 6, "%x", &wantA) == 1 && sscanf(data.c_str() + pb + 6, "%x", &wantB) == 1) haveSum = true;
+      }
+    } else if (r.type == "scidac-binary-data") {
+      payload = r.data_offset;
+    }
+    limeSkip(f, r);
+  }
+  if (payload < 0) errorQuda("%s: no scidac-binary-data record", fname);
+  for (int d = 0; d < 4; d++) if (fd[d] != G[d]) errorQuda("%s holds a %d x %d x %d x %d lattice, this run has %d x %d x %d x %d", fname, fd[0], fd[1], fd[2], fd[3], G[0], G[1], G[2], G[3]);
+  if (prec != 'F' || typesize != (int)(nReal * sizeof(float))) errorQuda("%s: records of precision %c with %d bytes per site and vector (this level needs fp32, %d bytes)", fname, prec ? prec : '?', typesize, (int)(nReal * sizeof(float)));
+  if (fileCount < nvec) errorQuda("%s holds %d vectors, %d are needed", fname, fileCount, nvec);
+  if (fileCount > nvec) warningQuda("%s holds %d vectors, this level uses the first %d", fname, fileCount, nvec);
+  const uint64_t siteBytes = (uint64_t)fileCount * nReal * sizeof(float);
+  const long Vh = (long)X[0] * X[1] * X[2] * X[3] / 2;
+  std::vector<float> row((size_t)X[0] * fileCount * nReal);
+  const bool swap = !hostIsBigEndian();
+  uint32_t suma = 0, sumb = 0;
+  for (int t = 0; t < X[3]; t++)
+    for (int z = 0; z < X[2]; z++)
+      for (int y = 0; y < X[1]; y++) {
+        const uint64_t rank0 = (((uint64_t)(t + off[3]) * G[2] + (z + off[2])) * G[1] + (y + off[1])) * G[0] + off[0];
+        if (fseek(f, payload + (long)(rank0 * siteBytes), SEEK_SET) != 0 || fread(row.data(), sizeof(float), row.size(), f) != row.size()) errorQuda("short read on %s", fname);
+        for (int x = 0; x < X[0]; x++) {
+          const uint32_t c = crc32_bytes((const unsigned char *)&row[(size_t)x * fileCount * nReal], siteBytes);
+          const unsigned r29 = (unsigned)((rank0 + x) % 29), r31 = (unsigned)((rank0 + x) % 31);
+          suma ^= (c << r29) | (r29 ? c >> (32 - r29) : 0u);
+          sumb ^= (c << r31) | (r31 ? c >> (32 - r31) : 0u);
+        }
+        if (swap) swap4(row.data(), row.size());
+        for (int x = 0; x < X[0]; x++) {
+          const int par = (x + y + z + t) & 1;
+          const long cb = ((((long)t * X[2] + z) * X[1] + y) * X[0] + x) >> 1;
+          for (int v = 0; v < nvec; v++) memcpy(vecs[v] + ((size_t)par * Vh + cb) * nReal, &row[((size_t)x * fileCount + v) * nReal], nReal * sizeof(float));
+        }
+      }
+  fclose(f);
+  xorAllreduce(suma, sumb);
+  if (haveSum && (suma != wantA || sumb != wantB)) errorQuda("%s: checksum mismatch (file %x %x, data %x %x)", fname, wantA, wantB, suma, sumb);
+  if (!haveSum) warningQuda("%s carries no scidac-checksum record", fname);
+}
+
 }  // namespace quda
 
 using namespace quda;
 
 extern "C" {
+
+// read_spinor_field / write_spinor_field of the reference (include/qio_field.h, lib/qio_field.cpp:198-328): Nvec host fields V[i] of the
+// local lattice X in even-odd site order, 2 nSpin nColor reals per site, fp32 or fp64 in memory; fp32 in the file
+void qudaAmdWriteSpinorFields(const char *filename, void *V[], QudaPrecision precision, const int *X, int nColor, int nSpin, int Nvec) {
+  if (precision != QUDA_DOUBLE_PRECISION && precision != QUDA_SINGLE_PRECISION) errorQuda("Error, file_prec=%d not supported", precision);
+  const size_t n = (size_t)X[0] * X[1] * X[2] * X[3] * 2 * nSpin * nColor;
+  std::vector<std::vector<float>> tmp;
+  std::vector<const float *> ptrs(Nvec);
+  for (int i = 0; i < Nvec; i++) {
+    if (precision == QUDA_SINGLE_PRECISION) { ptrs[i] = (const float *)V[i]; continue; }
+    tmp.emplace_back(n);
+    const double *d = (const double *)V[i];
+    for (size_t k = 0; k < n; k++) tmp.back()[k] = (float)d[k];
+    ptrs[i] = tmp.back().data();
+  }
+  scidacWriteSpinors(filename, ptrs, X, nSpin, nColor);
+}
+void qudaAmdReadSpinorFields(const char *filename, void *V[], QudaPrecision precision, const int *X, int nColor, int nSpin, int Nvec) {
+  if (precision != QUDA_DOUBLE_PRECISION && precision != QUDA_SINGLE_PRECISION) errorQuda("Error, cpu precision %d not supported", precision);
+  const size_t n = (size_t)X[0] * X[1] * X[2] * X[3] * 2 * nSpin * nColor;
+  std::vector<std::vector<float>> tmp(precision == QUDA_DOUBLE_PRECISION ? Nvec : 0);
+  std::vector<float *> ptrs(Nvec);
+  for (int i = 0; i < Nvec; i++) {
+    if (precision == QUDA_SINGLE_PRECISION) ptrs[i] = (float *)V[i];
+    else { tmp[i].resize(n); ptrs[i] = tmp[i].data(); }
+  }
+  scidacReadSpinors(filename, ptrs, X, nSpin, nColor);
+  if (precision == QUDA_DOUBLE_PRECISION)
+    for (int i = 0; i < Nvec; i++) { double *d = (double *)V[i]; for (size_t k = 0; k < n; k++) d[k] = (double)tmp[i][k]; }
+}
+
 
 void qudaAmdReadLimeGauge(void **gauge, const char *fname, QudaGaugeParam *param, QudaInvertParam *inv_param, const int gridSize[4]) {
   FILE *f = fopen(fname, "rb");

@@ -388,18 +388,17 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
 }
 
 // ---- null-vector persistence (reference MG::saveVectors / loadVectors, lib/multigrid.cpp:607-691: "<file>_level_<l>", all
-// Nvec vectors of a level in one file).  The reference hands the vectors to QIO/LIME (lib/qio_field.cpp), which this image does
-// not have; the container here is a 64-byte header (magic, lattice, nSpin, nColor, Nvec, process grid) followed by the
-// vectors in the order the reference gives QIO — site-major (parity*Vh + x_cb, spin, colour, re/im), fp32 — one file per
-// rank ("….rank<r>" when there is more than one). ----
-// `order` = 0x01020304 as written by the producer: a reader on a machine of the other endianness sees 0x04030201 and refuses the
-// file (version 1 files, "QAMDNV01", carry 0 there and are read as native)
+// Nvec vectors of a level in one file).  The reference hands the vectors to QIO (lib/qio_field.cpp write_spinor_field); files are
+// written in that container — SciDAC records inside LIME, one field record with datacount = Nvec, global lexicographic site order,
+// big-endian fp32, restated in csrc/lime_io.cpp — by all ranks into ONE file, as QIO_PARALLEL / QIO_SINGLEFILE does.  Vectors go
+// to the file in the host order the reference keeps them in: even-odd sites, (spin, colour, re/im), DeGrand-Rossi basis.
+// Files of this library's first two rounds (64-byte header "QAMDNV01/02" + raw vectors, one file per rank) are still read. ----
 struct NullVecHeader { char magic[8]; int X[4]; int nSpin, nColor, Nvec, precision; int grid[4]; int rank, order; };
 constexpr int kNullVecOrder = 0x01020304;
-static std::string nullVecFile(const char *base, int level) {
+static std::string nullVecFile(const char *base, int level, bool perRank) {
   std::string f(base);
   f += "_level_" + std::to_string(level);
-  if (commGrid().size > 1) f += ".rank" + std::to_string(commGrid().rank);
+  if (perRank && commGrid().size > 1) f += ".rank" + std::to_string(commGrid().rank);
   return f;
 }
 static ColorSpinorParam hostParamLike(const ColorSpinorField &dev, void *ptr) {
@@ -410,42 +409,55 @@ static ColorSpinorParam hostParamLike(const ColorSpinorField &dev, void *ptr) {
 }
 void MG::saveVectors(std::vector<ColorSpinorField *> &B) {
   if (!mgp.mg_global.vec_outfile[0]) return;
-  const std::string f = nullVecFile(mgp.mg_global.vec_outfile, mgp.level);
+  const std::string f = nullVecFile(mgp.mg_global.vec_outfile, mgp.level, false);
   if (getVerbosity() >= QUDA_SUMMARIZE) printfQuda("Start saving %zu vectors to %s\n", B.size(), f.c_str());
-  FILE *fp = fopen(f.c_str(), "wb");
-  if (!fp) errorQuda("cannot open %s for writing", f.c_str());
-  NullVecHeader h;
-  memset(&h, 0, sizeof(h));
-  memcpy(h.magic, "QAMDNV02", 8);
-  h.order = kNullVecOrder;
-  for (int d = 0; d < 4; d++) { h.X[d] = B[0]->X(d); h.grid[d] = commGrid().dims[d]; }
-  h.nSpin = B[0]->Nspin(); h.nColor = B[0]->Ncolor(); h.Nvec = (int)B.size(); h.precision = 4; h.rank = commGrid().rank;
-  const size_t n = (size_t)B[0]->Volume() * h.nSpin * h.nColor * 2;
-  std::vector<float> buf(n);
-  bool ok = fwrite(&h, sizeof(h), 1, fp) == 1;
-  for (size_t i = 0; i < B.size() && ok; i++) {
-    ColorSpinorField host(hostParamLike(*B[i], buf.data()));
-    host = *B[i];
-    ok = fwrite(buf.data(), sizeof(float), n, fp) == n;
+  const size_t n = (size_t)B[0]->Volume() * B[0]->Nspin() * B[0]->Ncolor() * 2;
+  std::vector<std::vector<float>> host(B.size());
+  std::vector<const float *> ptrs(B.size());
+  for (size_t i = 0; i < B.size(); i++) {
+    host[i].resize(n);
+    ColorSpinorField h(hostParamLike(*B[i], host[i].data()));
+    h = *B[i];
+    ptrs[i] = host[i].data();
   }
-  fclose(fp);
-  if (!ok) errorQuda("short write on %s", f.c_str());
+  int X[4];
+  for (int d = 0; d < 4; d++) X[d] = B[0]->X(d);
+  scidacWriteSpinors(f.c_str(), ptrs, X, B[0]->Nspin(), B[0]->Ncolor());
+  if (getVerbosity() >= QUDA_SUMMARIZE) printfQuda("Done saving vectors\n");
 }
 void MG::loadVectors(std::vector<ColorSpinorField *> &B) {
   if (!mgp.mg_global.vec_infile[0]) errorQuda("compute_null_vector = NO needs vec_infile (no null-space file defined)");
-  const std::string f = nullVecFile(mgp.mg_global.vec_infile, mgp.level);
+  std::string f = nullVecFile(mgp.mg_global.vec_infile, mgp.level, false);
+  const size_t n = (size_t)B[0]->Volume() * B[0]->Nspin() * B[0]->Ncolor() * 2;
+  if (scidacIsContainer(f.c_str())) {
+    if (getVerbosity() >= QUDA_SUMMARIZE) printfQuda("Start loading %zu vectors from %s\n", B.size(), f.c_str());
+    std::vector<std::vector<float>> host(B.size());
+    std::vector<float *> ptrs(B.size());
+    for (size_t i = 0; i < B.size(); i++) { host[i].resize(n); ptrs[i] = host[i].data(); }
+    int X[4];
+    for (int d = 0; d < 4; d++) X[d] = B[0]->X(d);
+    scidacReadSpinors(f.c_str(), ptrs, X, B[0]->Nspin(), B[0]->Ncolor());
+    for (size_t i = 0; i < B.size(); i++) {
+      ColorSpinorField h(hostParamLike(*B[i], host[i].data()));
+      *B[i] = h;
+      B[i]->twistFlavor = mgp.fineFlavor;
+    }
+    if (getVerbosity() >= QUDA_SUMMARIZE) printfQuda("Done loading vectors\n");
+    return;
+  }
+  // the private format of rounds 1 and 2: one file per rank
+  f = nullVecFile(mgp.mg_global.vec_infile, mgp.level, true);
   if (getVerbosity() >= QUDA_SUMMARIZE) printfQuda("Start loading %zu vectors from %s\n", B.size(), f.c_str());
   FILE *fp = fopen(f.c_str(), "rb");
   if (!fp) errorQuda("cannot open %s", f.c_str());
   NullVecHeader h;
   if (fread(&h, sizeof(h), 1, fp) != 1 || (memcmp(h.magic, "QAMDNV01", 8) && memcmp(h.magic, "QAMDNV02", 8)))
-    errorQuda("%s is not a null-vector file of this library (the reference's QIO / LIME vector files are a different container, see INTEGRATION.md)", f.c_str());
+    errorQuda("%s is neither a SciDAC / LIME vector file nor a null-vector file of this library", f.c_str());
   if (!memcmp(h.magic, "QAMDNV02", 8) && h.order != kNullVecOrder) errorQuda("%s was written on a machine of the other byte order", f.c_str());
   for (int d = 0; d < 4; d++)
     if (h.X[d] != B[0]->X(d) || h.grid[d] != commGrid().dims[d]) errorQuda("%s was written for lattice %d %d %d %d on grid %d %d %d %d", f.c_str(), h.X[0], h.X[1], h.X[2], h.X[3], h.grid[0], h.grid[1], h.grid[2], h.grid[3]);
   if (h.nSpin != B[0]->Nspin() || h.nColor != B[0]->Ncolor() || h.Nvec < (int)B.size() || h.rank != commGrid().rank) errorQuda("%s does not match this level (nSpin %d nColor %d Nvec %d rank %d)", f.c_str(), h.nSpin, h.nColor, h.Nvec, h.rank);
   if (h.Nvec > (int)B.size()) warningQuda("%s holds %d vectors, this level uses the first %zu", f.c_str(), h.Nvec, B.size());
-  const size_t n = (size_t)B[0]->Volume() * h.nSpin * h.nColor * 2;
   std::vector<float> buf(n);
   for (size_t i = 0; i < B.size(); i++) {
     if (fread(buf.data(), sizeof(float), n, fp) != n) errorQuda("short read on %s", f.c_str());
