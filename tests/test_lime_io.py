@@ -84,3 +84,68 @@ def test_writer_produces_the_same_payload(qa, tmp_path):
     # and back through the reader
     gp2 = qa.lib().newQudaGaugeParam()
     assert np.array_equal(qa.read_lime_gauge(path, gp2, (1, 1, 1, 1), None, int(np.prod(X))), gauge)
+
+
+# ---- vector files: the SciDAC / QIO single-file container the reference's write_spinor_field / read_spinor_field use
+# (lib/qio_field.cpp:198-328; MG::saveVectors / loadVectors, lib/multigrid.cpp:607-691) ----
+def _walk(raw):
+    pos, records = 0, []
+    while pos < len(raw):
+        magic, version, flags, nbytes = struct.unpack(">IHHQ", raw[pos:pos + 16])
+        assert magic == 0x456789AB and version == 1
+        records.append((raw[pos + 16:pos + 144].split(b"\0")[0].decode(), raw[pos + 144:pos + 144 + nbytes], flags))
+        pos += 144 + (nbytes + 7) // 8 * 8
+    assert pos == len(raw)
+    return records
+
+
+def _vectors(X, nvec, nreal, seed):
+    """even-odd ordered host fields whose every real encodes (vector, global lexicographic site, component)"""
+    V = int(np.prod(X))
+    t, z, y, x = np.meshgrid(*[np.arange(n) for n in (X[3], X[2], X[1], X[0])], indexing="ij")
+    lex = (((t * X[2] + z) * X[1] + y) * X[0] + x).reshape(-1)
+    eo = ((t + z + y + x) & 1).reshape(-1) * (V // 2) + lex // 2
+    out = []
+    for v in range(nvec):
+        f = np.zeros((V, nreal), dtype=np.float32)
+        f[eo] = (lex[:, None] * 8 + v) + np.arange(nreal)[None, :] / 128.0 + seed
+        out.append(f)
+    return out, lex, eo
+
+
+@pytest.mark.parametrize("X,nspin,ncolor,nvec", [((4, 4, 4, 4), 4, 3, 3), ((6, 4, 2, 8), 2, 8, 5)])
+def test_scidac_vector_file_records_and_round_trip(qa, tmp_path, X, nspin, ncolor, nvec):
+    import ctypes as C
+    import zlib
+    nreal = 2 * nspin * ncolor
+    V = int(np.prod(X))
+    fields, lex, eo = _vectors(X, nvec, nreal, 0.5)
+    path = str(tmp_path / "vecs_level_0").encode()
+    ptrs = (C.c_void_p * nvec)(*[f.ctypes.data for f in fields])
+    Xc = (C.c_int * 4)(*X)
+    qa.lib().qudaAmdWriteSpinorFields(path, ptrs, 4, Xc, ncolor, nspin, nvec)
+    recs = _walk(open(path, "rb").read())
+    assert [r[0] for r in recs] == ["scidac-private-file-xml", "scidac-file-xml", "scidac-private-record-xml", "scidac-record-xml", "scidac-binary-data", "scidac-checksum"]
+    assert ("<dims>%d %d %d %d </dims>" % tuple(X)).encode() in recs[0][1] and b"<volfmt>0</volfmt>" in recs[0][1]
+    assert recs[1][1].rstrip(b"\0") == b"Dummy user file XML"
+    assert ("<datatype>QUDA_FNs%dNc%d_ColorSpinorField</datatype><precision>F</precision><colors>%d</colors><spins>%d</spins><typesize>%d</typesize><datacount>%d</datacount>"
+            % (nspin, ncolor, ncolor, nspin, 4 * nreal, nvec)).encode() in recs[2][1]
+    # payload: global lexicographic sites, per site vector 0 .. nvec-1, big-endian fp32 — built here independently of the writer
+    want = np.zeros((V, nvec, nreal), dtype=">f4")
+    for v in range(nvec):
+        want[lex, v] = fields[v][eo]
+    assert recs[4][1] == want.tobytes()
+    # checksum as QIO accumulates it: CRC-32 of every site's bytes rotated by (site rank mod 29 / mod 31), XORed
+    suma = sumb = 0
+    for s in range(V):
+        c = zlib.crc32(want[s].tobytes()) & 0xFFFFFFFF
+        r29, r31 = s % 29, s % 31
+        suma ^= ((c << r29) | (c >> (32 - r29))) & 0xFFFFFFFF
+        sumb ^= ((c << r31) | (c >> (32 - r31))) & 0xFFFFFFFF
+    assert ("<suma>%x</suma><sumb>%x</sumb>" % (suma, sumb)).encode() in recs[5][1]
+    # back through the reader, fewer vectors than the file holds, into fp64 memory
+    back = [np.zeros((V, nreal)) for _ in range(nvec - 1)]
+    bptrs = (C.c_void_p * (nvec - 1))(*[f.ctypes.data for f in back])
+    qa.lib().qudaAmdReadSpinorFields(path, bptrs, 8, Xc, ncolor, nspin, nvec - 1)
+    for v in range(nvec - 1):
+        assert np.array_equal(back[v], fields[v].astype(np.float64))
