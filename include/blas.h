@@ -50,6 +50,8 @@ void caxpyXmazMR(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, con
 double caxpyXmazNormX(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z);
 void cabxpyAx(const double &a, const Complex &b, ColorSpinorField &x, ColorSpinorField &y);             // x = a x ; y += b x
 double cabxpyAxNorm(const double &a, const Complex &b, ColorSpinorField &x, ColorSpinorField &y);
+void caxXmaz(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z);   // y = a x ; x -= a z
+void caxInit(const Complex &a, const ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z, ColorSpinorField &w);   // y = a x ; w = x - a z
 Complex caxpyDotzy(const Complex &a, const ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z);  // y += a x ; (z,y)
 void caxpbypzYmbw(const Complex &a, const ColorSpinorField &x, const Complex &b, ColorSpinorField &y, ColorSpinorField &z,
                   const ColorSpinorField &w);                                         // z += a x + b y ; y -= b w

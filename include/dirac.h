@@ -62,6 +62,9 @@ class Dirac {
   // coarse-operator construction (coarse.h): out = H_dir in (full fields, hopping normalisation included), out = L in.
   virtual void hopDir(ColorSpinorField &out, const ColorSpinorField &in, int dir) const;
   virtual void localTerm(ColorSpinorField &out, const ColorSpinorField &in) const;
+  // the site-diagonal term A_pp of the operator on ONE parity (1, 1 + i a g5, clover + i a g5): the full-system residual behind an even-odd
+  // preconditioned smoother is (A r_hat, 0) for the symmetric preconditioning, see MG::cycleParity; out = in allowed
+  virtual void localTermParity(ColorSpinorField &out, const ColorSpinorField &in, int parity) const;
 
   void setMass(double m) { mass = m; }
   double Kappa() const { return kappa; }
@@ -90,6 +93,7 @@ class DiracWilson : public Dirac {
   void reconstruct(ColorSpinorField &x, const ColorSpinorField &b, const QudaSolutionType) const override;
   void hopDir(ColorSpinorField &out, const ColorSpinorField &in, int dir) const override;
   void localTerm(ColorSpinorField &out, const ColorSpinorField &in) const override;
+  void localTermParity(ColorSpinorField &out, const ColorSpinorField &in, int parity) const override;
 };
 
 class DiracWilsonPC : public DiracWilson {
@@ -113,6 +117,7 @@ class DiracTwistedMass : public DiracWilson {
   double Mu() const override { return mu; }
   void Twist(ColorSpinorField &out, const ColorSpinorField &in) const;
   void localTerm(ColorSpinorField &out, const ColorSpinorField &in) const override;
+  void localTermParity(ColorSpinorField &out, const ColorSpinorField &in, int parity) const override;
   void TwistedDslash(ColorSpinorField &out, const ColorSpinorField &in, QudaParity parity, QudaTwistDslashType t, double a, double b) const;
   void TwistedDslashXpay(ColorSpinorField &out, const ColorSpinorField &in, const ColorSpinorField &x, QudaParity parity,
                          QudaTwistDslashType t, double a, double b) const;
@@ -149,6 +154,7 @@ class DiracTwistedClover : public DiracWilson {
   CloverField *Clover() const override { return &clover; }
   void TwistClover(ColorSpinorField &out, const ColorSpinorField &in, const int parity) const;
   void localTerm(ColorSpinorField &out, const ColorSpinorField &in) const override;
+  void localTermParity(ColorSpinorField &out, const ColorSpinorField &in, int parity) const override;
   void M(ColorSpinorField &out, const ColorSpinorField &in) const override;
   void MdagM(ColorSpinorField &out, const ColorSpinorField &in) const override;
   void prepare(ColorSpinorField *&src, ColorSpinorField *&sol, ColorSpinorField &x, ColorSpinorField &b, const QudaSolutionType) const override;

@@ -58,7 +58,7 @@ class MG : public Solver {
   int nullVectorMethod = 0, nullVectorIterations = 0;
  private:
   void generateNullVectors(std::vector<ColorSpinorField *> &B);
-  void cycleParity(ColorSpinorField &x, ColorSpinorField &b);
+  void cycleParity(ColorSpinorField &x, ColorSpinorField &b, bool fullResidual);
   void saveVectors(std::vector<ColorSpinorField *> &B);
   void loadVectors(std::vector<ColorSpinorField *> &B);
 

@@ -50,6 +50,8 @@ class Solver {
   virtual ~Solver() {}
   virtual void operator()(ColorSpinorField &out, ColorSpinorField &in) = 0;
   virtual unsigned long long flops() const { return 0; }
+  // b - A x of the system the last call worked on, in the solver's work precision, if the solver keeps it (MR); else nullptr
+  virtual const ColorSpinorField *lastResidual() const { return nullptr; }
   static Solver *create(SolverParam &param, DiracMatrix &mat, DiracMatrix &matSloppy, DiracMatrix &matPrecon);  // reference lib/solver.cpp:13
   static double stopping(double tol, double b2, QudaResidualType type);
   bool convergence(double r2, double hq2, double r2_tol, double hq_tol) const;
@@ -60,10 +62,12 @@ class Solver {
 class MR : public Solver {
   const DiracMatrix &mat, &matSloppy;
   ColorSpinorField *rp, *Arp, *tmpp, *yp;
+  bool residualValid;
  public:
   MR(DiracMatrix &mat, DiracMatrix &matSloppy, SolverParam &param);
   ~MR() override;
   void operator()(ColorSpinorField &out, ColorSpinorField &in) override;
+  const ColorSpinorField *lastResidual() const override { return residualValid ? rp : nullptr; }
 };
 
 class BiCGstab : public Solver {

@@ -22,6 +22,7 @@ class Transfer {
   int fineSpin, fineColor;     // of the level this transfer starts from
   int Xf[4], Xc[4];            // fine / coarse full lattice extents
   int blockVol;                // sites per aggregate
+  bool parityMajor = false;    // sites of an aggregate numbered even half first (transfer.hip block_coords), else lexicographically
   int lastGsFallbackBlocks = 0; // (aggregate, chirality) blocks the CholeskyQR2 orthonormalisation handed to Gram-Schmidt (ill-conditioned in fp32)
   int nAgg;                    // aggregates = coarse volume
   long fineVol;

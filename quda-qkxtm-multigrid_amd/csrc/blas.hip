@@ -318,6 +318,30 @@ template <int NRM> struct CaxpyXmazF { double ar, ai; QA_FLAGS(1, 1, 1, 0, 1, 1,
       if (NRM) r[0] += (double)x[i] * (double)x[i] + (double)x[i + 1] * (double)x[i + 1];
     }
   } };
+// y = a x ; x -= a z      (first iteration of MR from a zero start: y is not read)
+struct CaxXmazF { double ar, ai; QA_FLAGS(1, 0, 1, 0, 1, 1, 0, 0, 0)
+  template <typename real, int M> __device__ void operator()(real *x, real *y, real *z, real *, double *) const {
+#pragma unroll
+    for (int i = 0; i < M; i += 2) {
+      const real xr = x[i], xi = x[i + 1], zr = z[i], zi = z[i + 1];
+      y[i] = (real)ar * xr - (real)ai * xi;
+      y[i + 1] = (real)ar * xi + (real)ai * xr;
+      x[i] = xr - ((real)ar * zr - (real)ai * zi);
+      x[i + 1] = xi - ((real)ar * zi + (real)ai * zr);
+    }
+  } };
+// y = a x ; w = x - a z    (the same with the residual still in the source field x, which stays untouched)
+struct CaxInitF { double ar, ai; QA_FLAGS(1, 0, 1, 0, 0, 1, 0, 1, 0)
+  template <typename real, int M> __device__ void operator()(real *x, real *y, real *z, real *w, double *) const {
+#pragma unroll
+    for (int i = 0; i < M; i += 2) {
+      const real xr = x[i], xi = x[i + 1], zr = z[i], zi = z[i + 1];
+      y[i] = (real)ar * xr - (real)ai * xi;
+      y[i + 1] = (real)ar * xi + (real)ai * xr;
+      w[i] = xr - ((real)ar * zr - (real)ai * zi);
+      w[i + 1] = xi - ((real)ar * zi + (real)ai * zr);
+    }
+  } };
 // x = a x ; y += b x (+ |y|^2)
 template <int NRM> struct CabxpyAxF { double a, br, bi; QA_FLAGS(1, 1, 0, 0, 1, 1, 0, 0, NRM)
   template <typename real, int M> __device__ void operator()(real *x, real *y, real *, real *, double *r) const {
@@ -825,6 +849,12 @@ void caxpyXmaz(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, const
   CaxpyXmazF<0> f; f.ar = a.real(); f.ai = a.imag(); launch(f, x, &y, &z, nullptr, nullptr);
 }
 void caxpyXmazMR(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z) { caxpyXmaz(a, x, y, z); }
+void caxXmaz(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z) {
+  CaxXmazF f; f.ar = a.real(); f.ai = a.imag(); launch(f, x, &y, &z, nullptr, nullptr);
+}
+void caxInit(const Complex &a, const ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z, ColorSpinorField &w) {
+  CaxInitF f; f.ar = a.real(); f.ai = a.imag(); launch(f, x, &y, &z, &w, nullptr);
+}
 double caxpyXmazNormX(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z) {
   CaxpyXmazF<1> f; f.ar = a.real(); f.ai = a.imag(); double r[1]; launch(f, x, &y, &z, nullptr, r); return r[0];
 }

@@ -57,6 +57,7 @@ void Dirac::MMdag(ColorSpinorField &out, const ColorSpinorField &in) const {
 
 void Dirac::hopDir(ColorSpinorField &, const ColorSpinorField &, int) const { errorQuda("hopDir not available for Dirac type %d", type); }
 void Dirac::localTerm(ColorSpinorField &, const ColorSpinorField &) const { errorQuda("localTerm not available for Dirac type %d", type); }
+void Dirac::localTermParity(ColorSpinorField &, const ColorSpinorField &, int) const { errorQuda("localTermParity not available for Dirac type %d", type); }
 
 bool Dirac::isPC() const {
   return type == QUDA_WILSONPC_DIRAC || type == QUDA_TWISTED_MASSPC_DIRAC || type == QUDA_TWISTED_CLOVERPC_DIRAC || type == QUDA_COARSEPC_DIRAC ||
@@ -116,6 +117,7 @@ void DiracWilson::hopDir(ColorSpinorField &out, const ColorSpinorField &in, int 
   applyHopDir(out.Even(), in.Odd(), *gauge, QUDA_EVEN_PARITY, dir, -kappa);
 }
 void DiracWilson::localTerm(ColorSpinorField &out, const ColorSpinorField &in) const { blas::copy(out, in); }
+void DiracWilson::localTermParity(ColorSpinorField &out, const ColorSpinorField &in, int) const { if (out.V() != in.V()) blas::copy(out, in); }
 
 void DiracWilson::prepare(ColorSpinorField *&src, ColorSpinorField *&sol, ColorSpinorField &x, ColorSpinorField &b,
                           const QudaSolutionType solType) const {
@@ -193,6 +195,7 @@ void DiracTwistedMass::twistedApply(ColorSpinorField &out, const ColorSpinorFiel
 }
 void DiracTwistedMass::Twist(ColorSpinorField &out, const ColorSpinorField &in) const { twistedApply(out, in, QUDA_TWIST_GAMMA5_DIRECT); }
 void DiracTwistedMass::localTerm(ColorSpinorField &out, const ColorSpinorField &in) const { Twist(out, in); }  // L = 1 + i a gamma5
+void DiracTwistedMass::localTermParity(ColorSpinorField &out, const ColorSpinorField &in, int) const { Twist(out, in); }
 
 static DslashMode tmMode(QudaTwistDslashType t) {
   switch (t) {
@@ -367,6 +370,7 @@ void DiracTwistedClover::TwistClover(ColorSpinorField &out, const ColorSpinorFie
   twistedCloverApply(out, in, QUDA_TWIST_GAMMA5_DIRECT, parity);
 }
 
+void DiracTwistedClover::localTermParity(ColorSpinorField &out, const ColorSpinorField &in, int parity) const { TwistClover(out, in, parity); }
 void DiracTwistedClover::localTerm(ColorSpinorField &out, const ColorSpinorField &in) const {  // L = A + i a gamma5
   checkFullSpinor(out, in);
   TwistClover(out.Even(), in.Even(), QUDA_EVEN_PARITY);

@@ -501,26 +501,46 @@ void mgProfilePrint() {
 // reference (lib/multigrid.cpp:492-560, outer_solution_type = QUDA_MATPC_SOLUTION) this needs the even-odd preconditioned
 // smoother; the single-parity residual is injected into the coarse grid (Transfer::setSiteSubset), the coarse problem is
 // the usual full coarse operator, and only the solved parity of the prolongated correction is added.
-void MG::cycleParity(ColorSpinorField &x, ColorSpinorField &b) {
+// fullResidual: the caller solves the FULL system behind an even-odd preconditioned smoother (prepare -> this -> reconstruct).  With the
+// reconstructed odd sites x_o = A^-1 (b_o + kappa D x_e) the full residual b - M x vanishes on the odd sites and equals A_ee r_hat on the
+// even ones for the symmetric preconditioning (r_hat = b_tilde - Mhat x_e; plain r_hat for the asymmetric one) — so the "restrict the
+// full residual" cycle (coarse_grid_solution_type = QUDA_MAT_SOLUTION, reference lib/multigrid.cpp:540-560) is THIS cycle with the
+// site-diagonal term applied to r_hat: no reconstruction before the coarse-grid correction, no application of the full operator, and
+// R and P touch one parity (half of V with the parity-major aggregates of transfer.hip).  The smoother hands over the residual it
+// ended with (Solver::lastResidual) instead of the cycle applying Mhat once more.
+void MG::cycleParity(ColorSpinorField &x, ColorSpinorField &b, bool fullResidual) {
   if (mgp.level != 0) errorQuda("a single-parity source can only enter the multigrid cycle on the finest level");
   if (!pcSmooth) errorQuda("For this coarse grid solution type, a preconditioned smoother is required");
   const Dirac &dirac = *mgp.matSmooth.Expose();
   const bool odd = dirac.getMatPCType() == QUDA_MATPC_ODD_ODD || dirac.getMatPCType() == QUDA_MATPC_ODD_ODD_ASYMMETRIC;
+  const bool symmetric = dirac.getMatPCType() == QUDA_MATPC_EVEN_EVEN || dirac.getMatPCType() == QUDA_MATPC_ODD_ODD;
   x.twistFlavor = b.twistFlavor;
   if (mgp.level == mgp.Nlevel - 1) { (*presmoother)(x, b); return; }
   ColorSpinorField &rp = odd ? r->Odd() : r->Even();
   r->twistFlavor = rp.twistFlavor = b.twistFlavor;
   g_mgCalls[mgp.level]++;
   { StageTimer t(mgp.level, 0); (*presmoother)(x, b); }
+  const ColorSpinorField *rin = &rp;
   {
     StageTimer t(mgp.level, 1);
-    mgp.matSmooth(rp, x);
-    blas::axpby(1.0, b, -1.0, rp);   // preconditioned residual rhat = b - Mhat x
+    static int reuse = -1;
+    if (reuse < 0) { const char *e = getenv("QUDA_AMD_MG_SMOOTHER_RESIDUAL"); reuse = e ? atoi(e) : 1; }
+    const ColorSpinorField *res = reuse && mgp.nu_pre > 0 ? presmoother->lastResidual() : nullptr;
+    if (res && res->Precision() == QUDA_SINGLE_PRECISION && !(fullResidual && symmetric)) {
+      rin = res;                          // restricted as it is
+    } else if (res) {
+      if (fullResidual && symmetric && res->Precision() == QUDA_SINGLE_PRECISION) dirac.localTermParity(rp, *res, odd ? 1 : 0);
+      else { blas::copy(rp, *res); if (fullResidual && symmetric) dirac.localTermParity(rp, rp, odd ? 1 : 0); }   // 16-bit smoother fields
+    } else {
+      mgp.matSmooth(rp, x);
+      blas::axpby(1.0, b, -1.0, rp);   // preconditioned residual rhat = b - Mhat x
+      if (fullResidual && symmetric) dirac.localTermParity(rp, rp, odd ? 1 : 0);
+    }
   }
   {
     StageTimer t(mgp.level, 2);
     transfer->setSiteSubset(QUDA_PARITY_SITE_SUBSET, odd ? QUDA_ODD_PARITY : QUDA_EVEN_PARITY);
-    transfer->R(*r_coarse, rp);
+    transfer->R(*r_coarse, *rin);
     blas::zero(*x_coarse);
   }
   { StageTimer t(mgp.level, 3); (*coarse_solver)(*x_coarse, *r_coarse); }
@@ -535,18 +555,25 @@ void MG::cycleParity(ColorSpinorField &x, ColorSpinorField &b) {
 }
 
 void MG::operator()(ColorSpinorField &x, ColorSpinorField &b) {
-  if (b.SiteSubset() != QUDA_FULL_SITE_SUBSET) { cycleParity(x, b); return; }
+  if (b.SiteSubset() != QUDA_FULL_SITE_SUBSET) { cycleParity(x, b, false); return; }
   const Dirac &dirac = *mgp.matSmooth.Expose();
-  if (mgp.level == 0 && mgp.level < mgp.Nlevel - 1 && pcSmooth && mgp.mg_global.coarse_grid_solution_type[0] == QUDA_MATPC_SOLUTION) {
-    // full-system outer solve with single-parity injection (reference outer QUDA_MAT_SOLUTION / inner QUDA_MATPC_SOLUTION,
-    // lib/multigrid.cpp:513-560): Schur-prepare the source, run the parity cycle, reconstruct the other parity
+  static int parityRoute = -1;
+  if (parityRoute < 0) { const char *e = getenv("QUDA_AMD_MG_PARITY_CYCLE"); parityRoute = e ? atoi(e) : 1; }
+  const bool matpc = mgp.mg_global.coarse_grid_solution_type[0] == QUDA_MATPC_SOLUTION;
+  if (mgp.level == 0 && mgp.level < mgp.Nlevel - 1 && pcSmooth && (matpc || parityRoute)) {
+    // full-system outer solve through the parity cycle: Schur-prepare the source, run the cycle on the solved parity, reconstruct the
+    // other one.  coarse_grid_solution_type QUDA_MATPC_SOLUTION: single-parity injection of the preconditioned residual (reference outer
+    // QUDA_MAT_SOLUTION / inner QUDA_MATPC_SOLUTION, lib/multigrid.cpp:513-560); QUDA_MAT_SOLUTION: the full residual, which behind an
+    // even-odd smoother lives on that parity as well (cycleParity, fullResidual) — the same cycle as the full-field code below in exact
+    // arithmetic, without its reconstruct + full-operator application per cycle and with half the transfer traffic
+    // (QUDA_AMD_MG_PARITY_CYCLE=0 keeps the full-field form)
     ColorSpinorField *out = nullptr, *in = nullptr;
     r->twistFlavor = x.twistFlavor = b.twistFlavor;
     blas::copy(*r, b);
     dirac.prepare(in, out, x, *r, QUDA_MAT_SOLUTION);
     b_tilde->twistFlavor = b.twistFlavor;
     blas::copy(*b_tilde, *in);     // cycleParity overwrites r's parity halves
-    cycleParity(*out, *b_tilde);
+    cycleParity(*out, *b_tilde, !matpc);
     dirac.reconstruct(x, b, QUDA_MAT_SOLUTION);
     return;
   }

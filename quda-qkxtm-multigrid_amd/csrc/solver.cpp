@@ -98,9 +98,19 @@ static ColorSpinorField *like(const ColorSpinorField &x, QudaPrecision prec, boo
 // ================================================================================================
 // MR — used as the smoother (fixed iteration count, relaxation omega)
 // ================================================================================================
-MR::MR(DiracMatrix &mat_, DiracMatrix &matSloppy_, SolverParam &p) : Solver(p), mat(mat_), matSloppy(matSloppy_), rp(nullptr), Arp(nullptr), tmpp(nullptr), yp(nullptr) {}
+MR::MR(DiracMatrix &mat_, DiracMatrix &matSloppy_, SolverParam &p) : Solver(p), mat(mat_), matSloppy(matSloppy_), rp(nullptr), Arp(nullptr), tmpp(nullptr), yp(nullptr), residualValid(false) {}
 MR::~MR() { delete rp; delete Arp; delete tmpp; delete yp; }
 
+// The recurrence is the reference's (lib/inv_mr_quda.cpp:40-200: alpha = (Ar, r) / |Ar|^2, x += omega alpha r, r -= omega alpha Ar); what
+// is re-designed is the traffic around it, because as the multigrid smoother it runs two iterations at a time and the BLAS around
+// four stencil applications was 10 % of a 48^3 x 96 solve (profiles/r03a_c5_mg_solve_table.json: copy b, norm, zero x, zero y,
+// normalise r, ..., scale y, copy to x = 25 field passes for 2 iterations):
+//   * no normalisation of the residual (alpha is scale-invariant; 16-bit fields carry a scale per site) — the source's norm is only
+//     computed where somebody asks for it;
+//   * the iteration runs on x itself when x has the work precision, and the first one of a zero start reads b in place of r and writes
+//     x and r without reading them (CaxInitF): 13 passes for 2 iterations, 17 with an initial guess;
+//   * the residual the iteration ends with, b - A x in the work precision, stays available (lastResidual): the multigrid cycle
+//     restricts it instead of applying the operator once more.
 void MR::operator()(ColorSpinorField &x, ColorSpinorField &b) {
   blas::setGlobalReduction(param.global_reduction);
   auto fits = [&](ColorSpinorField *f) { return f && f->VolumeCB() == x.VolumeCB() && f->SiteSubset() == x.SiteSubset() && f->Ncolor() == x.Ncolor(); };
@@ -108,47 +118,49 @@ void MR::operator()(ColorSpinorField &x, ColorSpinorField &b) {
     delete rp; delete Arp; delete tmpp; delete yp;
     Arp = like(x, param.precision_sloppy, true);
     rp = like(x, param.precision_sloppy, true);
-    yp = like(x, param.precision_sloppy, true);
+    yp = nullptr;
     tmpp = nullptr;
   }
-  for (ColorSpinorField *f : {rp, Arp, yp}) f->twistFlavor = b.twistFlavor;
-  ColorSpinorField &r = *rp, &Ar = *Arp, &y = *yp;
+  const bool same = x.Precision() == param.precision_sloppy;
+  if (!same && !yp) yp = like(x, param.precision_sloppy, true);
+  for (ColorSpinorField *f : {rp, Arp, yp}) if (f) f->twistFlavor = b.twistFlavor;
+  ColorSpinorField &r = *rp, &Ar = *Arp;
+  ColorSpinorField &y = same ? x : *yp;   // where the iteration accumulates
   const double t0 = now();
-
-  double r2 = 0.0;
-  if (param.use_init_guess == QUDA_USE_INIT_GUESS_YES) {
-    blas::copy(y, x);
-    matSloppy(r, y);
-    blas::copy(y, b);
-    r2 = blas::xmyNorm(y, r);  // r = b - A x0
-  } else {
-    blas::copy(r, b);
-    r2 = blas::norm2(r);
-    blas::zero(x);
-  }
-  blas::zero(y);
-  const double b2 = param.is_preconditioner ? r2 : blas::norm2(b);
-  const double c2 = r2;
-  if (c2 > 0.0) { blas::ax(1.0 / sqrt(c2), r); r2 = 1.0; }
-  if (!param.is_preconditioner) blas::flops = 0;
+  const bool guess = param.use_init_guess == QUDA_USE_INIT_GUESS_YES;
   const double omega = param.omega;
+  residualValid = false;
+  if (!param.is_preconditioner) blas::flops = 0;
+  const double b2 = param.is_preconditioner ? 0.0 : blas::norm2(b);
+
+  bool fresh = !guess;   // y (and, for `same`, r) not written yet: the first iteration defines them
+  if (guess) {
+    if (same) { matSloppy(r, x); blas::axpby(1.0, b, -1.0, r); }                           // r = b - A x, then iterate on x itself
+    else { blas::copy(y, x); matSloppy(r, y); blas::copy(y, b); blas::axpby(1.0, y, -1.0, r); blas::zero(y); }
+  } else if (!same) {
+    blas::copy(r, b);   // precision change
+  }
   int k = 0;
-  while (k < param.maxiter && r2 > 0.0) {
-    matSloppy(Ar, r);
-    const double3_t Ar3 = blas::cDotProductNormA(Ar, r);
-    const Complex alpha = Complex(Ar3.x, Ar3.y) / Ar3.z;
-    blas::caxpyXmaz(omega * alpha, r, y, Ar);  // y += a r ; r -= a Ar
+  while (k < param.maxiter) {
+    const ColorSpinorField &rin = (fresh && same) ? b : r;   // zero start in the work precision: b IS the residual
+    matSloppy(Ar, rin);
+    const double3_t Ar3 = blas::cDotProductNormA(Ar, rin);
+    if (!(Ar3.z > 0.0)) break;   // zero source (or breakdown): nothing to add
+    const Complex alpha = omega * Complex(Ar3.x, Ar3.y) / Ar3.z;
+    if (fresh && same) blas::caxInit(alpha, b, y, Ar, r);        // y = a b ; r = b - a Ar
+    else if (fresh) blas::caxXmaz(alpha, r, y, Ar);              // y = a r ; r -= a Ar
+    else blas::caxpyXmaz(alpha, r, y, Ar);                       // y += a r ; r -= a Ar
+    fresh = false;
     k++;
     if (getVerbosity() >= QUDA_DEBUG_VERBOSE) printfQuda("MR: %d iterations, <r|A|r> = (%e, %e)\n", k, Ar3.x, Ar3.y);
   }
-  const double scale = c2 > 0.0 ? sqrt(c2) : 1.0;
-  if (param.use_init_guess == QUDA_USE_INIT_GUESS_YES) {
-    if (x.Precision() == y.Precision()) blas::axpy(scale, y, x);
-    else { blas::ax(scale, y); ColorSpinorField *t = like(x, x.Precision(), false); blas::copy(*t, y); blas::xpy(*t, x); delete t; }
-  } else {
-    blas::ax(scale, y);
-    blas::copy(x, y);
+  if (fresh) {   // no iteration happened
+    if (!guess) { blas::zero(x); if (same) blas::copy(r, b); }
+  } else if (!same) {
+    if (guess) { ColorSpinorField *t = like(x, x.Precision(), false); blas::copy(*t, y); blas::xpy(*t, x); delete t; }
+    else blas::copy(x, y);
   }
+  residualValid = true;
   if (!param.is_preconditioner) {
     param.secs += now() - t0;
     param.gflops += (blas::flops + mat.flops() + matSloppy.flops()) * 1e-9;

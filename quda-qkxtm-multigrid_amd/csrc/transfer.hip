@@ -61,15 +61,30 @@ struct MaskArg {
   int boundary;  // 1: keep sites whose dir-neighbour is outside the aggregate, 0: inside
   int bs[4];
   int single[4]; // coarse extent 1 in that dimension: the neighbour always wraps into the same aggregate
+  int pm;        // parity-major order of the sites inside an aggregate (Transfer::parityMajor), else lexicographic
 };
+// coordinates of site b of an aggregate.  Lexicographic (x fastest), or — parity-major, all block extents even — the even sites of the
+// aggregate first, then the odd ones, each half in lexicographic order halved (the checkerboard numbering of the lattice applied to
+// the block): a single-parity fine field (Transfer::setSiteSubset) then meets ONE contiguous half of every (component, vector pair)
+// row of V, and the waves that own the absent parity issue no loads at all — half the V bytes for R and P of an even-odd cycle.
+__device__ __forceinline__ void block_coords(int *y, const MaskArg &m, int b) {
+  int l = b, p = 0;
+  if (m.pm) {
+    const int half = (m.bs[0] * m.bs[1] * m.bs[2] * m.bs[3]) >> 1;
+    p = b >= half;
+    l = 2 * (b - p * half);
+  }
+  y[0] = l % m.bs[0]; l /= m.bs[0];
+  y[1] = l % m.bs[1]; l /= m.bs[1];
+  y[2] = l % m.bs[2]; y[3] = l / m.bs[2];
+  if (m.pm) y[0] += (p + y[1] + y[2] + y[3]) & 1;   // y[0] is even here: the site of the pair that has parity p
+}
 
 __device__ __forceinline__ bool mask_keep(const MaskArg &m, int b) {
   if (m.dir < 0) return true;
   const int mu = m.dir >> 1, fwd = !(m.dir & 1);
-  int y[4], l = b;
-  y[0] = l % m.bs[0]; l /= m.bs[0];
-  y[1] = l % m.bs[1]; l /= m.bs[1];
-  y[2] = l % m.bs[2]; y[3] = l / m.bs[2];
+  int y[4];
+  block_coords(y, m, b);
   const bool out = !m.single[mu] && (fwd ? y[mu] == m.bs[mu] - 1 : y[mu] == 0);
   return out == (m.boundary != 0);
 }
@@ -94,10 +109,8 @@ __device__ __forceinline__ float4 block_sum4(float4 v, float4 *lds) {
 // mask.dir neighbour leaves the aggregate go into `out`, the others into `out2`, in ONE pass over V (V is the whole cost) ----
 __device__ __forceinline__ bool mask_outside(const MaskArg &m, int b) {
   const int mu = m.dir >> 1, fwd = !(m.dir & 1);
-  int y[4], l = b;
-  y[0] = l % m.bs[0]; l /= m.bs[0];
-  y[1] = l % m.bs[1]; l /= m.bs[1];
-  y[2] = l % m.bs[2]; y[3] = l / m.bs[2];
+  int y[4];
+  block_coords(y, m, b);
   return !m.single[mu] && (fwd ? y[mu] == m.bs[mu] - 1 : y[mu] == 0);
 }
 
@@ -200,10 +213,8 @@ struct Multi4 {
 };
 __device__ __forceinline__ bool mask_outside_dir(const MaskArg &m, int dir, int b) {
   const int mu = dir >> 1, fwd = !(dir & 1);
-  int y[4], l = b;
-  y[0] = l % m.bs[0]; l /= m.bs[0];
-  y[1] = l % m.bs[1]; l /= m.bs[1];
-  y[2] = l % m.bs[2]; y[3] = l / m.bs[2];
+  int y[4];
+  block_coords(y, m, b);
   return !m.single[mu] && (fwd ? y[mu] == m.bs[mu] - 1 : y[mu] == 0);
 }
 // every wave keeps its partial sums of ALL (chirality, vector pair) steps in its own LDS rows, so the steps run back to back
@@ -781,6 +792,12 @@ Transfer::Transfer(const std::vector<ColorSpinorField *> &B, int Nvec_, int *gbs
   if (blockVol == 1) errorQuda("Total geometric block size is 1");
   if (blockVol > 1024) errorQuda("aggregate of %d sites exceeds one work-group", blockVol);
   if (getVerbosity() >= QUDA_VERBOSE) printfQuda("Transfer: using block size %d x %d x %d x %d\n", geo_bs[0], geo_bs[1], geo_bs[2], geo_bs[3]);
+  // order of the sites inside an aggregate: parity-major on the finest level when every block extent is even (block_coords above)
+  {
+    static int pmEnv = -1;
+    if (pmEnv < 0) { const char *e = getenv("QUDA_AMD_V_PARITY_MAJOR"); pmEnv = e ? atoi(e) : 1; }
+    parityMajor = pmEnv && fineSpin == 4 && geo_bs[0] % 2 == 0 && geo_bs[1] % 2 == 0 && geo_bs[2] % 2 == 0 && geo_bs[3] % 2 == 0;
+  }
   createGeoMap();
   HIP_CHECK(qaMalloc((void **)&V, vBytes()));
   fillAndOrthonormalise(B);
@@ -824,7 +841,8 @@ void Transfer::createGeoMap() {
       const int cpar = (xc[0] + xc[1] + xc[2] + xc[3]) & 1;
       const long clex = ((long)(xc[3] * Xc[2] + xc[2]) * Xc[1] + xc[1]) * Xc[0] + xc[0];
       const long A = cpar * Vhc + clex / 2;
-      const int b = ((yb[3] * geo_bs[2] + yb[2]) * geo_bs[1] + yb[1]) * geo_bs[0] + yb[0];
+      int b = ((yb[3] * geo_bs[2] + yb[2]) * geo_bs[1] + yb[1]) * geo_bs[0] + yb[0];
+      if (parityMajor) b = ((yb[0] + yb[1] + yb[2] + yb[3]) & 1) * (blockVol / 2) + b / 2;   // block extents even: site parity = block-local parity
       const long f = parity * Vh + i;
       b2f[A * blockVol + b] = (int)f;
       f2b[f] = (int)(A * blockVol + b);
@@ -957,7 +975,7 @@ void Transfer::R(ColorSpinorField &coarse, const ColorSpinorField &fine, int dir
   const FineVec in = fineVec(fine, sub ? (int)subset_parity : -1);
   const CoarseVec out = coarseVec(coarse);
   MaskArg m;
-  m.dir = dir; m.boundary = boundary;
+  m.dir = dir; m.boundary = boundary; m.pm = parityMajor ? 1 : 0;
   for (int d = 0; d < 4; d++) { m.bs[d] = geo_bs[d]; m.single[d] = Xc[d] == 1; }
   const int threads = (blockVol + 63) / 64 * 64;
   int gs = 1; while (gs < blockVol) gs <<= 1;
@@ -987,7 +1005,7 @@ void Transfer::RSplit(ColorSpinorField &leaving, ColorSpinorField &staying, cons
   const FineVec in = fineVec(fine);
   const CoarseVec out = coarseVec(leaving), out2 = coarseVec(staying);
   MaskArg m;
-  m.dir = dir; m.boundary = 1;
+  m.dir = dir; m.boundary = 1; m.pm = parityMajor ? 1 : 0;
   for (int d = 0; d < 4; d++) { m.bs[d] = geo_bs[d]; m.single[d] = Xc[d] == 1; }
   const int threads = (blockVol + 63) / 64 * 64;
   int gs = 1; while (gs < blockVol) gs <<= 1;
@@ -1058,7 +1076,7 @@ void Transfer::RSplit4(ColorSpinorField *const leaving[4], ColorSpinorField *con
     a.in[q] = fineVec(*fine[q]); a.out[q] = coarseVec(*leaving[q]); a.out2[q] = coarseVec(*staying[q]); a.dir[q] = dir[q];
   }
   MaskArg m;
-  m.dir = 0; m.boundary = 1;
+  m.dir = 0; m.boundary = 1; m.pm = parityMajor ? 1 : 0;
   for (int d = 0; d < 4; d++) { m.bs[d] = geo_bs[d]; m.single[d] = Xc[d] == 1; }
   const int threads = (blockVol + 63) / 64 * 64;
   switch (Nvec) {
