@@ -35,6 +35,7 @@ struct MGParam : SolverParam {
   QudaInverterType smoother;
   DiracMatrix &matResidual, &matSmooth;
   QudaTwistFlavorType fineFlavor;
+  bool vectorsPreset = false;   // level 0: B already holds the vectors to build the hierarchy from (multigrid_solver::refine)
   MGParam(QudaMultigridParam &g, std::vector<ColorSpinorField *> &B, DiracMatrix &matResidual, DiracMatrix &matSmooth, int level, QudaTwistFlavorType flavor);
 };
 
@@ -97,6 +98,11 @@ struct multigrid_solver {
   QudaMultigridParam mg_param_copy;
   QudaInvertParam inv_param_copy;
   explicit multigrid_solver(QudaMultigridParam &mg_param);
+  // Set-up refinement (not in the reference, whose null vectors are final once BiCGstab stops): `passes` times, every null vector v of
+  // level 0 is replaced by K^cycles v, K = one multigrid cycle of the CURRENT hierarchy as approximate inverse — an inverse iteration
+  // through the hierarchy, which enriches the vectors in exactly the low modes the first set-up resolved poorly (at a critical kappa its
+  // BiCGstab solves stop at their iteration cap) — and the hierarchy is rebuilt from them (transfer, Galerkin operators, coarse levels).
+  void refine(int passes, int cycles);
   ~multigrid_solver();
 };
 

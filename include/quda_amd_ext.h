@@ -80,6 +80,10 @@ void qudaAmdMultigridCycle(void *mg_instance, void *h_x, void *h_b, QudaInvertPa
  * does the same at newMultigridQuda. */
 void qudaAmdMultigridSetHalfStorage(void *mg_instance, int on);
 int qudaAmdMultigridLevels(void *mg_instance);
+/* set-up refinement: every level-0 null vector is replaced by (one multigrid cycle)^cycles applied to it and the hierarchy is rebuilt, `passes`
+ * times (an inverse iteration through the hierarchy; for problems at a critical kappa, where the first BiCGstab set-up stops at its cap).
+ * The QudaMultigridParam the hierarchy was created from need not be alive any more.  Returns the seconds spent. */
+double qudaAmdMultigridRefine(void *mg_instance, int passes, int cycles);
 int qudaAmdMultigridOrthoFallbackBlocks(void *mg_instance, int level); /* blocks the fp32 CholeskyQR2 block orthonormalisation handed to Gram-Schmidt (ill-conditioned) */
 void qudaAmdMultigridLevelInfo(void *mg_instance, int level, int info[18]); /* Xf[4] Xc[4] fineSpin fineColor Nvec geo_bs[4] spin_bs null_vector_method (0 sequential solves / loaded, 1 lockstep on the multi-rhs fine stencil, 2 lockstep on the MFMA coarse operator) lockstep_iterations */
 void qudaAmdMultigridGetNullVector(void *mg_instance, int level, int k, float *h_out);

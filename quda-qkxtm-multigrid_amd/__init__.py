@@ -119,7 +119,7 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
                  "qudaAmdMultigridVerify", "qudaAmdMultigridCycle", "qudaAmdTimeAxpy", "qudaAmdMultigridLevels", "qudaAmdMultigridLevelInfo",
                  "qudaAmdMultigridSetHalfStorage", "qudaAmdMultigridGetNullVector", "qudaAmdMultigridGetV", "qudaAmdMultigridGetCoarseLinks", "qudaAmdMultigridApply", "qudaAmdMultigridApplyBlock",
                  "qudaAmdMultigridTimeApply", "qudaAmdMultigridTimeTransfer", "qudaAmdSetExitLine", "qudaAmdDiracPrepare", "qudaAmdDiracReconstruct", "qudaAmdSpinorRawInfo", "qudaAmdGaugeRawInfo", "qudaAmdCloverRawInfo", "qudaAmdRawDeviceCopy",
-                 "qudaAmdSetSolutionSink", "qudaAmdCommStats", "qudaAmdDescribeHaloError", "qudaAmdMultigridOrthoFallbackBlocks", "qudaAmdProfileMarker", "qudaAmdAccountStart", "qudaAmdAccountDump", "qudaAmdWriteSpinorFields", "qudaAmdReadSpinorFields"]
+                 "qudaAmdSetSolutionSink", "qudaAmdCommStats", "qudaAmdDescribeHaloError", "qudaAmdMultigridOrthoFallbackBlocks", "qudaAmdProfileMarker", "qudaAmdAccountStart", "qudaAmdAccountDump", "qudaAmdWriteSpinorFields", "qudaAmdReadSpinorFields", "qudaAmdMultigridRefine"]
 
 _lib = None
 
@@ -194,6 +194,8 @@ def lib():
         L.qudaAmdMultigridSetHalfStorage.argtypes = [_p, _i]
         L.qudaAmdMultigridLevels.argtypes = [_p]
         L.qudaAmdMultigridOrthoFallbackBlocks.argtypes = [_p, _i]
+        L.qudaAmdMultigridRefine.argtypes = [_p, _i, _i]
+        L.qudaAmdMultigridRefine.restype = _d
         L.qudaAmdProfileMarker.argtypes = [_i]
         L.qudaAmdAccountDump.argtypes = [C.c_char_p]
         L.qudaAmdCommStats.argtypes = [C.POINTER(C.c_longlong)]
@@ -585,6 +587,10 @@ class Multigrid:
         lib().qudaAmdMultigridLevelInfo(self.h, level, a)
         v = list(a)
         return dict(Xf=v[0:4], Xc=v[4:8], fineSpin=v[8], fineColor=v[9], Nvec=v[10], geo_bs=v[11:15], spin_bs=v[15], null_method=v[16], null_iters=v[17])
+
+    def refine(self, passes=1, cycles=1):
+        """set-up refinement: inverse iteration of the null vectors through the current hierarchy, hierarchy rebuilt; seconds spent"""
+        return float(lib().qudaAmdMultigridRefine(self.h, int(passes), int(cycles)))
 
     def ortho_fallback_blocks(self, level):
         return int(lib().qudaAmdMultigridOrthoFallbackBlocks(self.h, int(level)))

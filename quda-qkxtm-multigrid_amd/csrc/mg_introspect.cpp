@@ -58,6 +58,16 @@ void qudaAmdMultigridLevelInfo(void *mg_instance, int level, int info[18]) {
   info[16] = lv->nullVectorMethod; info[17] = lv->nullVectorIterations;
 }
 
+// set-up refinement (multigrid.h multigrid_solver::refine): `passes` inverse-iteration passes of `cycles` multigrid cycles per null vector,
+// the hierarchy rebuilt after each; returns the seconds it took
+double qudaAmdMultigridRefine(void *mg_instance, int passes, int cycles) {
+  multigrid_solver *s = static_cast<multigrid_solver *>(mg_instance);
+  if (!s) errorQuda("null multigrid instance");
+  const double before = s->mg_param_copy.secs;
+  s->refine(passes, cycles);
+  return s->mg_param_copy.secs - before;
+}
+
 // (aggregate, chirality) blocks of the level's transfer operator that the fp32 CholeskyQR2 orthonormalisation handed to Gram-Schmidt
 int qudaAmdMultigridOrthoFallbackBlocks(void *mg_instance, int level) {
   const Transfer *T = levelOf(mg_instance, level)->getTransfer();

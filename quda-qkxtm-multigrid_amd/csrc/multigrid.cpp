@@ -63,7 +63,9 @@ MG::MG(MGParam &p)
   if (pcSmooth != p.matSmooth.isPC()) errorQuda("smoother_solve_type[%d] and the smoother operator disagree about even-odd preconditioning", p.level);
 
   if (!coarsest) {
-    if (p.mg_global.compute_null_vector == QUDA_COMPUTE_NULL_VECTOR_YES && (p.mg_global.generate_all_levels == QUDA_BOOLEAN_YES || p.level == 0)) {
+    if (p.vectorsPreset && p.level == 0) {
+      // refinement pass: the caller has put the vectors into B
+    } else if (p.mg_global.compute_null_vector == QUDA_COMPUTE_NULL_VECTOR_YES && (p.mg_global.generate_all_levels == QUDA_BOOLEAN_YES || p.level == 0)) {
       const double t0 = now();
       generateNullVectors(p.B);
       HIP_CHECK(hipStreamSynchronize(computeStream()));
@@ -744,11 +746,41 @@ multigrid_solver::multigrid_solver(QudaMultigridParam &mg_param)
   if (mg_param.run_verify == QUDA_BOOLEAN_YES) { double dev[3]; mg->verify(dev); }
   mg_param_copy = mg_param;
   inv_param_copy = *param;
+  { const char *e = getenv("QUDA_AMD_MG_REFINE"); if (e && atoi(e) > 0) refine(atoi(e), 1); }
   { const char *e = getenv("QUDA_AMD_MG_HALF"); if (e && atoi(e)) multigridSetHalfStorage(*this, true); }
   mg_param.secs = now() - t0;
   // the block work fields of the lockstep solves (7 x 4 GB at 48^3 x 96) stay parked in the pool for the next hierarchy (the down-flavour
   // one of the QKXTM drivers is built right after this one); QUDA_AMD_POOL_KEEP=0 hands everything of 256 MB and more back now
   { const char *e = getenv("QUDA_AMD_POOL_KEEP"); if (e && !atoi(e)) { HIP_CHECK(hipStreamSynchronize(computeStream())); poolDeviceFlush((size_t)256 << 20); } }
+}
+
+void multigrid_solver::refine(int passes, int cycles) {
+  if (passes <= 0) return;
+  const double t0 = now();
+  ColorSpinorField *y = likeField(*B[0]);
+  const QudaTwistFlavorType flavor = B[0]->TwistFlavor();
+  y->twistFlavor = flavor;
+  mg_param_copy.invert_param = &inv_param_copy;
+  for (int pass = 0; pass < passes; pass++) {
+    for (size_t i = 0; i < B.size(); i++) {
+      for (int c = 0; c < (cycles > 0 ? cycles : 1); c++) {
+        (*mg)(*y, *B[i]);          // y = K v: one cycle of the current hierarchy
+        blas::copy(*B[i], *y);
+        const double n2 = blas::norm2(*B[i]);
+        if (!(n2 > 0.0) || !std::isfinite(n2)) errorQuda("set-up refinement: null vector %zu collapsed (|K v|^2 = %e)", i, n2);
+        blas::ax(1.0 / sqrt(n2), *B[i]);
+      }
+    }
+    HIP_CHECK(hipStreamSynchronize(computeStream()));
+    delete mg;
+    delete mgParam;
+    mgParam = new MGParam(mg_param_copy, B, *m, mSmooth ? *mSmooth : *m, 0, flavor);
+    mgParam->vectorsPreset = true;
+    mg = new MG(*mgParam);
+    if (getVerbosity() >= QUDA_SUMMARIZE || mgProfiling()) printfQuda("MG set-up refinement pass %d of %d done (%.3f s so far)\n", pass + 1, passes, now() - t0);
+  }
+  delete y;
+  mg_param_copy.secs += now() - t0;
 }
 
 void multigridSetHalfStorage(multigrid_solver &mgs, bool on) {

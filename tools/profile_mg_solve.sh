@@ -10,4 +10,5 @@ grep "^SOLVE" $out/run.log > gpurun_out/${tag}_mg_solve.log
 secs=$(python3 -c "import json,sys; print(json.loads(open('gpurun_out/${tag}_mg_solve.log').read()[6:])['solver_secs'])")
 python3 tools/summarize_solve_trace.py $(find $out -name "*kernel_trace.csv" | head -1) $out/acct.json profiles/${tag}_mg_solve_table.json $secs >> gpurun_out/${tag}_mg_solve.log 2>&1
 cp $(find $out -name "*kernel_stats.csv" | head -1) profiles/${tag}_mg_solve_whole_run_kernel_stats.csv
+cp profiles/${tag}_mg_solve_table.json profiles/${tag}_mg_solve_whole_run_kernel_stats.csv gpurun_out/ 2>/dev/null || true
 cat gpurun_out/${tag}_mg_solve.log
