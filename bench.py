@@ -122,14 +122,17 @@ def run_mg_ranks(qa, dist, X, kappa=0.124, mu=0.005):
     levels = 3 if all(x % 4 == 0 for x in Xl) and all(v == 2 for v in b1) else 2
     dist.barrier()
     t0 = time.perf_counter()
-    mp = qa.multigrid_param(ip, n_level=levels, geo_block=[(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)][:levels], n_vec=24, setup_maxiter=500, setup_tol=5e-6, smoother_pc=True)
+    mp = qa.multigrid_param(ip, n_level=levels, geo_block=[(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)][:levels], n_vec=24, setup_maxiter=500, setup_tol=5e-6, smoother_pc=True,
+                            cycle=qa.QUDA_MG_CYCLE_VCYCLE)   # the plain V-cycle of BASELINE.json configs[4], as extra.mg_gcr at N = 1
     mg = qa.Multigrid(mp)
     setup = dist.max_over_ranks(time.perf_counter() - t0)
+    lv0 = mg.level_info(0)
     ip.inv_type_precondition = qa.QUDA_MG_INVERTER
     ip.preconditioner = mg.h
     ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
     wall, inner, iters, x = timed_solve()
-    out = dict(lattice="x".join(map(str, X)), local_lattice="x".join(map(str, Xl)), process_grid=list(dist.grid), kappa=kappa, mu=mu, levels=levels, n_vec=24,
+    out = dict(lattice="x".join(map(str, X)), local_lattice="x".join(map(str, Xl)), process_grid=list(dist.grid), kappa=kappa, mu=mu, levels=levels, n_vec=24, cycle="V-cycle",
+               null_vectors_level0={0: "sequential BiCGstab solves", 1: "lockstep block BiCGstab on the multi-rhs stencil (ghost zones behind the block fields)"}.get(lv0["null_method"], "?"),
                setup_secs=round(setup, 3), solve_secs=round(wall, 4), solver_secs=round(inner, 4), iters=iters, true_res=global_res(x), plain_gcr=plain,
                timing="slowest rank, best of 2 after 1 warm-up solve; residual = global |b - M x| / |b| through MatQuda")
     mg.free()
@@ -137,10 +140,10 @@ def run_mg_ranks(qa, dist, X, kappa=0.124, mu=0.005):
 
 
 def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)), gauge=None, extras=True, kappa=0.124, mu=0.005, plain_maxiter=5000,
-           coarse_bench=True, setup_repeats=1, dslash="tm", csw=1.57551):
+           coarse_bench=True, setup_repeats=1, dslash="tm", csw=1.57551, cycle="V", refine=0):
     """MG-preconditioned GCR to |r|/|b| <= 1e-10 (the second half of the metric) on one GPU: 3-level K-cycle, 24 null
-    vectors, 4^4 then 2^4 aggregates, even-odd preconditioned MR smoother — the reference harness' default shape
-    (tests/multigrid_invert_test.cpp:224-286) on a smooth synthetic gauge field (synth.smooth_gauge: far easier than a production
+    vectors, 4^4 then 2^4 aggregates, even-odd preconditioned MR smoother — the reference harness' shape (tests/multigrid_invert_test.cpp:224-286)
+    with the plain V-cycle BASELINE.json configs[4] names (cycle="K": the harness' default K-cycle, reported next to it) on a smooth synthetic gauge field (synth.smooth_gauge: far easier than a production
     configuration — plain GCR needs only 76 iterations — so the MG / plain ratio here understates what MG buys at the physical point).  Setup (null
     vectors + Galerkin operators) and solve are timed separately; the residual is re-computed with MatQuda."""
     qa.lib().freeCloverQuda()
@@ -191,7 +194,8 @@ def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2,
     for rep in range(setup_repeats):
         if rep:
             mg.free()
-        mp = qa.multigrid_param(ip, n_level=3, geo_block=[tuple(bk) for bk in blocks], n_vec=24, setup_maxiter=500, setup_tol=5e-6, smoother_pc=True)
+        mp = qa.multigrid_param(ip, n_level=3, geo_block=[tuple(bk) for bk in blocks], n_vec=24, setup_maxiter=500, setup_tol=5e-6, smoother_pc=True,
+                                cycle=qa.QUDA_MG_CYCLE_VCYCLE if cycle == "V" else qa.QUDA_MG_CYCLE_RECURSIVE)
         mg = qa.Multigrid(mp)
         setups.append(round(mp.secs, 3))
     ip.inv_type_precondition = qa.QUDA_MG_INVERTER
@@ -199,15 +203,25 @@ def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2,
     ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
     wall, inner, iters, x = timed_solve()
     res = float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b))
+    refined = None
+    if refine:
+        # set-up refinement (not in the reference): inverse iteration of the null vectors through the hierarchy, hierarchy rebuilt; the
+        # numbers of the plain set-up stay in the line next to the refined ones
+        refined = dict(plain_setup=dict(iters=iters, solve_secs=round(wall, 4), solver_secs=round(inner, 4), true_res=res), passes=refine)
+        refined["refine_secs"] = round(mg.refine(refine, 1), 3)
+        wall, inner, iters, x = timed_solve()
+        res = float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b))
     # solve_secs: wall clock of invertQuda (host source in, host solution out, as SURVEY 8d defines it: includes the two
     # PCIe transfers and the operator / field set-up); solver_secs: the GCR loop alone (QudaInvertParam.secs)
     lv0, lv1 = mg.level_info(0), mg.level_info(1)
     out = dict(lattice="x".join(map(str, X)), action={"tm": "twisted mass", "tmc": "twisted clover (device-built clover, csw %g)" % csw}[dslash], kappa=kappa, mu=mu, levels=3, n_vec=24, blocks=[list(bk) for bk in blocks[:2]],
-               null_vectors=dict(level0={0: "sequential BiCGstab solves", 1: "lockstep block BiCGstab on the multi-rhs stencil", 2: "lockstep block BiCGstab on the MFMA coarse operator"}[lv0["null_method"]],
+               cycle={"V": "V-cycle (QUDA_MG_CYCLE_VCYCLE)", "K": "K-cycle (QUDA_MG_CYCLE_RECURSIVE)"}[cycle], null_vectors=dict(level0={0: "sequential BiCGstab solves", 1: "lockstep block BiCGstab on the multi-rhs stencil", 2: "lockstep block BiCGstab on the MFMA coarse operator"}[lv0["null_method"]],
                                  level0_lockstep_iters=lv0["null_iters"], level1={0: "sequential BiCGstab solves", 1: "lockstep (fine stencil)", 2: "lockstep block BiCGstab on the MFMA coarse operator"}[lv1["null_method"]],
                                  level1_lockstep_iters=lv1["null_iters"]),
                setup_secs=min(setups), setup_secs_all=setups, solve_secs=round(wall, 4),
                solver_secs=round(inner, 4), iters=iters, true_res=res, plain_gcr=plain, timing="best of 3 after 1 warm-up solve")
+    if refined:
+        out["setup_refinement"] = refined
     # the multi-right-hand-side coarse operator on the matrix cores (level 1: 2 Nvec = 48 rows, 9 dense matrices per site) against
     # the single-vector kernel: seconds per application, HBM rate on the ALGORITHMIC bytes (links once + in/out panels) and MFMA rate
     try:
@@ -247,6 +261,15 @@ def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2,
     out["half_precision_cycle"] = dict(solve_secs=round(wall, 4), solver_secs=round(inner, 4), iters=iters,
                                       true_res=float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b)))
     mg.set_half_storage(False)
+    mg.free()
+    # the other cycle type on the same problem (one more set-up)
+    other = "K" if cycle == "V" else "V"
+    mp = qa.multigrid_param(ip, n_level=3, geo_block=[tuple(bk) for bk in blocks], n_vec=24, setup_maxiter=500, setup_tol=5e-6, smoother_pc=True,
+                            cycle=qa.QUDA_MG_CYCLE_VCYCLE if other == "V" else qa.QUDA_MG_CYCLE_RECURSIVE)
+    mg = qa.Multigrid(mp)
+    ip.preconditioner = mg.h
+    wall, inner, iters, x = timed_solve()
+    out["%s_cycle" % other.lower()] = dict(solve_secs=round(wall, 4), solver_secs=round(inner, 4), iters=iters, true_res=float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b)))
     mg.free()
     return out
 
@@ -455,7 +478,7 @@ def main():
         extra["mg_gcr_tmc"] = run_mg(qa, (32, 32, 32, 32), gauge=g32, dslash="tmc", coarse_bench=False)
         # where multigrid matters: the same field at its critical kappa (tools/mg_kappa_scan.py, profiles/r02_mg_kappa_scan_32x4_c.json:
         # plain GCR(20) needs > 10^4 iterations there and stagnates beyond it; the twisted mass keeps the operator regular)
-        extra["mg_gcr_critical"] = run_mg(qa, (32, 32, 32, 32), gauge=g32, extras=False, kappa=0.147, mu=0.001, plain_maxiter=30000, coarse_bench=False)
+        extra["mg_gcr_critical"] = run_mg(qa, (32, 32, 32, 32), gauge=g32, extras=False, kappa=0.147, mu=0.001, plain_maxiter=30000, coarse_bench=False, refine=3)
         del g32
         # the SAME small problem on the GPU and, below, on the host cores (cpu_baseline.solver): 16^4, same field family, kappa, mu
         g16 = smooth_gauge((16, 16, 16, 16), 0.35)
