@@ -90,6 +90,7 @@ struct multigrid_solver {
   Dirac *dSmooth; // level-0 smoother operator (== d, or its even-odd preconditioned form)
   DiracM *mSmooth;
   GaugeField *gaugeHalf;   // 16-bit copy of the links for the half-precision smoother (multigridSetHalfStorage), owned
+  CloverField *cloverHalf; // and of the clover term (twisted clover), owned
   Dirac *dSmoothHalf;
   DiracM *mSmoothHalf;
   std::vector<ColorSpinorField *> B;

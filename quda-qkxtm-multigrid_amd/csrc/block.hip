@@ -283,7 +283,9 @@ const int *coarseNeighbourTable(const int Xc[4]) {
   g_nbrTables.push_back(t);
   return t.d;
 }
+namespace blockblas { void end(); }
 void freeBlockTables() {   // endQuda
+  blockblas::end();
   for (NbrTable &t : g_nbrTables) (void)hipFree(t.d);
   g_nbrTables.clear();
   if (g_blockSend) { poolDeviceFree(g_blockSend, g_blockSendBytes); g_blockSend = nullptr; g_blockSendBytes = 0; }
@@ -505,6 +507,11 @@ static double *d_part = nullptr;   // [block][sum][rhs]
 static double *h_res = nullptr;    // pinned
 static double *h_res_dev = nullptr;
 
+void end() {
+  if (d_part) (void)hipFree(d_part);
+  if (h_res) (void)hipHostFree(h_res);
+  d_part = nullptr; h_res = nullptr; h_res_dev = nullptr;
+}
 static void ensureBuffers() {
   if (d_part) return;
   HIP_CHECK(qaMalloc((void **)&d_part, (size_t)kMaxBlocks * 3 * kMaxBlockRhs * sizeof(double)));

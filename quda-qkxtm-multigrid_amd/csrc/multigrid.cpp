@@ -697,7 +697,7 @@ void MG::verify(double dev[3]) {
 // ================================================================================================
 // reference multigrid_solver ctor, lib/interface_quda.cpp:2161-2255
 multigrid_solver::multigrid_solver(QudaMultigridParam &mg_param)
-    : d(nullptr), m(nullptr), dSmooth(nullptr), mSmooth(nullptr), gaugeHalf(nullptr), dSmoothHalf(nullptr), mSmoothHalf(nullptr), mgParam(nullptr), mg(nullptr) {
+    : d(nullptr), m(nullptr), dSmooth(nullptr), mSmooth(nullptr), gaugeHalf(nullptr), cloverHalf(nullptr), dSmoothHalf(nullptr), mSmoothHalf(nullptr), mgParam(nullptr), mg(nullptr) {
   QudaInvertParam *param = mg_param.invert_param;
   if (!param) errorQuda("QudaMultigridParam.invert_param is NULL");
   if (mg_param.n_level < 2 || mg_param.n_level > QUDA_MAX_MG_LEVEL) errorQuda("Requested MG levels %d outside 2..%d", mg_param.n_level, QUDA_MAX_MG_LEVEL);
@@ -786,10 +786,10 @@ void multigrid_solver::refine(int passes, int cycles) {
 void multigridSetHalfStorage(multigrid_solver &mgs, bool on) {
   if (on) {
     mgs.mg->makeHalfMirrors();
-    // 16-bit level-0 smoother (the work fields and the operator of the MR iterations; source and result stay fp32): only
-    // with the even-odd smoother of the twisted-mass / Wilson operators (a 16-bit clover copy is not made)
+    // 16-bit level-0 smoother (the work fields and the operator of the MR iterations; source and result stay fp32) with the even-odd
+    // smoother; twisted clover (round 3): a 16-bit copy of the clover term is made too, its (A^2 + mu2)^-1 recomputed on the device
     QudaInvertParam *param = &mgs.inv_param_copy;
-    if (mgs.mSmooth && !mgs.mSmoothHalf && param->dslash_type != QUDA_TWISTED_CLOVER_DSLASH) {
+    if (mgs.mSmooth && !mgs.mSmoothHalf) {
       GaugeField *g = gaugePrecondition ? gaugePrecondition : (gaugeSloppy ? gaugeSloppy : gaugePrecise);
       mgs.gaugeHalf = new GaugeField(g->geom, QUDA_HALF_PRECISION, g->reconstruct, g->t_boundary, g->anisotropy);
       mgs.gaugeHalf->copyFrom(*g);
@@ -800,6 +800,15 @@ void multigridSetHalfStorage(multigrid_solver &mgs, bool on) {
       DiracParam dps;
       setDiracPreParam(dps, param, true);
       dps.gauge = mgs.gaugeHalf;
+      if (param->dslash_type == QUDA_TWISTED_CLOVER_DSLASH) {
+        if (!dps.clover) errorQuda("Clover field not allocated");
+        std::vector<double> host((size_t)g->geom.V * 72);
+        dps.clover->savePacked(host.data(), QUDA_DOUBLE_PRECISION);
+        mgs.cloverHalf = new CloverField(g->geom, QUDA_HALF_PRECISION);
+        mgs.cloverHalf->loadPacked(host.data(), nullptr, QUDA_DOUBLE_PRECISION);
+        mgs.cloverHalf->computeInverse(4.0 * param->kappa * param->kappa * param->mu * param->mu);
+        dps.clover = mgs.cloverHalf;
+      }
       mgs.dSmoothHalf = Dirac::create(dps);
       mgs.mSmoothHalf = new DiracM(*mgs.dSmoothHalf);
       param->kappa = orig_kappa; param->mu = orig_mu; param->mass = orig_mass;
@@ -820,6 +829,7 @@ multigrid_solver::~multigrid_solver() {
   delete mSmoothHalf;
   delete dSmoothHalf;
   delete gaugeHalf;
+  delete cloverHalf;
   delete mSmooth;
   delete dSmooth;
   delete m;

@@ -305,3 +305,29 @@ def test_dense_clover_twist_inverse_in_the_lockstep_solve(qa, oracle):
         assert worst < 0.5 * scale, (worst, scale)
     finally:
         mg.free()
+
+
+def test_twisted_clover_half_precision_cycle(qa, oracle):
+    """fp16 mirrors of V and the coarse links AND a 16-bit level-0 smoother on the twisted-clover operator (16-bit copies of the links and of
+    the clover term, its twisted inverse recomputed on the device; round 3): the outer fp64 GCR still reaches 1e-10 with the residual
+    recomputed on the host by tmc_mat, in at most two iterations more, and switching back restores the fp32 solve bit for bit."""
+    X, kappa, mu = (16, 8, 8, 16), 0.124, 0.005
+    gauge, clover, ip = _setup(qa, oracle, X, kappa, mu)
+    b = np.random.default_rng(29).random(int(np.prod(X)) * 24)
+    mp = qa.multigrid_param(ip, n_level=3, geo_block=[(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)], n_vec=8, setup_maxiter=300, setup_tol=1e-5, smoother_pc=True)
+    mg = qa.Multigrid(mp)
+    try:
+        _use_mg(qa, ip, mg)
+        x32 = qa.invert(b, ip)
+        it32 = ip.iter
+        mg.set_half_storage(True)
+        x16 = qa.invert(b, ip)
+        it16 = ip.iter
+        assert _true_residual(oracle, gauge, clover, X, kappa, mu, +1, x16, b) < 1e-10
+        assert it16 <= it32 + 2, (it16, it32)
+        mg.set_half_storage(False)
+        x32b = qa.invert(b, ip)
+        assert ip.iter == it32 and np.array_equal(x32b, x32)
+    finally:
+        mg.set_half_storage(False)
+        mg.free()
