@@ -536,9 +536,31 @@ void DiracCoarse::build() {
     herm = !full && (analyticLocal || (!four && pt == QUDA_COARSE_DIRAC));
     for (int d = 0; d < 4; d++) if (commGrid().partitioned(d)) herm = false;
   }
+  // fine parent with plain hop term (Wilson / twisted mass / twisted clover): the forward links and S as ONE batched product per direction
+  // on the matrix cores instead of 2 Nvec probes (Transfer::directGalerkinVUV); twisted clover keeps probing for its local term only
+  bool direct = false;
+  {
+    const QudaDiracType pt = parent->getDiracType();
+    direct = T.canDirectGalerkin() && (pt == QUDA_WILSON_DIRAC || pt == QUDA_TWISTED_MASS_DIRAC || pt == QUDA_TWISTED_CLOVER_DIRAC) && parent->Gauge() &&
+             parent->Gauge()->precision == QUDA_SINGLE_PRECISION && parent->Gauge()->reconstruct == QUDA_RECONSTRUCT_NO;
+    static int full = -1;
+    if (full < 0) { const char *e = getenv("QUDA_AMD_GALERKIN_FULL"); full = e ? atoi(e) : 0; }
+    if (full) direct = false;
+    if (direct && pt == QUDA_TWISTED_CLOVER_DIRAC) herm = true;   // hop part by completion, local term probed below (analyticLocal is false)
+  }
+  if (herm && direct) {
+    const size_t wbytes = T.vBytes();
+    float *W0 = (float *)poolDeviceMalloc(wbytes), *W1 = (float *)poolDeviceMalloc(wbytes);
+    for (int mu = 0; mu < 4; mu++) {
+      galerkinUV(W0, W1, T.V, *parent->Gauge(), 2 * mu, -parent->Kappa(), T.fine_to_block, T.blockVol, T.Nvec);
+      T.directGalerkinVUV(links->data, W0, W1, mu, mu > 0);
+    }
+    HIP_CHECK(hipStreamSynchronize(computeStream()));
+    poolDeviceFree(W0, wbytes); poolDeviceFree(W1, wbytes);
+  }
   if (herm) {
     const int fdirs[4] = {0, 2, 4, 6};
-    for (int j = 0; j < n; j++) {
+    for (int j = 0; j < (direct ? 0 : n); j++) {
       T.column(*phi, j);
       if (four) {
         for (int q = 0; q < 4; q++) parent->hopDir(*w8[q], *phi, fdirs[q]);

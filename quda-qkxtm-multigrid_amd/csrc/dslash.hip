@@ -963,6 +963,11 @@ struct FineBlockArg {
   int commMask;
   int ghostBase[4][2];
   BlockOrder order;
+  // compact work-group tiles (NRHS = 8, 32 sites per work-group): 4 x 4 x 2 x 2 lattice sites = 32 sites of the output parity instead of 32
+  // consecutive checkerboard sites.  The 256 neighbour panels a work-group reads are then only 128 distinct ones (every input site inside
+  // the tile is the neighbour of up to 8 of its output sites), so half of the requests can be served by the CU's L1 instead of the L2:
+  // the kernel is bound by the latency of its L2 requests (~100 KB in flight per CU), not by HBM.  tile = 0: the linear mapping.
+  int tile, tilesX, tilesY, tilesZ;
 };
 
 template <int NRHS, int CL = 0> __global__ void __launch_bounds__(256) fine_block_kernel(const FineBlockArg arg) {
@@ -971,14 +976,34 @@ template <int NRHS, int CL = 0> __global__ void __launch_bounds__(256) fine_bloc
   constexpr int TSTR = 144 + 4;                       // the dense clover-twist matrices of a site: 2 x 36 complex, same bank spread
   __shared__ float ulds[SPB * USTR];
   __shared__ __attribute__((aligned(16))) float tlds[CL ? SPB * TSTR : 4];
-  const int lb = arg.order.map(blockIdx.x);
   const int s = threadIdx.x / NRHS, i = threadIdx.x - s * NRHS;
-  const int idx0 = lb * SPB, idx = idx0 + s;
+  // site ss of this work-group -> checkerboard index
+  int idx0 = 0, tbase = 0;
+  if (NRHS == 8 && arg.tile) {
+    // work-groups dealt to the XCDs in contiguous eighths of the tile list (t slowest), tile -> its corner
+    const int nwg = (int)gridDim.x, b = (int)blockIdx.x;
+    int tl = (nwg & 7) == 0 ? (b & 7) * (nwg >> 3) + (b >> 3) : b;
+    const int tx = tl % arg.tilesX; tl /= arg.tilesX;
+    const int ty = tl % arg.tilesY; tl /= arg.tilesY;
+    const int tz = tl % arg.tilesZ; const int tt = tl / arg.tilesZ;
+    tbase = ((2 * tt * arg.Z + 2 * tz) * arg.Y + 4 * ty) * arg.Xh + 2 * tx;
+  } else {
+    idx0 = arg.order.map(blockIdx.x) * SPB;
+  }
+  auto site_of = [&](int ss) -> int {
+    if (NRHS == 8 && arg.tile) {   // ss = ((t_l 2 + z_l) 4 + y_l) 2 + xh_l
+      const int xl = ss & 1, yl = (ss >> 1) & 3, zl = (ss >> 3) & 1, tl = ss >> 4;
+      return tbase + ((tl * arg.Z + zl) * arg.Y + yl) * arg.Xh + xl;
+    }
+    return idx0 + ss;
+  };
+  const int idx = site_of(s);
   if (CL) {   // 36 float4 per site, contiguous in memory
     for (int e = threadIdx.x; e < 36 * SPB; e += blockDim.x) {
       const int ss = e / 36, q = e - ss * 36;
       typedef float f32x4_t __attribute__((ext_vector_type(4)));
-      if (idx0 + ss < arg.Vh) *reinterpret_cast<f32x4_t *>(&tlds[ss * TSTR + 4 * q]) = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(arg.tmat) + (size_t)(idx0 + ss) * 36 + q);
+      const int sidx = site_of(ss);
+      if (sidx < arg.Vh) *reinterpret_cast<f32x4_t *>(&tlds[ss * TSTR + 4 * q]) = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(arg.tmat) + (size_t)sidx * 36 + q);
     }
   }
   // ---- stage the links of the SPB sites: [site][dir][18]; planes 0..3 are float4, plane 4 the trailing float2 ----
@@ -986,12 +1011,13 @@ template <int NRHS, int CL = 0> __global__ void __launch_bounds__(256) fine_bloc
     const int ss = e % SPB, pl = (e / SPB) % 5, d = e / (5 * SPB);
     const char *blk = arg.gauge + (size_t)d * arg.link_bytes;
     float *dst = &ulds[ss * USTR + d * 18 + pl * 4];
-    if (idx0 + ss < arg.Vh) {
+    const int sidx = site_of(ss);
+    if (sidx < arg.Vh) {
       if (pl < 4) {
-        const float4 v = reinterpret_cast<const float4 *>(blk)[(size_t)pl * arg.g_stride + idx0 + ss];
+        const float4 v = reinterpret_cast<const float4 *>(blk)[(size_t)pl * arg.g_stride + sidx];
         dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
       } else {
-        const float2 v = reinterpret_cast<const float2 *>(blk + (size_t)4 * arg.g_stride * 16)[idx0 + ss];
+        const float2 v = reinterpret_cast<const float2 *>(blk + (size_t)4 * arg.g_stride * 16)[sidx];
         dst[0] = v.x; dst[1] = v.y;
       }
     }
@@ -1213,7 +1239,16 @@ void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_o
   arg.dXh = g.dXh; arg.dY = g.dY; arg.dZ = g.dZ;
   arg.s0 = (float)s0; arg.a0 = (float)a0; arg.k1 = (float)k1; arg.a1 = (float)a1;
   arg.order = makeBlockOrder(g, spb);
-  const int nb = (g.Vh + spb - 1) / spb;
+  int nb = (g.Vh + spb - 1) / spb;
+  arg.tile = 0; arg.tilesX = arg.tilesY = arg.tilesZ = 1;
+  {
+    static int tileEnv = -1;
+    if (tileEnv < 0) { const char *e = getenv("QUDA_AMD_BLOCK_FINE_TILE"); tileEnv = e ? atoi(e) : 1; }
+    if (tileEnv && nrhs == 8 && g.X[0] % 4 == 0 && g.X[1] % 4 == 0 && g.X[2] % 2 == 0 && g.X[3] % 2 == 0) {
+      arg.tile = 1; arg.tilesX = g.X[0] / 4; arg.tilesY = g.X[1] / 4; arg.tilesZ = g.X[2] / 2;
+      nb = arg.tilesX * arg.tilesY * arg.tilesZ * (g.X[3] / 2);   // = Vh / 32
+    }
+  }
   arg.parity = parity;
   arg.out = out; arg.in_same = in_same ? in_same : in_other; arg.in_other = in_other;
   arg.gauge = (const char *)U.parityBase(parity);
@@ -1967,6 +2002,96 @@ void applyCovariantShift(ColorSpinorField &out, const ColorSpinorField &in, cons
     case QUDA_DOUBLE_PRECISION: r12 ? launchHopDir<double, 12>(out, in, U, parity, dir, coef, true, x, xcoef) : launchHopDir<double, 18>(out, in, U, parity, dir, coef, true, x, xcoef); break;
     case QUDA_SINGLE_PRECISION: r12 ? launchHopDir<float, 12>(out, in, U, parity, dir, coef, true, x, xcoef) : launchHopDir<float, 18>(out, in, U, parity, dir, coef, true, x, xcoef); break;
     default: errorQuda("covariant shift: fp64/fp32 only");
+  }
+}
+
+// ---- direct Galerkin construction, step 1 ("UV", reference ComputeUV lib/coarse_op.cuh:59-125): the single-direction hop of hop_dir_kernel
+// applied to ALL columns of the transfer matrix V at once — the links are read once per site and vector pair instead of once per probe —
+// and separately for the upper / lower chirality of the neighbour (column (chi', v') of the coarse link is the hop of V's column v' with
+// only the spins of chirality chi' kept, Transfer::column):
+//     W_chi'(x)[s, c; v'] = coef [ (1 -+ gamma_mu) U_mu(x) ]_{s s'} V(x + mu)[s' in chi', c'; v']
+// V, W0, W1 in the aggregate-major order of the transfer operator, [aggregate][spin-colour][vector pair][site in aggregate] float4.
+// One thread per (site of `parity`, vector pair); same projector / link conventions as the probing path by construction (hop_arith).
+__global__ void __launch_bounds__(256) galerkin_uv_kernel(const DslashArg<float> arg, int dir, float coef, const float4 *V, float4 *W0, float4 *W1, const int *fine_to_block,
+                                                          int blockVol, int nvp) {
+  const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const int vp = (int)(t % nvp), idx = (int)(t / nvp);
+  if (idx >= arg.Vh) return;
+  const uint32_t za = arg.dXh.div((uint32_t)idx);
+  const int xh = idx - (int)za * arg.Xh;
+  const uint32_t zb = arg.dY.div(za);
+  const int y = (int)za - (int)zb * arg.Y;
+  const int tt = (int)arg.dZ.div(zb);
+  const int z = (int)zb - tt * arg.Z;
+  const int xodd = (y + z + tt + arg.parity) & 1;
+  const int Xh = arg.Xh, sy = Xh, sz = Xh * arg.Y, st = Xh * arg.Y * arg.Z;
+  int nbr;
+  float sign = 1;
+  switch (dir) {
+    case 0: nbr = xodd ? (xh == Xh - 1 ? idx - (Xh - 1) : idx + 1) : idx; break;
+    case 1: nbr = xodd ? idx : (xh == 0 ? idx + (Xh - 1) : idx - 1); break;
+    case 2: nbr = y == arg.Y - 1 ? idx - (arg.Y - 1) * sy : idx + sy; break;
+    case 3: nbr = y == 0 ? idx + (arg.Y - 1) * sy : idx - sy; break;
+    case 4: nbr = z == arg.Z - 1 ? idx - (arg.Z - 1) * sz : idx + sz; break;
+    case 5: nbr = z == 0 ? idx + (arg.Z - 1) * sz : idx - sz; break;
+    case 6: nbr = tt == arg.T - 1 ? idx - (arg.T - 1) * st : idx + st; if (tt == arg.T - 1) sign = arg.tsign_fwd; break;
+    default: nbr = tt == 0 ? idx + (arg.T - 1) * st : idx - st; if (tt == 0) sign = arg.tsign_bwd; break;
+  }
+  const int posN = fine_to_block[(1 - arg.parity) * arg.Vh + nbr], posX = fine_to_block[arg.parity * arg.Vh + idx];
+  const int AN = posN / blockVol, bN = posN - AN * blockVol, AX = posX / blockVol, bX = posX - AX * blockVol;
+  float psi[2][24], U[18];
+#pragma unroll
+  for (int k = 0; k < 12; k++) {
+    const float4 v = V[(((size_t)AN * 12 + k) * nvp + vp) * blockVol + bN];
+    psi[0][2 * k] = v.x; psi[0][2 * k + 1] = v.y; psi[1][2 * k] = v.z; psi[1][2 * k + 1] = v.w;
+  }
+  Link<float, 18>::load(U, arg.gauge + (size_t)dir * arg.link_bytes, arg.g_stride, idx, sign);
+  float out[2][2][24];   // [chirality of the source spins][vector of the pair][24]
+#pragma unroll
+  for (int chi = 0; chi < 2; chi++)
+#pragma unroll
+    for (int vec = 0; vec < 2; vec++) {
+      float p[24], acc[24];
+#pragma unroll
+      for (int k = 0; k < 24; k++) { p[k] = (k / 12 == chi) ? psi[vec][k] : 0.f; acc[k] = 0.f; }
+      switch (dir) {
+        case 0: hop_arith<0, false, 0>(acc, p, U, arg); break;
+        case 1: hop_arith<1, false, 0>(acc, p, U, arg); break;
+        case 2: hop_arith<2, false, 0>(acc, p, U, arg); break;
+        case 3: hop_arith<3, false, 0>(acc, p, U, arg); break;
+        case 4: hop_arith<4, false, 0>(acc, p, U, arg); break;
+        case 5: hop_arith<5, false, 0>(acc, p, U, arg); break;
+        case 6: hop_arith<6, false, 0>(acc, p, U, arg); break;
+        default: hop_arith<7, false, 0>(acc, p, U, arg); break;
+      }
+#pragma unroll
+      for (int k = 0; k < 24; k++) out[chi][vec][k] = coef * acc[k];
+    }
+#pragma unroll
+  for (int k = 0; k < 12; k++) {
+    const size_t o = (((size_t)AX * 12 + k) * nvp + vp) * blockVol + bX;
+    W0[o] = make_float4(out[0][0][2 * k], out[0][0][2 * k + 1], out[0][1][2 * k], out[0][1][2 * k + 1]);
+    W1[o] = make_float4(out[1][0][2 * k], out[1][0][2 * k + 1], out[1][1][2 * k], out[1][1][2 * k + 1]);
+  }
+}
+// both parities of the lattice; fp32 recon-18 links, unpartitioned lattice (the neighbour's V would live on another rank)
+void galerkinUV(float *W0, float *W1, const float *V, const GaugeField &U, int dir, double coef, const int *fine_to_block, int blockVol, int nvec) {
+  if (U.precision != QUDA_SINGLE_PRECISION || U.reconstruct != QUDA_RECONSTRUCT_NO) errorQuda("direct Galerkin construction: fp32 recon-18 links");
+  const LatticeGeom &g = U.geom;
+  for (int parity = 0; parity < 2; parity++) {
+    DslashArg<float> arg;
+    memset(&arg, 0, sizeof(arg));
+    arg.gauge = (const char *)U.parityBase(parity);
+    arg.link_bytes = U.link_bytes; arg.g_stride = U.stride;
+    arg.Vh = g.Vh; arg.Xh = g.Xh; arg.Y = g.X[1]; arg.Z = g.X[2]; arg.T = g.X[3];
+    arg.dXh = g.dXh; arg.dY = g.dY; arg.dZ = g.dZ;
+    arg.parity = parity; arg.sfwd = 1;
+    arg.tsign_fwd = 1; arg.tsign_bwd = 1;   // recon 18: the boundary condition is in the stored links
+    const int nvp = nvec / 2;
+    const long total = (long)g.Vh * nvp;
+    hipLaunchKernelGGL(galerkin_uv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), arg, dir, (float)coef, (const float4 *)V, (float4 *)W0, (float4 *)W1,
+                       fine_to_block, blockVol, nvp);
+    HIP_CHECK(hipGetLastError());
   }
 }
 

@@ -738,6 +738,131 @@ template <int NVEC> __global__ void __launch_bounds__(256) block_cholqr_kernel(f
   if (threadIdx.x == 0 && *bad) { atomicAdd(failed, 1); failedBlock[blockIdx.x] = 1; }
 }
 
+// ================================================================================================
+// Direct Galerkin construction, step 2 ("VUV", reference ComputeVUV lib/coarse_op.cuh:487-600) on the matrix cores: for one forward
+// direction mu and every aggregate A
+//     Y[(chi, v)][(chi', v')] = sum_{x in A} sum_{s in chi, c} conj(V(x)[s, c; v]) W_chi'(x)[s, c; v']          (W from galerkin_uv_kernel)
+// — the sites whose mu-neighbour lies in the next aggregate give the coarse link Y_{2 mu}(A), all others the part S(A) of the local
+// matrix (hermitian completion by the caller, coarse.hip).  The probing path gets the same numbers from 2 Nvec passes over V with a
+// block reduction per coefficient; here the sum over the 256 sites of the aggregate IS the K dimension of a GEMM:
+// per row block chi a real GEMM  M = Nvec rows (v; padded to 16 / 32), N = 4 Nvec real columns ((chi', v') x re / im), K = 256 x 6 x 2
+// on v_mfma_f32_16x16x4_f32 (exact fp32).  One work-group per aggregate, 4 waves; wave w takes the 64 sites with block coordinate
+// y_mu = w, so wave 3 holds the link and waves 0..2 the local part without any masking.  A k-step is 4 sites of one (spin-colour, re/im):
+//     A operand  lane (row v, kq): Re or Im of V(x_kq)[s, c; v]                      one float4 load serves re and im of 2 rows
+//     B operand  lane (col (j, o), kq): from W_chi'(j)(x_kq)[s, c; v'(j)] = (wr, wi):   re step: o ? wi : wr     im step: o ? -wr : wi
+// so that column (j, re) collects Vr Wr + Vi Wi and (j, im) Vr Wi - Vi Wr, i.e. conj(V) W.  Operands come straight from global memory
+// (every float4 of the aggregate's V / W rows is used by some lane of the work-group within microseconds: L1 / L2 absorb the 32-byte
+// pieces); partial tiles are summed through LDS and written in the link layout [site][matrix][column pair][row] float4.
+// Fine level only: 4 x 3 spin-colour, 4^4 aggregates, Nvec 8 or 24, unpartitioned.
+// ================================================================================================
+typedef float gf32x4 __attribute__((ext_vector_type(4)));
+// 8 waves: wave = 4 chi + w takes row block chi (its 6 spin-colour rows of K) of the 64 sites with y_mu = w — 12 accumulator tiles per
+// wave (48 registers) instead of 24 with four waves, which sat at 256 registers and one wave per SIMD
+template <int NVEC> __global__ void __launch_bounds__(512) galerkin_vuv_kernel(float *G, const float4 *V, const float4 *W0, const float4 *W1, int mu, int accumulateLocal, int pm) {
+  constexpr int NVP = NVEC / 2, MT = (NVEC + 15) / 16, NT = NVEC / 4, n = 2 * NVEC, BV = 256;
+  extern __shared__ float glds[];   // [wave][mt][nt][reg][lane]
+  const int A = blockIdx.x, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int cls = wave & 3, chiR = wave >> 2;
+  const int row16 = lane & 15, kq = lane >> 4;
+  // site list of this wave: y_mu = cls, the other three coordinates from pos = 0 .. 63; b = place of the site inside the aggregate
+  auto site_b = [&](int pos) -> int {
+    int y[4], q = pos;
+    for (int d = 0; d < 4; d++) if (d != mu) { y[d] = q & 3; q >>= 2; }
+    y[mu] = cls;
+    const int lex = ((y[3] * 4 + y[2]) * 4 + y[1]) * 4 + y[0];
+    return pm ? ((y[0] + y[1] + y[2] + y[3]) & 1) * (BV / 2) + (lex >> 1) : lex;
+  };
+  gf32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) acc[mt][nt] = (gf32x4){0.f, 0.f, 0.f, 0.f};
+  // what this lane contributes to the operands: A rows v = 16 mt + row16 (beyond Nvec: zero), B columns (j = 8 nt + row16 / 2, o = row16 & 1)
+  const int o = row16 & 1;
+  for (int g = 0; g < 16; g++) {
+    const int b = site_b(4 * g + kq);
+#pragma unroll 2
+    for (int s6 = 0; s6 < 6; s6++) {
+      const size_t rowBase = ((size_t)A * 12 + 6 * chiR + s6) * NVP;
+      float are[MT], aim[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) {
+        const int v = 16 * mt + row16;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (v < NVEC) a = V[(rowBase + (v >> 1)) * BV + b];
+        are[mt] = (v & 1) ? a.z : a.x; aim[mt] = (v & 1) ? a.w : a.y;
+      }
+      float bre[NT], bim[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+        const int j = 8 * nt + (row16 >> 1), chiC = j / NVEC, vc = j - chiC * NVEC;
+        const float4 w = (chiC ? W1 : W0)[(rowBase + (vc >> 1)) * BV + b];
+        const float wr = (vc & 1) ? w.z : w.x, wi = (vc & 1) ? w.w : w.y;
+        bre[nt] = o ? wi : wr;
+        bim[nt] = o ? -wr : wi;
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(are[mt], bre[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aim[mt], bim[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+  }
+  // ---- partial tiles -> LDS; per row block: classes 0..2 summed = local part, class 3 = link ----
+  constexpr int TILE = MT * NT * 4 * 64;   // floats per wave
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) glds[wave * TILE + ((mt * NT + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
+  __syncthreads();
+  // output element (row i = (chi, v), complex column j): tile (v / 16, j / 8) of the waves of row block chi; D layout: row = 4 (lane / 16) + reg, col = lane & 15
+  float4 *G4 = reinterpret_cast<float4 *>(G);
+  for (int e = threadIdx.x; e < 2 * n * (n / 2); e += blockDim.x) {
+    const int which = e / (n * (n / 2)), r2 = e - which * (n * (n / 2));   // 0: link (class 3), 1: local (classes 0..2)
+    const int jp = r2 / n, i = r2 - jp * n;
+    const int chi = i / NVEC, v = i - chi * NVEC, mt = v >> 4, rr = v & 15;
+    const float *base = glds + (size_t)4 * chi * TILE;
+    float val[4];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int j = 2 * jp + h, nt = j >> 3;
+#pragma unroll
+      for (int oo = 0; oo < 2; oo++) {
+        const int col = 2 * (j & 7) + oo;
+        const int off = ((mt * NT + nt) * 4 + (rr & 3)) * 64 + (rr >> 2) * 16 + col;
+        val[2 * h + oo] = which ? base[off] + base[TILE + off] + base[2 * TILE + off] : base[3 * TILE + off];
+      }
+    }
+    const size_t dst = (((size_t)A * 9 + (which ? 8 : 2 * mu)) * (n / 2) + jp) * n + i;
+    if (which && accumulateLocal) { const float4 old = G4[dst]; val[0] += old.x; val[1] += old.y; val[2] += old.z; val[3] += old.w; }
+    G4[dst] = make_float4(val[0], val[1], val[2], val[3]);
+  }
+}
+
+bool Transfer::canDirectGalerkin() const {
+  static int off = -1;
+  if (off < 0) { const char *e = getenv("QUDA_AMD_GALERKIN_DIRECT"); off = (e && !atoi(e)) ? 1 : 0; }
+  if (off || fineSpin != 4 || fineColor != 3 || spin_bs != 2 || (Nvec != 8 && Nvec != 24)) return false;
+  for (int d = 0; d < 4; d++) if (geo_bs[d] != 4 || Xc[d] == 1 || commGrid().partitioned(d)) return false;
+  return true;
+}
+// forward link Y_{2 mu} and the in-aggregate part S of all coarse sites from W = galerkinUV(V): slots 2 mu and 8 of the coarse links
+void Transfer::directGalerkinVUV(float *links, const float *W0, const float *W1, int mu, bool accumulateLocal) const {
+  if (!canDirectGalerkin()) errorQuda("direct Galerkin construction not available for this transfer operator");
+  const size_t lds = (size_t)8 * ((Nvec + 15) / 16) * (Nvec / 4) * 4 * 64 * sizeof(float);
+#define QA_VUV(NV) { static bool attr = false; \
+    if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void *)galerkin_vuv_kernel<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; } \
+    hipLaunchKernelGGL((galerkin_vuv_kernel<NV>), dim3(nAgg), dim3(512), lds, computeStream(), links, (const float4 *)V, (const float4 *)W0, (const float4 *)W1, mu, accumulateLocal ? 1 : 0, parityMajor ? 1 : 0); }
+  if (Nvec == 24) QA_VUV(24) else QA_VUV(8)
+#undef QA_VUV
+  HIP_CHECK(hipGetLastError());
+}
+
 // ---- random source ----
 __device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long i) {
   unsigned long long z = seed + 0x9E3779B97F4A7C15ULL * (i + 1);
