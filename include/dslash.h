@@ -58,9 +58,10 @@ void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_o
 // in_other); it is filled here (pack + grouped exchange) before the launch
 // out[site][chirality][6][6] complex fp32 = A + i a s (s = +-1 for the upper / lower chirality) of one parity, or its inverse
 int haloWireFormat();
-// direct Galerkin construction, step 1: W_chi'(x) = coef x [single-direction hop `dir` of V's columns restricted to chirality chi'] for all
-// columns at once, V / W in the aggregate-major order of the transfer operator (dslash.hip galerkin_uv_kernel)
-void galerkinUV(float *W0, float *W1, const float *V, const GaugeField &U, int dir, double coef, const int *fine_to_block, int blockVol, int nvec);
+// direct Galerkin construction, step 1 (dslash.hip galerkin_uv_kernel): UV(x) = coef U_dir(x) V(x + dhat(dir)) for all columns of the transfer
+// matrix at once, V / UV in its aggregate-major order (4^4 aggregates); and the same for the site-diagonal term A + i a g5 of twisted clover
+void galerkinUV(float *UV, const float *V, const GaugeField &U, int dir, double coef, const int *block_to_fine, const int *fine_to_block, int nAgg, int blockVol, int nvec);
+void galerkinLocalUV(float *L, const float *V, const CloverField &C, double a, const int *block_to_fine, int nAgg, int blockVol, int nvec);
 void cloverTwistDense(float *out, const CloverField &C, int parity, double a, bool inverse);
 
 // site-local kernels

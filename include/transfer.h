@@ -51,9 +51,9 @@ class Transfer {
   bool canSplit4() const;
   // direct Galerkin construction of the first coarse level on the matrix cores (transfer.hip galerkin_vuv_kernel; reference ComputeVUV,
   // lib/coarse_op.cuh:487-600): forward link 2 mu and in-aggregate part S (slot 8, accumulated over the directions) of every coarse site
-  // from W0 / W1 = dslash.h galerkinUV(V); 4^4 aggregates of a 4 x 3 fine level, Nvec 8 / 24, unpartitioned
+  // from UV = dslash.h galerkinUV(V); 4^4 aggregates of a 4 x 3 fine level, Nvec 8 / 24, unpartitioned
   bool canDirectGalerkin() const;
-  void directGalerkinVUV(float *links, const float *W0, const float *W1, int mu, bool accumulateLocal) const;
+  void directGalerkinVUV(float *links, const float *UV, int mu, bool accumulateLocal, bool local = false) const;   // local: UV is a chirality-diagonal site term, everything goes to slot 8
   void RSplit4(ColorSpinorField *const leaving[4], ColorSpinorField *const staying[4], ColorSpinorField *const fine[4], const int dir[4]) const;
   // fine = P e_j for the coarse unit vector j (same component at every coarse site): column j of V, without streaming all of V
   void column(ColorSpinorField &fine, int j) const;

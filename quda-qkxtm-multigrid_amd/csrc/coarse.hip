@@ -550,13 +550,13 @@ void DiracCoarse::build() {
   }
   if (herm && direct) {
     const size_t wbytes = T.vBytes();
-    float *W0 = (float *)poolDeviceMalloc(wbytes), *W1 = (float *)poolDeviceMalloc(wbytes);
+    float *UV = (float *)poolDeviceMalloc(wbytes);
     for (int mu = 0; mu < 4; mu++) {
-      galerkinUV(W0, W1, T.V, *parent->Gauge(), 2 * mu, -parent->Kappa(), T.fine_to_block, T.blockVol, T.Nvec);
-      T.directGalerkinVUV(links->data, W0, W1, mu, mu > 0);
+      galerkinUV(UV, T.V, *parent->Gauge(), 2 * mu, -parent->Kappa(), T.block_to_fine, T.fine_to_block, (int)T.nAgg, T.blockVol, T.Nvec);
+      T.directGalerkinVUV(links->data, UV, mu, mu > 0);
     }
     HIP_CHECK(hipStreamSynchronize(computeStream()));
-    poolDeviceFree(W0, wbytes); poolDeviceFree(W1, wbytes);
+    poolDeviceFree(UV, wbytes);
   }
   if (herm) {
     const int fdirs[4] = {0, 2, 4, 6};
@@ -603,7 +603,15 @@ void DiracCoarse::build() {
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(computeStream()));
     poolDeviceFree(S, (size_t)links->nSites * per * sizeof(float4));
-    if (!analyticLocal)
+    if (!analyticLocal && direct && parent->Clover() && parent->Clover()->precision == QUDA_SINGLE_PRECISION) {
+      // twisted clover: V^dagger (A + i a g5) V as one more batched product, added to the completed hop part
+      const size_t wbytes = T.vBytes();
+      float *L = (float *)poolDeviceMalloc(wbytes);
+      galerkinLocalUV(L, T.V, *parent->Clover(), 2.0 * parent->Kappa() * (double)fineFlavor * parent->Mu(), T.block_to_fine, (int)T.nAgg, T.blockVol, T.Nvec);
+      T.directGalerkinVUV(links->data, L, 0, true, true);
+      HIP_CHECK(hipStreamSynchronize(computeStream()));
+      poolDeviceFree(L, wbytes);
+    } else if (!analyticLocal)
       for (int j = 0; j < n; j++) {   // the dense local matrix of a coarse parent, on top of the completed hop part
         T.column(*phi, j);
         parent->localTerm(*w, *phi);

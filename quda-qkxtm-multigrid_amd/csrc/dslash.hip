@@ -967,6 +967,9 @@ struct FineBlockArg {
   // consecutive checkerboard sites.  The 256 neighbour panels a work-group reads are then only 128 distinct ones (every input site inside
   // the tile is the neighbour of up to 8 of its output sites), so half of the requests can be served by the CU's L1 instead of the L2:
   // the kernel is bound by the latency of its L2 requests (~100 KB in flight per CU), not by HBM.  tile = 0: the linear mapping.
+  // MEASURED (round 3, 48^4, tools/fine_block_timing.py): 2278 us per parity launch with the tiles against 2027 us with the linear mapping
+  // (twisted clover 2568 / 2281) — the scattered link staging and the lost XCD z-slab order cost more than the L1 hits gain; kept as an
+  // opt-in (QUDA_AMD_BLOCK_FINE_TILE=1) for the record, the linear mapping stays the default.
   int tile, tilesX, tilesY, tilesZ;
 };
 
@@ -1243,7 +1246,7 @@ void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_o
   arg.tile = 0; arg.tilesX = arg.tilesY = arg.tilesZ = 1;
   {
     static int tileEnv = -1;
-    if (tileEnv < 0) { const char *e = getenv("QUDA_AMD_BLOCK_FINE_TILE"); tileEnv = e ? atoi(e) : 1; }
+    if (tileEnv < 0) { const char *e = getenv("QUDA_AMD_BLOCK_FINE_TILE"); tileEnv = e ? atoi(e) : 0; }   // measured SLOWER (48^4: 2278 against 2027 us per launch): off
     if (tileEnv && nrhs == 8 && g.X[0] % 4 == 0 && g.X[1] % 4 == 0 && g.X[2] % 2 == 0 && g.X[3] % 2 == 0) {
       arg.tile = 1; arg.tilesX = g.X[0] / 4; arg.tilesY = g.X[1] / 4; arg.tilesZ = g.X[2] / 2;
       nb = arg.tilesX * arg.tilesY * arg.tilesZ * (g.X[3] / 2);   // = Vh / 32
@@ -2005,28 +2008,27 @@ void applyCovariantShift(ColorSpinorField &out, const ColorSpinorField &in, cons
   }
 }
 
-// ---- direct Galerkin construction, step 1 ("UV", reference ComputeUV lib/coarse_op.cuh:59-125): the single-direction hop of hop_dir_kernel
-// applied to ALL columns of the transfer matrix V at once — the links are read once per site and vector pair instead of once per probe —
-// and separately for the upper / lower chirality of the neighbour (column (chi', v') of the coarse link is the hop of V's column v' with
-// only the spins of chirality chi' kept, Transfer::column):
-//     W_chi'(x)[s, c; v'] = coef [ (1 -+ gamma_mu) U_mu(x) ]_{s s'} V(x + mu)[s' in chi', c'; v']
-// V, W0, W1 in the aggregate-major order of the transfer operator, [aggregate][spin-colour][vector pair][site in aggregate] float4.
-// One thread per (site of `parity`, vector pair); same projector / link conventions as the probing path by construction (hop_arith).
-__global__ void __launch_bounds__(256) galerkin_uv_kernel(const DslashArg<float> arg, int dir, float coef, const float4 *V, float4 *W0, float4 *W1, const int *fine_to_block,
-                                                          int blockVol, int nvp) {
-  const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  const int vp = (int)(t % nvp), idx = (int)(t / nvp);
-  if (idx >= arg.Vh) return;
+// ---- direct Galerkin construction, step 1 ("UV", reference ComputeUV lib/coarse_op.cuh:59-125): UV(x)[s, c; v] = coef U_mu(x) V(x + mu)[s, c; v]
+// for ALL columns v of the transfer matrix at once — the link is read once per site instead of once per probe.  No spin projector here:
+// (1 -+ gamma_mu) only permutes the spin rows of UV and multiplies them by +-1 / +-i, which galerkin_vuv_kernel does while it builds
+// its operands (spin_partner_phase below) — half the bytes of a projected, chirality-split product.  V, UV in the aggregate-major order of
+// the transfer operator, [aggregate][spin-colour][vector pair][site in aggregate] float4.  One work-group per aggregate, one thread per
+// site of it (stores of a wave are 1 KiB contiguous), loop over the vector pairs.
+__global__ void __launch_bounds__(256) galerkin_uv_kernel(const DslashArg<float> arg, const char *gaugeEven, const char *gaugeOdd, int dir, float coef, const float4 *V, float4 *UV,
+                                                          const int *block_to_fine, const int *fine_to_block, int nvp) {
+  constexpr int BV = 256;
+  const int A = blockIdx.x, b = threadIdx.x;
+  const int f = block_to_fine[(size_t)A * BV + b];
+  const int parity = f >= arg.Vh, idx = f - parity * arg.Vh;
   const uint32_t za = arg.dXh.div((uint32_t)idx);
   const int xh = idx - (int)za * arg.Xh;
   const uint32_t zb = arg.dY.div(za);
   const int y = (int)za - (int)zb * arg.Y;
   const int tt = (int)arg.dZ.div(zb);
   const int z = (int)zb - tt * arg.Z;
-  const int xodd = (y + z + tt + arg.parity) & 1;
+  const int xodd = (y + z + tt + parity) & 1;
   const int Xh = arg.Xh, sy = Xh, sz = Xh * arg.Y, st = Xh * arg.Y * arg.Z;
   int nbr;
-  float sign = 1;
   switch (dir) {
     case 0: nbr = xodd ? (xh == Xh - 1 ? idx - (Xh - 1) : idx + 1) : idx; break;
     case 1: nbr = xodd ? idx : (xh == 0 ? idx + (Xh - 1) : idx - 1); break;
@@ -2034,65 +2036,85 @@ __global__ void __launch_bounds__(256) galerkin_uv_kernel(const DslashArg<float>
     case 3: nbr = y == 0 ? idx + (arg.Y - 1) * sy : idx - sy; break;
     case 4: nbr = z == arg.Z - 1 ? idx - (arg.Z - 1) * sz : idx + sz; break;
     case 5: nbr = z == 0 ? idx + (arg.Z - 1) * sz : idx - sz; break;
-    case 6: nbr = tt == arg.T - 1 ? idx - (arg.T - 1) * st : idx + st; if (tt == arg.T - 1) sign = arg.tsign_fwd; break;
-    default: nbr = tt == 0 ? idx + (arg.T - 1) * st : idx - st; if (tt == 0) sign = arg.tsign_bwd; break;
+    case 6: nbr = tt == arg.T - 1 ? idx - (arg.T - 1) * st : idx + st; break;
+    default: nbr = tt == 0 ? idx + (arg.T - 1) * st : idx - st; break;
   }
-  const int posN = fine_to_block[(1 - arg.parity) * arg.Vh + nbr], posX = fine_to_block[arg.parity * arg.Vh + idx];
-  const int AN = posN / blockVol, bN = posN - AN * blockVol, AX = posX / blockVol, bX = posX - AX * blockVol;
-  float psi[2][24], U[18];
+  const int posN = fine_to_block[(1 - parity) * arg.Vh + nbr];
+  const int AN = posN / BV, bN = posN - AN * BV;
+  float U[18];
+  Link<float, 18>::load(U, (parity ? gaugeOdd : gaugeEven) + (size_t)dir * arg.link_bytes, arg.g_stride, idx, 1.f);
 #pragma unroll
-  for (int k = 0; k < 12; k++) {
-    const float4 v = V[(((size_t)AN * 12 + k) * nvp + vp) * blockVol + bN];
-    psi[0][2 * k] = v.x; psi[0][2 * k + 1] = v.y; psi[1][2 * k] = v.z; psi[1][2 * k + 1] = v.w;
-  }
-  Link<float, 18>::load(U, arg.gauge + (size_t)dir * arg.link_bytes, arg.g_stride, idx, sign);
-  float out[2][2][24];   // [chirality of the source spins][vector of the pair][24]
+  for (int k = 0; k < 18; k++) U[k] *= coef;
+  for (int vp = 0; vp < nvp; vp++) {
+    float psi[2][24];
 #pragma unroll
-  for (int chi = 0; chi < 2; chi++)
-#pragma unroll
-    for (int vec = 0; vec < 2; vec++) {
-      float p[24], acc[24];
-#pragma unroll
-      for (int k = 0; k < 24; k++) { p[k] = (k / 12 == chi) ? psi[vec][k] : 0.f; acc[k] = 0.f; }
-      switch (dir) {
-        case 0: hop_arith<0, false, 0>(acc, p, U, arg); break;
-        case 1: hop_arith<1, false, 0>(acc, p, U, arg); break;
-        case 2: hop_arith<2, false, 0>(acc, p, U, arg); break;
-        case 3: hop_arith<3, false, 0>(acc, p, U, arg); break;
-        case 4: hop_arith<4, false, 0>(acc, p, U, arg); break;
-        case 5: hop_arith<5, false, 0>(acc, p, U, arg); break;
-        case 6: hop_arith<6, false, 0>(acc, p, U, arg); break;
-        default: hop_arith<7, false, 0>(acc, p, U, arg); break;
-      }
-#pragma unroll
-      for (int k = 0; k < 24; k++) out[chi][vec][k] = coef * acc[k];
+    for (int k = 0; k < 12; k++) {
+      const float4 v = V[(((size_t)AN * 12 + k) * nvp + vp) * BV + bN];
+      psi[0][2 * k] = v.x; psi[0][2 * k + 1] = v.y; psi[1][2 * k] = v.z; psi[1][2 * k + 1] = v.w;
     }
+    float out[2][24];
 #pragma unroll
-  for (int k = 0; k < 12; k++) {
-    const size_t o = (((size_t)AX * 12 + k) * nvp + vp) * blockVol + bX;
-    W0[o] = make_float4(out[0][0][2 * k], out[0][0][2 * k + 1], out[0][1][2 * k], out[0][1][2 * k + 1]);
-    W1[o] = make_float4(out[1][0][2 * k], out[1][0][2 * k + 1], out[1][1][2 * k], out[1][1][2 * k + 1]);
+    for (int vec = 0; vec < 2; vec++)
+#pragma unroll
+      for (int sp = 0; sp < 4; sp++) su3_mv(out[vec] + 6 * sp, U, psi[vec] + 6 * sp);
+#pragma unroll
+    for (int k = 0; k < 12; k++) UV[(((size_t)A * 12 + k) * nvp + vp) * BV + b] = make_float4(out[0][2 * k], out[0][2 * k + 1], out[1][2 * k], out[1][2 * k + 1]);
   }
 }
-// both parities of the lattice; fp32 recon-18 links, unpartitioned lattice (the neighbour's V would live on another rank)
-void galerkinUV(float *W0, float *W1, const float *V, const GaugeField &U, int dir, double coef, const int *fine_to_block, int blockVol, int nvec) {
+// fp32 recon-18 links (boundary condition inside the stored links), 4^4 aggregates, unpartitioned lattice (the neighbour's V would live on another rank)
+void galerkinUV(float *UVout, const float *V, const GaugeField &U, int dir, double coef, const int *block_to_fine, const int *fine_to_block, int nAgg, int blockVol, int nvec) {
   if (U.precision != QUDA_SINGLE_PRECISION || U.reconstruct != QUDA_RECONSTRUCT_NO) errorQuda("direct Galerkin construction: fp32 recon-18 links");
+  if (blockVol != 256) errorQuda("direct Galerkin construction: 4^4 aggregates");
   const LatticeGeom &g = U.geom;
-  for (int parity = 0; parity < 2; parity++) {
-    DslashArg<float> arg;
-    memset(&arg, 0, sizeof(arg));
-    arg.gauge = (const char *)U.parityBase(parity);
-    arg.link_bytes = U.link_bytes; arg.g_stride = U.stride;
-    arg.Vh = g.Vh; arg.Xh = g.Xh; arg.Y = g.X[1]; arg.Z = g.X[2]; arg.T = g.X[3];
-    arg.dXh = g.dXh; arg.dY = g.dY; arg.dZ = g.dZ;
-    arg.parity = parity; arg.sfwd = 1;
-    arg.tsign_fwd = 1; arg.tsign_bwd = 1;   // recon 18: the boundary condition is in the stored links
-    const int nvp = nvec / 2;
-    const long total = (long)g.Vh * nvp;
-    hipLaunchKernelGGL(galerkin_uv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), arg, dir, (float)coef, (const float4 *)V, (float4 *)W0, (float4 *)W1,
-                       fine_to_block, blockVol, nvp);
-    HIP_CHECK(hipGetLastError());
+  DslashArg<float> arg;
+  memset(&arg, 0, sizeof(arg));
+  arg.link_bytes = U.link_bytes; arg.g_stride = U.stride;
+  arg.Vh = g.Vh; arg.Xh = g.Xh; arg.Y = g.X[1]; arg.Z = g.X[2]; arg.T = g.X[3];
+  arg.dXh = g.dXh; arg.dY = g.dY; arg.dZ = g.dZ;
+  hipLaunchKernelGGL(galerkin_uv_kernel, dim3(nAgg), dim3(256), 0, computeStream(), arg, (const char *)U.parityBase(0), (const char *)U.parityBase(1), dir, (float)coef, (const float4 *)V,
+                     (float4 *)UVout, block_to_fine, fine_to_block, nvec / 2);
+  HIP_CHECK(hipGetLastError());
+}
+
+// the same for the site-diagonal term of the twisted-clover operator: L(x)[s, c; v] = (A_chi(s)(x) + i a s_chi) V(x)[s, c; v] — chirality-diagonal, so
+// galerkin_vuv_kernel runs it in its "local" mode (no cross-chirality columns, every site belongs to the local matrix)
+__global__ void __launch_bounds__(256) galerkin_local_uv_kernel(const float4 *V, float4 *L, const void *clEven, const void *clOdd, int cl_stride, int Vh, float a,
+                                                                const int *block_to_fine, int nvp) {
+  constexpr int BV = 256;
+  const int A = blockIdx.x, b = threadIdx.x;
+  const int f = block_to_fine[(size_t)A * BV + b];
+  const int parity = f >= Vh, idx = f - parity * Vh;
+  const void *clA = parity ? clOdd : clEven;
+  float C[2][36];
+#pragma unroll
+  for (int chi = 0; chi < 2; chi++) Planar<float, 36>::load(C[chi], (const char *)clA + (size_t)chi * 36 * sizeof(float) * cl_stride, cl_stride, idx, nullptr, 0);
+  for (int vp = 0; vp < nvp; vp++) {
+    float psi[2][24], o[2][24];
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      const float4 v = V[(((size_t)A * 12 + k) * nvp + vp) * BV + b];
+      psi[0][2 * k] = v.x; psi[0][2 * k + 1] = v.y; psi[1][2 * k] = v.z; psi[1][2 * k + 1] = v.w;
+    }
+#pragma unroll
+    for (int vec = 0; vec < 2; vec++)
+#pragma unroll
+      for (int chi = 0; chi < 2; chi++) {
+        const float *v = psi[vec] + 12 * chi;
+        float *r = o[vec] + 12 * chi;
+        clover_block_mv(r, C[chi], v);
+        const float sa = chi ? -a : a;
+#pragma unroll
+        for (int k = 0; k < 6; k++) { r[2 * k] -= sa * v[2 * k + 1]; r[2 * k + 1] += sa * v[2 * k]; }
+      }
+#pragma unroll
+    for (int k = 0; k < 12; k++) L[(((size_t)A * 12 + k) * nvp + vp) * BV + b] = make_float4(o[0][2 * k], o[0][2 * k + 1], o[1][2 * k], o[1][2 * k + 1]);
   }
+}
+void galerkinLocalUV(float *Lout, const float *V, const CloverField &C, double a, const int *block_to_fine, int nAgg, int blockVol, int nvec) {
+  if (C.precision != QUDA_SINGLE_PRECISION) errorQuda("direct Galerkin construction: fp32 clover field");
+  if (blockVol != 256) errorQuda("direct Galerkin construction: 4^4 aggregates");
+  hipLaunchKernelGGL(galerkin_local_uv_kernel, dim3(nAgg), dim3(256), 0, computeStream(), (const float4 *)V, (float4 *)Lout, C.A(0), C.A(1), C.stride, C.geom.Vh, (float)a, block_to_fine, nvec / 2);
+  HIP_CHECK(hipGetLastError());
 }
 
 void applyHopDir(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, int parity, int dir, double coef) {

@@ -741,24 +741,28 @@ template <int NVEC> __global__ void __launch_bounds__(256) block_cholqr_kernel(f
 // ================================================================================================
 // Direct Galerkin construction, step 2 ("VUV", reference ComputeVUV lib/coarse_op.cuh:487-600) on the matrix cores: for one forward
 // direction mu and every aggregate A
-//     Y[(chi, v)][(chi', v')] = sum_{x in A} sum_{s in chi, c} conj(V(x)[s, c; v]) W_chi'(x)[s, c; v']          (W from galerkin_uv_kernel)
+//     Y[(chi, v)][(chi', v')] = sum_{x in A} sum_{s in chi, c} conj(V(x)[s, c; v]) [ (1 - gamma_mu) UV(x) ]^{chi'}[s, c; v']      (UV from galerkin_uv_kernel)
 // — the sites whose mu-neighbour lies in the next aggregate give the coarse link Y_{2 mu}(A), all others the part S(A) of the local
 // matrix (hermitian completion by the caller, coarse.hip).  The probing path gets the same numbers from 2 Nvec passes over V with a
 // block reduction per coefficient; here the sum over the 256 sites of the aggregate IS the K dimension of a GEMM:
 // per row block chi a real GEMM  M = Nvec rows (v; padded to 16 / 32), N = 4 Nvec real columns ((chi', v') x re / im), K = 256 x 6 x 2
-// on v_mfma_f32_16x16x4_f32 (exact fp32).  One work-group per aggregate, 4 waves; wave w takes the 64 sites with block coordinate
-// y_mu = w, so wave 3 holds the link and waves 0..2 the local part without any masking.  A k-step is 4 sites of one (spin-colour, re/im):
-//     A operand  lane (row v, kq): Re or Im of V(x_kq)[s, c; v]                      one float4 load serves re and im of 2 rows
-//     B operand  lane (col (j, o), kq): from W_chi'(j)(x_kq)[s, c; v'(j)] = (wr, wi):   re step: o ? wi : wr     im step: o ? -wr : wi
+// on v_mfma_f32_16x16x4_f32 (exact fp32).  The projector is applied on the fly: a column of chirality chi' = chi sees UV[s, c] itself, one of the
+// other chirality phi(mu, s) UV[partner(mu, s), c] with phi in {+-1, +-i} (table below, read off spin_project / spin_reconstruct of dslash.hip).
+// One work-group per aggregate, 8 waves: wave = 4 chi + w takes row block chi of the 64 sites with block coordinate y_mu = w, so the
+// class-3 waves hold the link and classes 0..2 the local part without any masking.  A k-step is 4 sites of one (spin-colour, re/im):
+//     A operand  lane (row v, kq): Re or Im of V(x_kq)[s, c; v]                      one 8-byte load serves the re and the im step
+//     B operand  lane (col (j, o), kq): from w = phi UV(x_kq)[s', c; v'(j)] = (wr, wi):   re step: o ? wi : wr     im step: o ? -wr : wi
 // so that column (j, re) collects Vr Wr + Vi Wi and (j, im) Vr Wi - Vi Wr, i.e. conj(V) W.  Operands come straight from global memory
-// (every float4 of the aggregate's V / W rows is used by some lane of the work-group within microseconds: L1 / L2 absorb the 32-byte
-// pieces); partial tiles are summed through LDS and written in the link layout [site][matrix][column pair][row] float4.
+// (every 16-byte word of the aggregate's V / UV rows is used by lanes of the work-group within microseconds: L1 / L2 absorb the pieces);
+// partial tiles are summed through LDS and written in the link layout [site][matrix][column pair][row] float4.
+// local = 1: UV is a chirality-diagonal site term (twisted clover, galerkin_local_uv_kernel): no cross columns, every class is local.
 // Fine level only: 4 x 3 spin-colour, 4^4 aggregates, Nvec 8 or 24, unpartitioned.
 // ================================================================================================
 typedef float gf32x4 __attribute__((ext_vector_type(4)));
-// 8 waves: wave = 4 chi + w takes row block chi (its 6 spin-colour rows of K) of the 64 sites with y_mu = w — 12 accumulator tiles per
-// wave (48 registers) instead of 24 with four waves, which sat at 256 registers and one wave per SIMD
-template <int NVEC> __global__ void __launch_bounds__(512) galerkin_vuv_kernel(float *G, const float4 *V, const float4 *W0, const float4 *W1, int mu, int accumulateLocal, int pm) {
+// forward hop (1 - gamma_mu) in the chiral basis of dslash.hip: row s of the OTHER chirality's contribution is i^k UV[partner]
+__device__ __constant__ int kGalPartner[4][4] = {{3, 2, 1, 0}, {3, 2, 1, 0}, {2, 3, 0, 1}, {2, 3, 0, 1}};
+__device__ __constant__ int kGalPhase[4][4] = {{3, 3, 1, 1}, {0, 2, 2, 0}, {3, 1, 1, 3}, {2, 2, 2, 2}};
+template <int NVEC> __global__ void __launch_bounds__(512) galerkin_vuv_kernel(float *G, const float2 *V, const float2 *UV, int mu, int accumulateLocal, int pm, int local) {
   constexpr int NVP = NVEC / 2, MT = (NVEC + 15) / 16, NT = NVEC / 4, n = 2 * NVEC, BV = 256;
   extern __shared__ float glds[];   // [wave][mt][nt][reg][lane]
   const int A = blockIdx.x, lane = threadIdx.x & 63;
@@ -782,25 +786,34 @@ template <int NVEC> __global__ void __launch_bounds__(512) galerkin_vuv_kernel(f
   const int o = row16 & 1;
   for (int g = 0; g < 16; g++) {
     const int b = site_b(4 * g + kq);
-#pragma unroll 2
+#pragma unroll
     for (int s6 = 0; s6 < 6; s6++) {
-      const size_t rowBase = ((size_t)A * 12 + 6 * chiR + s6) * NVP;
+      const int spin = 2 * chiR + s6 / 3, col = s6 % 3;
+      const int scSame = 3 * spin + col, scCross = 3 * kGalPartner[mu][spin] + col, ph = kGalPhase[mu][spin];
+      const size_t rowV = ((size_t)A * 12 + scSame) * NVP, rowX = ((size_t)A * 12 + scCross) * NVP;
       float are[MT], aim[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; mt++) {
         const int v = 16 * mt + row16;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (v < NVEC) a = V[(rowBase + (v >> 1)) * BV + b];
-        are[mt] = (v & 1) ? a.z : a.x; aim[mt] = (v & 1) ? a.w : a.y;
+        float2 a = make_float2(0.f, 0.f);
+        if (v < NVEC) a = V[((rowV + (v >> 1)) * BV + b) * 2 + (v & 1)];
+        are[mt] = a.x; aim[mt] = a.y;
       }
       float bre[NT], bim[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; nt++) {
-        const int j = 8 * nt + (row16 >> 1), chiC = j / NVEC, vc = j - chiC * NVEC;
-        const float4 w = (chiC ? W1 : W0)[(rowBase + (vc >> 1)) * BV + b];
-        const float wr = (vc & 1) ? w.z : w.x, wi = (vc & 1) ? w.w : w.y;
-        bre[nt] = o ? wi : wr;
-        bim[nt] = o ? -wr : wi;
+        const int j = 8 * nt + (row16 >> 1), chiC = nt >= NT / 2, vc = j - chiC * NVEC;
+        const bool same = chiC == chiR;
+        float2 w = make_float2(0.f, 0.f);
+        if (same || !local) w = UV[(((same ? rowV : rowX) + (vc >> 1)) * BV + b) * 2 + (vc & 1)];
+        if (!same) {   // i^ph w
+          const float2 t = w;
+          if (ph == 1) w = make_float2(-t.y, t.x);
+          else if (ph == 2) w = make_float2(-t.x, -t.y);
+          else if (ph == 3) w = make_float2(t.y, -t.x);
+        }
+        bre[nt] = o ? w.y : w.x;
+        bim[nt] = o ? -w.x : w.y;
       }
 #pragma unroll
       for (int mt = 0; mt < MT; mt++)
@@ -821,8 +834,9 @@ template <int NVEC> __global__ void __launch_bounds__(512) galerkin_vuv_kernel(f
       for (int r = 0; r < 4; r++) glds[wave * TILE + ((mt * NT + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
   __syncthreads();
   // output element (row i = (chi, v), complex column j): tile (v / 16, j / 8) of the waves of row block chi; D layout: row = 4 (lane / 16) + reg, col = lane & 15
+  // local (site-diagonal term of the fine operator): every class belongs to the local matrix, no link is written
   float4 *G4 = reinterpret_cast<float4 *>(G);
-  for (int e = threadIdx.x; e < 2 * n * (n / 2); e += blockDim.x) {
+  for (int e = threadIdx.x + (local ? n * (n / 2) : 0); e < 2 * n * (n / 2); e += blockDim.x) {
     const int which = e / (n * (n / 2)), r2 = e - which * (n * (n / 2));   // 0: link (class 3), 1: local (classes 0..2)
     const int jp = r2 / n, i = r2 - jp * n;
     const int chi = i / NVEC, v = i - chi * NVEC, mt = v >> 4, rr = v & 15;
@@ -835,7 +849,7 @@ template <int NVEC> __global__ void __launch_bounds__(512) galerkin_vuv_kernel(f
       for (int oo = 0; oo < 2; oo++) {
         const int col = 2 * (j & 7) + oo;
         const int off = ((mt * NT + nt) * 4 + (rr & 3)) * 64 + (rr >> 2) * 16 + col;
-        val[2 * h + oo] = which ? base[off] + base[TILE + off] + base[2 * TILE + off] : base[3 * TILE + off];
+        val[2 * h + oo] = which ? base[off] + base[TILE + off] + base[2 * TILE + off] + (local ? base[3 * TILE + off] : 0.f) : base[3 * TILE + off];
       }
     }
     const size_t dst = (((size_t)A * 9 + (which ? 8 : 2 * mu)) * (n / 2) + jp) * n + i;
@@ -851,13 +865,13 @@ bool Transfer::canDirectGalerkin() const {
   for (int d = 0; d < 4; d++) if (geo_bs[d] != 4 || Xc[d] == 1 || commGrid().partitioned(d)) return false;
   return true;
 }
-// forward link Y_{2 mu} and the in-aggregate part S of all coarse sites from W = galerkinUV(V): slots 2 mu and 8 of the coarse links
-void Transfer::directGalerkinVUV(float *links, const float *W0, const float *W1, int mu, bool accumulateLocal) const {
+// forward link Y_{2 mu} and the in-aggregate part S of all coarse sites from UV = galerkinUV(V): slots 2 mu and 8 of the coarse links
+void Transfer::directGalerkinVUV(float *links, const float *UV, int mu, bool accumulateLocal, bool local) const {
   if (!canDirectGalerkin()) errorQuda("direct Galerkin construction not available for this transfer operator");
   const size_t lds = (size_t)8 * ((Nvec + 15) / 16) * (Nvec / 4) * 4 * 64 * sizeof(float);
 #define QA_VUV(NV) { static bool attr = false; \
     if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void *)galerkin_vuv_kernel<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; } \
-    hipLaunchKernelGGL((galerkin_vuv_kernel<NV>), dim3(nAgg), dim3(512), lds, computeStream(), links, (const float4 *)V, (const float4 *)W0, (const float4 *)W1, mu, accumulateLocal ? 1 : 0, parityMajor ? 1 : 0); }
+    hipLaunchKernelGGL((galerkin_vuv_kernel<NV>), dim3(nAgg), dim3(512), lds, computeStream(), links, (const float2 *)V, (const float2 *)UV, mu, accumulateLocal ? 1 : 0, parityMajor ? 1 : 0, local ? 1 : 0); }
   if (Nvec == 24) QA_VUV(24) else QA_VUV(8)
 #undef QA_VUV
   HIP_CHECK(hipGetLastError());
