@@ -762,9 +762,80 @@ typedef float gf32x4 __attribute__((ext_vector_type(4)));
 // forward hop (1 - gamma_mu) in the chiral basis of dslash.hip: row s of the OTHER chirality's contribution is i^k UV[partner]
 __device__ __constant__ int kGalPartner[4][4] = {{3, 2, 1, 0}, {3, 2, 1, 0}, {2, 3, 0, 1}, {2, 3, 0, 1}};
 __device__ __constant__ int kGalPhase[4][4] = {{3, 3, 1, 1}, {0, 2, 2, 0}, {3, 1, 1, 3}, {2, 2, 2, 2}};
+// the K loop of one wave (row block CHI, its class of 64 sites).  Branch-free on purpose: the first version selected same / cross rows, the
+// phase and the padding rows with conditionals, which the compiler turned into ~300 branches with an s_waitcnt vmcnt(0) behind every load —
+// 37 ms per direction at 48^3 x 96, no faster with two work-groups per CU.  Here every lane multiplies what it loads by a complex
+// constant fixed before the loop: i^(3 o) for a column of the wave's own chirality (o: the lane's real / imaginary column), i^(phase + 3 o)
+// for the other chirality (0 in local mode), 0 for a padding row of A — so that (bre, bim) = c w and the two MFMA steps follow.
+template <int NVEC, int CHI, typename SiteB>
+__device__ __forceinline__ void galerkin_vuv_accumulate(gf32x4 (&acc)[(NVEC + 15) / 16][NVEC / 4], const float2 *V, const float2 *UV, int A, int mu, int local, int row16, int kq, SiteB site_b) {
+  constexpr int NVP = NVEC / 2, MT = (NVEC + 15) / 16, NT = NVEC / 4, BV = 256;
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) acc[mt][nt] = (gf32x4){0.f, 0.f, 0.f, 0.f};
+  const int o = row16 & 1;
+  // i^k as (re, im)
+  auto ipow = [](int k) -> float2 { k &= 3; return make_float2(k == 0 ? 1.f : (k == 2 ? -1.f : 0.f), k == 1 ? 1.f : (k == 3 ? -1.f : 0.f)); };
+  const float2 cSame = ipow(3 * o);
+  float2 cCross[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    cCross[h] = ipow(kGalPhase[mu][2 * CHI + h] + 3 * o);
+    if (local) cCross[h] = make_float2(0.f, 0.f);
+  }
+  // per-lane element offsets (float2 units) inside a (spin-colour) row of the aggregate: A rows v = 16 mt + row16 (padding rows: clamped, scaled by 0)
+  int aOff[MT]; float aScale[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++) {
+    const int v = 16 * mt + row16, vv = v < NVEC ? v : NVEC - 1;
+    aOff[mt] = (vv >> 1) * BV * 2 + (vv & 1);
+    aScale[mt] = v < NVEC ? 1.f : 0.f;
+  }
+  int bOff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) {
+    const int j = 8 * nt + (row16 >> 1), vc = j - (nt >= NT / 2 ? NVEC : 0);
+    bOff[nt] = (vc >> 1) * BV * 2 + (vc & 1);
+  }
+  const float2 *Va = V + (size_t)A * 12 * NVP * BV * 2, *Ua = UV + (size_t)A * 12 * NVP * BV * 2;
+  constexpr int ROW = NVP * BV * 2;   // float2 elements per (spin-colour) row
+  for (int g = 0; g < 16; g++) {
+    const int b2 = 2 * site_b(4 * g + kq);
+#pragma unroll
+    for (int s6 = 0; s6 < 6; s6++) {
+      const int spin = 2 * CHI + s6 / 3, col = s6 % 3;
+      const int rowSame = (3 * spin + col) * ROW, rowCross = (3 * kGalPartner[mu][spin] + col) * ROW;
+      float are[MT], aim[MT], bre[NT], bim[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++) {
+        const float2 a = Va[rowSame + aOff[mt] + b2];
+        are[mt] = aScale[mt] * a.x; aim[mt] = aScale[mt] * a.y;
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; nt++) {
+        constexpr int dummy = 0; (void)dummy;
+        const bool same = (nt >= NT / 2) == (CHI == 1);
+        const float2 w = Ua[(same ? rowSame : rowCross) + bOff[nt] + b2];
+        const float2 c = same ? cSame : cCross[s6 / 3];
+        bre[nt] = c.x * w.x - c.y * w.y;
+        bim[nt] = c.x * w.y + c.y * w.x;
+      }
+      // all re steps, then all im steps: consecutive matrix instructions on different accumulators
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(are[mt], bre[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aim[mt], bim[nt], acc[mt][nt], 0, 0, 0);
+    }
+  }
+}
 template <int NVEC> __global__ void __launch_bounds__(512) galerkin_vuv_kernel(float *G, const float2 *V, const float2 *UV, int mu, int accumulateLocal, int pm, int local) {
   constexpr int NVP = NVEC / 2, MT = (NVEC + 15) / 16, NT = NVEC / 4, n = 2 * NVEC, BV = 256;
-  extern __shared__ float glds[];   // [wave][mt][nt][reg][lane]
+  extern __shared__ float glds[];   // [class][mt][nt][reg][lane], one row block at a time
   const int A = blockIdx.x, lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int cls = wave & 3, chiR = wave >> 2;
@@ -778,83 +849,44 @@ template <int NVEC> __global__ void __launch_bounds__(512) galerkin_vuv_kernel(f
     return pm ? ((y[0] + y[1] + y[2] + y[3]) & 1) * (BV / 2) + (lex >> 1) : lex;
   };
   gf32x4 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) acc[mt][nt] = (gf32x4){0.f, 0.f, 0.f, 0.f};
-  // what this lane contributes to the operands: A rows v = 16 mt + row16 (beyond Nvec: zero), B columns (j = 8 nt + row16 / 2, o = row16 & 1)
-  const int o = row16 & 1;
-  for (int g = 0; g < 16; g++) {
-    const int b = site_b(4 * g + kq);
-#pragma unroll
-    for (int s6 = 0; s6 < 6; s6++) {
-      const int spin = 2 * chiR + s6 / 3, col = s6 % 3;
-      const int scSame = 3 * spin + col, scCross = 3 * kGalPartner[mu][spin] + col, ph = kGalPhase[mu][spin];
-      const size_t rowV = ((size_t)A * 12 + scSame) * NVP, rowX = ((size_t)A * 12 + scCross) * NVP;
-      float are[MT], aim[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; mt++) {
-        const int v = 16 * mt + row16;
-        float2 a = make_float2(0.f, 0.f);
-        if (v < NVEC) a = V[((rowV + (v >> 1)) * BV + b) * 2 + (v & 1)];
-        are[mt] = a.x; aim[mt] = a.y;
-      }
-      float bre[NT], bim[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; nt++) {
-        const int j = 8 * nt + (row16 >> 1), chiC = nt >= NT / 2, vc = j - chiC * NVEC;
-        const bool same = chiC == chiR;
-        float2 w = make_float2(0.f, 0.f);
-        if (same || !local) w = UV[(((same ? rowV : rowX) + (vc >> 1)) * BV + b) * 2 + (vc & 1)];
-        if (!same) {   // i^ph w
-          const float2 t = w;
-          if (ph == 1) w = make_float2(-t.y, t.x);
-          else if (ph == 2) w = make_float2(-t.x, -t.y);
-          else if (ph == 3) w = make_float2(t.y, -t.x);
-        }
-        bre[nt] = o ? w.y : w.x;
-        bim[nt] = o ? -w.x : w.y;
-      }
+  if (chiR == 0) galerkin_vuv_accumulate<NVEC, 0>(acc, V, UV, A, mu, local, row16, kq, site_b);
+  else galerkin_vuv_accumulate<NVEC, 1>(acc, V, UV, A, mu, local, row16, kq, site_b);
+  // ---- partial tiles -> LDS, one row block (chi) at a time so that the buffer is 4 waves x 12 KB and two work-groups share a CU;
+  // classes 0..2 summed = local part, class 3 = link ----
+  constexpr int TILE = MT * NT * 4 * 64;   // floats per wave
+  float4 *G4 = reinterpret_cast<float4 *>(G);
+  for (int chi = 0; chi < 2; chi++) {
+    if (chi) __syncthreads();
+    if (chiR == chi) {
 #pragma unroll
       for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(are[mt], bre[nt], acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aim[mt], bim[nt], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) glds[cls * TILE + ((mt * NT + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
+    }
+    __syncthreads();
+    // output element (row i = (chi, v), complex column j): tile (v / 16, j / 8); D layout: row = 4 (lane / 16) + reg, col = lane & 15
+    // local (site-diagonal term of the fine operator): every class belongs to the local matrix, no link is written
+    constexpr int HALF = NVEC * (n / 2);   // (row v, column pair) elements of one row block
+    for (int e = threadIdx.x + (local ? HALF : 0); e < 2 * HALF; e += blockDim.x) {
+      const int which = e / HALF, r2 = e - which * HALF;   // 0: link (class 3), 1: local (classes 0..2)
+      const int jp = r2 / NVEC, v = r2 - jp * NVEC, i = chi * NVEC + v, mt = v >> 4, rr = v & 15;
+      float val[4];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int j = 2 * jp + h, nt = j >> 3;
+#pragma unroll
+        for (int oo = 0; oo < 2; oo++) {
+          const int col = 2 * (j & 7) + oo;
+          const int off = ((mt * NT + nt) * 4 + (rr & 3)) * 64 + (rr >> 2) * 16 + col;
+          val[2 * h + oo] = which ? glds[off] + glds[TILE + off] + glds[2 * TILE + off] + (local ? glds[3 * TILE + off] : 0.f) : glds[3 * TILE + off];
         }
-    }
-  }
-  // ---- partial tiles -> LDS; per row block: classes 0..2 summed = local part, class 3 = link ----
-  constexpr int TILE = MT * NT * 4 * 64;   // floats per wave
-#pragma unroll
-  for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) glds[wave * TILE + ((mt * NT + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
-  __syncthreads();
-  // output element (row i = (chi, v), complex column j): tile (v / 16, j / 8) of the waves of row block chi; D layout: row = 4 (lane / 16) + reg, col = lane & 15
-  // local (site-diagonal term of the fine operator): every class belongs to the local matrix, no link is written
-  float4 *G4 = reinterpret_cast<float4 *>(G);
-  for (int e = threadIdx.x + (local ? n * (n / 2) : 0); e < 2 * n * (n / 2); e += blockDim.x) {
-    const int which = e / (n * (n / 2)), r2 = e - which * (n * (n / 2));   // 0: link (class 3), 1: local (classes 0..2)
-    const int jp = r2 / n, i = r2 - jp * n;
-    const int chi = i / NVEC, v = i - chi * NVEC, mt = v >> 4, rr = v & 15;
-    const float *base = glds + (size_t)4 * chi * TILE;
-    float val[4];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int j = 2 * jp + h, nt = j >> 3;
-#pragma unroll
-      for (int oo = 0; oo < 2; oo++) {
-        const int col = 2 * (j & 7) + oo;
-        const int off = ((mt * NT + nt) * 4 + (rr & 3)) * 64 + (rr >> 2) * 16 + col;
-        val[2 * h + oo] = which ? base[off] + base[TILE + off] + base[2 * TILE + off] + (local ? base[3 * TILE + off] : 0.f) : base[3 * TILE + off];
       }
+      const size_t dst = (((size_t)A * 9 + (which ? 8 : 2 * mu)) * (n / 2) + jp) * n + i;
+      if (which && accumulateLocal) { const float4 old = G4[dst]; val[0] += old.x; val[1] += old.y; val[2] += old.z; val[3] += old.w; }
+      G4[dst] = make_float4(val[0], val[1], val[2], val[3]);
     }
-    const size_t dst = (((size_t)A * 9 + (which ? 8 : 2 * mu)) * (n / 2) + jp) * n + i;
-    if (which && accumulateLocal) { const float4 old = G4[dst]; val[0] += old.x; val[1] += old.y; val[2] += old.z; val[3] += old.w; }
-    G4[dst] = make_float4(val[0], val[1], val[2], val[3]);
   }
 }
 
@@ -868,7 +900,7 @@ bool Transfer::canDirectGalerkin() const {
 // forward link Y_{2 mu} and the in-aggregate part S of all coarse sites from UV = galerkinUV(V): slots 2 mu and 8 of the coarse links
 void Transfer::directGalerkinVUV(float *links, const float *UV, int mu, bool accumulateLocal, bool local) const {
   if (!canDirectGalerkin()) errorQuda("direct Galerkin construction not available for this transfer operator");
-  const size_t lds = (size_t)8 * ((Nvec + 15) / 16) * (Nvec / 4) * 4 * 64 * sizeof(float);
+  const size_t lds = (size_t)4 * ((Nvec + 15) / 16) * (Nvec / 4) * 4 * 64 * sizeof(float);
 #define QA_VUV(NV) { static bool attr = false; \
     if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void *)galerkin_vuv_kernel<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; } \
     hipLaunchKernelGGL((galerkin_vuv_kernel<NV>), dim3(nAgg), dim3(512), lds, computeStream(), links, (const float2 *)V, (const float2 *)UV, mu, accumulateLocal ? 1 : 0, parityMajor ? 1 : 0, local ? 1 : 0); }
