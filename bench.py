@@ -215,7 +215,7 @@ def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2,
     # PCIe transfers and the operator / field set-up); solver_secs: the GCR loop alone (QudaInvertParam.secs)
     lv0, lv1 = mg.level_info(0), mg.level_info(1)
     out = dict(lattice="x".join(map(str, X)), action={"tm": "twisted mass", "tmc": "twisted clover (device-built clover, csw %g)" % csw}[dslash], kappa=kappa, mu=mu, levels=3, n_vec=24, blocks=[list(bk) for bk in blocks[:2]],
-               cycle={"V": "V-cycle (QUDA_MG_CYCLE_VCYCLE)", "K": "K-cycle (QUDA_MG_CYCLE_RECURSIVE)"}[cycle], null_vectors=dict(level0={0: "sequential BiCGstab solves", 1: "lockstep block BiCGstab on the multi-rhs stencil", 2: "lockstep block BiCGstab on the MFMA coarse operator"}[lv0["null_method"]],
+               cycle={"V": "V-cycle (QUDA_MG_CYCLE_VCYCLE)", "K": "K-cycle (QUDA_MG_CYCLE_RECURSIVE)"}[cycle], null_vectors=dict(level0={0: "preset (refined from the first hierarchy)" if refined else "sequential BiCGstab solves", 1: "lockstep block BiCGstab on the multi-rhs stencil", 2: "lockstep block BiCGstab on the MFMA coarse operator"}[lv0["null_method"]],
                                  level0_lockstep_iters=lv0["null_iters"], level1={0: "sequential BiCGstab solves", 1: "lockstep (fine stencil)", 2: "lockstep block BiCGstab on the MFMA coarse operator"}[lv1["null_method"]],
                                  level1_lockstep_iters=lv1["null_iters"]),
                setup_secs=min(setups), setup_secs_all=setups, solve_secs=round(wall, 4),

@@ -10,6 +10,7 @@
 
 #include "blas.h"
 
+#include <algorithm>
 #include <cstring>
 
 namespace quda {
@@ -549,11 +550,17 @@ void DiracCoarse::build() {
     if (direct && pt == QUDA_TWISTED_CLOVER_DIRAC) herm = true;   // hop part by completion, local term probed below (analyticLocal is false)
   }
   if (herm && direct) {
-    const size_t wbytes = T.vBytes();
+    // in chunks of aggregates (the product of an aggregate needs UV on its own sites only): the temporary is ~3 GB instead of a second V
+    // (24.5 GB at 48^3 x 96, whose allocation alone cost more than the products) and fits a buffer the null-vector stage left in the pool
+    const int chunk = (int)std::min<long>(T.nAgg, std::max<long>(512, (T.nAgg + 7) / 8));
+    const size_t wbytes = (size_t)chunk * 12 * T.Nvec * T.blockVol * 2 * sizeof(float);
     float *UV = (float *)poolDeviceMalloc(wbytes);
-    for (int mu = 0; mu < 4; mu++) {
-      galerkinUV(UV, T.V, *parent->Gauge(), 2 * mu, -parent->Kappa(), T.block_to_fine, T.fine_to_block, (int)T.nAgg, T.blockVol, T.Nvec);
-      T.directGalerkinVUV(links->data, UV, mu, mu > 0);
+    for (long a0 = 0; a0 < T.nAgg; a0 += chunk) {
+      const int na = (int)std::min<long>(chunk, T.nAgg - a0);
+      for (int mu = 0; mu < 4; mu++) {
+        galerkinUV(UV, T.V, *parent->Gauge(), 2 * mu, -parent->Kappa(), T.block_to_fine, T.fine_to_block, (int)a0, na, T.blockVol, T.Nvec);
+        T.directGalerkinVUV(links->data, UV, mu, mu > 0, false, (int)a0, na);
+      }
     }
     HIP_CHECK(hipStreamSynchronize(computeStream()));
     poolDeviceFree(UV, wbytes);
@@ -605,10 +612,14 @@ void DiracCoarse::build() {
     poolDeviceFree(S, (size_t)links->nSites * per * sizeof(float4));
     if (!analyticLocal && direct && parent->Clover() && parent->Clover()->precision == QUDA_SINGLE_PRECISION) {
       // twisted clover: V^dagger (A + i a g5) V as one more batched product, added to the completed hop part
-      const size_t wbytes = T.vBytes();
+      const int chunk = (int)std::min<long>(T.nAgg, std::max<long>(512, (T.nAgg + 7) / 8));
+      const size_t wbytes = (size_t)chunk * 12 * T.Nvec * T.blockVol * 2 * sizeof(float);
       float *L = (float *)poolDeviceMalloc(wbytes);
-      galerkinLocalUV(L, T.V, *parent->Clover(), 2.0 * parent->Kappa() * (double)fineFlavor * parent->Mu(), T.block_to_fine, (int)T.nAgg, T.blockVol, T.Nvec);
-      T.directGalerkinVUV(links->data, L, 0, true, true);
+      for (long a0 = 0; a0 < T.nAgg; a0 += chunk) {
+        const int na = (int)std::min<long>(chunk, T.nAgg - a0);
+        galerkinLocalUV(L, T.V, *parent->Clover(), 2.0 * parent->Kappa() * (double)fineFlavor * parent->Mu(), T.block_to_fine, (int)a0, na, T.blockVol, T.Nvec);
+        T.directGalerkinVUV(links->data, L, 0, true, true, (int)a0, na);
+      }
       HIP_CHECK(hipStreamSynchronize(computeStream()));
       poolDeviceFree(L, wbytes);
     } else if (!analyticLocal)

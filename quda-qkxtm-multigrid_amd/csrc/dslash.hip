@@ -2015,9 +2015,9 @@ void applyCovariantShift(ColorSpinorField &out, const ColorSpinorField &in, cons
 // the transfer operator, [aggregate][spin-colour][vector pair][site in aggregate] float4.  One work-group per aggregate, one thread per
 // site of it (stores of a wave are 1 KiB contiguous), loop over the vector pairs.
 __global__ void __launch_bounds__(256) galerkin_uv_kernel(const DslashArg<float> arg, const char *gaugeEven, const char *gaugeOdd, int dir, float coef, const float4 *V, float4 *UV,
-                                                          const int *block_to_fine, const int *fine_to_block, int nvp) {
+                                                          const int *block_to_fine, const int *fine_to_block, int nvp, int aggOffset) {
   constexpr int BV = 256;
-  const int A = blockIdx.x, b = threadIdx.x;
+  const int A = blockIdx.x + aggOffset, Aloc = blockIdx.x, b = threadIdx.x;   // UV holds the aggregates [aggOffset, aggOffset + gridDim) only
   const int f = block_to_fine[(size_t)A * BV + b];
   const int parity = f >= arg.Vh, idx = f - parity * arg.Vh;
   const uint32_t za = arg.dXh.div((uint32_t)idx);
@@ -2058,11 +2058,11 @@ __global__ void __launch_bounds__(256) galerkin_uv_kernel(const DslashArg<float>
 #pragma unroll
       for (int sp = 0; sp < 4; sp++) su3_mv(out[vec] + 6 * sp, U, psi[vec] + 6 * sp);
 #pragma unroll
-    for (int k = 0; k < 12; k++) UV[(((size_t)A * 12 + k) * nvp + vp) * BV + b] = make_float4(out[0][2 * k], out[0][2 * k + 1], out[1][2 * k], out[1][2 * k + 1]);
+    for (int k = 0; k < 12; k++) UV[(((size_t)Aloc * 12 + k) * nvp + vp) * BV + b] = make_float4(out[0][2 * k], out[0][2 * k + 1], out[1][2 * k], out[1][2 * k + 1]);
   }
 }
 // fp32 recon-18 links (boundary condition inside the stored links), 4^4 aggregates, unpartitioned lattice (the neighbour's V would live on another rank)
-void galerkinUV(float *UVout, const float *V, const GaugeField &U, int dir, double coef, const int *block_to_fine, const int *fine_to_block, int nAgg, int blockVol, int nvec) {
+void galerkinUV(float *UVout, const float *V, const GaugeField &U, int dir, double coef, const int *block_to_fine, const int *fine_to_block, int aggOffset, int nAgg, int blockVol, int nvec) {
   if (U.precision != QUDA_SINGLE_PRECISION || U.reconstruct != QUDA_RECONSTRUCT_NO) errorQuda("direct Galerkin construction: fp32 recon-18 links");
   if (blockVol != 256) errorQuda("direct Galerkin construction: 4^4 aggregates");
   const LatticeGeom &g = U.geom;
@@ -2072,16 +2072,16 @@ void galerkinUV(float *UVout, const float *V, const GaugeField &U, int dir, doub
   arg.Vh = g.Vh; arg.Xh = g.Xh; arg.Y = g.X[1]; arg.Z = g.X[2]; arg.T = g.X[3];
   arg.dXh = g.dXh; arg.dY = g.dY; arg.dZ = g.dZ;
   hipLaunchKernelGGL(galerkin_uv_kernel, dim3(nAgg), dim3(256), 0, computeStream(), arg, (const char *)U.parityBase(0), (const char *)U.parityBase(1), dir, (float)coef, (const float4 *)V,
-                     (float4 *)UVout, block_to_fine, fine_to_block, nvec / 2);
+                     (float4 *)UVout, block_to_fine, fine_to_block, nvec / 2, aggOffset);
   HIP_CHECK(hipGetLastError());
 }
 
 // the same for the site-diagonal term of the twisted-clover operator: L(x)[s, c; v] = (A_chi(s)(x) + i a s_chi) V(x)[s, c; v] — chirality-diagonal, so
 // galerkin_vuv_kernel runs it in its "local" mode (no cross-chirality columns, every site belongs to the local matrix)
 __global__ void __launch_bounds__(256) galerkin_local_uv_kernel(const float4 *V, float4 *L, const void *clEven, const void *clOdd, int cl_stride, int Vh, float a,
-                                                                const int *block_to_fine, int nvp) {
+                                                                const int *block_to_fine, int nvp, int aggOffset) {
   constexpr int BV = 256;
-  const int A = blockIdx.x, b = threadIdx.x;
+  const int A = blockIdx.x + aggOffset, Aloc = blockIdx.x, b = threadIdx.x;
   const int f = block_to_fine[(size_t)A * BV + b];
   const int parity = f >= Vh, idx = f - parity * Vh;
   const void *clA = parity ? clOdd : clEven;
@@ -2107,13 +2107,13 @@ __global__ void __launch_bounds__(256) galerkin_local_uv_kernel(const float4 *V,
         for (int k = 0; k < 6; k++) { r[2 * k] -= sa * v[2 * k + 1]; r[2 * k + 1] += sa * v[2 * k]; }
       }
 #pragma unroll
-    for (int k = 0; k < 12; k++) L[(((size_t)A * 12 + k) * nvp + vp) * BV + b] = make_float4(o[0][2 * k], o[0][2 * k + 1], o[1][2 * k], o[1][2 * k + 1]);
+    for (int k = 0; k < 12; k++) L[(((size_t)Aloc * 12 + k) * nvp + vp) * BV + b] = make_float4(o[0][2 * k], o[0][2 * k + 1], o[1][2 * k], o[1][2 * k + 1]);
   }
 }
-void galerkinLocalUV(float *Lout, const float *V, const CloverField &C, double a, const int *block_to_fine, int nAgg, int blockVol, int nvec) {
+void galerkinLocalUV(float *Lout, const float *V, const CloverField &C, double a, const int *block_to_fine, int aggOffset, int nAgg, int blockVol, int nvec) {
   if (C.precision != QUDA_SINGLE_PRECISION) errorQuda("direct Galerkin construction: fp32 clover field");
   if (blockVol != 256) errorQuda("direct Galerkin construction: 4^4 aggregates");
-  hipLaunchKernelGGL(galerkin_local_uv_kernel, dim3(nAgg), dim3(256), 0, computeStream(), (const float4 *)V, (float4 *)Lout, C.A(0), C.A(1), C.stride, C.geom.Vh, (float)a, block_to_fine, nvec / 2);
+  hipLaunchKernelGGL(galerkin_local_uv_kernel, dim3(nAgg), dim3(256), 0, computeStream(), (const float4 *)V, (float4 *)Lout, C.A(0), C.A(1), C.stride, C.geom.Vh, (float)a, block_to_fine, nvec / 2, aggOffset);
   HIP_CHECK(hipGetLastError());
 }
 

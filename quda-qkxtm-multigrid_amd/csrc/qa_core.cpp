@@ -124,17 +124,22 @@ void acctDump(const char *path) {
   g_acct.clear();
 }
 
-static std::map<size_t, std::vector<void *>> g_pool;
+// Size-bucketed device pool with best-fit reuse: a request is served by the smallest parked buffer of at least that size and at most 1.5 x
+// it (the multigrid set-up parks 4 GB block fields and 24 GB vector matrices; the next stage's temporaries are a little smaller or equal and
+// a fresh hipMalloc of that size costs 0.1-1 s); the real size of every buffer is remembered, the size passed to poolDeviceFree is ignored.
+static std::multimap<size_t, void *> g_pool;
+static std::map<void *, size_t> g_poolSize;
 
 void *poolDeviceMalloc(size_t bytes) {
-  auto it = g_pool.find(bytes);
-  if (it != g_pool.end() && !it->second.empty()) {
-    void *p = it->second.back();
-    it->second.pop_back();
+  auto it = g_pool.lower_bound(bytes);
+  if (it != g_pool.end() && it->first <= bytes + bytes / 2) {
+    void *p = it->second;
+    g_pool.erase(it);
     return p;
   }
   void *p = nullptr;
   HIP_CHECK(qaMallocRaw(&p, bytes));
+  g_poolSize[p] = bytes;
   return p;
 }
 hipError_t qaMallocRaw(void **p, size_t bytes) {
@@ -146,15 +151,17 @@ hipError_t qaMallocRaw(void **p, size_t bytes) {
   }
   return e;
 }
-void poolDeviceFree(void *ptr, size_t bytes) {
-  if (ptr) g_pool[bytes].push_back(ptr);
+void poolDeviceFree(void *ptr, size_t) {
+  if (!ptr) return;
+  auto it = g_poolSize.find(ptr);
+  if (it == g_poolSize.end()) errorQuda("poolDeviceFree of a pointer the pool did not hand out");
+  g_pool.insert({it->second, ptr});
 }
 void poolDeviceFlush(size_t atLeast) {
-  for (auto it = g_pool.begin(); it != g_pool.end();) {
-    if (it->first >= atLeast) {
-      for (void *p : it->second) (void)hipFree(p);
-      it = g_pool.erase(it);
-    } else ++it;
+  for (auto it = g_pool.lower_bound(atLeast); it != g_pool.end();) {
+    (void)hipFree(it->second);
+    g_poolSize.erase(it->second);
+    it = g_pool.erase(it);
   }
 }
 

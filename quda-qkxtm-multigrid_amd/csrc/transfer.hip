@@ -768,7 +768,7 @@ __device__ __constant__ int kGalPhase[4][4] = {{3, 3, 1, 1}, {0, 2, 2, 0}, {3, 1
 // constant fixed before the loop: i^(3 o) for a column of the wave's own chirality (o: the lane's real / imaginary column), i^(phase + 3 o)
 // for the other chirality (0 in local mode), 0 for a padding row of A — so that (bre, bim) = c w and the two MFMA steps follow.
 template <int NVEC, int CHI, typename SiteB>
-__device__ __forceinline__ void galerkin_vuv_accumulate(gf32x4 (&acc)[(NVEC + 15) / 16][NVEC / 4], const float2 *V, const float2 *UV, int A, int mu, int local, int row16, int kq, SiteB site_b) {
+__device__ __forceinline__ void galerkin_vuv_accumulate(gf32x4 (&acc)[(NVEC + 15) / 16][NVEC / 4], const float2 *V, const float2 *UV, int A, int Aloc, int mu, int local, int row16, int kq, SiteB site_b) {
   constexpr int NVP = NVEC / 2, MT = (NVEC + 15) / 16, NT = NVEC / 4, BV = 256;
 #pragma unroll
   for (int mt = 0; mt < MT; mt++)
@@ -798,7 +798,7 @@ __device__ __forceinline__ void galerkin_vuv_accumulate(gf32x4 (&acc)[(NVEC + 15
     const int j = 8 * nt + (row16 >> 1), vc = j - (nt >= NT / 2 ? NVEC : 0);
     bOff[nt] = (vc >> 1) * BV * 2 + (vc & 1);
   }
-  const float2 *Va = V + (size_t)A * 12 * NVP * BV * 2, *Ua = UV + (size_t)A * 12 * NVP * BV * 2;
+  const float2 *Va = V + (size_t)A * 12 * NVP * BV * 2, *Ua = UV + (size_t)Aloc * 12 * NVP * BV * 2;
   constexpr int ROW = NVP * BV * 2;   // float2 elements per (spin-colour) row
   for (int g = 0; g < 16; g++) {
     const int b2 = 2 * site_b(4 * g + kq);
@@ -833,10 +833,10 @@ __device__ __forceinline__ void galerkin_vuv_accumulate(gf32x4 (&acc)[(NVEC + 15
     }
   }
 }
-template <int NVEC> __global__ void __launch_bounds__(512) galerkin_vuv_kernel(float *G, const float2 *V, const float2 *UV, int mu, int accumulateLocal, int pm, int local) {
+template <int NVEC> __global__ void __launch_bounds__(512) galerkin_vuv_kernel(float *G, const float2 *V, const float2 *UV, int mu, int accumulateLocal, int pm, int local, int aggOffset) {
   constexpr int NVP = NVEC / 2, MT = (NVEC + 15) / 16, NT = NVEC / 4, n = 2 * NVEC, BV = 256;
   extern __shared__ float glds[];   // [class][mt][nt][reg][lane], one row block at a time
-  const int A = blockIdx.x, lane = threadIdx.x & 63;
+  const int A = blockIdx.x + aggOffset, lane = threadIdx.x & 63;   // UV holds the aggregates [aggOffset, aggOffset + gridDim) only
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int cls = wave & 3, chiR = wave >> 2;
   const int row16 = lane & 15, kq = lane >> 4;
@@ -849,8 +849,8 @@ template <int NVEC> __global__ void __launch_bounds__(512) galerkin_vuv_kernel(f
     return pm ? ((y[0] + y[1] + y[2] + y[3]) & 1) * (BV / 2) + (lex >> 1) : lex;
   };
   gf32x4 acc[MT][NT];
-  if (chiR == 0) galerkin_vuv_accumulate<NVEC, 0>(acc, V, UV, A, mu, local, row16, kq, site_b);
-  else galerkin_vuv_accumulate<NVEC, 1>(acc, V, UV, A, mu, local, row16, kq, site_b);
+  if (chiR == 0) galerkin_vuv_accumulate<NVEC, 0>(acc, V, UV, A, (int)blockIdx.x, mu, local, row16, kq, site_b);
+  else galerkin_vuv_accumulate<NVEC, 1>(acc, V, UV, A, (int)blockIdx.x, mu, local, row16, kq, site_b);
   // ---- partial tiles -> LDS, one row block (chi) at a time so that the buffer is 4 waves x 12 KB and two work-groups share a CU;
   // classes 0..2 summed = local part, class 3 = link ----
   constexpr int TILE = MT * NT * 4 * 64;   // floats per wave
@@ -898,12 +898,12 @@ bool Transfer::canDirectGalerkin() const {
   return true;
 }
 // forward link Y_{2 mu} and the in-aggregate part S of all coarse sites from UV = galerkinUV(V): slots 2 mu and 8 of the coarse links
-void Transfer::directGalerkinVUV(float *links, const float *UV, int mu, bool accumulateLocal, bool local) const {
+void Transfer::directGalerkinVUV(float *links, const float *UV, int mu, bool accumulateLocal, bool local, int aggOffset, int nAggChunk) const {
   if (!canDirectGalerkin()) errorQuda("direct Galerkin construction not available for this transfer operator");
   const size_t lds = (size_t)4 * ((Nvec + 15) / 16) * (Nvec / 4) * 4 * 64 * sizeof(float);
 #define QA_VUV(NV) { static bool attr = false; \
     if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void *)galerkin_vuv_kernel<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; } \
-    hipLaunchKernelGGL((galerkin_vuv_kernel<NV>), dim3(nAgg), dim3(512), lds, computeStream(), links, (const float2 *)V, (const float2 *)UV, mu, accumulateLocal ? 1 : 0, parityMajor ? 1 : 0, local ? 1 : 0); }
+    hipLaunchKernelGGL((galerkin_vuv_kernel<NV>), dim3(nAggChunk > 0 ? nAggChunk : (int)nAgg), dim3(512), lds, computeStream(), links, (const float2 *)V, (const float2 *)UV, mu, accumulateLocal ? 1 : 0, parityMajor ? 1 : 0, local ? 1 : 0, aggOffset); }
   if (Nvec == 24) QA_VUV(24) else QA_VUV(8)
 #undef QA_VUV
   HIP_CHECK(hipGetLastError());

@@ -24,6 +24,7 @@ Ls = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 Lt = int(sys.argv[2]) if len(sys.argv) > 2 else 96
 dslash = sys.argv[3] if len(sys.argv) > 3 else "tm"
 acct = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "gpurun_out", "mg_solve_acct.json")
+cycle = sys.argv[5] if len(sys.argv) > 5 else "V"   # V: the plain V-cycle of BASELINE.json configs[4] (bench.py), K: the harness' K-cycle
 X = (Ls, Ls, Ls, Lt)
 kappa, mu = 0.124, 0.005
 qa.init(0)
@@ -37,7 +38,8 @@ if dslash == "tmc":
     qa.load_clover(None, None, ip)
 b1 = tuple(2 if ((x // 4) % 2 == 0 and (x // 8) % 2 == 0) else (2 if (x // 4) % 2 == 0 else 1) for x in X)
 blocks = [(4, 4, 4, 4), (2, 2, 2, 4) if X == (48, 48, 48, 96) else (2, 2, 2, 2), (2, 2, 2, 2)]
-mp = qa.multigrid_param(ip, n_level=3, geo_block=blocks, n_vec=24, setup_maxiter=500, setup_tol=5e-6, smoother_pc=True)
+mp = qa.multigrid_param(ip, n_level=3, geo_block=blocks, n_vec=24, setup_maxiter=500, setup_tol=5e-6, smoother_pc=True,
+                        cycle=qa.QUDA_MG_CYCLE_VCYCLE if cycle == "V" else qa.QUDA_MG_CYCLE_RECURSIVE)
 t0 = time.perf_counter()
 mg = qa.Multigrid(mp)
 setup = time.perf_counter() - t0
@@ -56,6 +58,6 @@ qa.lib().qudaAmdAccountDump(acct.encode())
 qa.lib().qudaAmdProfileMarker(2)
 qa.lib().qudaAmdDeviceSynchronize()
 res = float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b))
-print("SOLVE " + json.dumps(dict(lattice="x".join(map(str, X)), action=dslash, iters=ip.iter, solver_secs=ip.secs, solve_secs=wall, setup_secs=setup, true_res=res, acct=os.path.basename(acct))), flush=True)
+print("SOLVE " + json.dumps(dict(lattice="x".join(map(str, X)), action=dslash, cycle=cycle, iters=ip.iter, solver_secs=ip.secs, solve_secs=wall, setup_secs=setup, true_res=res, acct=os.path.basename(acct))), flush=True)
 mg.free()
 qa.end()
