@@ -80,6 +80,7 @@ struct DslashTune {
   int remap = 1;       // XCD-aware block mapping on / off
   int order = 1;       // legacy slab order: 1 = t-interleave over the whole XCD slab, n > 1 = over n slices
   int store_aux = -1;  // cache policy of the output stores: -1 automatic (nt from 2^18 checkerboard sites), 0 default, 2 nt
+  int link_aux = -1;   // cache policy of 16-bit link loads: -1 automatic (nt once an application's working set exceeds the 256 MiB Infinity Cache), 0 default, 2 nt
   int tiled = -1;      // plane-tiled order: -1 automatic (on where the lattice allows), 0 off, 1 chunk-major tiles, 2 z-major tiles
   int nxz = 0, tz = 0, tt = 0;   // plane-tiled order: XCDs along z, tile extents in z and t (0: automatic)
   int lds_pad = 0;     // dynamic LDS per block, only to cap the blocks per CU (measurement aid)

@@ -29,6 +29,7 @@ struct ColorSpinorParam {
   int x[QUDA_MAX_DIM] = {0, 0, 0, 0, 0, 0};  // x[0] already halved for parity fields (reference convention)
   QudaPrecision precision = QUDA_DOUBLE_PRECISION;
   int pad = 0;
+  bool planePad = true;  // device spin-4 fields: add the library's plane padding (fieldPadSites) to pad; false in the param() of an existing field, whose pad already holds it
   QudaTwistFlavorType twistFlavor = QUDA_TWIST_NO;
   QudaSiteSubset siteSubset = QUDA_PARITY_SITE_SUBSET;
   QudaSiteOrder siteOrder = QUDA_EVEN_ODD_SITE_ORDER;

@@ -202,7 +202,7 @@ int qudaAmdHaloTransport(void);
 /* launch geometry of the fine-grid stencil kernel, the counterpart of the reference's autotuner entries for the dslash kernels
  * (lib/tune.cpp, TuneParam block / grid): key = "block" (threads per block, 0 automatic), "remap" (XCD-aware block mapping),
  * "order" (legacy slab order), "tiled" / "nxz" / "tz" / "tt" (plane-tiled block order: XCDs along z, tile extents),
- * "store_aux", "lds_pad".  Results never depend on these. */
+ * "store_aux", "link_aux", "lds_pad".  Results never depend on these. */
 void qudaAmdSetDslashTune(const char *key, int value);
 
 #ifdef __cplusplus

@@ -381,7 +381,16 @@ __device__ __forceinline__ void ghost_ll_load(real *h, const void *zone, int fac
 // before the arithmetic of direction d (register double-buffering), fenced with sched_barrier so hipcc neither
 // hoists all 8 directions' loads to the top (fp64: 512 registers + scratch spills, 1 wave/SIMD) nor serialises them.
 // GAUX: cache policy of the link stream (0 default, 2 = nt: read-once data that should not displace the spinor
-// working set from L2 / Infinity Cache).
+// working set from L2 / Infinity Cache).  QA_GAUX / QA_GAUX16 / QA_PAUX: build-time overrides for A/B timing (tools/build_variant.sh).
+#ifndef QA_GAUX
+#define QA_GAUX 2
+#endif
+#ifndef QA_GAUX16
+#define QA_GAUX16 0
+#endif
+#ifndef QA_PAUX
+#define QA_PAUX 0
+#endif
 // GH: 0 = every neighbour is local; 1 = off-node neighbours are read from the ghost zone (exterior pass); 2 = off-node hops are
 // skipped here and done by ghost_hop() once the faces have arrived (single-launch peer-store path)
 // hop_load only REQUESTS (raw register images, device_io.h RawBlock): the 16-bit -> fp32 conversion and the third row of a
@@ -401,7 +410,7 @@ __device__ __forceinline__ void hop_load(RawBlock<T, 24> &psi, typename Link<T, 
     const char *gb = arg.ghost[MU][(DIR & 1) ? 0 : 1];
     psi.template load12<17>(gb, arg.faceCB[MU], face, reinterpret_cast<const float *>(gb + arg.ghostNormOff[MU]), face);
   } else {
-    psi.load(arg.in, arg.sp_stride, nbr, arg.inNorm, nbr);
+    psi.template load<QA_PAUX>(arg.in, arg.sp_stride, nbr, arg.inNorm, nbr);
   }
   Link<T, R>::template request<GAUX>(U, arg.gauge + (size_t)DIR * arg.link_bytes, arg.g_stride, idx);
 }
@@ -1075,15 +1084,31 @@ template <int NRHS, int CL = 0> __global__ void __launch_bounds__(256) fine_bloc
   // Same register discipline as stencil_site: two panel buffers, the loads of hop d + 1 issued before the arithmetic of hop d,
   // fenced so the compiler neither hoists all 108 loads to the top (256 registers, one wave per SIMD: 12.7 ms per launch at
   // 48^3 x 96, four times the bandwidth bound) nor serialises them.
-  float pA[24], pB[24];
-  auto load_panel = [&](float *psi, const float2 *base, int site) {
-    const float2 *p = base + ((long)site * 12) * NRHS + i;
+  // The panels travel as 16-byte words: lane pair (i, i ^ 1) of a site shares its loads — the even lane fetches the even components of
+  // right-hand sides (i, i + 1), the odd lane the odd components, one 128-byte line per site and instruction (8-byte-per-lane loads
+  // run at 0.54-0.70 of the 16-byte rate on gfx950, and the kernel is bound by its L2 -> L1 requests); the 2 x 2 transposition
+  // between the two lanes is a DPP quad permute on the loaded data, in the compute phase behind the fence.
+  const int io = i & 1, ipr = i & ~1;
+  float4 pA[6], pB[6];
+  auto load_panel = [&](float4 *raw, const float2 *base, int site) {
+    const float4 *p = reinterpret_cast<const float4 *>(base + ((long)site * 12 + io) * NRHS + ipr);
 #pragma unroll
-    for (int j = 0; j < 12; j++) { const float2 v = p[j * NRHS]; psi[2 * j] = v.x; psi[2 * j + 1] = v.y; }
+    for (int k = 0; k < 6; k++) raw[k] = p[k * NRHS];   // component 2k + io, right-hand sides ipr and ipr + 1
   };
-  auto hop = [&](auto DIRC, float *psi) {
+  auto swap1 = [](float v) -> float { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); };   // quad_perm [1,0,3,2]
+  auto unpack_panel = [&](float *psi, const float4 *raw) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      const float4 v = raw[k];
+      const float kx = io ? v.z : v.x, ky = io ? v.w : v.y;          // this lane's right-hand side of the component it loaded
+      const float rx = swap1(io ? v.x : v.z), ry = swap1(io ? v.y : v.w);   // ... and of the component the partner loaded
+      psi[4 * k] = io ? rx : kx; psi[4 * k + 1] = io ? ry : ky; psi[4 * k + 2] = io ? kx : rx; psi[4 * k + 3] = io ? ky : ry;
+    }
+  };
+  auto hop = [&](auto DIRC, const float4 *raw) {
     constexpr int DIR = decltype(DIRC)::value, MU = DIR / 2;
-    float h[12], g[12], U[18];
+    float psi[24], h[12], g[12], U[18];
+    unpack_panel(psi, raw);
 #pragma unroll
     for (int k = 0; k < 18; k++) U[k] = U0[DIR * 18 + k];
     const float sgn = (DIR & 1) ? -1.f : 1.f;
@@ -1105,11 +1130,13 @@ template <int NRHS, int CL = 0> __global__ void __launch_bounds__(256) fine_bloc
 #undef FB_PIN
 #undef FB_LD
 #undef FB_CP
-  float2 *o = arg.out + ((size_t)idx * 12) * NRHS + i;
+  float same[24];
+  if (arg.s0 != 0.f) unpack_panel(same, pA);
+  float outv[24];
   if (CL) {
     // dense 6 x 6 complex matrix per chirality on the hop sum (CL = 1) or on the site's own panel (CL = 2); rows read as three
     // 16-byte LDS words, the same address for the NRHS lanes of a site
-    float *src = CL == 1 ? acc : pA;
+    float *src = CL == 1 ? acc : same;
     float res[24];
     const float *T0 = &tlds[s * TSTR];
 #pragma unroll
@@ -1133,27 +1160,35 @@ template <int NRHS, int CL = 0> __global__ void __launch_bounds__(256) fine_bloc
         re = arg.k1 * res[2 * j]; im = arg.k1 * res[2 * j + 1];
         if (arg.s0 != 0.f) {
           const float a0 = (j < 6 ? 1.f : -1.f) * arg.a0;
-          re += arg.s0 * (pA[2 * j] - a0 * pA[2 * j + 1]); im += arg.s0 * (pA[2 * j + 1] + a0 * pA[2 * j]);
+          re += arg.s0 * (same[2 * j] - a0 * same[2 * j + 1]); im += arg.s0 * (same[2 * j + 1] + a0 * same[2 * j]);
         }
       } else {
         const float a1 = (j < 6 ? 1.f : -1.f) * arg.a1;
         re = arg.k1 * (acc[2 * j] - a1 * acc[2 * j + 1]) + arg.s0 * res[2 * j];
         im = arg.k1 * (acc[2 * j + 1] + a1 * acc[2 * j]) + arg.s0 * res[2 * j + 1];
       }
-      o[j * NRHS] = make_float2(re, im);
+      outv[2 * j] = re; outv[2 * j + 1] = im;
     }
-    return;
-  }
+  } else {
 #pragma unroll
-  for (int j = 0; j < 12; j++) {
-    const float sg = j < 6 ? 1.f : -1.f;   // g5 = diag(+,+,-,-): spins 0,1 are components 0..5
-    const float a1 = sg * arg.a1;
-    float re = arg.k1 * (acc[2 * j] - a1 * acc[2 * j + 1]), im = arg.k1 * (acc[2 * j + 1] + a1 * acc[2 * j]);
-    if (arg.s0 != 0.f) {
-      const float a0 = sg * arg.a0;
-      re += arg.s0 * (pA[2 * j] - a0 * pA[2 * j + 1]); im += arg.s0 * (pA[2 * j + 1] + a0 * pA[2 * j]);
+    for (int j = 0; j < 12; j++) {
+      const float sg = j < 6 ? 1.f : -1.f;   // g5 = diag(+,+,-,-): spins 0,1 are components 0..5
+      const float a1 = sg * arg.a1;
+      float re = arg.k1 * (acc[2 * j] - a1 * acc[2 * j + 1]), im = arg.k1 * (acc[2 * j + 1] + a1 * acc[2 * j]);
+      if (arg.s0 != 0.f) {
+        const float a0 = sg * arg.a0;
+        re += arg.s0 * (same[2 * j] - a0 * same[2 * j + 1]); im += arg.s0 * (same[2 * j + 1] + a0 * same[2 * j]);
+      }
+      outv[2 * j] = re; outv[2 * j + 1] = im;
     }
-    o[j * NRHS] = make_float2(re, im);
+  }
+  // store as the panels were loaded: the lane pair exchanges one component each and writes 16-byte words, a full line per site
+  float4 *o = reinterpret_cast<float4 *>(arg.out + ((size_t)idx * 12 + io) * NRHS + ipr);
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const float kx = io ? outv[4 * k + 2] : outv[4 * k], ky = io ? outv[4 * k + 3] : outv[4 * k + 1];   // component 2k + io, this lane's right-hand side
+    const float rx = swap1(io ? outv[4 * k] : outv[4 * k + 2]), ry = swap1(io ? outv[4 * k + 1] : outv[4 * k + 3]);   // the same component of the partner's
+    o[k * NRHS] = io ? make_float4(rx, ry, kx, ky) : make_float4(kx, ky, rx, ry);
   }
 }
 
@@ -1433,6 +1468,7 @@ DslashTune &dslashTune() {
     t.remap = env("QUDA_AMD_XCD_REMAP", 1);
     t.order = env("QUDA_AMD_DSLASH_ORDER", 1);
     t.store_aux = env("QUDA_AMD_STORE_AUX", -1);
+    t.link_aux = env("QUDA_AMD_LINK_AUX", -1);
     t.tiled = env("QUDA_AMD_DSLASH_TILED", -1);
     t.nxz = env("QUDA_AMD_DSLASH_NXZ", 0);
     t.tz = env("QUDA_AMD_DSLASH_TZ", 0);
@@ -1452,6 +1488,7 @@ void setDslashTune(const char *key, int value) {
   else if (k == "remap") t.remap = value;
   else if (k == "order") t.order = value;
   else if (k == "store_aux") t.store_aux = value;
+  else if (k == "link_aux") t.link_aux = value;
   else if (k == "tiled") t.tiled = value;
   else if (k == "nxz") t.nxz = value;
   else if (k == "tz") t.tz = value;
@@ -1680,7 +1717,7 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
   // link/clover stream cache policy: nt for the 16-byte-per-lane formats (measured on 32^4: fp64 4.67 -> 5.2 TB/s, fp32
   // 4.68 -> 5.16 TB/s algorithmic; the read-once links no longer evict the re-used spinors), default for the 8-byte 16-bit format
   // (nt there costs 18 %).
-  constexpr int GAUX = sizeof(T) == 2 ? 0 : 2;
+  constexpr int GAUX = sizeof(T) == 2 ? QA_GAUX16 : QA_GAUX;
   int mask = 0;
   for (int d = 0; d < 4; d++) if (commGrid().partitioned(d)) mask |= 1 << d;
   hipStream_t cs = computeStream();
@@ -1689,6 +1726,18 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
     // output stores: nt from 2^18 checkerboard sites up (measured +1...+5 % at 32^4 and 48^3 x 96 in every precision and action,
     // +10 % for 16-bit twisted clover; on the 65k-site sub-lattice of an 8-GPU split it costs fp32 5 %), QUDA_AMD_STORE_AUX / "store_aux" = 0 | 2 overrides
     const bool ntStore = tune.store_aux >= 0 ? tune.store_aux == 2 : g.Vh >= (1 << 18);
+    if constexpr (sizeof(T) == 2 && GAUX == 0) {
+      // 16-bit links: default policy while one application's working set fits the Infinity Cache (32^4: 205 MB of 256 MiB — the links
+      // are re-read from it by the next application, nt costs 13 % there), nt beyond it (48^3 x 96, 2.1 GB: 405 -> 381 us, measured twice)
+      const size_t working = (size_t)g.Vh * (size_t)dslashBytesPerSite(in.Precision(), R, p.mode, p.x != nullptr);
+      const bool ntLinks = tune.link_aux >= 0 ? tune.link_aux == 2 : working > ((size_t)256 << 20);
+      if (ntLinks) {
+        if (ntStore) hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, 2, 0, 2>), dim3(nb), dim3(bs), lds, cs, arg);
+        else hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, 2, 0, 0>), dim3(nb), dim3(bs), lds, cs, arg);
+        HIP_CHECK(hipGetLastError());
+        return;
+      }
+    }
     if (ntStore) hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 0, 2>), dim3(nb), dim3(bs), lds, cs, arg);
     else hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 0, 0>), dim3(nb), dim3(bs), lds, cs, arg);
     HIP_CHECK(hipGetLastError());
@@ -2189,6 +2238,7 @@ template <typename T> static void launchSite(ColorSpinorField &out, const ColorS
                                              const CloverField *cl, int parity, bool inverse) {
   using real = typename Store<T>::real;
   SiteArg<real> arg;
+  if (out.Stride() != in.Stride() || out.VolumeCB() != in.VolumeCB()) errorQuda("site operator: output stride %d / volume %d against input %d / %d", out.Stride(), out.VolumeCB(), in.Stride(), in.VolumeCB());
   arg.out = out.V(); arg.outNorm = (float *)out.Norm();
   arg.in = in.V(); arg.inNorm = (const float *)in.Norm();
   arg.sp_stride = in.Stride(); arg.Vh = in.VolumeCB(); arg.op = op;

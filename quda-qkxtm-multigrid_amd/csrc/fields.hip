@@ -38,6 +38,18 @@ ColorSpinorParam::ColorSpinorParam(void *V, const QudaInvertParam &inv, const in
 
 static size_t alignUp(size_t n, size_t a) { return (n + a - 1) / a * a; }
 
+// Plane padding (sites) of the device fields, QUDA_AMD_FIELD_PAD: the planes of a field are stride x 16 bytes apart, which is a multiple
+// of 1 MiB on 32^4 and 48^3 x 96 — every plane of a site then falls into the same L2 set window (the reference pads for the same
+// reason, "partition camping": sp_pad / ga_pad / cl_pad of QudaInvertParam / QudaGaugeParam).
+int fieldPadSites() {
+  static int v = [] { const char *e = getenv("QUDA_AMD_FIELD_PAD"); return e ? atoi(e) : 0; }();
+  return v;
+}
+static int gaugePadSites() {
+  static int v = [] { const char *e = getenv("QUDA_AMD_GAUGE_PAD"); return e ? atoi(e) : fieldPadSites(); }();
+  return v;
+}
+
 ColorSpinorField::ColorSpinorField(const ColorSpinorParam &p)
     : location(p.location), nColor(p.nColor), nSpin(p.nSpin), nDim(p.nDim), pad(p.pad), precision(p.precision),
       siteSubset(p.siteSubset), siteOrder(p.siteOrder), fieldOrder(p.fieldOrder), gammaBasis(p.gammaBasis),
@@ -48,6 +60,7 @@ ColorSpinorField::ColorSpinorField(const ColorSpinorParam &p)
   const int nsub = siteSubset == QUDA_FULL_SITE_SUBSET ? 2 : 1;
   volumeCB = volume / nsub;
   if (location == QUDA_CPU_FIELD_LOCATION) pad = 0;
+  else if (p.planePad && p.create != QUDA_REFERENCE_FIELD_CREATE && nSpin == 4) pad += fieldPadSites();
   stride = volumeCB + pad;
   if (location == QUDA_CUDA_FIELD_LOCATION) {
     fieldOrder = (precision == QUDA_DOUBLE_PRECISION || nSpin != 4) ? QUDA_FLOAT2_FIELD_ORDER : QUDA_FLOAT4_FIELD_ORDER;
@@ -75,7 +88,7 @@ ColorSpinorField::ColorSpinorField(const ColorSpinorParam &p)
       v_ = malloc(bytes);
       if (!v_) errorQuda("host allocation of %zu bytes failed", bytes);
     }
-    if (p.create == QUDA_ZERO_FIELD_CREATE) zero();
+    if (p.create == QUDA_ZERO_FIELD_CREATE || (pad > 0 && location == QUDA_CUDA_FIELD_LOCATION)) zero();   // the flat BLAS kernels run over the pad too
   }
 }
 
@@ -83,7 +96,7 @@ ColorSpinorParam ColorSpinorField::param() const {
   ColorSpinorParam p;
   p.location = location; p.nColor = nColor; p.nSpin = nSpin; p.nDim = nDim;
   for (int d = 0; d < 4; d++) p.x[d] = x[d];
-  p.precision = precision; p.pad = pad; p.twistFlavor = twistFlavor; p.siteSubset = siteSubset; p.siteOrder = siteOrder;
+  p.precision = precision; p.pad = pad; p.planePad = false; p.twistFlavor = twistFlavor; p.siteSubset = siteSubset; p.siteOrder = siteOrder;
   p.fieldOrder = fieldOrder; p.gammaBasis = gammaBasis; p.create = QUDA_NULL_FIELD_CREATE;
   return p;
 }
@@ -361,7 +374,7 @@ void copyColorSpinor(ColorSpinorField &dst, const ColorSpinorField &src) {
 // GaugeField
 // ================================================================================================
 GaugeField::GaugeField(const LatticeGeom &g, QudaPrecision prec, QudaReconstructType recon, QudaTboundary tb, double aniso)
-    : geom(g), precision(prec), reconstruct(recon), t_boundary(tb), anisotropy(aniso), stride(g.Vh), data(nullptr), tbc_folded(true) {
+    : geom(g), precision(prec), reconstruct(recon), t_boundary(tb), anisotropy(aniso), stride(g.Vh + gaugePadSites()), data(nullptr), tbc_folded(true) {
   if (recon != QUDA_RECONSTRUCT_NO && recon != QUDA_RECONSTRUCT_12) errorQuda("reconstruct %d not supported (18, 12)", recon);
   if (prec == QUDA_HALF_PRECISION && aniso != 1.0) errorQuda("16-bit links need anisotropy 1 (fixed-point range)");
   link_bytes = alignUp((size_t)stride * (int)recon * (int)prec, 1024);
@@ -516,7 +529,7 @@ void GaugeField::copyFrom(const GaugeField &src) {
 // CloverField
 // ================================================================================================
 CloverField::CloverField(const LatticeGeom &g, QudaPrecision prec)
-    : geom(g), precision(prec), stride(g.Vh), clover(nullptr), cloverInv(nullptr), norm(nullptr), invNorm(nullptr), twisted(false), mu2(0) {
+    : geom(g), precision(prec), stride(g.Vh + gaugePadSites()), clover(nullptr), cloverInv(nullptr), norm(nullptr), invNorm(nullptr), twisted(false), mu2(0) {
   parity_bytes = alignUp((size_t)stride * 72 * (int)prec, 1024);
   bytes = 2 * parity_bytes;
   HIP_CHECK(qaMalloc(&clover, bytes));

@@ -917,9 +917,10 @@ __device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned 
   z ^= z >> 31;
   return (float)((z >> 40) * (1.0 / 16777216.0));
 }
-template <typename real> __global__ void random_kernel(real *v, long n, unsigned long long seed, unsigned long long offset) {
+// vec reals per 16-byte (8-byte) plane element: the padding sites [Vh, stride) of every plane stay zero — the flat BLAS kernels run over them
+template <typename real> __global__ void random_kernel(real *v, long n, unsigned long long seed, unsigned long long offset, int vec, int stride, int Vh) {
   const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (i < n) v[i] = (real)hash_uniform(seed, offset + i);
+  if (i < n) v[i] = (int)((i / vec) % stride) < Vh ? (real)hash_uniform(seed, offset + i) : (real)0;
 }
 void spinorRandom(ColorSpinorField &f, unsigned long long seed) {
   if (f.Location() != QUDA_CUDA_FIELD_LOCATION) errorQuda("device field required");
@@ -929,8 +930,9 @@ void spinorRandom(ColorSpinorField &f, unsigned long long seed) {
   for (int s = 0; s < nseg; s++) {
     void *p = nseg == 2 ? (s ? f.Odd().V() : f.Even().V()) : f.V();
     const int bs = 256; const long nb = (n + bs - 1) / bs;
-    if (f.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((random_kernel<double>), dim3(nb), dim3(bs), 0, computeStream(), (double *)p, n, seed, rank_off + (unsigned long long)s * n);
-    else if (f.Precision() == QUDA_SINGLE_PRECISION) hipLaunchKernelGGL((random_kernel<float>), dim3(nb), dim3(bs), 0, computeStream(), (float *)p, n, seed, rank_off + (unsigned long long)s * n);
+    const int vec = f.Nspin() == 4 && f.Precision() == QUDA_SINGLE_PRECISION ? 4 : 2;
+    if (f.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((random_kernel<double>), dim3(nb), dim3(bs), 0, computeStream(), (double *)p, n, seed, rank_off + (unsigned long long)s * n, vec, f.Stride(), f.VolumeCB());
+    else if (f.Precision() == QUDA_SINGLE_PRECISION) hipLaunchKernelGGL((random_kernel<float>), dim3(nb), dim3(bs), 0, computeStream(), (float *)p, n, seed, rank_off + (unsigned long long)s * n, vec, f.Stride(), f.VolumeCB());
     else errorQuda("random source needs fp64/fp32 storage");
   }
   HIP_CHECK(hipGetLastError());

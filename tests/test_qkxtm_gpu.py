@@ -73,7 +73,7 @@ def test_plaquette_and_ape_smearing_match_oracle(qa, oracle, X, mask, prec, reco
         qa.lib().qudaAmdSetPartitionMask(0)
 
 
-def _check_propagators(qa, oracle, gauge, g_lex, X, kappa, mu, ip, pos, nsmear, alpha, normalized):
+def _check_propagators(qa, oracle, gauge, g_lex, X, kappa, mu, ip, pos, nsmear, alpha, normalized, clover=None):
     V = int(np.prod(X))
     up, dn = qa.calc_mg_propagators(g_lex, ip, pos, nsmear, alpha, V)
     worst = 0.0
@@ -89,7 +89,8 @@ def _check_propagators(qa, oracle, gauge, g_lex, X, kappa, mu, ip, pos, nsmear, 
                 x = oracle.lex_to_eo(oracle.ukqcd_to_dr(prop[isc].reshape(-1, 24)).reshape(-1), list(X), 24)
                 if normalized:
                     x = x / (2 * kappa)
-                res = float(np.linalg.norm(b - oracle.tm_mat(gauge, x, list(X), kappa, mu, flavor, 0)) / np.linalg.norm(b))
+                mx = oracle.tm_mat(gauge, x, list(X), kappa, mu, flavor, 0) if clover is None else oracle.tmc_mat(gauge, clover, x, list(X), kappa, mu, flavor, 0)
+                res = float(np.linalg.norm(b - mx) / np.linalg.norm(b))
                 worst = max(worst, res)
     finally:
         oracle.set_threads(1)
@@ -143,6 +144,46 @@ def test_propagators_with_up_and_down_hierarchies(qa, oracle):
         ip.preconditionerUP, ip.preconditionerDN = hier[+1][0].h, hier[-1][0].h
         worst = _check_propagators(qa, oracle, gauge, g_lex, X, kappa, mu, ip, (3, 0, 7, 9), 6, 1.0, False)
         print("24 MG-GCR solves: %d outer iterations in total, %.3f s in the solvers, worst true residual %.2e" % (ip.iter, ip.secs, worst))
+        assert worst < 5e-10, worst
+        assert ip.iter < 24 * 30, ip.iter
+    finally:
+        for h, _, _ in hier.values():
+            h.free()
+
+
+def test_twisted_clover_propagators_with_up_and_down_hierarchies(qa, oracle):
+    """the production ACTION in the production shape (qkxtm/CalcMG_2pt3pt_EvenOdd.cpp:222-240): QUDA_TWISTED_CLOVER_DSLASH, the clover term
+    built on the device by loadCloverQuda(NULL, NULL), one hierarchy per flavour; all 24 solutions checked with the HOST tmc_mat on a clover
+    field the oracle constructs independently from the same links"""
+    X, kappa, mu = (8, 8, 8, 16), 0.124, 0.005
+    coeff = kappa * 1.57551
+    gauge = smooth_gauge(X, 0.35)
+    gp = qa.gauge_param(X, cuda_prec=8, prec_sloppy=4, prec_precondition=4, t_boundary=qa.QUDA_PERIODIC_T)
+    qa.load_gauge(gauge, gp)
+    g_lex = _lex_gauge(oracle, gauge, X)
+    clover = oracle.clover_compute(gauge, coeff, list(X))
+    hier = {}
+    try:
+        for flavor in (+1, -1):
+            ipm = qa.invert_param(qa.QUDA_TWISTED_CLOVER_DSLASH, kappa, mu, flavor, "ee", 0, cuda_prec=8, prec_sloppy=4, prec_precondition=4,
+                                  solution_type=qa.QUDA_MAT_SOLUTION)
+            ipm.solve_type, ipm.clover_coeff = qa.QUDA_DIRECT_SOLVE, coeff
+            ipm.inv_type, ipm.gcrNkrylov, ipm.tol, ipm.maxiter, ipm.reliable_delta, ipm.verbosity = qa.QUDA_GCR_INVERTER, 20, 1e-10, 2000, 1e-4, qa.QUDA_SILENT
+            if flavor == +1:
+                qa.load_clover(None, None, ipm)
+            mp = qa.multigrid_param(ipm, n_level=3, geo_block=[(4, 4, 4, 4), (1, 1, 1, 2), (2, 2, 2, 2)], n_vec=8, setup_maxiter=300, setup_tol=1e-5, smoother_pc=True,
+                                    coarse_matpc=True)
+            hier[flavor] = (qa.Multigrid(mp), ipm, mp)
+        ip = qa.invert_param(qa.QUDA_TWISTED_CLOVER_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=8, prec_sloppy=4, prec_precondition=4,
+                             solution_type=qa.QUDA_MAT_SOLUTION, gamma_basis=qa.QUDA_UKQCD_GAMMA_BASIS)
+        ip.clover_coeff = coeff
+        ip.solve_type, ip.inv_type, ip.gcrNkrylov, ip.tol, ip.maxiter, ip.reliable_delta = qa.QUDA_DIRECT_PC_SOLVE, qa.QUDA_GCR_INVERTER, 20, 1e-10, 2000, 1e-4
+        ip.verbosity = qa.QUDA_SILENT
+        ip.inv_type_precondition = qa.QUDA_MG_INVERTER
+        ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
+        ip.preconditionerUP, ip.preconditionerDN = hier[+1][0].h, hier[-1][0].h
+        worst = _check_propagators(qa, oracle, gauge, g_lex, X, kappa, mu, ip, (5, 1, 2, 11), 4, 0.8, False, clover=clover)
+        print("24 twisted-clover MG-GCR solves: %d outer iterations in total, %.3f s in the solvers, worst true residual %.2e" % (ip.iter, ip.secs, worst))
         assert worst < 5e-10, worst
         assert ip.iter < 24 * 30, ip.iter
     finally:
