@@ -735,11 +735,16 @@ static void finishPlan(const RedPlan &p, const RedCtl &c, int nred, double *out,
   if (p.peer && h_red[kMaxRed - 1] == 0.0) finishAllreduceOnHost(c.buf, c.expect, nred, h_red);
   for (int k = 0; k < nred; k++) out[k] = h_red[k];
 }
-static int multiGrid(long chunks) {
-  static int cap = 0;
-  if (!cap) { const char *e = getenv("QUDA_AMD_BLAS_BLOCKS"); cap = e ? atoi(e) : 512; if (cap < 1 || cap > kMaxBlocks) cap = 512; }
+// work-groups of the multi-field kernels.  Measured at 48^3 x 96 (fp32, k = 1..9 fields, tools/profile_mg_solve.sh with QUDA_AMD_BLAS_BLOCKS):
+// the k-field update runs at 0.43 / 0.61 / 0.69 of the HBM roofline with 512 / 1024 / 2048 work-groups (one chunk of every field per
+// thread and trip: more resident waves, not deeper loops, keep the k + 2 streams busy), the k-field dots at 0.56 / 0.59 / 0.54 (their
+// 43-value block reduction grows with the grid); the one- to four-field kernels above prefer 512 (0.72 against 0.67).
+static int multiGrid(long chunks, int dflt) {
+  static int cap = -1;
+  if (cap < 0) { const char *e = getenv("QUDA_AMD_BLAS_BLOCKS"); cap = e ? atoi(e) : 0; if (cap < 1 || cap > kMaxBlocks) cap = 0; }
+  const int c = cap ? cap : dflt;
   const long b = (chunks + 255) / 256;
-  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+  return (int)(b > c ? c : (b < 1 ? 1 : b));
 }
 static void fillMulti(MultiArg &a, const std::vector<ColorSpinorField *> &f, int k, const ColorSpinorField &y, const ColorSpinorField *r) {
   if (!multiSupported(y, k)) errorQuda("multi-field blas: %d fields of precision %d not supported", k, y.Precision());
@@ -765,8 +770,8 @@ void multiDot(Complex *beta, Complex &yr, double &ynorm, const std::vector<Color
   fillMulti(a, f, k, y, &r);
   const RedPlan p = planReduction(a.c, NRED);
   hipStream_t s = computeStream();
-#define QA_MD(KB) { if (y.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((multi_dot_kernel<double, 2, KB>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a); \
-                   else hipLaunchKernelGGL((multi_dot_kernel<float, 4, KB>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a); }
+#define QA_MD(KB) { if (y.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((multi_dot_kernel<double, 2, KB>), dim3(multiGrid(a.n * a.nseg, 1024)), dim3(256), 0, s, a); \
+                   else hipLaunchKernelGGL((multi_dot_kernel<float, 4, KB>), dim3(multiGrid(a.n * a.nseg, 1024)), dim3(256), 0, s, a); }
   if (k <= 4) QA_MD(4) else if (k <= 8) QA_MD(8) else if (k <= 12) QA_MD(12) else if (k <= 16) QA_MD(16) else QA_MD(20)
 #undef QA_MD
   HIP_CHECK(hipGetLastError());
@@ -786,8 +791,8 @@ void multiCaxpyResidual(double &r2, double &y2, const Complex *c, const std::vec
   a.scale = scale; a.ar = a_.real(); a.ai = a_.imag();
   const RedPlan p = planReduction(a.c, 2);
   hipStream_t s = computeStream();
-#define QA_MC(KB) { if (y.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((multi_caxpy_kernel<double, 2, true, KB>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a); \
-                   else hipLaunchKernelGGL((multi_caxpy_kernel<float, 4, true, KB>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a); }
+#define QA_MC(KB) { if (y.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((multi_caxpy_kernel<double, 2, true, KB>), dim3(multiGrid(a.n * a.nseg, 2048)), dim3(256), 0, s, a); \
+                   else hipLaunchKernelGGL((multi_caxpy_kernel<float, 4, true, KB>), dim3(multiGrid(a.n * a.nseg, 2048)), dim3(256), 0, s, a); }
   if (k <= 4) QA_MC(4) else if (k <= 8) QA_MC(8) else if (k <= 12) QA_MC(12) else if (k <= 16) QA_MC(16) else QA_MC(20)
 #undef QA_MC
   HIP_CHECK(hipGetLastError());
@@ -804,8 +809,8 @@ void multiCaxpy(const Complex *c, const std::vector<ColorSpinorField *> &f, int 
   for (int i = 0; i < k; i++) { a.cr[i] = c[i].real(); a.ci[i] = c[i].imag(); }
   memset(&a.c, 0, sizeof(a.c));
   hipStream_t s = computeStream();
-#define QA_MC(KB) { if (y.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((multi_caxpy_kernel<double, 2, false, KB>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a); \
-                   else hipLaunchKernelGGL((multi_caxpy_kernel<float, 4, false, KB>), dim3(multiGrid(a.n * a.nseg)), dim3(256), 0, s, a); }
+#define QA_MC(KB) { if (y.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((multi_caxpy_kernel<double, 2, false, KB>), dim3(multiGrid(a.n * a.nseg, 2048)), dim3(256), 0, s, a); \
+                   else hipLaunchKernelGGL((multi_caxpy_kernel<float, 4, false, KB>), dim3(multiGrid(a.n * a.nseg, 2048)), dim3(256), 0, s, a); }
   if (k <= 4) QA_MC(4) else if (k <= 8) QA_MC(8) else if (k <= 12) QA_MC(12) else if (k <= 16) QA_MC(16) else QA_MC(20)
 #undef QA_MC
   HIP_CHECK(hipGetLastError());

@@ -204,6 +204,106 @@ load_fine_site<NV, K>(r, base, in.stride, x);
   }
 }
 
+// ---- the restrictor of the solve phase (fine level, no split): the V stream without a barrier per step.  restrict_kernel above sums
+// every (chirality, vector pair) step over the work-group behind two barriers with only that step's six V entries in flight: bound
+// by latency, and with a single-parity source (even-odd cycle, half of the waves idle) it moved the half V in the time the full one
+// takes (0.48 of the HBM roofline at 48^3 x 96 against 0.78 for full fields; fp16 V 0.30).  Here a wave keeps three steps of requests
+// in flight (raw register images, converted at their use), sums four steps at a time with a reduce-scatter butterfly (17 cross-lane
+// moves per four steps instead of 96) into its own LDS row, and the work-group meets at ONE barrier.  A wave without a site of the
+// present parity (parity-major V) issues nothing.
+typedef float f32x4_raw_t __attribute__((ext_vector_type(4)));
+template <bool HALF> struct VRaw { typedef f32x4_raw_t type; };
+template <> struct VRaw<true> { typedef vhalf4_t type; };
+template <bool HALF> __device__ __forceinline__ typename VRaw<HALF>::type load_v_raw(const void *V, size_t i) {
+  if constexpr (HALF) return reinterpret_cast<const vhalf4_t *>(V)[i];
+  else return __builtin_nontemporal_load(reinterpret_cast<const f32x4_raw_t *>(V) + i);
+}
+__device__ __forceinline__ float4 v_unpack(const f32x4_raw_t &t) { return make_float4(t.x, t.y, t.z, t.w); }
+__device__ __forceinline__ float4 v_unpack(const vhalf4_t &h) { return make_float4((float)h.x, (float)h.y, (float)h.z, (float)h.w); }
+
+template <int NSF, int NCF, int NVEC, int NV, bool HALF>
+__global__ void __launch_bounds__(256) restrict_stream_kernel(CoarseVec out, FineVec in, const void *V, const int *block_to_fine, int blockVol, MaskArg mask, AggMap amap) {
+  constexpr int K = NSF * NCF, KH = K / 2, NVP = NVEC / 2, NST = 2 * NVP;
+  static_assert(NVP % 4 == 0 && NST <= 64, "steps are summed four at a time");
+  typedef typename VRaw<HALF>::type raw_t;
+  __shared__ float4 part[4][NST];   // [wave][chirality * NVP + vector pair]
+  const int A = aggregate_of_block(amap), b = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  float2 r[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) r[k] = make_float2(0.f, 0.f);
+  bool have = false;
+  if (b < blockVol && mask_keep(mask, b)) {
+    const int f = block_to_fine[(size_t)A * blockVol + b];
+    const int parity = f >= in.Vh, x = f - parity * in.Vh;
+    const float *base = in.v[parity];
+    if (base) { have = true; load_fine_site<NV, K>(r, base, in.stride, x); }   // nullptr: this parity is absent from a single-parity field
+  }
+  if (__builtin_amdgcn_ballot_w64(have) == 0) {   // wave-uniform
+    if (lane < NST) part[wave][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    // unconditional loads (a lane without a site reads entry 0 against r = 0): a load under a per-lane condition is its own basic
+    // block and the wait counts fall back to vmcnt(0)
+    const int bl = b < blockVol ? b : 0;
+#pragma unroll
+    for (int chi = 0; chi < 2; chi++) {
+      raw_t w0[KH], w1[KH], w2[KH];
+      auto vload = [&](raw_t *dst, int vpl) {
+        if (vpl >= NVP) return;
+#pragma unroll
+        for (int kk = 0; kk < KH; kk++) dst[kk] = load_v_raw<HALF>(V, (((size_t)A * K + chi * KH + kk) * NVP + vpl) * blockVol + bl);
+      };
+      vload(w0, 0); vload(w1, 1); vload(w2, 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < NVP / 4; g++) {
+        float w[16];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+          const int vp = 4 * g + s4, ph = vp % 3;
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int kk = 0; kk < KH; kk++) {
+            const float4 v = v_unpack(ph == 0 ? w0[kk] : (ph == 1 ? w1[kk] : w2[kk]));
+            const float2 rr = r[chi * KH + kk];
+            acc.x += v.x * rr.x + v.y * rr.y; acc.y += v.x * rr.y - v.y * rr.x;   // conj(V) r
+            acc.z += v.z * rr.x + v.w * rr.y; acc.w += v.z * rr.y - v.w * rr.x;
+          }
+          w[4 * s4] = acc.x; w[4 * s4 + 1] = acc.y; w[4 * s4 + 2] = acc.z; w[4 * s4 + 3] = acc.w;
+          __builtin_amdgcn_sched_barrier(0);
+          if (ph == 0) vload(w0, vp + 3); else if (ph == 1) vload(w1, vp + 3); else vload(w2, vp + 3);   // the buffer just used: three steps ahead
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#define QA_BFLY(HALFN, M)                                                                  \
+        {                                                                                  \
+          const bool up = (lane & M) != 0;                                                 \
+          _Pragma("unroll") for (int j = 0; j < HALFN; j++) {                              \
+            const float keep = up ? w[HALFN + j] : w[j], give = up ? w[j] : w[HALFN + j]; \
+            w[j] = keep + __shfl_xor(give, M, 64);                                         \
+          }                                                                                \
+        }
+        QA_BFLY(8, 1) QA_BFLY(4, 2) QA_BFLY(2, 4) QA_BFLY(1, 8)
+#undef QA_BFLY
+        w[0] += __shfl_xor(w[0], 16, 64);
+        w[0] += __shfl_xor(w[0], 32, 64);
+        if (lane < 16) {   // lane l holds the total of value index (bit-reversed l): 4 * step + component
+          const int vi = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+          reinterpret_cast<float *>(&part[wave][chi * NVP + 4 * g])[vi] = w[0];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < NST) {
+    const int it = threadIdx.x;
+    float4 s = part[0][it];
+    for (int w2 = 1; w2 < nw; w2++) { const float4 t = part[w2][it]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+    const int cpar = A >= out.Vh, xc = A - cpar * out.Vh, c0 = 2 * it;   // = chi * NVEC + 2 * vp
+    float *ob = out.v[cpar];
+    ob[((size_t)c0 * out.stride + xc) * 2] = s.x; ob[((size_t)c0 * out.stride + xc) * 2 + 1] = s.y;
+    ob[((size_t)(c0 + 1) * out.stride + xc) * 2] = s.z; ob[((size_t)(c0 + 1) * out.stride + xc) * 2 + 1] = s.w;
+  }
+}
+
 // ---- four right-hand sides per pass over V (Galerkin construction of the first coarse level: the 8 single-direction hops of
 // one probe are restricted in two launches instead of eight; V is the whole cost of a restriction) ----
 struct Multi4 {
@@ -459,7 +559,7 @@ __global__ void __launch_bounds__(512) prolong_small_kernel(FineVec out, CoarseV
 
 // ---- prolongator ----
 template <int NSF, int NCF, int NVEC, int NV, bool HALF = false>
-__global__ void prolong_kernel(FineVec out, CoarseVec in, const void *V, const int *block_to_fine, int blockVol, int spin_bs, AggMap amap) {
+__global__ void __launch_bounds__(512) prolong_kernel(FineVec out, CoarseVec in, const void *V, const int *block_to_fine, int blockVol, int spin_bs, AggMap amap) {
   constexpr int K = NSF * NCF;
   __shared__ float2 xc_s[2 * NVEC];
   const int A = aggregate_of_block(amap), b = threadIdx.x;
@@ -480,6 +580,40 @@ __global__ void prolong_kernel(FineVec out, CoarseVec in, const void *V, const i
   float2 acc[K];
 #pragma unroll
   for (int k = 0; k < K; k++) acc[k] = make_float2(0.f, 0.f);
+  if constexpr (NSF == 4) {
+    // fine level: three steps of V requests in flight per thread (raw register images, converted at their use), every step fully
+    // unrolled and fenced — as a rolled loop the 6 x unroll loads of an iteration were drained before the next ones were issued
+    constexpr int KH = K / 2, NVP = NVEC / 2;
+    typedef typename VRaw<HALF>::type raw_t;
+#pragma unroll
+    for (int chi = 0; chi < 2; chi++) {
+      raw_t w0[KH], w1[KH], w2[KH];
+      auto vload = [&](raw_t *dst, int vpl) {
+        if (vpl >= NVP) return;
+#pragma unroll
+        for (int kk = 0; kk < KH; kk++) dst[kk] = load_v_raw<HALF>(V, (((size_t)A * K + chi * KH + kk) * NVP + vpl) * blockVol + b);
+      };
+      vload(w0, 0); vload(w1, 1); vload(w2, 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int vp = 0; vp < NVP; vp++) {
+        const int ph = vp % 3;
+        const float2 c0 = xc_s[chi * NVEC + 2 * vp], c1 = xc_s[chi * NVEC + 2 * vp + 1];
+#pragma unroll
+        for (int kk = 0; kk < KH; kk++) {
+          const float4 w = v_unpack(ph == 0 ? w0[kk] : (ph == 1 ? w1[kk] : w2[kk]));
+          acc[chi * KH + kk].x += w.x * c0.x - w.y * c0.y + w.z * c1.x - w.w * c1.y;
+          acc[chi * KH + kk].y += w.x * c0.y + w.y * c0.x + w.z * c1.y + w.w * c1.x;
+        }
+        // pin the sums here: without it the multiply-adds sink below the last fence and every load stays live (256 registers + scratch)
+#pragma unroll
+        for (int kk = 0; kk < KH; kk++) asm volatile("" : "+v"(acc[chi * KH + kk].x), "+v"(acc[chi * KH + kk].y));
+        __builtin_amdgcn_sched_barrier(0);
+        if (ph == 0) vload(w0, vp + 3); else if (ph == 1) vload(w1, vp + 3); else vload(w2, vp + 3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
 #pragma unroll
   for (int chi = 0; chi < 2; chi++) {
 #pragma unroll 2
@@ -493,6 +627,7 @@ __global__ void prolong_kernel(FineVec out, CoarseVec in, const void *V, const i
         acc[k].y += w.x * c0.y + w.y * c0.x + w.z * c1.y + w.w * c1.x;
       }
     }
+  }
   }
   if (NV == 4) {
 #pragma unroll
@@ -1154,15 +1289,26 @@ void Transfer::R(ColorSpinorField &coarse, const ColorSpinorField &fine, int dir
   int gs = 1; while (gs < blockVol) gs <<= 1;
   const bool small = blockVol <= 32;
   const bool half = coarseHalfStorage() && V_h != nullptr && dir < 0;   // the Galerkin-split variants always use the fp32 master
+  // the barrier-free restrictor (restrict_stream_kernel): fine level with two chiralities of K / 2 rows, at most four waves per aggregate
+  static int streamOff = -1;
+  if (streamOff < 0) { const char *e = getenv("QUDA_AMD_RESTRICT_STREAM"); streamOff = (e && !atoi(e)) ? 1 : 0; }
+  const bool stream = !streamOff && !small && threads <= 256 && spin_bs == 2;
 #define QA_R(NSF, NCF, NVEC, NV) \
   if (small && half) hipLaunchKernelGGL((restrict_small_kernel<NSF, NCF, NVEC, NV, false, true>), dim3(nAgg), dim3(512), 0, computeStream(), out, out, in, (const void *)V_h, block_to_fine, blockVol, gs, spin_bs, m); \
   else if (small) hipLaunchKernelGGL((restrict_small_kernel<NSF, NCF, NVEC, NV, false, false>), dim3(nAgg), dim3(512), 0, computeStream(), out, out, in, (const void *)V, block_to_fine, blockVol, gs, spin_bs, m); \
+  else if constexpr (NSF == 4 && NVEC % 8 == 0) { \
+    if (stream && half) hipLaunchKernelGGL((restrict_stream_kernel<NSF, NCF, NVEC, NV, true>), dim3(nAgg), dim3(threads), 0, computeStream(), out, in, (const void *)V_h, block_to_fine, blockVol, m, aggMapOf(*this)); \
+    else if (stream) hipLaunchKernelGGL((restrict_stream_kernel<NSF, NCF, NVEC, NV, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, in, (const void *)V, block_to_fine, blockVol, m, aggMapOf(*this)); \
+    else if (half) hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, false, true>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out, in, (const void *)V_h, block_to_fine, blockVol, spin_bs, m, aggMapOf(*this)); \
+    else hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, false, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out, in, (const void *)V, block_to_fine, blockVol, spin_bs, m, aggMapOf(*this)); \
+  } \
   else if (half) hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, false, true>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out, in, (const void *)V_h, block_to_fine, blockVol, spin_bs, m, aggMapOf(*this)); \
   else hipLaunchKernelGGL((restrict_kernel<NSF, NCF, NVEC, NV, false, false>), dim3(nAgg), dim3(threads), 0, computeStream(), out, out, in, (const void *)V, block_to_fine, blockVol, spin_bs, m, aggMapOf(*this))
   if (g_acctOn) {   // V once (fp32 or its fp16 mirror; a single-parity source touches half of it) + fine vector + coarse vector
     const double frac = sub ? 0.5 : 1.0;
     char tag[48]; snprintf(tag, sizeof(tag), "level %s -> coarse%s", fineSpin == 4 ? "0" : "c", half ? " fp16 V" : "");
-    acct(small ? "restrict_small_kernel" : "restrict_kernel", frac * fineVol * ((double)fineSpin * fineColor * Nvec * (half ? 4 : 8) + fineSpin * fineColor * 8.0) + (double)nAgg * 2 * Nvec * 8, tag);
+    const bool streamed = stream && fineSpin == 4 && Nvec % 8 == 0;
+    acct(small ? "restrict_small_kernel" : (streamed ? "restrict_stream_kernel" : "restrict_kernel"), frac * fineVol * ((double)fineSpin * fineColor * Nvec * (half ? 4 : 8) + fineSpin * fineColor * 8.0) + (double)nAgg * 2 * Nvec * 8, tag);
   }
   QA_TRANSFER_DISPATCH(QA_R)
 #undef QA_R
@@ -1200,6 +1346,7 @@ void Transfer::P(ColorSpinorField &fine, const ColorSpinorField &coarse) const {
   const FineVec out = fineVec(fine, sub ? (int)subset_parity : -1);
   const CoarseVec in = coarseVec(coarse);
   const int threads = (blockVol + 63) / 64 * 64;
+  if (threads > 512) errorQuda("aggregates of %d sites: the prolongator runs one work-group of at most 512 threads per aggregate", blockVol);
   int gs = 1; while (gs < blockVol) gs <<= 1;
   const bool small = blockVol <= 32;
   const bool half = coarseHalfStorage() && V_h != nullptr;
