@@ -121,43 +121,85 @@ class Dist:
         self.qa.end()
 
 
+def _launcher_token():
+    """identifies the process that launched this rank (torch.distributed.run's agent, bench.py's own launcher, a shell script): its pid
+    and its start time in clock ticks (/proc/<pid>/stat field 22) — the same for all sibling ranks, never the same for two launches"""
+    ppid = os.getppid()
+    try:
+        with open("/proc/%d/stat" % ppid) as f:
+            start = f.read().rsplit(")", 1)[1].split()[19]
+    except OSError:
+        start = "0"
+    return "%d_%s" % (ppid, start)
+
+
 def _broadcast_id(rank, world, payload):
-    """Out-of-band broadcast of the 128-byte RCCL id over a plain TCP socket on MASTER_ADDR (port MASTER_PORT + 1).
-    Deliberately NOT torch.distributed: importing torch would load a second HIP runtime (torch bundles its own ROCm
-    libraries) next to the /opt/rocm one libquda.so is linked against."""
+    """Out-of-band broadcast of the 128-byte RCCL id from rank 0.  Deliberately NOT torch.distributed: importing torch would load a
+    second HIP runtime (torch bundles its own ROCm libraries) next to the /opt/rocm one libquda.so is linked against.
+    Two channels, both always open: a file in the node's temp directory named after the launcher (pid + start time: sibling ranks agree
+    on it, no earlier launch can have left one) — the ranks of one node need nothing else, and no port can be taken — and a TCP socket on
+    MASTER_ADDR, port MASTER_PORT + 1 (QUDA_AMD_BOOTSTRAP_PORT), for ranks that do not share the launcher or the file system.  A rank
+    takes the file if it appears within QUDA_AMD_BOOTSTRAP_FILE_WAIT seconds (default 20), the socket otherwise."""
     import socket
+    import tempfile
+    import threading
     import time
 
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = int(os.environ.get("QUDA_AMD_BOOTSTRAP_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
+    path = os.path.join(tempfile.gettempdir(), ".quda_amd_rccl_id_%s_%s" % (os.environ.get("MASTER_PORT", "0"), _launcher_token()))
     if rank == 0:
-        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        srv.bind((addr, port))
-        srv.listen(world)
-        for _ in range(world - 1):
-            c, _a = srv.accept()
-            c.sendall(payload)
-            c.close()
-        srv.close()
+        tmp = path + ".part"
+        with open(tmp, "wb") as f:
+            f.write(payload)
+        os.replace(tmp, path)   # appears whole or not at all
+        import atexit
+        atexit.register(lambda: os.path.exists(path) and os.remove(path))
+
+        def serve():
+            try:
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                srv.bind((addr, port))
+                srv.listen(world)
+            except OSError:
+                return   # port taken: the file is the channel
+            while True:
+                try:
+                    c, _a = srv.accept()
+                    c.sendall(payload)
+                    c.close()
+                except OSError:
+                    return
+        threading.Thread(target=serve, daemon=True).start()
         return payload
-    deadline = time.time() + 300
+    file_wait = float(os.environ.get("QUDA_AMD_BOOTSTRAP_FILE_WAIT", "20"))
+    t0 = time.time()
+    deadline = t0 + 300
     while True:
-        try:
-            c = socket.create_connection((addr, port), timeout=10)
-            break
-        except OSError:
-            if time.time() > deadline:
-                raise
-            time.sleep(0.2)
-    buf = b""
-    while len(buf) < 128:
-        chunk = c.recv(128 - len(buf))
-        if not chunk:
-            raise RuntimeError("bootstrap connection closed early")
-        buf += chunk
-    c.close()
-    return buf
+        if os.path.exists(path):
+            with open(path, "rb") as f:
+                buf = f.read()
+            if len(buf) == 128:
+                return buf
+        if time.time() - t0 > file_wait:
+            try:
+                c = socket.create_connection((addr, port), timeout=5)
+                c.settimeout(10)
+                buf = b""
+                while len(buf) < 128:
+                    chunk = c.recv(128 - len(buf))
+                    if not chunk:
+                        break
+                    buf += chunk
+                c.close()
+                if len(buf) == 128:
+                    return buf
+            except OSError:
+                pass
+        if time.time() > deadline:
+            raise RuntimeError("rank %d: no RCCL id from rank 0 after 300 s (file %s, socket %s:%d)" % (rank, path, addr, port))
+        time.sleep(0.05)
 
 
 def setup(qa, rank, world, local_rank, X, grid=None):
