@@ -19,10 +19,10 @@ CoarseGauge::CoarseGauge(const int xc[4], int n_) : n(n_), data(nullptr), data_h
   nSites = 1;
   for (int d = 0; d < 4; d++) { Xc[d] = xc[d]; nSites *= xc[d]; }
   bytes = (size_t)nSites * 9 * n * n * 2 * sizeof(float);
-  HIP_CHECK(qaMalloc((void **)&data, bytes));
+  data = (float *)poolDeviceMalloc(bytes);   // 7 GB at 12^3 x 24, n = 48: reused by the next hierarchy like V (transfer.hip)
   HIP_CHECK(hipMemsetAsync(data, 0, bytes, computeStream()));
 }
-CoarseGauge::~CoarseGauge() { if (data) (void)hipFree(data); if (data_h) (void)hipFree(data_h); }
+CoarseGauge::~CoarseGauge() { if (data) poolDeviceFree(data, 0); if (data_h) poolDeviceFree(data_h, 0); }
 
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 __global__ void to_half_kernel(half4_t *out, const float4 *in, size_t n) {
@@ -36,7 +36,7 @@ __global__ void to_half_kernel(half4_t *out, const float4 *in, size_t n) {
 void CoarseGauge::makeHalf() const {
   if (data_h) return;
   const size_t n4 = bytes / sizeof(float4);
-  HIP_CHECK(qaMalloc(&data_h, n4 * sizeof(half4_t)));
+  data_h = poolDeviceMalloc(n4 * sizeof(half4_t));
   hipLaunchKernelGGL(to_half_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, computeStream(), (half4_t *)data_h, (const float4 *)data, n4);
   HIP_CHECK(hipGetLastError());
 }
