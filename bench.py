@@ -489,6 +489,8 @@ def main():
         Xc5 = (48, 48, 48, 96)
         gc5 = smooth_gauge_cayley(Xc5, 0.35, workers=min(16, os.cpu_count() or 8))
         extra["mg_gcr_c5_one_gpu"] = run_mg(qa, Xc5, blocks=((4, 4, 4, 4), (2, 2, 2, 4), (2, 2, 2, 2)), gauge=gc5, setup_repeats=2)
+        # ... and with the production action (twisted clover, clover term built on the device) at the production volume
+        extra["mg_gcr_c5_tmc_one_gpu"] = run_mg(qa, Xc5, blocks=((4, 4, 4, 4), (2, 2, 2, 4), (2, 2, 2, 2)), gauge=gc5, dslash="tmc", extras=False, coarse_bench=False)
         # the stencil at that production volume (Vh = 5.3 M sites: one time slice is 10.6 MB, the fields no longer sit in the 256 MB
         # Infinity Cache as they do at 32^4), same byte model
         Vh5 = int(np.prod(Xc5)) // 2
