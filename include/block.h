@@ -88,6 +88,10 @@ void bicgstabUpdate(Complex *rho, double *r2, const Complex *a, const BlockField
                     const BlockField &r0);
 // p_i = r_i + a_i v_i + b_i p_i   (as blas::cxpaypbz)
 void cxpaypbz(const BlockField &r, const Complex *a, const BlockField &v, const Complex *b, BlockField &p);
+// (t_i, s_i), |t_i|^2, (r0_i, s_i), (r0_i, t_i) in one pass: omega and, by linearity, rho' = (r0, s - omega t) before r is formed
+void bicgstabDots(Complex *ts, double *tt, Complex *r0s, Complex *r0t, const BlockField &t, const BlockField &s, const BlockField &r0);
+// x_i += a_i p_i + w_i s_i ; r_i = s_i - w_i t_i (in place of s) ; p_i = r_i + b_i (p_i - w_i v_i) ; r2_i = |r_i|^2   (one pass: 5 reads, 3 writes)
+void bicgstabFused(double *r2, const Complex *a, const Complex *w, const Complex *b, BlockField &p, BlockField &r, BlockField &x, const BlockField &t, const BlockField &v);
 void negate(BlockField &x);                                                           // x = -x
 }  // namespace blockblas
 

@@ -503,6 +503,7 @@ namespace blockblas {
 
 constexpr int kBS = 192;
 constexpr int kMaxBlocks = 1024;
+constexpr int kMaxSums = 8;        // real sums per right-hand side of one kernel
 static double *d_part = nullptr;   // [block][sum][rhs]
 static double *h_res = nullptr;    // pinned
 static double *h_res_dev = nullptr;
@@ -514,12 +515,12 @@ void end() {
 }
 static void ensureBuffers() {
   if (d_part) return;
-  HIP_CHECK(qaMalloc((void **)&d_part, (size_t)kMaxBlocks * 3 * kMaxBlockRhs * sizeof(double)));
-  HIP_CHECK(hipHostMalloc((void **)&h_res, 3 * kMaxBlockRhs * sizeof(double), hipHostMallocMapped));
+  HIP_CHECK(qaMalloc((void **)&d_part, (size_t)kMaxBlocks * kMaxSums * kMaxBlockRhs * sizeof(double)));
+  HIP_CHECK(hipHostMalloc((void **)&h_res, kMaxSums * kMaxBlockRhs * sizeof(double), hipHostMallocMapped));
   HIP_CHECK(hipHostGetDevicePointer((void **)&h_res_dev, h_res, 0));
 }
 
-struct Coef { float2 a[kMaxBlockRhs], b[kMaxBlockRhs]; };
+struct Coef { float2 a[kMaxBlockRhs], b[kMaxBlockRhs], c[kMaxBlockRhs]; };
 static void setCoef(float2 *dst, const Complex *src, int n) {
   for (int i = 0; i < kMaxBlockRhs; i++) dst[i] = i < n && src ? make_float2((float)src[i].real(), (float)src[i].imag()) : make_float2(0.f, 0.f);
 }
@@ -531,8 +532,9 @@ __device__ __forceinline__ void cacc(double &re, double &im, float2 x, float2 y)
 }
 
 // OP: 0 norm2(x) | 1 cDot(x,y) | 2 y += a x | 3 (x,y) + |x|^2 | 4 bicgstab update | 5 z = x + a y + b z | 6 x = -x
+//     7 the five sums of a BiCGstab half step | 8 solution, residual and search direction of a BiCGstab iteration in one sweep
 // fields: x, y, z, w, u (meaning per op, see the wrappers)
-struct BArg { const float4 *x, *y, *w, *u; float4 *yo, *zo; long n4; int half; double *part; Coef c; };
+struct BArg { const float4 *x, *y, *w, *u; float4 *yo, *zo, *xo; long n4; int half; double *part; Coef c; };
 
 template <int OP, int NSUM> __global__ void __launch_bounds__(kBS) block_blas_kernel(const BArg arg) {
   const int pr = threadIdx.x % arg.half;           // pair of right-hand sides (2 pr, 2 pr + 1) this thread owns
@@ -578,6 +580,32 @@ template <int OP, int NSUM> __global__ void __launch_bounds__(kBS) block_blas_ke
       const float2 bz0 = cmul(b0, make_float2(z.x, z.y)), bz1 = cmul(b1, make_float2(z.z, z.w));
       z = make_float4(x.x + ay0.x + bz0.x, x.y + ay0.y + bz0.y, x.z + ay1.x + bz1.x, x.w + ay1.y + bz1.y);
       arg.zo[q] = z;
+    } else if (OP == 7) {
+      // x = t, y = s, u = r0:  (t, s) [0, 1], |t|^2 [2], (r0, s) [3, 4], (r0, t) [5, 6]
+      const float4 t = arg.x[q], sv = arg.y[q], r0 = arg.u[q];
+      cacc(s[0][0], s[1][0], make_float2(t.x, t.y), make_float2(sv.x, sv.y));
+      cacc(s[0][1], s[1][1], make_float2(t.z, t.w), make_float2(sv.z, sv.w));
+      s[2][0] += (double)t.x * t.x + (double)t.y * t.y; s[2][1] += (double)t.z * t.z + (double)t.w * t.w;
+      cacc(s[3][0], s[4][0], make_float2(r0.x, r0.y), make_float2(sv.x, sv.y));
+      cacc(s[3][1], s[4][1], make_float2(r0.z, r0.w), make_float2(sv.z, sv.w));
+      cacc(s[5][0], s[6][0], make_float2(r0.x, r0.y), make_float2(t.x, t.y));
+      cacc(s[5][1], s[6][1], make_float2(r0.z, r0.w), make_float2(t.z, t.w));
+    } else if (OP == 8) {
+      // x = p (in, out xo), y = s (in, out yo = r), zo = solution (in / out), w = t, u = v;  a = alpha, b = omega, c = beta:
+      //   solution += alpha p + omega s ;  r = s - omega t ;  p = r + beta (p - omega v) ;  |r|^2 [0]
+      const float2 c0 = arg.c.c[2 * pr], c1 = arg.c.c[2 * pr + 1];
+      const float4 p = arg.x[q], t = arg.w[q], v = arg.u[q];
+      float4 r = arg.y[q], z = arg.zo[q];
+      const float2 ap0 = cmul(a0, make_float2(p.x, p.y)), ap1 = cmul(a1, make_float2(p.z, p.w));
+      const float2 wr0 = cmul(b0, make_float2(r.x, r.y)), wr1 = cmul(b1, make_float2(r.z, r.w));
+      z.x += ap0.x + wr0.x; z.y += ap0.y + wr0.y; z.z += ap1.x + wr1.x; z.w += ap1.y + wr1.y;
+      const float2 wt0 = cmul(b0, make_float2(t.x, t.y)), wt1 = cmul(b1, make_float2(t.z, t.w));
+      r.x -= wt0.x; r.y -= wt0.y; r.z -= wt1.x; r.w -= wt1.y;
+      const float2 wv0 = cmul(b0, make_float2(v.x, v.y)), wv1 = cmul(b1, make_float2(v.z, v.w));
+      const float2 d0 = cmul(c0, make_float2(p.x - wv0.x, p.y - wv0.y)), d1 = cmul(c1, make_float2(p.z - wv1.x, p.w - wv1.y));
+      arg.zo[q] = z; arg.yo[q] = r;
+      arg.xo[q] = make_float4(r.x + d0.x, r.y + d0.y, r.z + d1.x, r.w + d1.y);
+      s[0][0] += (double)r.x * r.x + (double)r.y * r.y; s[0][1] += (double)r.z * r.z + (double)r.w * r.w;
     } else {
       const float4 x = arg.yo[q];
       arg.yo[q] = make_float4(-x.x, -x.y, -x.z, -x.w);
@@ -683,6 +711,29 @@ void cxpaypbz(const BlockField &r, const Complex *ca, const BlockField &v, const
   setCoef(a.c.a, ca, r.nrhs); setCoef(a.c.b, cb, r.nrhs);
   run<5, 0>(a, r);
 }
+// the sums of the second half step: omega = (t, s) / |t|^2, and (r0, s), (r0, t) from which rho' = (r0, s - omega t) follows by linearity — so
+// the next beta is known before r is formed and the three updates of an iteration become ONE sweep (bicgstabFused)
+void bicgstabDots(Complex *ts, double *tt, Complex *r0s, Complex *r0t, const BlockField &t, const BlockField &s, const BlockField &r0) {
+  check(t, s); check(t, r0);
+  BArg a = {};
+  a.x = (const float4 *)t.v; a.y = (const float4 *)s.v; a.u = (const float4 *)r0.v;
+  run<7, 7>(a, t);
+  const int n = t.nrhs;
+  for (int i = 0; i < n; i++) {
+    ts[i] = Complex(h_res[i], h_res[n + i]); tt[i] = h_res[2 * n + i];
+    r0s[i] = Complex(h_res[3 * n + i], h_res[4 * n + i]); r0t[i] = Complex(h_res[5 * n + i], h_res[6 * n + i]);
+  }
+}
+// x += alpha p + omega s ; r = s - omega t (in place of s) ; p = r + beta (p - omega v) ; |r|^2: 5 reads, 3 writes instead of the 7 + 4 of
+// bicgstabUpdate + cxpaypbz
+void bicgstabFused(double *r2, const Complex *al, const Complex *om, const Complex *be, BlockField &p, BlockField &r, BlockField &x, const BlockField &t, const BlockField &v) {
+  check(p, r); check(p, x); check(p, t); check(p, v);
+  BArg a = {};
+  a.x = (const float4 *)p.v; a.xo = (float4 *)p.v; a.y = (const float4 *)r.v; a.yo = (float4 *)r.v; a.zo = (float4 *)x.v; a.w = (const float4 *)t.v; a.u = (const float4 *)v.v;
+  setCoef(a.c.a, al, p.nrhs); setCoef(a.c.b, om, p.nrhs); setCoef(a.c.c, be, p.nrhs);
+  run<8, 1>(a, p);
+  for (int i = 0; i < p.nrhs; i++) r2[i] = h_res[i];
+}
 void negate(BlockField &x) {
   BArg a = {};
   a.yo = (float4 *)x.v;
@@ -717,6 +768,9 @@ int blockBiCGstabNull(BlockField &x, BlockMatVec mat, void *ctx, double tol, int
   blockblas::copy(p, r);
   int k = 0;
   auto allDone = [&]() { for (int i = 0; i < n; i++) if (!done[i]) return false; return true; };
+  // QUDA_AMD_BLOCK_BICG_FUSED=0: the three separate sweeps of round 2 (bicgstabUpdate + cxpaypbz with rho' from the updated residual)
+  static int fusedEnv = -1;
+  if (fusedEnv < 0) { const char *e = getenv("QUDA_AMD_BLOCK_BICG_FUSED"); fusedEnv = e ? atoi(e) : 1; }
   while (!allDone() && k < maxiter) {
     mat(v, p, ctx);
     blockblas::cDot(r0v, r0, v);
@@ -724,12 +778,32 @@ int blockBiCGstabNull(BlockField &x, BlockMatVec mat, void *ctx, double tol, int
       alpha[i] = (done[i] || std::abs(rho[i]) == 0.0) ? Complex(0.0) : rho[i] / r0v[i];
       ca[i] = -alpha[i];
     }
-    blockblas::caxpy(ca, v, r);                 // r -= alpha v
+    blockblas::caxpy(ca, v, r);                 // r -= alpha v   (= s)
     mat(t, r, ctx);
-    blockblas::cDotNormA(tr, tn, t, r);
-    for (int i = 0; i < n; i++) omega[i] = (done[i] || tn[i] == 0.0) ? Complex(0.0) : Complex(tr[i].real() / tn[i], tr[i].imag() / tn[i]);
     Complex rhoNew[kMaxBlockRhs];
     double r2New[kMaxBlockRhs];
+    if (fusedEnv) {
+      // omega and — by linearity, rho' = (r0, s - omega t) = (r0, s) - omega (r0, t) — the next beta from ONE pass over t, s, r0; then solution,
+      // residual and search direction in one sweep: 2 + 3 + 3 + 8 = 16 field passes per iteration instead of 18
+      Complex r0s[kMaxBlockRhs], r0t[kMaxBlockRhs];
+      blockblas::bicgstabDots(tr, tn, r0s, r0t, t, r, r0);
+      for (int i = 0; i < n; i++) {
+        omega[i] = (done[i] || tn[i] == 0.0) ? Complex(0.0) : Complex(tr[i].real() / tn[i], tr[i].imag() / tn[i]);
+        rhoNew[i] = r0s[i] - omega[i] * r0t[i];
+        beta[i] = (done[i] || std::abs(rhoNew[i] * alpha[i]) == 0.0 || std::abs(omega[i]) == 0.0 || std::abs(rho[i]) == 0.0) ? Complex(0.0) : (rhoNew[i] / rho[i]) * (alpha[i] / omega[i]);
+      }
+      blockblas::bicgstabFused(r2New, alpha, omega, beta, p, r, x, t, v);   // a finished right-hand side: all coefficients zero, p = r as before
+      k++;
+      for (int i = 0; i < n; i++) {
+        if (done[i]) continue;
+        rho0[i] = rho[i]; rho[i] = rhoNew[i]; r2[i] = r2New[i];
+        its[i] = k;
+        if (!(r2[i] > stop[i]) || !std::isfinite(r2[i])) done[i] = true;
+      }
+      continue;
+    }
+    blockblas::cDotNormA(tr, tn, t, r);
+    for (int i = 0; i < n; i++) omega[i] = (done[i] || tn[i] == 0.0) ? Complex(0.0) : Complex(tr[i].real() / tn[i], tr[i].imag() / tn[i]);
     blockblas::bicgstabUpdate(rhoNew, r2New, alpha, p, omega, r, x, t, r0);   // x += alpha p + omega r ; r -= omega t
     k++;
     for (int i = 0; i < n; i++) {
