@@ -99,6 +99,9 @@ void negate(BlockField &x);                                                     
 // b = 0, x_i the initial guesses, b2_i := |M x_i|^2, shadow residual r0 = r), each stopping at |r_i|^2 <= tol^2 b2_i or maxiter.
 // Returns the number of iterations of the slowest right-hand side; iters[i] per right-hand side if not null.
 typedef void (*BlockMatVec)(BlockField &out, BlockField &in, void *ctx);   // `in` not const: its ghost zone is filled by the operator
-int blockBiCGstabNull(BlockField &x, BlockMatVec mat, void *ctx, double tol, int maxiter, int *iters);
+// optional: the operator application that also returns inner products of a BiCGstab half step (an operator that has `out` and `in` in
+// registers anyway): mode 1: sums = (r0, out) [re | im][nrhs]; mode 2: (out, in) [re | im], |out|^2, (r0, in) [re | im], (r0, out) [re | im]
+typedef void (*BlockMatVecDots)(BlockField &out, BlockField &in, void *ctx, const BlockField &r0, int mode, double *sums);
+int blockBiCGstabNull(BlockField &x, BlockMatVec mat, void *ctx, double tol, int maxiter, int *iters, BlockMatVecDots matDots = nullptr);
 
 }  // namespace quda

@@ -52,8 +52,15 @@ void applyFineBlockM(float2 *out, float2 *in, int nrhs, const GaugeField &U, dou
 // one parity of the generalised form: out = s0 (1 + i a0 g5) in_same + k1 (1 + i a1 g5) [8 hops of in_other], single-parity panels.
 // tmat != nullptr: dense site matrices [Vh][2 chiralities][6 x 6 complex] of the output parity in place of (1 + i a1 g5) on the hop
 // sum (tmode 1) or of (1 + i a0 g5) on in_same (tmode 2) — the twisted-clover operators (reference lib/dirac_twisted_clover.cpp:191-330)
+// dots != nullptr (8 right-hand sides): inner products per right-hand side in the kernel's epilogue, where `out` and `in_same` are in registers — mode 1:
+// (a, out); mode 2: (out, in_same), |out|^2, (a, in_same), (a, out) — finished by fineBlockDotsFinish(sums): sums[k * nrhs + i], k = re / im of
+// the products in that order (2 resp. 7 values per right-hand side), global sums on a grid-decomposed lattice
+struct FineBlockDots { const float2 *a; int mode; };
 void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_other, int nrhs, const GaugeField &U, int parity, double s0, double a0, double k1,
-                          double a1, const float *tmat = nullptr, int tmode = 0, float2 *ghost = nullptr);
+                          double a1, const float *tmat = nullptr, int tmode = 0, float2 *ghost = nullptr, const FineBlockDots *dots = nullptr);
+bool fineBlockDotsSupported(int nrhs);
+void fineBlockDotsFinish(double *sums, int nrhs, int mode);
+void freeFineBlockDots();
 // ghost: on a grid-decomposed lattice the ghost zone of in_other (blockGhost(X, true).nGhost panels, a whole number of panels away from
 // in_other); it is filled here (pack + grouped exchange) before the launch
 // out[site][chirality][6][6] complex fp32 = A + i a s (s = +-1 for the upper / lower chirality) of one parity, or its inverse

@@ -748,7 +748,7 @@ void negate(BlockField &x) {
 // restates reference lib/inv_bicgstab_quda.cpp:96-330; a converged right-hand side gets zero coefficients and stays put).
 // No reliable updates: with delta = 1e-7 < setup tolerance none would trigger in the single-vector solver either.
 // ================================================================================================
-int blockBiCGstabNull(BlockField &x, BlockMatVec mat, void *ctx, double tol, int maxiter, int *iters) {
+int blockBiCGstabNull(BlockField &x, BlockMatVec mat, void *ctx, double tol, int maxiter, int *iters, BlockMatVecDots matDots) {
   const int n = x.nrhs;
   // p and r are operator inputs: they carry the ghost zone of x
   BlockField r(x.nSites, x.ncomp, n, x.nGhost), p(x.nSites, x.ncomp, n, x.nGhost), v(x.nSites, x.ncomp, n), t(x.nSites, x.ncomp, n), r0(x.nSites, x.ncomp, n);
@@ -771,22 +771,35 @@ int blockBiCGstabNull(BlockField &x, BlockMatVec mat, void *ctx, double tol, int
   // QUDA_AMD_BLOCK_BICG_FUSED=0: the three separate sweeps of round 2 (bicgstabUpdate + cxpaypbz with rho' from the updated residual)
   static int fusedEnv = -1;
   if (fusedEnv < 0) { const char *e = getenv("QUDA_AMD_BLOCK_BICG_FUSED"); fusedEnv = e ? atoi(e) : 1; }
+  if (!fusedEnv) matDots = nullptr;
+  double sums[7 * kMaxBlockRhs];
   while (!allDone() && k < maxiter) {
-    mat(v, p, ctx);
-    blockblas::cDot(r0v, r0, v);
+    if (matDots) {
+      matDots(v, p, ctx, r0, 1, sums);
+      for (int i = 0; i < n; i++) r0v[i] = Complex(sums[i], sums[n + i]);
+    } else {
+      mat(v, p, ctx);
+      blockblas::cDot(r0v, r0, v);
+    }
     for (int i = 0; i < n; i++) {
       alpha[i] = (done[i] || std::abs(rho[i]) == 0.0) ? Complex(0.0) : rho[i] / r0v[i];
       ca[i] = -alpha[i];
     }
     blockblas::caxpy(ca, v, r);                 // r -= alpha v   (= s)
-    mat(t, r, ctx);
+    if (matDots) matDots(t, r, ctx, r0, 2, sums);
+    else mat(t, r, ctx);
     Complex rhoNew[kMaxBlockRhs];
     double r2New[kMaxBlockRhs];
     if (fusedEnv) {
       // omega and — by linearity, rho' = (r0, s - omega t) = (r0, s) - omega (r0, t) — the next beta from ONE pass over t, s, r0; then solution,
       // residual and search direction in one sweep: 2 + 3 + 3 + 8 = 16 field passes per iteration instead of 18
       Complex r0s[kMaxBlockRhs], r0t[kMaxBlockRhs];
-      blockblas::bicgstabDots(tr, tn, r0s, r0t, t, r, r0);
+      if (matDots) {   // the operator delivered them from its epilogue: 13 field passes per iteration
+        for (int i = 0; i < n; i++) {
+          tr[i] = Complex(sums[i], sums[n + i]); tn[i] = sums[2 * n + i];
+          r0s[i] = Complex(sums[3 * n + i], sums[4 * n + i]); r0t[i] = Complex(sums[5 * n + i], sums[6 * n + i]);
+        }
+      } else blockblas::bicgstabDots(tr, tn, r0s, r0t, t, r, r0);
       for (int i = 0; i < n; i++) {
         omega[i] = (done[i] || tn[i] == 0.0) ? Complex(0.0) : Complex(tr[i].real() / tn[i], tr[i].imag() / tn[i]);
         rhoNew[i] = r0s[i] - omega[i] * r0t[i];

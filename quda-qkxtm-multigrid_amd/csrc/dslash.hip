@@ -980,6 +980,11 @@ struct FineBlockArg {
   // (twisted clover 2568 / 2281) — the scattered link staging and the lost XCD z-slab order cost more than the L1 hits gain; kept as an
   // opt-in (QUDA_AMD_BLOCK_FINE_TILE=1) for the record, the linear mapping stays the default.
   int tile, tilesX, tilesY, tilesZ;
+  // inner products in the epilogue (NRHS = 8; dslash.h FineBlockDots): per right-hand side, summed over the work-group's sites in site order,
+  // one row of partials per work-group.  dotMode 1: (a, out) [2 sums]; 2: (out, same) [2], |out|^2 [1], (a, same) [2], (a, out) [2]
+  const float2 *dotA;
+  double *dotPart;
+  int dotMode;
 };
 
 template <int NRHS, int CL = 0> __global__ void __launch_bounds__(256) fine_block_kernel(const FineBlockArg arg) {
@@ -1182,6 +1187,44 @@ template <int NRHS, int CL = 0> __global__ void __launch_bounds__(256) fine_bloc
       outv[2 * j] = re; outv[2 * j + 1] = im;
     }
   }
+  if (NRHS == 8 && arg.dotMode) {   // uniform
+    // the two dot products of a BiCGstab half step where their operands already are: `out` and the site's own input panel in registers, one more
+    // panel (a = r0) loaded — instead of separate passes over the fields (blockblas::cDot / bicgstabDots: 2 resp. 3 field reads)
+    float4 ra[6];
+    load_panel(ra, arg.dotA, idx);
+    float av[24];
+    unpack_panel(av, ra);
+    const int ns = arg.dotMode == 1 ? 2 : 7;
+    float sm[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (arg.dotMode == 1) {
+#pragma unroll
+      for (int j = 0; j < 12; j++) {
+        sm[0] += av[2 * j] * outv[2 * j] + av[2 * j + 1] * outv[2 * j + 1];       // conj(a) out
+        sm[1] += av[2 * j] * outv[2 * j + 1] - av[2 * j + 1] * outv[2 * j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 12; j++) {
+        const float orr = outv[2 * j], oi = outv[2 * j + 1], sr = same[2 * j], si = same[2 * j + 1], ar = av[2 * j], ai = av[2 * j + 1];
+        sm[0] += orr * sr + oi * si; sm[1] += orr * si - oi * sr;    // conj(out) same
+        sm[2] += orr * orr + oi * oi;
+        sm[3] += ar * sr + ai * si; sm[4] += ar * si - ai * sr;      // conj(a) same
+        sm[5] += ar * orr + ai * oi; sm[6] += ar * oi - ai * orr;    // conj(a) out
+      }
+    }
+    __syncthreads();   // every wave is through its hops: the staged links are dead, their LDS holds the partial sums now
+    float *red = ulds;
+    for (int k = 0; k < ns; k++) red[k * 256 + threadIdx.x] = sm[k];
+    __syncthreads();
+    if ((int)threadIdx.x < ns * NRHS) {
+      const int k = threadIdx.x / NRHS, ii = threadIdx.x - k * NRHS;
+      int nact = SPB;
+      if (!arg.tile) { const int left = arg.Vh - idx0; nact = left < SPB ? left : SPB; }
+      double t = 0.0;
+      for (int ss = 0; ss < nact; ss++) t += (double)red[k * 256 + ss * NRHS + ii];
+      arg.dotPart[((size_t)blockIdx.x * ns + k) * NRHS + ii] = t;
+    }
+  }
   // store as the panels were loaded: the lane pair exchanges one component each and writes 16-byte words, a full line per site
   float4 *o = reinterpret_cast<float4 *>(arg.out + ((size_t)idx * 12 + io) * NRHS + ipr);
 #pragma unroll
@@ -1263,8 +1306,59 @@ bool fineBlockSupported(const GaugeField &U, int nrhs) {
 // one parity of the generalised multi-right-hand-side stencil:
 //   out(x) = s0 (1 + i a0 g5) in_same(x) + k1 (1 + i a1 g5) sum_{8 hops} U P in_other(x + mu)       x of parity `parity`
 // all three fields are single-parity block panels [Vh][12][nrhs]; in_same may be nullptr when s0 = 0
+// ---- epilogue inner products of fine_block_kernel: work-group partials -> 128 chunk sums -> pinned host memory, in a fixed order ----
+static double *g_fbPart = nullptr, *g_fbPart2 = nullptr, *g_fbRes = nullptr, *g_fbResDev = nullptr;
+static size_t g_fbPartBytes = 0;
+static int g_fbBlocks = 0, g_fbVals = 0;
+constexpr int kFbChunks = 128;
+__global__ void __launch_bounds__(512) fine_block_dots_reduce(double *part2, const double *part, int nblocks, int nval) {
+  // work-group g sums its contiguous range of partial rows; thread (row, val): flat, contiguous reads
+  __shared__ double red[512];
+  const int rows = blockDim.x / nval, row = threadIdx.x / nval, val = threadIdx.x - row * nval;
+  const int per = (nblocks + gridDim.x - 1) / gridDim.x, b0 = blockIdx.x * per, b1 = min(nblocks, b0 + per);
+  double t = 0.0;
+  if (row < rows) for (int b = b0 + row; b < b1; b += rows) t += part[(size_t)b * nval + val];
+  red[threadIdx.x] = row < rows ? t : 0.0;
+  __syncthreads();
+  if ((int)threadIdx.x < nval) {
+    double u = 0.0;
+    for (int r = 0; r < rows; r++) u += red[r * nval + threadIdx.x];
+    part2[(size_t)blockIdx.x * nval + threadIdx.x] = u;
+  }
+}
+__global__ void fine_block_dots_finish(double *res, const double *part2, int nchunks, int nval) {
+  const int v = blockIdx.x, lane = threadIdx.x;
+  double t = 0.0;
+  for (int c = lane; c < nchunks; c += 64) t += part2[(size_t)c * nval + v];
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+  if (lane == 0) res[v] = t;
+}
+void freeFineBlockDots() {
+  if (g_fbPart) { poolDeviceFree(g_fbPart, 0); g_fbPart = nullptr; g_fbPartBytes = 0; }
+  if (g_fbPart2) { (void)hipFree(g_fbPart2); g_fbPart2 = nullptr; }
+  if (g_fbRes) { (void)hipHostFree(g_fbRes); g_fbRes = nullptr; g_fbResDev = nullptr; }
+}
+bool fineBlockDotsSupported(int nrhs) {
+  static int off = -1;
+  if (off < 0) { const char *e = getenv("QUDA_AMD_BLOCK_FINE_DOTS"); off = (e && !atoi(e)) ? 1 : 0; }
+  return !off && nrhs == 8;
+}
+// after a launch with dots: sums[k * nrhs + i], k as in FineBlockArg::dotMode; a global sum on a grid-decomposed lattice
+void fineBlockDotsFinish(double *sums, int nrhs, int mode) {
+  const int ns = mode == 1 ? 2 : 7, nval = ns * nrhs;
+  if (!g_fbBlocks || g_fbVals != nval) errorQuda("no multi-right-hand-side stencil launch with inner products (mode %d) to finish", mode);
+  const int threads = 512 / nval * nval;
+  hipLaunchKernelGGL(fine_block_dots_reduce, dim3(kFbChunks), dim3(threads), 0, computeStream(), g_fbPart2, (const double *)g_fbPart, g_fbBlocks, nval);
+  hipLaunchKernelGGL(fine_block_dots_finish, dim3(nval), dim3(64), 0, computeStream(), g_fbResDev, (const double *)g_fbPart2, kFbChunks, nval);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(computeStream()));
+  for (int q = 0; q < nval; q++) sums[q] = g_fbRes[q];
+  if (commReductionsNeeded()) comm_allreduce(sums, nval);
+  g_fbBlocks = 0;
+}
+
 void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_other, int nrhs, const GaugeField &U, int parity, double s0, double a0, double k1,
-                          double a1, const float *tmat, int tmode, float2 *ghost) {
+                          double a1, const float *tmat, int tmode, float2 *ghost, const FineBlockDots *dots) {
   if (!fineBlockSupported(U, nrhs)) errorQuda("multi-right-hand-side fine operator: fp32 recon-18 links, 8/16/24/32 right-hand sides");
   if (s0 != 0.0 && !in_same) errorQuda("same-parity input missing");
   if (tmat && (tmode != 1 && tmode != 2)) errorQuda("site-matrix mode %d (1: on the hop sum, 2: on the same-parity input)", tmode);
@@ -1291,6 +1385,26 @@ void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_o
   arg.out = out; arg.in_same = in_same ? in_same : in_other; arg.in_other = in_other;
   arg.gauge = (const char *)U.parityBase(parity);
   arg.tmat = tmat;
+  arg.dotA = nullptr; arg.dotPart = nullptr; arg.dotMode = 0;
+  if (dots) {
+    if (!fineBlockDotsSupported(nrhs)) errorQuda("inner products in the stencil epilogue: 8 right-hand sides only");
+    if (dots->mode != 1 && dots->mode != 2) errorQuda("inner-product mode %d", dots->mode);
+    if (dots->mode == 2 && s0 == 0.0) errorQuda("inner products with the same-parity input, but that input is switched off");
+    const int ns = dots->mode == 1 ? 2 : 7;
+    const size_t need = (size_t)nb * ns * nrhs * sizeof(double);
+    if (need > g_fbPartBytes) {
+      if (g_fbPart) poolDeviceFree(g_fbPart, 0);
+      g_fbPart = (double *)poolDeviceMalloc(need);
+      g_fbPartBytes = need;
+    }
+    if (!g_fbPart2) {
+      HIP_CHECK(qaMalloc((void **)&g_fbPart2, (size_t)kFbChunks * 7 * 8 * sizeof(double)));
+      HIP_CHECK(hipHostMalloc((void **)&g_fbRes, 7 * 8 * sizeof(double), hipHostMallocMapped));
+      HIP_CHECK(hipHostGetDevicePointer((void **)&g_fbResDev, g_fbRes, 0));
+    }
+    arg.dotA = dots->a; arg.dotPart = g_fbPart; arg.dotMode = dots->mode;
+    g_fbBlocks = nb; g_fbVals = ns * nrhs;
+  }
   // grid-decomposed lattice: the faces of in_other (parity 1 - parity) go to the neighbours' ghost zones first — one pack launch and one
   // grouped exchange on the compute stream (setup-time traffic; the solve-time stencil has its own overlapped transports, halo.h)
   arg.commMask = 0;

@@ -148,6 +148,7 @@ void endQuda(void) {
   freeCloverQuda();
   freeStagingBuffer();
   freeBlockTables();
+  freeFineBlockDots();
   poolDeviceFlush();
   blas::end();
   commFinalize();

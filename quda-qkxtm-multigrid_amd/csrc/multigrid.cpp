@@ -340,7 +340,22 @@ void MG::generateNullVectors(std::vector<ColorSpinorField *> &B) {
               applyFineBlockParity(out.v, in.v, x->tmp->v, in.nrhs, *x->U, 0, 1.0, 0.0, -x->kappa * x->kappa * x->binv, -x->a, nullptr, 0, gtmp);
             }
             x->applies++;
-          }, &ctx, sp.tol, sp.maxiter, iters);
+          }, &ctx, sp.tol, sp.maxiter, iters,
+          // the same operator with the inner products of the BiCGstab half step taken in the second launch's epilogue (dslash.h FineBlockDots)
+          !fineBlockDotsSupported(nb) ? (BlockMatVecDots) nullptr : [](BlockField &out, BlockField &in, void *c, const BlockField &r0, int mode, double *sums) {
+            Ctx *x = (Ctx *)c;
+            float2 *gin = in.nGhost ? in.v + in.elems() : nullptr, *gtmp = x->tmp->nGhost ? x->tmp->v + x->tmp->elems() : nullptr;
+            const FineBlockDots dots = {r0.v, mode};
+            if (x->tmat[0]) {
+              applyFineBlockParity(x->tmp->v, nullptr, in.v, in.nrhs, *x->U, 1, 0.0, 0.0, 1.0, 0.0, x->tmat[1], 1, gin);
+              applyFineBlockParity(out.v, in.v, x->tmp->v, in.nrhs, *x->U, 0, 1.0, 0.0, -x->kappa * x->kappa, 0.0, x->tmat[0], 1, gtmp, &dots);
+            } else {
+              applyFineBlockParity(x->tmp->v, nullptr, in.v, in.nrhs, *x->U, 1, 0.0, 0.0, x->binv, -x->a, nullptr, 0, gin);
+              applyFineBlockParity(out.v, in.v, x->tmp->v, in.nrhs, *x->U, 0, 1.0, 0.0, -x->kappa * x->kappa * x->binv, -x->a, nullptr, 0, gtmp, &dots);
+            }
+            fineBlockDotsFinish(sums, in.nrhs, mode);
+            x->applies++;
+          });
           // x_o = kappa A^-1 D_oe x_e
           if (tmc) applyFineBlockParity(Xo.v, nullptr, Xe.v, nb, *df->Gauge(), 1, 0.0, 0.0, kappa, 0.0, tmat[1], 1, ghostOf(Xe));
           else applyFineBlockParity(Xo.v, nullptr, Xe.v, nb, *df->Gauge(), 1, 0.0, 0.0, kappa * binv, -a, nullptr, 0, ghostOf(Xe));
