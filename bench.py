@@ -454,7 +454,7 @@ def main():
                     if mask and not fmt:
                         row["transport"] = {1: "direct peer stores", 0: "RCCL send/recv", -1: "none"}[int(qa.lib().qudaAmdHaloTransport())]
                     src.free(); dst.free(); d.free()
-                qa.lib().qudaAmdSetDslashTune(b"halo_format", 0)
+                qa.lib().qudaAmdSetDslashTune(b"halo_format", -1)
                 site_bytes = {8: (192, 128), 4: (96, 64), 2: (64, 32)}[prec]
                 row["wire_bytes_per_face_site"] = {"flag_in_data": site_bytes[0], "sector_format": site_bytes[1], "payload": {8: 96, 4: 48, 2: 28}[prec]}
                 row["y_face_bytes"] = {"flag_in_data": site_bytes[0] * 32 * 16 * 16 // 2, "sector_format": site_bytes[1] * 32 * 16 * 16 // 2}

@@ -1590,11 +1590,19 @@ DslashTune &dslashTune() {
     t.lds_pad = env("QUDA_AMD_DSLASH_LDS", 0);
     t.ygroups = env("QUDA_AMD_DSLASH_YGROUPS", -1);
     t.edge_first = env("QUDA_AMD_EDGE_FIRST", 1);
-    { const char *e = getenv("QUDA_AMD_HALO_FORMAT"); t.halo_format = (e && (!strcmp(e, "sector") || !strcmp(e, "line128") || !strcmp(e, "1"))) ? 1 : 0; }
+    { const char *e = getenv("QUDA_AMD_HALO_FORMAT"); t.halo_format = !e ? -1 : ((!strcmp(e, "sector") || !strcmp(e, "line128") || !strcmp(e, "1")) ? 1 : 0); }
   }
   return t;
 }
-int haloWireFormat() { return dslashTune().halo_format ? 1 : 0; }
+// automatic (-1): the sector format between DEVICES — two thirds of flag-in-data's bytes on the wire (fp64 / fp32; half for 16-bit), and in a 1 x 2 x 2 x 2
+// grid the +mu and -mu neighbour are the same GPU, so both faces of a dimension share one xGMI link: 1.57 MB per link and application in fp64
+// against 1.05 MB, i.e. ~26 against ~17 us at 60 GB/s next to a 20 us interior kernel — and flag-in-data where no link is crossed (ranks sharing a
+// device in a rehearsal, the self-neighbour emulation on one rank), where its packing is 1 us cheaper.  The same on every rank by construction.
+int haloWireFormat() {
+  const int f = dslashTune().halo_format;
+  if (f >= 0) return f ? 1 : 0;
+  return (commGrid().size > 1 && !p2pDeviceShared()) ? 1 : 0;
+}
 void setDslashTune(const char *key, int value) {
   DslashTune &t = dslashTune();
   const std::string k(key);

@@ -320,7 +320,7 @@ def test_partitioned_dslash_self_neighbour(qa, mask, fmt):
         assert int(qa.lib().qudaAmdHaloTransport()) == 1 and qa.comm_stats()["fine_peer_store_exchanges"] > 0
     finally:
         qa.lib().qudaAmdSetPartitionMask(0)
-        qa.lib().qudaAmdSetDslashTune(b"halo_format", 0)
+        qa.lib().qudaAmdSetDslashTune(b"halo_format", -1)
 
 
 @pytest.mark.parametrize("fmt", [0, 1], ids=["flag-in-data", "sectors-128B-line"])
@@ -349,7 +349,7 @@ def test_partitioned_dslash_at_the_8gpu_sublattice(qa, oracle, fmt):
         assert int(qa.lib().qudaAmdHaloTransport()) == 1
     finally:
         qa.lib().qudaAmdSetPartitionMask(0)
-        qa.lib().qudaAmdSetDslashTune(b"halo_format", 0)
+        qa.lib().qudaAmdSetDslashTune(b"halo_format", -1)
 
 
 def test_rccl_call_sequence_self_loop():
