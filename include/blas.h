@@ -50,6 +50,13 @@ void caxpyXmazMR(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, con
 double caxpyXmazNormX(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z);
 void cabxpyAx(const double &a, const Complex &b, ColorSpinorField &x, ColorSpinorField &y);             // x = a x ; y += b x
 double cabxpyAxNorm(const double &a, const Complex &b, ColorSpinorField &x, ColorSpinorField &y);
+// device-side scalars (rank-local reductions only): (x, y) and |x|^2 stay in device memory, and the three MR updates take
+// alpha = omega (x, y) / |x|^2 from there — no host round trip between the operator application and the update
+bool deviceScalars();
+void cDotProductNormADev(const ColorSpinorField &x, const ColorSpinorField &y);
+void caxpyXmazDev(double omega, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z);
+void caxXmazDev(double omega, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z);
+void caxInitDev(double omega, const ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z, ColorSpinorField &w);
 void caxXmaz(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z);   // y = a x ; x -= a z
 void caxInit(const Complex &a, const ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z, ColorSpinorField &w);   // y = a x ; w = x - a z
 Complex caxpyDotzy(const Complex &a, const ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z);  // y += a x ; (z,y)

@@ -454,6 +454,21 @@ template <int NRED> __device__ __forceinline__ void finish_reduction(const doubl
   }
 }
 
+// ---- device-side scalars: the coefficient of an update comes from the sums the PREVIOUS kernel of the stream left in device memory, so a fixed-length
+// iteration (the MR smoother: alpha = omega (Ar, r) / |Ar|^2, lib/inv_mr_quda.cpp:60-120) runs without a host round trip per step — 10-15 us of idle
+// device per step, which is a quarter of a multigrid cycle once the kernels are 8 x shorter on an 8-GPU sub-lattice.  Rank-local sums only
+// (the smoothers' global_reduction = false): a global sum goes through the host or the peer windows. ----
+template <typename Base> struct DevAlpha : Base {
+  const double *dres; double omega;
+  __device__ __forceinline__ void prepare() {
+    const double z = dres[2];                 // (re, im, |Ar|^2) of CDotF<1>
+    const double sc = z > 0.0 ? omega / z : 0.0;   // zero source or breakdown: nothing to add (the host loop breaks there)
+    this->ar = sc * dres[0]; this->ai = sc * dres[1];
+  }
+};
+template <typename F> __device__ __forceinline__ auto blas_prepare(F &f, int) -> decltype(f.prepare(), void()) { f.prepare(); }
+template <typename F> __device__ __forceinline__ void blas_prepare(F &, long) {}
+
 // ---- kernel ----
 template <typename T, int M, bool SITE, typename F>
 __global__ void __launch_bounds__(256) blas_kernel(BlasArg<F> arg) {
@@ -462,6 +477,8 @@ __global__ void __launch_bounds__(256) blas_kernel(BlasArg<F> arg) {
 #pragma unroll
   for (int k = 0; k < (F::nred > 0 ? F::nred : 1); k++) red[k] = 0.0;
   const long total = arg.n * arg.nseg;
+  F f = arg.f;
+  blas_prepare(f, 0);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int seg = i >= arg.n ? 1 : 0;
     const long j = i - seg * arg.n;
@@ -481,7 +498,7 @@ __global__ void __launch_bounds__(256) blas_kernel(BlasArg<F> arg) {
       if (F::rz) *reinterpret_cast<V *>(z) = reinterpret_cast<const V *>(arg.z.v[seg])[j];
       if (F::rw) *reinterpret_cast<V *>(w) = reinterpret_cast<const V *>(arg.w.v[seg])[j];
     }
-    arg.f.template operator()<real, M>(x, y, z, w, red);
+    f.template operator()<real, M>(x, y, z, w, red);
     if (SITE) {
       if (F::wx) Planar<T, M>::store(x, arg.x.v[seg], arg.stride, (int)j, arg.x.norm[seg], (int)j);
       if (F::wy) Planar<T, M>::store(y, arg.y.v[seg], arg.stride, (int)j, arg.y.norm[seg], (int)j);
@@ -684,7 +701,9 @@ static void launch(const F &f, const ColorSpinorField &x, const ColorSpinorField
     default: errorQuda("bad precision %d", x.Precision());
   }
   HIP_CHECK(hipGetLastError());
-  if (F::nred > 0) {
+  if (F::nred > 0 && !out) {   // deferred: the sums stay in d_red for the next kernel of the stream (DevAlpha); rank-local sums only
+    if (allreduce || peer) errorQuda("a deferred reduction cannot be a global one");
+  } else if (F::nred > 0) {
     if (allreduce) {
       commAllreduceDevice(d_red, F::nred, s);  // RCCL all-reduce of the rank sums, in stream order
       HIP_CHECK(hipMemcpyAsync(h_red, d_red, F::nred * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -854,6 +873,24 @@ void caxpyXmaz(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, const
   CaxpyXmazF<0> f; f.ar = a.real(); f.ai = a.imag(); launch(f, x, &y, &z, nullptr, nullptr);
 }
 void caxpyXmazMR(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z) { caxpyXmaz(a, x, y, z); }
+bool deviceScalars() {
+  static int on = -1;
+  if (on < 0) { const char *e = getenv("QUDA_AMD_DEVICE_SCALARS"); on = e ? atoi(e) : 1; }
+  return on && !(g_global_reduction && commReductionsNeeded());
+}
+void cDotProductNormADev(const ColorSpinorField &x, const ColorSpinorField &y) {
+  if (!deviceScalars()) errorQuda("device-side scalars need rank-local reductions");
+  launch(CDotF<1>(), x, &y, nullptr, nullptr, nullptr);
+}
+void caxpyXmazDev(double omega, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z) {
+  DevAlpha<CaxpyXmazF<0>> f; f.ar = f.ai = 0; f.dres = d_red; f.omega = omega; launch(f, x, &y, &z, nullptr, nullptr);
+}
+void caxXmazDev(double omega, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z) {
+  DevAlpha<CaxXmazF> f; f.ar = f.ai = 0; f.dres = d_red; f.omega = omega; launch(f, x, &y, &z, nullptr, nullptr);
+}
+void caxInitDev(double omega, const ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z, ColorSpinorField &w) {
+  DevAlpha<CaxInitF> f; f.ar = f.ai = 0; f.dres = d_red; f.omega = omega; launch(f, x, &y, &z, &w, nullptr);
+}
 void caxXmaz(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z) {
   CaxXmazF f; f.ar = a.real(); f.ai = a.imag(); launch(f, x, &y, &z, nullptr, nullptr);
 }

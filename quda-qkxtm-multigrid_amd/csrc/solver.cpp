@@ -141,9 +141,20 @@ void MR::operator()(ColorSpinorField &x, ColorSpinorField &b) {
     blas::copy(r, b);   // precision change
   }
   int k = 0;
+  // as a smoother (fixed number of steps, rank-local sums): alpha stays on the device, no host round trip per step (blas.h deviceScalars)
+  const bool devAlpha = param.is_preconditioner && getVerbosity() < QUDA_DEBUG_VERBOSE && blas::deviceScalars();
   while (k < param.maxiter) {
     const ColorSpinorField &rin = (fresh && same) ? b : r;   // zero start in the work precision: b IS the residual
     matSloppy(Ar, rin);
+    if (devAlpha) {
+      blas::cDotProductNormADev(Ar, rin);
+      if (fresh && same) blas::caxInitDev(omega, b, y, Ar, r);
+      else if (fresh) blas::caxXmazDev(omega, r, y, Ar);
+      else blas::caxpyXmazDev(omega, r, y, Ar);
+      fresh = false;
+      k++;
+      continue;
+    }
     const double3_t Ar3 = blas::cDotProductNormA(Ar, rin);
     if (!(Ar3.z > 0.0)) break;   // zero source (or breakdown): nothing to add
     const Complex alpha = omega * Complex(Ar3.x, Ar3.y) / Ar3.z;
