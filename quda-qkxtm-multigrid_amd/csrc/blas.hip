@@ -546,7 +546,6 @@ struct MultiArg {
 // them (a per-field `if (d < k)` made every load its own basic block: load, wait, use — twenty dependent latencies per chunk); the
 // surplus slots point at field 0 again and carry a zero coefficient / an ignored sum
 template <typename real, int M, int KB> __global__ void __launch_bounds__(256) multi_dot_kernel(const MultiArg arg) {
-  constexpr int NRED = 2 * kMaxDirs + 3;
   double red[2 * KB + 3];
 #pragma unroll
   for (int q = 0; q < 2 * KB + 3; q++) red[q] = 0.0;
@@ -574,13 +573,9 @@ template <typename real, int M, int KB> __global__ void __launch_bounds__(256) m
       }
     }
   }
-  double full[NRED];
-#pragma unroll
-  for (int q = 0; q < NRED; q++) full[q] = 0.0;
-#pragma unroll
-  for (int q = 0; q < 2 * KB; q++) full[q] = red[q];
-  full[2 * kMaxDirs] = red[2 * KB]; full[2 * kMaxDirs + 1] = red[2 * KB + 1]; full[2 * kMaxDirs + 2] = red[2 * KB + 2];
-  finish_reduction<NRED>(full, arg.c);
+  // the bucket's own 2 KB + 3 sums, not the 43 of the largest one: the last block adds the partials of every sum over all blocks, which at 43 sums
+  // and 1024 blocks was 65 of the 82 us this kernel took on a 12.6 MB field (the 32 x 16 x 16 x 16 sub-lattice of an 8-GPU split)
+  finish_reduction<2 * KB + 3>(red, arg.c);
 }
 template <typename real, int M, bool RES, int KB> __global__ void __launch_bounds__(256) multi_caxpy_kernel(const MultiArg arg) {
   double red[2] = {0.0, 0.0};
@@ -787,7 +782,8 @@ void multiDot(Complex *beta, Complex &yr, double &ynorm, const std::vector<Color
   constexpr int NRED = 2 * kMaxDirs + 3;
   MultiArg a;
   fillMulti(a, f, k, y, &r);
-  const RedPlan p = planReduction(a.c, NRED);
+  const int KBsel = k <= 4 ? 4 : (k <= 8 ? 8 : (k <= 12 ? 12 : (k <= 16 ? 16 : 20))), nred = 2 * KBsel + 3;   // sums of the bucket: [2 d], [2 d + 1] for its KBsel fields, then (y, r) and |y|^2
+  const RedPlan p = planReduction(a.c, nred);
   hipStream_t s = computeStream();
 #define QA_MD(KB) { if (y.Precision() == QUDA_DOUBLE_PRECISION) hipLaunchKernelGGL((multi_dot_kernel<double, 2, KB>), dim3(multiGrid(a.n * a.nseg, 1024)), dim3(256), 0, s, a); \
                    else hipLaunchKernelGGL((multi_dot_kernel<float, 4, KB>), dim3(multiGrid(a.n * a.nseg, 1024)), dim3(256), 0, s, a); }
@@ -795,10 +791,10 @@ void multiDot(Complex *beta, Complex &yr, double &ynorm, const std::vector<Color
 #undef QA_MD
   HIP_CHECK(hipGetLastError());
   double out[NRED];
-  finishPlan(p, a.c, NRED, out, s);
+  finishPlan(p, a.c, nred, out, s);
   for (int i = 0; i < k; i++) beta[i] = Complex(out[2 * i], out[2 * i + 1]);
-  yr = Complex(out[2 * kMaxDirs], out[2 * kMaxDirs + 1]);
-  ynorm = out[2 * kMaxDirs + 2];
+  yr = Complex(out[2 * KBsel], out[2 * KBsel + 1]);
+  ynorm = out[2 * KBsel + 2];
   acct("multi_dot_kernel", (double)(k + 2) * y.RealLength() * y.Precision(), y.Nspin() == 4 ? "level 0" : "coarse");
   bytes += (unsigned long long)(k + 2) * y.RealLength() * y.Precision();
   flops += (unsigned long long)(8 * k + 12) * (y.RealLength() / 2);

@@ -260,6 +260,7 @@ struct CoarsePackArg {
   unsigned *peerFlag[8];   // peer-store transport: thread counters of the faces in the neighbours' windows (send[] then point there too)
   int p2p;
 };
+constexpr int kCoarsePackChunk = 4;   // divides every supported n (16, 32, 48, 64); the arrival counters count (face site, chunk) pairs
 __global__ void __launch_bounds__(256) coarse_pack_kernel(const CoarsePackArg arg) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid < arg.start[8]) {
@@ -280,14 +281,21 @@ __global__ void __launch_bounds__(256) coarse_pack_kernel(const CoarsePackArg ar
   const int idx = (((c[3] * arg.Xc[2] + c[2]) * arg.Xc[1] + c[1]) * arg.Xc[0] + c[0]) >> 1;
   const float2 *src = reinterpret_cast<const float2 *>(arg.in.v[par]) + idx;
   float2 *dst = arg.send[slot] + (size_t)q * arg.n * nf + f;
+  // kCoarsePackChunk components per thread (blockIdx.y picks the chunk), loads first: one thread per face site walking all n components
+  // was n dependent load -> store round trips — 18 us per launch on the 8 x 4 x 4 x 4 coarse lattice of an 8-GPU split, a fifth of the
+  // whole MG-GCR solve there (profiles/r03j_sub8_masked_mg_solve.log)
+  const int j0 = (int)blockIdx.y * kCoarsePackChunk;
+  float2 v[kCoarsePackChunk];
+#pragma unroll
+  for (int jj = 0; jj < kCoarsePackChunk; jj++) v[jj] = src[(size_t)(j0 + jj) * arg.in.stride];
   if (arg.p2p) {
     // system-scope write-through stores into the neighbour's window (8-byte granules)
-    for (int j = 0; j < arg.n; j++) {
-      const float2 v = src[(size_t)j * arg.in.stride];
-      __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + (size_t)j * nf), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+#pragma unroll
+    for (int jj = 0; jj < kCoarsePackChunk; jj++)
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + (size_t)(j0 + jj) * nf), __builtin_bit_cast(unsigned long long, v[jj]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   } else {
-    for (int j = 0; j < arg.n; j++) dst[(size_t)j * nf] = src[(size_t)j * arg.in.stride];
+#pragma unroll
+    for (int jj = 0; jj < kCoarsePackChunk; jj++) dst[(size_t)(j0 + jj) * nf] = v[jj];
   }
   }
   if (arg.p2p) {
@@ -336,13 +344,13 @@ static void exchangeCoarseGhost(CoarseArg &arg, const CoarseGauge &G, int single
         pa.peerFlag[2 * d] = cg.peerFlag[d][0] + buf;
         arg.ghost[2 * d] = cg.ghostBuf[d][1][buf];
         arg.waitFlag[2 * d] = cg.flag[d][1] + buf;
-        arg.waitCount[2 * d] = (cg.uses[d][1][buf] += (unsigned)(nq * cg.faceCB[d]));
+        arg.waitCount[2 * d] = (cg.uses[d][1][buf] += (unsigned)(nq * cg.faceCB[d] * (G.n / kCoarsePackChunk)));
       }
       if (needBwd) {
         pa.peerFlag[2 * d + 1] = cg.peerFlag[d][1] + buf;
         arg.ghost[2 * d + 1] = cg.ghostBuf[d][0][buf];
         arg.waitFlag[2 * d + 1] = cg.flag[d][0] + buf;
-        arg.waitCount[2 * d + 1] = (cg.uses[d][0][buf] += (unsigned)(nq * cg.faceCB[d]));
+        arg.waitCount[2 * d + 1] = (cg.uses[d][0][buf] += (unsigned)(nq * cg.faceCB[d] * (G.n / kCoarsePackChunk)));
       }
     } else {
       if (needBwd) { msgs.push_back({d, +1, cg.send[d][1], cg.ghost[d][0], bytes}); arg.ghost[2 * d + 1] = cg.ghost[d][0]; }
@@ -350,7 +358,8 @@ static void exchangeCoarseGhost(CoarseArg &arg, const CoarseGauge &G, int single
     }
   }
   pa.start[8] = nt;
-  hipLaunchKernelGGL(coarse_pack_kernel, dim3((nt + 255) / 256), dim3(256), 0, computeStream(), pa);
+  if (G.n % kCoarsePackChunk) errorQuda("coarse halo pack: n = %d is not a multiple of %d", G.n, kCoarsePackChunk);
+  hipLaunchKernelGGL(coarse_pack_kernel, dim3((nt + 255) / 256, G.n / kCoarsePackChunk), dim3(256), 0, computeStream(), pa);
   HIP_CHECK(hipGetLastError());
   if (cg.p2p) { arg.waitTicks = p2pTimeoutTicks(); arg.errWord = p2pErrorWord(); }
   else commExchange(msgs, computeStream());

@@ -26,9 +26,13 @@ dslash = sys.argv[3] if len(sys.argv) > 3 else "tm"
 acct = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "gpurun_out", "mg_solve_acct.json")
 cycle = sys.argv[5] if len(sys.argv) > 5 else "V"   # V: the plain V-cycle of BASELINE.json configs[4] (bench.py), K: the harness' K-cycle
 X = (Ls, Ls, Ls, Lt)
+if os.environ.get("QA_PROFILE_LATTICE"):   # any lattice, e.g. the 32x16x16x16 sub-lattice of one rank of an 8-GPU split of 32^4 ...
+    X = tuple(int(v) for v in os.environ["QA_PROFILE_LATTICE"].split(","))
 kappa, mu = 0.124, 0.005
 qa.init(0)
-gauge = smooth_gauge_cayley(X, 0.35, workers=min(16, os.cpu_count() or 8)) if Ls >= 32 else smooth_gauge(X, 0.35)
+if os.environ.get("QA_PROFILE_MASK"):      # ... with its partitioned dimensions emulated by self-neighbour exchanges (bit d: dimension d)
+    qa.lib().qudaAmdSetPartitionMask(int(os.environ["QA_PROFILE_MASK"]))
+gauge = smooth_gauge_cayley(X, 0.35, workers=min(16, os.cpu_count() or 8)) if min(X) >= 32 else smooth_gauge(X, 0.35)
 qa.load_gauge(gauge, qa.gauge_param(X, cuda_prec=8, prec_sloppy=4, prec_precondition=4, t_boundary=qa.QUDA_PERIODIC_T))
 ip = qa.invert_param(qa.QUDA_TWISTED_CLOVER_DSLASH if dslash == "tmc" else qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=8, prec_sloppy=4, prec_precondition=4,
                      solution_type=qa.QUDA_MAT_SOLUTION)
