@@ -592,7 +592,7 @@ def main():
             "metric": "twisted-mass Dslash GFLOP/s (even-odd, 32^4)" if X == [32, 32, 32, 32] else "twisted-mass Dslash GFLOP/s",
             "value": round(gflops, 2), "unit": "GFLOP/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "prewarm_applications": r["prewarm"],   # untimed, in front of the W contract warm-ups: brings the device to steady clocks
-            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong",   # the global lattice is fixed (BASELINE: 32^4 on 1/2/4/8 GPUs), N ranks cut it into N sub-lattices
             "vs_baseline": None, "dtype": dtype_name[args.prec], "data": "synthetic",
             "config": {"workload": "%s even-odd Dslash (DiracTwistedMassPC::Dslash, kappa=%g mu=%g), %s lattice, recon-%d, fields resident in HBM"
                        % ({"tm": "twisted-mass", "tmc": "twisted-clover", "wilson": "Wilson"}[args.dslash], kappa, mu, "x".join(map(str, X)), args.recon),
