@@ -67,7 +67,7 @@ void freeFineBlockDots();
 int haloWireFormat();
 // direct Galerkin construction, step 1 (dslash.hip galerkin_uv_kernel): UV(x) = coef U_dir(x) V(x + dhat(dir)) for all columns of the transfer
 // matrix at once, V / UV in its aggregate-major order (4^4 aggregates); and the same for the site-diagonal term A + i a g5 of twisted clover
-void galerkinUV(float *UV, const float *V, const GaugeField &U, int dir, double coef, const int *block_to_fine, const int *fine_to_block, int aggOffset, int nAgg, int blockVol, int nvec);   // aggregates [aggOffset, aggOffset + nAgg) -> UV[0 .. nAgg)
+void galerkinUV(float *UV, const float *V, const GaugeField &U, int dir, double coef, const int *block_to_fine, const int *fine_to_block, int aggOffset, int nAgg, int blockVol, int nvec, bool classMajor = false);   // classMajor: sites of a row ordered by (block coordinate along mu, the other three)   // aggregates [aggOffset, aggOffset + nAgg) -> UV[0 .. nAgg)
 void galerkinLocalUV(float *L, const float *V, const CloverField &C, double a, const int *block_to_fine, int aggOffset, int nAgg, int blockVol, int nvec);
 void cloverTwistDense(float *out, const CloverField &C, int parity, double a, bool inverse);
 

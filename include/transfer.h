@@ -53,7 +53,7 @@ class Transfer {
   // lib/coarse_op.cuh:487-600): forward link 2 mu and in-aggregate part S (slot 8, accumulated over the directions) of every coarse site
   // from UV = dslash.h galerkinUV(V); 4^4 aggregates of a 4 x 3 fine level, Nvec 8 / 24, unpartitioned
   bool canDirectGalerkin() const;
-  void directGalerkinVUV(float *links, const float *UV, int mu, bool accumulateLocal, bool local = false, int aggOffset = 0, int nAggChunk = 0) const;   // local: UV is a chirality-diagonal site term, everything goes to slot 8; UV holds the aggregates [aggOffset, aggOffset + nAggChunk)
+  void directGalerkinVUV(float *links, const float *UV, int mu, bool accumulateLocal, bool local = false, int aggOffset = 0, int nAggChunk = 0, bool classMajor = false) const;   // local: UV is a chirality-diagonal site term, everything goes to slot 8; UV holds the aggregates [aggOffset, aggOffset + nAggChunk)
   void RSplit4(ColorSpinorField *const leaving[4], ColorSpinorField *const staying[4], ColorSpinorField *const fine[4], const int dir[4]) const;
   // fine = P e_j for the coarse unit vector j (same component at every coarse site): column j of V, without streaming all of V
   void column(ColorSpinorField &fine, int j) const;

@@ -563,12 +563,18 @@ void DiracCoarse::build() {
     // (24.5 GB at 48^3 x 96, whose allocation alone cost more than the products) and fits a buffer the null-vector stage left in the pool
     const int chunk = (int)std::min<long>(T.nAgg, std::max<long>(512, (T.nAgg + 7) / 8));
     const size_t wbytes = (size_t)chunk * 12 * T.Nvec * T.blockVol * 2 * sizeof(float);
+    static int cmEnv = -1;
+    if (cmEnv < 0) { const char *e = getenv("QUDA_AMD_GALERKIN_CLASS_MAJOR"); cmEnv = e ? atoi(e) : 0; }
+    // UV (this routine's own temporary) with the sites of a row ordered by the class of galerkin_vuv_kernel's waves.  MEASURED at 48^3 x 96: coarse operator
+    // 0.172 s with it, 0.166 s without — what helped was walking a wave's sites inside one spin-colour row (0.216 -> 0.166 s, transfer.hip
+    // galerkin_vuv_accumulate); the scattered stores of the class-major UV cost what its reads gain.  Off by default.
+    const bool classMajor = cmEnv != 0;
     float *UV = (float *)poolDeviceMalloc(wbytes);
     for (long a0 = 0; a0 < T.nAgg; a0 += chunk) {
       const int na = (int)std::min<long>(chunk, T.nAgg - a0);
       for (int mu = 0; mu < 4; mu++) {
-        galerkinUV(UV, T.V, *parent->Gauge(), 2 * mu, -parent->Kappa(), T.block_to_fine, T.fine_to_block, (int)a0, na, T.blockVol, T.Nvec);
-        T.directGalerkinVUV(links->data, UV, mu, mu > 0, false, (int)a0, na);
+        galerkinUV(UV, T.V, *parent->Gauge(), 2 * mu, -parent->Kappa(), T.block_to_fine, T.fine_to_block, (int)a0, na, T.blockVol, T.Nvec, classMajor);
+        T.directGalerkinVUV(links->data, UV, mu, mu > 0, false, (int)a0, na, classMajor);
       }
     }
     HIP_CHECK(hipStreamSynchronize(computeStream()));

@@ -2186,7 +2186,7 @@ void applyCovariantShift(ColorSpinorField &out, const ColorSpinorField &in, cons
 // the transfer operator, [aggregate][spin-colour][vector pair][site in aggregate] float4.  One work-group per aggregate, one thread per
 // site of it (stores of a wave are 1 KiB contiguous), loop over the vector pairs.
 __global__ void __launch_bounds__(256) galerkin_uv_kernel(const DslashArg<float> arg, const char *gaugeEven, const char *gaugeOdd, int dir, float coef, const float4 *V, float4 *UV,
-                                                          const int *block_to_fine, const int *fine_to_block, int nvp, int aggOffset) {
+                                                          const int *block_to_fine, const int *fine_to_block, int nvp, int aggOffset, int classMajor) {
   constexpr int BV = 256;
   const int A = blockIdx.x + aggOffset, Aloc = blockIdx.x, b = threadIdx.x;   // UV holds the aggregates [aggOffset, aggOffset + gridDim) only
   const int f = block_to_fine[(size_t)A * BV + b];
@@ -2212,6 +2212,18 @@ __global__ void __launch_bounds__(256) galerkin_uv_kernel(const DslashArg<float>
   }
   const int posN = fine_to_block[(1 - parity) * arg.Vh + nbr];
   const int AN = posN / BV, bN = posN - AN * BV;
+  // where this site's UV goes inside a (spin-colour, vector pair) row: classMajor — by its block coordinate along mu first (the class of sites one
+  // wave of galerkin_vuv_kernel owns), then the other three coordinates: that wave then reads 64 consecutive entries of every row instead of
+  // 16-byte pieces scattered over the whole row
+  int bOut = b;
+  if (classMajor) {
+    const int c4[4] = {(2 * xh + xodd) & 3, y & 3, z & 3, tt & 3};
+    const int mu = dir >> 1;
+    int pos = 0, sh = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) if (d != mu) { pos |= c4[d] << sh; sh += 2; }
+    bOut = c4[mu] * 64 + pos;
+  }
   float U[18];
   Link<float, 18>::load(U, (parity ? gaugeOdd : gaugeEven) + (size_t)dir * arg.link_bytes, arg.g_stride, idx, 1.f);
 #pragma unroll
@@ -2229,11 +2241,11 @@ __global__ void __launch_bounds__(256) galerkin_uv_kernel(const DslashArg<float>
 #pragma unroll
       for (int sp = 0; sp < 4; sp++) su3_mv(out[vec] + 6 * sp, U, psi[vec] + 6 * sp);
 #pragma unroll
-    for (int k = 0; k < 12; k++) UV[(((size_t)Aloc * 12 + k) * nvp + vp) * BV + b] = make_float4(out[0][2 * k], out[0][2 * k + 1], out[1][2 * k], out[1][2 * k + 1]);
+    for (int k = 0; k < 12; k++) UV[(((size_t)Aloc * 12 + k) * nvp + vp) * BV + bOut] = make_float4(out[0][2 * k], out[0][2 * k + 1], out[1][2 * k], out[1][2 * k + 1]);
   }
 }
 // fp32 recon-18 links (boundary condition inside the stored links), 4^4 aggregates, unpartitioned lattice (the neighbour's V would live on another rank)
-void galerkinUV(float *UVout, const float *V, const GaugeField &U, int dir, double coef, const int *block_to_fine, const int *fine_to_block, int aggOffset, int nAgg, int blockVol, int nvec) {
+void galerkinUV(float *UVout, const float *V, const GaugeField &U, int dir, double coef, const int *block_to_fine, const int *fine_to_block, int aggOffset, int nAgg, int blockVol, int nvec, bool classMajor) {
   if (U.precision != QUDA_SINGLE_PRECISION || U.reconstruct != QUDA_RECONSTRUCT_NO) errorQuda("direct Galerkin construction: fp32 recon-18 links");
   if (blockVol != 256) errorQuda("direct Galerkin construction: 4^4 aggregates");
   const LatticeGeom &g = U.geom;
@@ -2243,7 +2255,7 @@ void galerkinUV(float *UVout, const float *V, const GaugeField &U, int dir, doub
   arg.Vh = g.Vh; arg.Xh = g.Xh; arg.Y = g.X[1]; arg.Z = g.X[2]; arg.T = g.X[3];
   arg.dXh = g.dXh; arg.dY = g.dY; arg.dZ = g.dZ;
   hipLaunchKernelGGL(galerkin_uv_kernel, dim3(nAgg), dim3(256), 0, computeStream(), arg, (const char *)U.parityBase(0), (const char *)U.parityBase(1), dir, (float)coef, (const float4 *)V,
-                     (float4 *)UVout, block_to_fine, fine_to_block, nvec / 2, aggOffset);
+                     (float4 *)UVout, block_to_fine, fine_to_block, nvec / 2, aggOffset, classMajor ? 1 : 0);
   HIP_CHECK(hipGetLastError());
 }
 

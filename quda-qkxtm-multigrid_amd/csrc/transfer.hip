@@ -903,7 +903,7 @@ __device__ __constant__ int kGalPhase[4][4] = {{3, 3, 1, 1}, {0, 2, 2, 0}, {3, 1
 // constant fixed before the loop: i^(3 o) for a column of the wave's own chirality (o: the lane's real / imaginary column), i^(phase + 3 o)
 // for the other chirality (0 in local mode), 0 for a padding row of A — so that (bre, bim) = c w and the two MFMA steps follow.
 template <int NVEC, int CHI, typename SiteB>
-__device__ __forceinline__ void galerkin_vuv_accumulate(gf32x4 (&acc)[(NVEC + 15) / 16][NVEC / 4], const float2 *V, const float2 *UV, int A, int Aloc, int mu, int local, int row16, int kq, SiteB site_b) {
+__device__ __forceinline__ void galerkin_vuv_accumulate(gf32x4 (&acc)[(NVEC + 15) / 16][NVEC / 4], const float2 *V, const float2 *UV, int A, int Aloc, int mu, int local, int row16, int kq, SiteB site_b, int cmBase) {
   constexpr int NVP = NVEC / 2, MT = (NVEC + 15) / 16, NT = NVEC / 4, BV = 256;
 #pragma unroll
   for (int mt = 0; mt < MT; mt++)
@@ -935,10 +935,13 @@ __device__ __forceinline__ void galerkin_vuv_accumulate(gf32x4 (&acc)[(NVEC + 15
   }
   const float2 *Va = V + (size_t)A * 12 * NVP * BV * 2, *Ua = UV + (size_t)Aloc * 12 * NVP * BV * 2;
   constexpr int ROW = NVP * BV * 2;   // float2 elements per (spin-colour) row
-  for (int g = 0; g < 16; g++) {
-    const int b2 = 2 * site_b(4 * g + kq);
+  // spin-colour row outermost, the wave's 64 sites (16 k-steps of 4) inside: with UV in class-major order (cmBase >= 0: the wave's sites are entries
+  // cmBase .. cmBase + 63 of every UV row) consecutive k-steps read consecutive 64-byte pieces — every 128-byte line of UV is fetched once
 #pragma unroll
-    for (int s6 = 0; s6 < 6; s6++) {
+  for (int s6 = 0; s6 < 6; s6++) {
+    for (int g = 0; g < 16; g++) {
+      const int b2 = 2 * site_b(4 * g + kq), u2 = cmBase >= 0 ? 2 * (cmBase + 4 * g + kq) : b2;
+      {
       const int spin = 2 * CHI + s6 / 3, col = s6 % 3;
       const int rowSame = (3 * spin + col) * ROW, rowCross = (3 * kGalPartner[mu][spin] + col) * ROW;
       float are[MT], aim[MT], bre[NT], bim[NT];
@@ -951,7 +954,7 @@ __device__ __forceinline__ void galerkin_vuv_accumulate(gf32x4 (&acc)[(NVEC + 15
       for (int nt = 0; nt < NT; nt++) {
         constexpr int dummy = 0; (void)dummy;
         const bool same = (nt >= NT / 2) == (CHI == 1);
-        const float2 w = Ua[(same ? rowSame : rowCross) + bOff[nt] + b2];
+        const float2 w = Ua[(same ? rowSame : rowCross) + bOff[nt] + u2];
         const float2 c = same ? cSame : cCross[s6 / 3];
         bre[nt] = c.x * w.x - c.y * w.y;
         bim[nt] = c.x * w.y + c.y * w.x;
@@ -965,10 +968,11 @@ __device__ __forceinline__ void galerkin_vuv_accumulate(gf32x4 (&acc)[(NVEC + 15
       for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aim[mt], bim[nt], acc[mt][nt], 0, 0, 0);
+      }
     }
   }
 }
-template <int NVEC> __global__ void __launch_bounds__(512) galerkin_vuv_kernel(float *G, const float2 *V, const float2 *UV, int mu, int accumulateLocal, int pm, int local, int aggOffset) {
+template <int NVEC> __global__ void __launch_bounds__(512) galerkin_vuv_kernel(float *G, const float2 *V, const float2 *UV, int mu, int accumulateLocal, int pm, int local, int aggOffset, int classMajor) {
   constexpr int NVP = NVEC / 2, MT = (NVEC + 15) / 16, NT = NVEC / 4, n = 2 * NVEC, BV = 256;
   extern __shared__ float glds[];   // [class][mt][nt][reg][lane], one row block at a time
   const int A = blockIdx.x + aggOffset, lane = threadIdx.x & 63;   // UV holds the aggregates [aggOffset, aggOffset + gridDim) only
@@ -984,8 +988,9 @@ template <int NVEC> __global__ void __launch_bounds__(512) galerkin_vuv_kernel(f
     return pm ? ((y[0] + y[1] + y[2] + y[3]) & 1) * (BV / 2) + (lex >> 1) : lex;
   };
   gf32x4 acc[MT][NT];
-  if (chiR == 0) galerkin_vuv_accumulate<NVEC, 0>(acc, V, UV, A, (int)blockIdx.x, mu, local, row16, kq, site_b);
-  else galerkin_vuv_accumulate<NVEC, 1>(acc, V, UV, A, (int)blockIdx.x, mu, local, row16, kq, site_b);
+  const int cmBase = classMajor ? cls * 64 : -1;
+  if (chiR == 0) galerkin_vuv_accumulate<NVEC, 0>(acc, V, UV, A, (int)blockIdx.x, mu, local, row16, kq, site_b, cmBase);
+  else galerkin_vuv_accumulate<NVEC, 1>(acc, V, UV, A, (int)blockIdx.x, mu, local, row16, kq, site_b, cmBase);
   // ---- partial tiles -> LDS, one row block (chi) at a time so that the buffer is 4 waves x 12 KB and two work-groups share a CU;
   // classes 0..2 summed = local part, class 3 = link ----
   constexpr int TILE = MT * NT * 4 * 64;   // floats per wave
@@ -1033,12 +1038,12 @@ bool Transfer::canDirectGalerkin() const {
   return true;
 }
 // forward link Y_{2 mu} and the in-aggregate part S of all coarse sites from UV = galerkinUV(V): slots 2 mu and 8 of the coarse links
-void Transfer::directGalerkinVUV(float *links, const float *UV, int mu, bool accumulateLocal, bool local, int aggOffset, int nAggChunk) const {
+void Transfer::directGalerkinVUV(float *links, const float *UV, int mu, bool accumulateLocal, bool local, int aggOffset, int nAggChunk, bool classMajor) const {
   if (!canDirectGalerkin()) errorQuda("direct Galerkin construction not available for this transfer operator");
   const size_t lds = (size_t)4 * ((Nvec + 15) / 16) * (Nvec / 4) * 4 * 64 * sizeof(float);
 #define QA_VUV(NV) { static bool attr = false; \
     if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void *)galerkin_vuv_kernel<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; } \
-    hipLaunchKernelGGL((galerkin_vuv_kernel<NV>), dim3(nAggChunk > 0 ? nAggChunk : (int)nAgg), dim3(512), lds, computeStream(), links, (const float2 *)V, (const float2 *)UV, mu, accumulateLocal ? 1 : 0, parityMajor ? 1 : 0, local ? 1 : 0, aggOffset); }
+    hipLaunchKernelGGL((galerkin_vuv_kernel<NV>), dim3(nAggChunk > 0 ? nAggChunk : (int)nAgg), dim3(512), lds, computeStream(), links, (const float2 *)V, (const float2 *)UV, mu, accumulateLocal ? 1 : 0, parityMajor ? 1 : 0, local ? 1 : 0, aggOffset, classMajor ? 1 : 0); }
   if (Nvec == 24) QA_VUV(24) else QA_VUV(8)
 #undef QA_VUV
   HIP_CHECK(hipGetLastError());
