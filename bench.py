@@ -596,7 +596,7 @@ def main():
             "vs_baseline": None, "dtype": dtype_name[args.prec], "data": "synthetic",
             "config": {"workload": "%s even-odd Dslash (DiracTwistedMassPC::Dslash, kappa=%g mu=%g), %s lattice, recon-%d, fields resident in HBM"
                        % ({"tm": "twisted-mass", "tmc": "twisted-clover", "wilson": "Wilson"}[args.dslash], kappa, mu, "x".join(map(str, X)), args.recon),
-                       "local_lattice": Xl, "halo_transport": {1: "direct peer stores (IPC-mapped ghost zones over xGMI)", 0: "RCCL send/recv", -1: "none (single rank)"}[int(qa.lib().qudaAmdHaloTransport())], "process_grid": dist.grid if dist else [1, 1, 1, 1], "flops_per_site": r["flops_site"],
+                       "local_lattice": Xl, "halo_transport": {1: "direct peer stores (IPC-mapped ghost zones over xGMI)", 0: "RCCL send/recv", -1: "none (single rank)"}[int(qa.lib().qudaAmdHaloTransport())], "halo_wire_format": {0: "flag-in-data", 1: "32-byte sectors"}[int(qa.lib().qudaAmdHaloWireFormat())] if dist else "none", "process_grid": dist.grid if dist else [1, 1, 1, 1], "flops_per_site": r["flops_site"],
                        "ranks_in_communicator": int(qa.lib().qudaAmdCommSize()), "per_rank_kernel_us": {"slowest": round(1e6 * r["sec"], 2), "fastest": round(1e6 * r["sec_min"], 2)},
                        "per_rank": ranks_dslash,   # transport + exchange / global-sum counters of every rank after the Dslash measurement
                        "other_configs": "BASELINE configs[3] (32^3 x 64 over 8 GPUs): --lattice 32,32,32,64 (grid 1x2x2x2, local 32x16x16x32)"},

@@ -114,7 +114,7 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
                  "qudaAmdSpinorSetTwist", "qudaAmdDiracCreate", "qudaAmdDiracDestroy", "qudaAmdDiracDslash", "qudaAmdDiracDslashXpay",
                  "qudaAmdDiracM", "qudaAmdDiracMdag", "qudaAmdDiracMdagM", "qudaAmdDiracFlops", "qudaAmdTimeDslash", "qudaAmdTimeM",
                  "qudaAmdBlasNorm2", "qudaAmdBlasCDot", "qudaAmdBlasAxpy", "qudaAmdDslashBytesPerSite", "qudaAmdDslashFlopsPerSite",
-                 "qudaAmdSetPartitionMask", "qudaAmdComputeStream", "qudaAmdDeviceSynchronize", "qudaAmdHaloTransport", "qudaAmdSetDslashTune", "qudaAmdCommGetUniqueId",
+                 "qudaAmdSetPartitionMask", "qudaAmdComputeStream", "qudaAmdDeviceSynchronize", "qudaAmdHaloTransport", "qudaAmdHaloWireFormat", "qudaAmdSetDslashTune", "qudaAmdCommGetUniqueId",
                  "qudaAmdCommInit", "qudaAmdCommRank", "qudaAmdCommSize", "qudaAmdCommCoords", "qudaAmdCommBarrier", "qudaAmdCommAllreduce", "qudaAmdCommAllreduceMax",
                  "qudaAmdMultigridVerify", "qudaAmdMultigridCycle", "qudaAmdTimeAxpy", "qudaAmdMultigridLevels", "qudaAmdMultigridLevelInfo",
                  "qudaAmdMultigridSetHalfStorage", "qudaAmdMultigridGetNullVector", "qudaAmdMultigridGetV", "qudaAmdMultigridGetCoarseLinks", "qudaAmdMultigridApply", "qudaAmdMultigridApplyBlock",

@@ -616,6 +616,7 @@ void qudaAmdSetPartitionMask(int mask) {
 }
 void *qudaAmdComputeStream(void) { return (void *)computeStream(); }
 int qudaAmdHaloTransport(void) { return p2pTransport(); }
+int qudaAmdHaloWireFormat(void) { return haloWireFormat(); }
 // profile post-processing (tools/mg_solve_profile.py): a marker dispatch that brackets a region in the rocprofv3 kernel trace, and the
 // launch accounting of qa_core.h
 __global__ void qa_profile_marker_kernel(int id, int *sink) { if (sink && id < 0) *sink = id; }
