@@ -204,6 +204,46 @@ def test_restrictor_and_prolongator_in_the_x_neighbour_order(qa, oracle, X):
         mg.free()
 
 
+@pytest.mark.parametrize("X,bs,nvec", [((8, 8, 8, 8), (4, 4, 4, 2), 32), ((8, 8, 8, 16), (2, 4, 4, 4), 24), ((8, 8, 8, 8), (4, 4, 2, 2), 8)],
+                         ids=["4x4x4x2-nvec32", "2x4x4x4-nvec24", "4x4x2x2-nvec8"])
+def test_transfer_kernels_on_other_aggregate_shapes(qa, oracle, X, bs, nvec):
+    """The barrier-free restrictor and the pipelined prolongator (transfer.hip restrict_stream_kernel / prolong_kernel) with aggregates of 128 and
+    64 sites (two waves / one wave per work-group, one parity per wave in the parity-major order) and 8 / 24 / 32 vectors: R and P element-wise
+    against the oracle with the device's own V, then an MG-GCR solve with the even-odd smoother — whose cycle restricts and prolongates ONE parity —
+    to 1e-10 with the residual recomputed on the host."""
+    kappa, mu = 0.124, 0.005
+    gauge, ip = _setup(qa, X, kappa, mu)
+    mp = qa.multigrid_param(ip, n_level=2, geo_block=bs, n_vec=nvec, setup_maxiter=100, setup_tol=1e-4, smoother_pc=True)
+    mg = qa.Multigrid(mp)
+    rng = np.random.default_rng(29)
+
+    def rel(a, b):
+        return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+    try:
+        i = mg.level_info(0)
+        Xf, Xc, gbs, Ns, Nc, Nv, sbs = i["Xf"], i["Xc"], i["geo_bs"], i["fineSpin"], i["fineColor"], i["Nvec"], i["spin_bs"]
+        assert list(gbs) == list(bs) and Nv == nvec
+        Vd = mg.V(0).astype(np.complex128)
+        phi = (rng.standard_normal((int(np.prod(Xf)), Ns, Nc)) + 1j * rng.standard_normal((int(np.prod(Xf)), Ns, Nc)))
+        eta = (rng.standard_normal((int(np.prod(Xc)), 2, Nv)) + 1j * rng.standard_normal((int(np.prod(Xc)), 2, Nv)))
+        assert rel(mg.apply(0, "R", phi), oracle.mg_restrict(phi, Vd, Xf, gbs, Ns, Nc, Nv, sbs)) < 2e-5
+        assert rel(mg.apply(0, "P", eta), oracle.mg_prolongate(eta, Vd, Xf, gbs, Ns, Nc, Nv, sbs)) < 2e-5
+        assert max(mg.verify()) < 1e-4
+        ip.inv_type_precondition, ip.preconditioner = qa.QUDA_MG_INVERTER, mg.h
+        ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
+        b = rng.random(int(np.prod(X)) * 24)
+        x = qa.invert(b, ip)
+        oracle.set_threads(8)
+        try:
+            res = float(np.linalg.norm(b - oracle.tm_mat(gauge, x, list(X), kappa, mu, +1, 0)) / np.linalg.norm(b))
+        finally:
+            oracle.set_threads(1)
+        assert res < 1e-10 and ip.iter < 60, (res, ip.iter)
+    finally:
+        mg.free()
+
+
 @pytest.mark.parametrize("mask", [0, 15, 9], ids=["unpartitioned", "self-neighbour-xyzt", "self-neighbour-xt"])
 @pytest.mark.parametrize("nvec,nrhs_list", [(8, (8, 16, 24, 32)), (24, (24, 8))], ids=["n16", "n48"])
 def test_block_coarse_operator_on_mfma(qa, oracle, nvec, nrhs_list, mask):
