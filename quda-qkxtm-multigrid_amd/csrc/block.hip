@@ -215,7 +215,14 @@ template <int N, int NRHS> struct BlockCoarseTraits {
   static constexpr int NG = 9 * SG;          // groups per site
   static constexpr int GI = (NG + 3) / 4;    // groups per wave (round-robin over the 4 waves)
   // depth of the request ring in groups (B fragments + RT A tiles each) and the period of its phase over the sites
-  static constexpr int GD = 4;
+#ifndef QA_CB_GD
+#define QA_CB_GD 4
+#endif
+#ifndef QA_CB_WPE
+#define QA_CB_WPE 1
+#endif
+  static constexpr int GD = (N == 48 && NRHS == 24) ? QA_CB_GD : 4;
+  static constexpr int WPE = (N == 48 && NRHS == 24) ? QA_CB_WPE : 1;   // waves per SIMD the register allocation has to leave room for
   static constexpr int gcd_(int a, int b) { return b ? gcd_(b, a % b) : a; }
   static constexpr int U = GD / gcd_(GI % GD == 0 ? GD : GI % GD, GD);
   static constexpr size_t ldsBytes = (size_t)4 * RT * NT * 256 * sizeof(float);   // partial tiles of the 4 waves
@@ -304,7 +311,7 @@ template <int N, int I = 0, typename F> static __device__ __forceinline__ void s
 // HBM latencies per site, which is what held the first multi-site version below the single-site one.
 static __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int N, int NRHS> __global__ void __launch_bounds__(256) coarse_block_kernel(const BlockCoarseArg arg) {
+template <int N, int NRHS> __global__ void __launch_bounds__(256, (BlockCoarseTraits<N, NRHS>::WPE)) coarse_block_kernel(const BlockCoarseArg arg) {
   using Tr = BlockCoarseTraits<N, NRHS>;
   constexpr int RT = Tr::RT, NT = Tr::NT, JP = Tr::JP, SG = Tr::SG, NG = Tr::NG, GI = Tr::GI, GD = Tr::GD;
   extern __shared__ float lds[];   // [4 waves][RT][NT][4][64] partial tiles
