@@ -892,7 +892,3 @@ void DiracCoarse::hopDir(ColorSpinorField &out, const ColorSpinorField &in, int 
 void DiracCoarse::localTerm(ColorSpinorField &out, const ColorSpinorField &in) const { applyCoarse(out, in, *links, 1 << 8, -1); }
 
 }  // namespace quda
-
-// force this translation unit's code object onto the device (HIP loads code objects lazily, at the first launch out of them: 0.5-0.7 s each for
-// the large ones — measured as 1.4 s on top of the FIRST multigrid set-up of a process); called from initQuda
-namespace quda { void preloadCode_coarse() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&quda::to_half_kernel)); (void)hipGetLastError(); } }

@@ -2435,7 +2435,3 @@ long long dslashBytesPerSite(QudaPrecision prec, int recon, DslashMode mode, boo
 }
 
 }  // namespace quda
-
-// force this translation unit's code object onto the device (HIP loads code objects lazily, at the first launch out of them: 0.5-0.7 s each for
-// the large ones — measured as 1.4 s on top of the FIRST multigrid set-up of a process); called from initQuda
-namespace quda { void preloadCode_dslash() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&quda::fine_block_dots_finish)); (void)hipGetLastError(); } }

@@ -1346,7 +1346,3 @@ void plaquette(const GaugeField &U, double plq[3]) {
 }
 
 }  // namespace quda
-
-// force this translation unit's code object onto the device (HIP loads code objects lazily, at the first launch out of them: 0.5-0.7 s each for
-// the large ones — measured as 1.4 s on top of the FIRST multigrid set-up of a process); called from initQuda
-namespace quda { void preloadCode_fields() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&quda::cl_accum_kernel)); (void)hipGetLastError(); } }

@@ -20,7 +20,6 @@ void createStreams();
 void destroyStreams();
 void freeStagingBuffer();
 void freeBlockTables();
-void preloadCode_blas(); void preloadCode_fields(); void preloadCode_dslash(); void preloadCode_p2p(); void preloadCode_block(); void preloadCode_transfer(); void preloadCode_coarse(); void preloadCode_qkxtm();
 
 // resident fields (reference lib/interface_quda.cpp:119-145)
 GaugeField *gaugePrecise = nullptr, *gaugeSloppy = nullptr, *gaugePrecondition = nullptr, *gaugeSmeared = nullptr;
@@ -131,11 +130,6 @@ void initQudaMemory(void) {
   }
   createStreams();
   blas::init();
-  {
-    // code objects of the kernel files onto the device now rather than inside the first Dslash / set-up that needs them (QUDA_AMD_PRELOAD=0: lazily, as HIP would)
-    const char *e = getenv("QUDA_AMD_PRELOAD");
-    if (!e || atoi(e)) { preloadCode_blas(); preloadCode_fields(); preloadCode_dslash(); preloadCode_p2p(); preloadCode_block(); preloadCode_transfer(); preloadCode_coarse(); preloadCode_qkxtm(); }
-  }
   g_initialized = true;
 }
 

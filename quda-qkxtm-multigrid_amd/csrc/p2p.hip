@@ -303,7 +303,3 @@ bool p2pHaloEnabled() {
 }
 
 }  // namespace quda
-
-// force this translation unit's code object onto the device (HIP loads code objects lazily, at the first launch out of them: 0.5-0.7 s each for
-// the large ones — measured as 1.4 s on top of the FIRST multigrid set-up of a process); called from initQuda
-namespace quda { void preloadCode_p2p() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&quda::p2p_probe_send)); (void)hipGetLastError(); } }

@@ -451,7 +451,3 @@ void calcMG_loop_wOneD_TSM_wExact(void **gaugeToPlaquette, QudaInvertParam *EVpa
   if (arpackInfo.nEv != 0) errorQuda("calcMG_loop_wOneD_TSM_wExact: exact deflation with %d eigenvectors needs ARPACK, which this library does not link; nEv = 0 runs the undeflated loop", arpackInfo.nEv);
   quda::loopSolves(param, loopInfo, info, "calcMG_loop_wOneD_TSM_wExact");
 }
-
-// force this translation unit's code object onto the device (HIP loads code objects lazily, at the first launch out of them: 0.5-0.7 s each for
-// the large ones — measured as 1.4 s on top of the FIRST multigrid set-up of a process); called from initQuda
-namespace quda { void preloadCode_qkxtm() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&quda::lex_to_dev_kernel)); (void)hipGetLastError(); } }
