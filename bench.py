@@ -143,7 +143,7 @@ def run_mg_ranks(qa, dist, X, kappa=0.124, mu=0.005):
 
 
 def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)), gauge=None, extras=True, kappa=0.124, mu=0.005, plain_maxiter=5000,
-           coarse_bench=True, setup_repeats=1, dslash="tm", csw=1.57551, cycle="V", refine=0):
+           coarse_bench=True, setup_repeats=1, dslash="tm", csw=1.57551, cycle="V", refine=0, recon_sloppy=None):
     """MG-preconditioned GCR to |r|/|b| <= 1e-10 (the second half of the metric) on one GPU: 3-level K-cycle, 24 null
     vectors, 4^4 then 2^4 aggregates, even-odd preconditioned MR smoother — the reference harness' shape (tests/multigrid_invert_test.cpp:224-286)
     with the plain V-cycle BASELINE.json configs[4] names (cycle="K": the harness' default K-cycle, reported next to it) on a smooth synthetic gauge field (synth.smooth_gauge: far easier than a production
@@ -152,7 +152,7 @@ def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2,
     qa.lib().freeCloverQuda()
     if gauge is None:
         gauge = smooth_gauge(X, 0.35)
-    gp = qa.gauge_param(X, cuda_prec=8, prec_sloppy=4, prec_precondition=4, t_boundary=qa.QUDA_PERIODIC_T)
+    gp = qa.gauge_param(X, cuda_prec=8, prec_sloppy=4, prec_precondition=4, t_boundary=qa.QUDA_PERIODIC_T, recon_sloppy=recon_sloppy)   # recon_sloppy: also the preconditioner links'
     qa.load_gauge(gauge, gp)
     del gauge
     ip = qa.invert_param(qa.QUDA_TWISTED_CLOVER_DSLASH if dslash == "tmc" else qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=8, prec_sloppy=4,
@@ -496,6 +496,10 @@ def main():
         Xc5 = (48, 48, 48, 96)
         gc5 = smooth_gauge_cayley(Xc5, 0.35, workers=min(16, os.cpu_count() or 8))
         extra["mg_gcr_c5_one_gpu"] = run_mg(qa, Xc5, blocks=((4, 4, 4, 4), (2, 2, 2, 4), (2, 2, 2, 2)), gauge=gc5, setup_repeats=2)
+        # ... with the sloppy and preconditioner links stored as 12 reals (reconstruct_sloppy = reconstruct_precondition = 12, the usual production choice;
+        # the precise links stay at 18): every fp32 stencil of the cycle moves 576 instead of 768 B per site
+        r12 = run_mg(qa, Xc5, blocks=((4, 4, 4, 4), (2, 2, 2, 4), (2, 2, 2, 2)), gauge=gc5, extras=False, coarse_bench=False, recon_sloppy=qa.QUDA_RECONSTRUCT_12)
+        extra["mg_gcr_c5_one_gpu"]["recon12_sloppy_links"] = {k: r12[k] for k in ("setup_secs", "solve_secs", "solver_secs", "iters", "true_res")}
         # ... and with the production action (twisted clover, clover term built on the device) at the production volume
         extra["mg_gcr_c5_tmc_one_gpu"] = run_mg(qa, Xc5, blocks=((4, 4, 4, 4), (2, 2, 2, 4), (2, 2, 2, 2)), gauge=gc5, dslash="tmc", extras=False, coarse_bench=False)
         # the stencil at that production volume (Vh = 5.3 M sites: one time slice is 10.6 MB, the fields no longer sit in the 256 MB

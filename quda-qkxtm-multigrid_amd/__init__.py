@@ -235,7 +235,7 @@ def _vp(a):
 
 # ---- helpers written the way the reference's tests set things up (tests/dslash_test.cpp:84-200) ----
 def gauge_param(X, cpu_prec=QUDA_DOUBLE_PRECISION, cuda_prec=QUDA_DOUBLE_PRECISION, recon=QUDA_RECONSTRUCT_NO,
-                prec_sloppy=None, recon_sloppy=None, prec_precondition=None, t_boundary=QUDA_ANTI_PERIODIC_T):
+                prec_sloppy=None, recon_sloppy=None, prec_precondition=None, t_boundary=QUDA_ANTI_PERIODIC_T, recon_precondition=None):
     gp = lib().newQudaGaugeParam()
     for d in range(4):
         gp.X[d] = int(X[d])
@@ -249,7 +249,7 @@ def gauge_param(X, cpu_prec=QUDA_DOUBLE_PRECISION, cuda_prec=QUDA_DOUBLE_PRECISI
     gp.cuda_prec_sloppy = prec_sloppy or cuda_prec
     gp.reconstruct_sloppy = recon_sloppy or recon
     gp.cuda_prec_precondition = prec_precondition or gp.cuda_prec_sloppy
-    gp.reconstruct_precondition = gp.reconstruct_sloppy
+    gp.reconstruct_precondition = recon_precondition or gp.reconstruct_sloppy
     gp.gauge_fix = QUDA_GAUGE_FIXED_NO
     gp.ga_pad = 0
     return gp

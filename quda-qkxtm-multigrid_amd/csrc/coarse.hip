@@ -552,7 +552,7 @@ void DiracCoarse::build() {
   {
     const QudaDiracType pt = parent->getDiracType();
     direct = T.canDirectGalerkin() && (pt == QUDA_WILSON_DIRAC || pt == QUDA_TWISTED_MASS_DIRAC || pt == QUDA_TWISTED_CLOVER_DIRAC) && parent->Gauge() &&
-             parent->Gauge()->precision == QUDA_SINGLE_PRECISION && parent->Gauge()->reconstruct == QUDA_RECONSTRUCT_NO;
+             parent->Gauge()->precision == QUDA_SINGLE_PRECISION && (parent->Gauge()->reconstruct == QUDA_RECONSTRUCT_NO || parent->Gauge()->reconstruct == QUDA_RECONSTRUCT_12);
     static int full = -1;
     if (full < 0) { const char *e = getenv("QUDA_AMD_GALERKIN_FULL"); full = e ? atoi(e) : 0; }
     if (full) direct = false;

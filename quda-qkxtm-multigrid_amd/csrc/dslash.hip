@@ -985,6 +985,10 @@ struct FineBlockArg {
   const float2 *dotA;
   double *dotPart;
   int dotMode;
+  // 12-real links (recon-12): the third row is rebuilt while the links are staged; tsign_*: sign of the rebuilt row of the t links that carry the
+  // folded antiperiodic boundary (forward links of the last time slice, backward links of the first), as in DslashArg
+  int recon;
+  float tsign_fwd, tsign_bwd;
 };
 
 template <int NRHS, int CL = 0> __global__ void __launch_bounds__(256) fine_block_kernel(const FineBlockArg arg) {
@@ -1024,6 +1028,25 @@ template <int NRHS, int CL = 0> __global__ void __launch_bounds__(256) fine_bloc
     }
   }
   // ---- stage the links of the SPB sites: [site][dir][18]; planes 0..3 are float4, plane 4 the trailing float2 ----
+  if (arg.recon == 12) {
+    // one thread per (site, direction): two stored rows in three 16-byte planes, the third rebuilt here — once per work-group, for NRHS right-hand sides
+    for (int e = threadIdx.x; e < 8 * SPB; e += blockDim.x) {
+      const int ss = e % SPB, d = e / SPB;
+      const int sidx = site_of(ss);
+      if (sidx < arg.Vh) {
+        float sign = 1.f;
+        if (d >= 6) {
+          const int tt = sidx / (arg.Xh * arg.Y * arg.Z);
+          sign = d == 6 ? (tt == arg.T - 1 ? arg.tsign_fwd : 1.f) : (tt == 0 ? arg.tsign_bwd : 1.f);
+        }
+        float U[18];
+        Link<float, 12>::load(U, arg.gauge + (size_t)d * arg.link_bytes, arg.g_stride, sidx, sign);
+        float *dst = &ulds[ss * USTR + d * 18];
+#pragma unroll
+        for (int k = 0; k < 18; k++) dst[k] = U[k];
+      }
+    }
+  } else
   for (int e = threadIdx.x; e < 8 * 5 * SPB; e += blockDim.x) {
     const int ss = e % SPB, pl = (e / SPB) % 5, d = e / (5 * SPB);
     const char *blk = arg.gauge + (size_t)d * arg.link_bytes;
@@ -1296,7 +1319,7 @@ void cloverTwistDense(float *out, const CloverField &C, int parity, double a, bo
 }
 
 bool fineBlockSupported(const GaugeField &U, int nrhs) {
-  if (U.precision != QUDA_SINGLE_PRECISION || U.reconstruct != QUDA_RECONSTRUCT_NO) return false;
+  if (U.precision != QUDA_SINGLE_PRECISION || (U.reconstruct != QUDA_RECONSTRUCT_NO && U.reconstruct != QUDA_RECONSTRUCT_12)) return false;
   if (nrhs != 8 && nrhs != 16 && nrhs != 24 && nrhs != 32) return false;
   static int off = -1;
   if (off < 0) { const char *e = getenv("QUDA_AMD_BLOCK_FINE"); off = (e && !atoi(e)) ? 1 : 0; }
@@ -1359,7 +1382,7 @@ void fineBlockDotsFinish(double *sums, int nrhs, int mode) {
 
 void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_other, int nrhs, const GaugeField &U, int parity, double s0, double a0, double k1,
                           double a1, const float *tmat, int tmode, float2 *ghost, const FineBlockDots *dots) {
-  if (!fineBlockSupported(U, nrhs)) errorQuda("multi-right-hand-side fine operator: fp32 recon-18 links, 8/16/24/32 right-hand sides");
+  if (!fineBlockSupported(U, nrhs)) errorQuda("multi-right-hand-side fine operator: fp32 links (18 or 12 reals), 8/16/24/32 right-hand sides");
   if (s0 != 0.0 && !in_same) errorQuda("same-parity input missing");
   if (tmat && (tmode != 1 && tmode != 2)) errorQuda("site-matrix mode %d (1: on the hop sum, 2: on the same-parity input)", tmode);
   if (tmat && tmode == 2 && s0 == 0.0) errorQuda("site matrix on the same-parity input, but that input is switched off");
@@ -1385,6 +1408,12 @@ void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_o
   arg.out = out; arg.in_same = in_same ? in_same : in_other; arg.in_other = in_other;
   arg.gauge = (const char *)U.parityBase(parity);
   arg.tmat = tmat;
+  arg.recon = (int)U.reconstruct;
+  {
+    const bool first_t = commGrid().coords[3] == 0, last_t = commGrid().coords[3] == commGrid().dims[3] - 1;
+    arg.tsign_fwd = (U.reconstruct == QUDA_RECONSTRUCT_12 && U.t_boundary == QUDA_ANTI_PERIODIC_T && last_t) ? -1.f : 1.f;
+    arg.tsign_bwd = (U.reconstruct == QUDA_RECONSTRUCT_12 && U.t_boundary == QUDA_ANTI_PERIODIC_T && first_t) ? -1.f : 1.f;
+  }
   arg.dotA = nullptr; arg.dotPart = nullptr; arg.dotMode = 0;
   if (dots) {
     if (!fineBlockDotsSupported(nrhs)) errorQuda("inner products in the stencil epilogue: 8 right-hand sides only");
@@ -2186,7 +2215,7 @@ void applyCovariantShift(ColorSpinorField &out, const ColorSpinorField &in, cons
 // the transfer operator, [aggregate][spin-colour][vector pair][site in aggregate] float4.  One work-group per aggregate, one thread per
 // site of it (stores of a wave are 1 KiB contiguous), loop over the vector pairs.
 __global__ void __launch_bounds__(256) galerkin_uv_kernel(const DslashArg<float> arg, const char *gaugeEven, const char *gaugeOdd, int dir, float coef, const float4 *V, float4 *UV,
-                                                          const int *block_to_fine, const int *fine_to_block, int nvp, int aggOffset, int classMajor) {
+                                                          const int *block_to_fine, const int *fine_to_block, int nvp, int aggOffset, int classMajor, int recon, float tsignFwd) {
   constexpr int BV = 256;
   const int A = blockIdx.x + aggOffset, Aloc = blockIdx.x, b = threadIdx.x;   // UV holds the aggregates [aggOffset, aggOffset + gridDim) only
   const int f = block_to_fine[(size_t)A * BV + b];
@@ -2225,7 +2254,8 @@ __global__ void __launch_bounds__(256) galerkin_uv_kernel(const DslashArg<float>
     bOut = c4[mu] * 64 + pos;
   }
   float U[18];
-  Link<float, 18>::load(U, (parity ? gaugeOdd : gaugeEven) + (size_t)dir * arg.link_bytes, arg.g_stride, idx, 1.f);
+  if (recon == 12) Link<float, 12>::load(U, (parity ? gaugeOdd : gaugeEven) + (size_t)dir * arg.link_bytes, arg.g_stride, idx, (dir == 6 && tt == arg.T - 1) ? tsignFwd : 1.f);
+  else Link<float, 18>::load(U, (parity ? gaugeOdd : gaugeEven) + (size_t)dir * arg.link_bytes, arg.g_stride, idx, 1.f);
 #pragma unroll
   for (int k = 0; k < 18; k++) U[k] *= coef;
   for (int vp = 0; vp < nvp; vp++) {
@@ -2246,7 +2276,8 @@ __global__ void __launch_bounds__(256) galerkin_uv_kernel(const DslashArg<float>
 }
 // fp32 recon-18 links (boundary condition inside the stored links), 4^4 aggregates, unpartitioned lattice (the neighbour's V would live on another rank)
 void galerkinUV(float *UVout, const float *V, const GaugeField &U, int dir, double coef, const int *block_to_fine, const int *fine_to_block, int aggOffset, int nAgg, int blockVol, int nvec, bool classMajor) {
-  if (U.precision != QUDA_SINGLE_PRECISION || U.reconstruct != QUDA_RECONSTRUCT_NO) errorQuda("direct Galerkin construction: fp32 recon-18 links");
+  if (U.precision != QUDA_SINGLE_PRECISION || (U.reconstruct != QUDA_RECONSTRUCT_NO && U.reconstruct != QUDA_RECONSTRUCT_12)) errorQuda("direct Galerkin construction: fp32 links (18 or 12 reals)");
+  if (dir & 1) errorQuda("direct Galerkin construction: forward directions only");
   if (blockVol != 256) errorQuda("direct Galerkin construction: 4^4 aggregates");
   const LatticeGeom &g = U.geom;
   DslashArg<float> arg;
@@ -2255,7 +2286,8 @@ void galerkinUV(float *UVout, const float *V, const GaugeField &U, int dir, doub
   arg.Vh = g.Vh; arg.Xh = g.Xh; arg.Y = g.X[1]; arg.Z = g.X[2]; arg.T = g.X[3];
   arg.dXh = g.dXh; arg.dY = g.dY; arg.dZ = g.dZ;
   hipLaunchKernelGGL(galerkin_uv_kernel, dim3(nAgg), dim3(256), 0, computeStream(), arg, (const char *)U.parityBase(0), (const char *)U.parityBase(1), dir, (float)coef, (const float4 *)V,
-                     (float4 *)UVout, block_to_fine, fine_to_block, nvec / 2, aggOffset, classMajor ? 1 : 0);
+                     (float4 *)UVout, block_to_fine, fine_to_block, nvec / 2, aggOffset, classMajor ? 1 : 0, (int)U.reconstruct,
+                     (U.reconstruct == QUDA_RECONSTRUCT_12 && U.t_boundary == QUDA_ANTI_PERIODIC_T && commGrid().coords[3] == commGrid().dims[3] - 1) ? -1.f : 1.f);
   HIP_CHECK(hipGetLastError());
 }
 

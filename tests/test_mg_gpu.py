@@ -204,6 +204,65 @@ def test_restrictor_and_prolongator_in_the_x_neighbour_order(qa, oracle, X):
         mg.free()
 
 
+@pytest.mark.parametrize("tb", ["periodic", "antiperiodic"])
+def test_twelve_real_links_in_the_fast_setup_path(qa, oracle, tb):
+    """Sloppy and preconditioner links stored as 12 reals (reconstruct_sloppy = reconstruct_precondition = QUDA_RECONSTRUCT_12, what production
+    runs of the reference use): the multi-right-hand-side stencil rebuilds the third row while it stages the links, the direct Galerkin product
+    when it loads them — so the set-up keeps its lockstep solves (null_method 1) and its batched products.  Antiperiodic: the rebuilt row of the
+    boundary t links carries the folded sign.  Stencil per right-hand side against the host tm_mat, Y and X against the oracle's calculateY
+    (2e-5), verify, and an MG-GCR solve with the residual recomputed on the host."""
+    X, kappa, mu = (8, 8, 8, 16), 0.124, 0.005
+    gauge = smooth_gauge(X, 0.35)
+    V, Vh = int(np.prod(X)), int(np.prod(X)) // 2
+    if tb == "antiperiodic":   # the host field carries the boundary, as the reference's applyGaugeFieldScaling leaves it (tests/test_util.cpp:1118-1141)
+        t_of = np.arange(Vh) // (X[0] // 2 * X[1] * X[2])
+        gauge[3].reshape(2, Vh, 18)[:, t_of == X[3] - 1, :] *= -1.0
+    gp = qa.gauge_param(X, cuda_prec=8, prec_sloppy=4, prec_precondition=4, recon_sloppy=qa.QUDA_RECONSTRUCT_12,
+                        t_boundary=qa.QUDA_ANTI_PERIODIC_T if tb == "antiperiodic" else qa.QUDA_PERIODIC_T)
+    assert gp.reconstruct_precondition == qa.QUDA_RECONSTRUCT_12
+    qa.load_gauge(gauge, gp)
+    ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=8, prec_sloppy=4, prec_precondition=4, solution_type=qa.QUDA_MAT_SOLUTION)
+    ip.solve_type, ip.inv_type, ip.gcrNkrylov, ip.tol, ip.maxiter, ip.reliable_delta, ip.verbosity = qa.QUDA_DIRECT_SOLVE, qa.QUDA_GCR_INVERTER, 20, 1e-10, 2000, 1e-4, qa.QUDA_SILENT
+    mp = qa.multigrid_param(ip, n_level=2, geo_block=(4, 4, 4, 4), n_vec=8, setup_maxiter=100, setup_tol=1e-4, smoother_pc=True)
+    mg = qa.Multigrid(mp)
+    rng = np.random.default_rng(41)
+
+    def rel(a, b):
+        return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+    try:
+        i = mg.level_info(0)
+        assert i["null_method"] == 1
+        phi = (rng.standard_normal((8, V, 4, 3)) + 1j * rng.standard_normal((8, V, 4, 3))).astype(np.complex64)
+        got, _ = mg.apply_block(0, phi)
+        oracle.set_threads(8)
+        try:
+            for k in range(8):
+                v = np.ascontiguousarray(phi[k].astype(np.complex128)).view(np.float64).reshape(-1)
+                want = oracle.tm_mat(gauge, v, list(X), kappa, mu, +1, 0)
+                assert rel(got[k], want.view(np.complex128).reshape(-1, 4, 3)) < 2e-5, k
+        finally:
+            oracle.set_threads(1)
+        Xf, bs, Nv = i["Xf"], i["geo_bs"], i["Nvec"]
+        Vd = mg.V(0).astype(np.complex128)
+        Yd, Xd = mg.coarse_links(0)
+        Yo, Xo = oracle.mg_coarse_op_fine(Vd, gauge, None, kappa, 2 * kappa * mu, Xf, bs, Nv)
+        assert rel(Xd, Xo) < 2e-5 and rel(Yd, -kappa * Yo) < 2e-5
+        assert max(mg.verify()) < 1e-4
+        ip.inv_type_precondition, ip.preconditioner = qa.QUDA_MG_INVERTER, mg.h
+        ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
+        b = rng.random(V * 24)
+        x = qa.invert(b, ip)
+        oracle.set_threads(8)
+        try:
+            res = float(np.linalg.norm(b - oracle.tm_mat(gauge, x, list(X), kappa, mu, +1, 0)) / np.linalg.norm(b))
+        finally:
+            oracle.set_threads(1)
+        assert res < 1e-10 and ip.iter < 40, (res, ip.iter)
+    finally:
+        mg.free()
+
+
 @pytest.mark.parametrize("X,bs,nvec", [((8, 8, 8, 8), (4, 4, 4, 2), 32), ((8, 8, 8, 16), (2, 4, 4, 4), 24), ((8, 8, 8, 8), (4, 4, 2, 2), 8)],
                          ids=["4x4x4x2-nvec32", "2x4x4x4-nvec24", "4x4x2x2-nvec8"])
 def test_transfer_kernels_on_other_aggregate_shapes(qa, oracle, X, bs, nvec):
