@@ -891,7 +891,7 @@ template <int NVEC> __global__ void __launch_bounds__(256) block_cholqr_kernel(f
 // (every 16-byte word of the aggregate's V / UV rows is used by lanes of the work-group within microseconds: L1 / L2 absorb the pieces);
 // partial tiles are summed through LDS and written in the link layout [site][matrix][column pair][row] float4.
 // local = 1: UV is a chirality-diagonal site term (twisted clover, galerkin_local_uv_kernel): no cross columns, every class is local.
-// Fine level only: 4 x 3 spin-colour, 4^4 aggregates, Nvec 8 or 24, unpartitioned.
+// Fine level only: 4 x 3 spin-colour, 4^4 aggregates, Nvec 8, 24 or 32, unpartitioned.
 // ================================================================================================
 typedef float gf32x4 __attribute__((ext_vector_type(4)));
 // forward hop (1 - gamma_mu) in the chiral basis of dslash.hip: row s of the OTHER chirality's contribution is i^k UV[partner]
@@ -1033,7 +1033,7 @@ template <int NVEC> __global__ void __launch_bounds__(512) galerkin_vuv_kernel(f
 bool Transfer::canDirectGalerkin() const {
   static int off = -1;
   if (off < 0) { const char *e = getenv("QUDA_AMD_GALERKIN_DIRECT"); off = (e && !atoi(e)) ? 1 : 0; }
-  if (off || fineSpin != 4 || fineColor != 3 || spin_bs != 2 || (Nvec != 8 && Nvec != 24)) return false;
+  if (off || fineSpin != 4 || fineColor != 3 || spin_bs != 2 || (Nvec != 8 && Nvec != 24 && Nvec != 32)) return false;
   for (int d = 0; d < 4; d++) if (geo_bs[d] != 4 || Xc[d] == 1 || commGrid().partitioned(d)) return false;
   return true;
 }
@@ -1044,7 +1044,7 @@ void Transfer::directGalerkinVUV(float *links, const float *UV, int mu, bool acc
 #define QA_VUV(NV) { static bool attr = false; \
     if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void *)galerkin_vuv_kernel<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; } \
     hipLaunchKernelGGL((galerkin_vuv_kernel<NV>), dim3(nAggChunk > 0 ? nAggChunk : (int)nAgg), dim3(512), lds, computeStream(), links, (const float2 *)V, (const float2 *)UV, mu, accumulateLocal ? 1 : 0, parityMajor ? 1 : 0, local ? 1 : 0, aggOffset, classMajor ? 1 : 0); }
-  if (Nvec == 24) QA_VUV(24) else QA_VUV(8)
+  if (Nvec == 24) QA_VUV(24) else if (Nvec == 32) QA_VUV(32) else QA_VUV(8)
 #undef QA_VUV
   HIP_CHECK(hipGetLastError());
 }

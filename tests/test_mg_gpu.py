@@ -263,8 +263,8 @@ def test_twelve_real_links_in_the_fast_setup_path(qa, oracle, tb):
         mg.free()
 
 
-@pytest.mark.parametrize("X,bs,nvec", [((8, 8, 8, 8), (4, 4, 4, 2), 32), ((8, 8, 8, 16), (2, 4, 4, 4), 24), ((8, 8, 8, 8), (4, 4, 2, 2), 8)],
-                         ids=["4x4x4x2-nvec32", "2x4x4x4-nvec24", "4x4x2x2-nvec8"])
+@pytest.mark.parametrize("X,bs,nvec", [((8, 8, 8, 8), (4, 4, 4, 2), 32), ((8, 8, 8, 16), (2, 4, 4, 4), 24), ((8, 8, 8, 8), (4, 4, 2, 2), 8), ((8, 8, 8, 8), (4, 4, 4, 4), 32)],
+                         ids=["4x4x4x2-nvec32", "2x4x4x4-nvec24", "4x4x2x2-nvec8", "4x4x4x4-nvec32"])
 def test_transfer_kernels_on_other_aggregate_shapes(qa, oracle, X, bs, nvec):
     """The barrier-free restrictor and the pipelined prolongator (transfer.hip restrict_stream_kernel / prolong_kernel) with aggregates of 128 and
     64 sites (two waves / one wave per work-group, one parity per wave in the parity-major order) and 8 / 24 / 32 vectors: R and P element-wise
@@ -288,6 +288,10 @@ def test_transfer_kernels_on_other_aggregate_shapes(qa, oracle, X, bs, nvec):
         eta = (rng.standard_normal((int(np.prod(Xc)), 2, Nv)) + 1j * rng.standard_normal((int(np.prod(Xc)), 2, Nv)))
         assert rel(mg.apply(0, "R", phi), oracle.mg_restrict(phi, Vd, Xf, gbs, Ns, Nc, Nv, sbs)) < 2e-5
         assert rel(mg.apply(0, "P", eta), oracle.mg_prolongate(eta, Vd, Xf, gbs, Ns, Nc, Nv, sbs)) < 2e-5
+        # Galerkin operator: the batched product on the matrix cores where the aggregates are 4^4 (Nvec 8 / 24 / 32), probing elsewhere
+        Yd, Xd = mg.coarse_links(0)
+        Yo, Xo = oracle.mg_coarse_op_fine(Vd, gauge, None, kappa, 2 * kappa * mu, Xf, gbs, Nv)
+        assert rel(Xd, Xo) < 2e-5 and rel(Yd, -kappa * Yo) < 2e-5
         assert max(mg.verify()) < 1e-4
         ip.inv_type_precondition, ip.preconditioner = qa.QUDA_MG_INVERTER, mg.h
         ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
