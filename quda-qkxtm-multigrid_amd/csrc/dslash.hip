@@ -991,16 +991,30 @@ struct FineBlockArg {
   float tsign_fwd, tsign_bwd;
 };
 
-template <int NRHS, int CL = 0> __global__ void __launch_bounds__(256) fine_block_kernel(const FineBlockArg arg) {
+// XY = 1 (NRHS = 8, CL = 0): the work-group is an 8 (x, checkerboard) x 4 (y) tile of one (z, t) plane and the panels its x and y hops need — 56 instead of
+// 4 x 32 — are fetched ONCE into LDS (dynamic, 60 slots of 896 B); the z and t hops keep the register pipeline.  The kernel is bound by its L2 -> L1 requests
+// (profiles/r03_fine_block_kernel_pmc.log): this takes a quarter of them out, at the price of two instead of four work-groups per CU (72.7 KB of LDS, 138 registers).
+// MEASURED (48^4, tools/fine_block_timing.py): 2459 us per parity launch against 1874 us for the linear mapping — the lost occupancy costs more than the
+// requests saved.  Correct under every partition mask (tools/fine_block_xy_check.py); kept as QUDA_AMD_BLOCK_FINE_XYTILE=1 for the record, off by default.
+template <int NRHS, int CL = 0, int XY = 0> __global__ void __launch_bounds__(256) fine_block_kernel(const FineBlockArg arg) {
   constexpr int SPB = NRHS == 24 ? 8 : 256 / NRHS;   // sites per work-group (192 threads for 24 right-hand sides, else 256)
   constexpr int USTR = 8 * 18 + 4;                    // floats per site of staged links: 148 = 20 mod 32, the up to 8 sites of a wave start on 8 different banks
   constexpr int TSTR = 144 + 4;                       // the dense clover-twist matrices of a site: 2 x 36 complex, same bank spread
   __shared__ float ulds[SPB * USTR];
   __shared__ __attribute__((aligned(16))) float tlds[CL ? SPB * TSTR : 4];
   const int s = threadIdx.x / NRHS, i = threadIdx.x - s * NRHS;
+  extern __shared__ __attribute__((aligned(16))) float plds[];   // XY: staged x / y neighbour panels
+  constexpr int PSTR = 224;   // floats per staged panel: 192 + 32 — consecutive slots start 128 B apart modulo the 256-byte bank row (two sites per 16-lane phase of a ds_read_b128)
   // site ss of this work-group -> checkerboard index
   int idx0 = 0, tbase = 0;
-  if (NRHS == 8 && arg.tile) {
+  int tX0 = 0, tY0 = 0, tZ = 0, tT = 0;
+  if (XY) {
+    const int m = arg.order.map(blockIdx.x), P = arg.tilesX * arg.tilesY;   // (t Z + z) P + tile of the plane, in the XCD-slab order of the linear mapping
+    const int yc = m % P, zt = m / P;
+    tZ = zt % arg.Z; tT = zt / arg.Z;
+    tX0 = (yc % arg.tilesX) * 8; tY0 = (yc / arg.tilesX) * 4;
+    tbase = ((tT * arg.Z + tZ) * arg.Y + tY0) * arg.Xh + tX0;
+  } else if (NRHS == 8 && arg.tile) {
     // work-groups dealt to the XCDs in contiguous eighths of the tile list (t slowest), tile -> its corner
     const int nwg = (int)gridDim.x, b = (int)blockIdx.x;
     int tl = (nwg & 7) == 0 ? (b & 7) * (nwg >> 3) + (b >> 3) : b;
@@ -1012,6 +1026,7 @@ template <int NRHS, int CL = 0> __global__ void __launch_bounds__(256) fine_bloc
     idx0 = arg.order.map(blockIdx.x) * SPB;
   }
   auto site_of = [&](int ss) -> int {
+    if (XY) return tbase + (ss >> 3) * arg.Xh + (ss & 7);   // ss = y_l 8 + xh_l
     if (NRHS == 8 && arg.tile) {   // ss = ((t_l 2 + z_l) 4 + y_l) 2 + xh_l
       const int xl = ss & 1, yl = (ss >> 1) & 3, zl = (ss >> 3) & 1, tl = ss >> 4;
       return tbase + ((tl * arg.Z + zl) * arg.Y + yl) * arg.Xh + xl;
@@ -1060,6 +1075,33 @@ template <int NRHS, int CL = 0> __global__ void __launch_bounds__(256) fine_bloc
         const float2 v = reinterpret_cast<const float2 *>(blk + (size_t)4 * arg.g_stride * 16)[sidx];
         dst[0] = v.x; dst[1] = v.y;
       }
+    }
+  }
+  if (XY) {
+    // slots (row r = 0..5: y0 - 1 .. y0 + 4, column c = 0..9: xh0 - 1 .. xh0 + 8), 48 sixteen-byte words each; the corner slots belong to no hop (they are
+    // filled with a valid panel all the same: unconditional loads, issued back to back, then the LDS stores).  A slot outside the lattice wraps around or,
+    // on a partitioned dimension, is the neighbour rank's panel in the ghost zone — column 0 only serves the -x hop, column 9 +x, row 0 -y, row 5 +y.
+    float4 stg[12];
+#pragma unroll
+    for (int q = 0; q < 12; q++) {
+      int e = (int)threadIdx.x + 256 * q;
+      e = e < 2880 ? e : 2879;
+      const int slot = e / 48, w = e - slot * 48, r = slot / 10, c = slot - r * 10;
+      int yy = tY0 + r - 1, xx = tX0 + c - 1;
+      long pn = -1;
+      if (xx < 0) { if (arg.commMask & 1) pn = arg.ghostBase[0][0] + ((((tT * arg.Z + tZ) * arg.Y + (yy < 0 ? 0 : (yy >= arg.Y ? arg.Y - 1 : yy)))) >> 1); else xx = arg.Xh - 1; }
+      else if (xx >= arg.Xh) { if (arg.commMask & 1) pn = arg.ghostBase[0][1] + ((((tT * arg.Z + tZ) * arg.Y + (yy < 0 ? 0 : (yy >= arg.Y ? arg.Y - 1 : yy)))) >> 1); else xx = 0; }
+      if (pn < 0) {
+        if (yy < 0) { if (arg.commMask & 2) pn = arg.ghostBase[1][0] + (tT * arg.Z + tZ) * arg.Xh + xx; else yy = arg.Y - 1; }
+        else if (yy >= arg.Y) { if (arg.commMask & 2) pn = arg.ghostBase[1][1] + (tT * arg.Z + tZ) * arg.Xh + xx; else yy = 0; }
+      }
+      if (pn < 0) pn = ((long)(tT * arg.Z + tZ) * arg.Y + yy) * arg.Xh + xx;
+      stg[q] = reinterpret_cast<const float4 *>(arg.in_other + pn * 12 * NRHS)[w];
+    }
+#pragma unroll
+    for (int q = 0; q < 12; q++) {
+      const int e = (int)threadIdx.x + 256 * q;
+      if (e < 2880) { const int slot = e / 48, w = e - slot * 48; *reinterpret_cast<float4 *>(&plds[slot * PSTR + 4 * w]) = stg[q]; }
     }
   }
   __syncthreads();
@@ -1149,11 +1191,31 @@ template <int NRHS, int CL = 0> __global__ void __launch_bounds__(256) fine_bloc
 #define FB_PIN() _Pragma("unroll") for (int k_ = 0; k_ < 24; k_++) asm volatile("" : "+v"(acc[k_]))
 #define FB_LD(B, D) load_panel(p##B, arg.in_other, nb[D])
 #define FB_CP(B, D) FB_FENCE(); hop(std::integral_constant<int, D>{}, p##B); FB_PIN(); FB_FENCE()
+  if constexpr (XY) {
+    // z / t panels requested first, the four x / y hops out of LDS while they travel
+    float4 pC[6];
+    const int r0 = (s >> 3) + 1, c0 = (s & 7) + 1;
+    auto load_lds = [&](float4 *raw, int slot) {
+      const float *b = &plds[slot * PSTR + (io * NRHS + ipr) * 2];
+#pragma unroll
+      for (int k = 0; k < 6; k++) raw[k] = *reinterpret_cast<const float4 *>(b + k * 4 * NRHS);   // component 2k + io: (2k + io) NRHS + ipr complex numbers into the panel
+    };
+    FB_LD(A, 4); FB_LD(B, 5);
+    load_lds(pC, r0 * 10 + c0 + (xodd ? 1 : 0)); FB_CP(C, 0);
+    load_lds(pC, r0 * 10 + c0 - (xodd ? 0 : 1)); FB_CP(C, 1);
+    load_lds(pC, (r0 + 1) * 10 + c0); FB_CP(C, 2);
+    load_lds(pC, (r0 - 1) * 10 + c0); FB_CP(C, 3);
+    FB_CP(A, 4); FB_LD(A, 6); FB_CP(B, 5); FB_LD(B, 7);
+    FB_CP(A, 6);
+    if (arg.s0 != 0.f) load_panel(pA, arg.in_same, idx);
+    FB_CP(B, 7);
+  } else {
   FB_LD(A, 0); FB_LD(B, 1); FB_CP(A, 0); FB_LD(A, 2); FB_CP(B, 1); FB_LD(B, 3); FB_CP(A, 2);
   FB_LD(A, 4); FB_CP(B, 3); FB_LD(B, 5); FB_CP(A, 4); FB_LD(A, 6); FB_CP(B, 5); FB_LD(B, 7);
   FB_CP(A, 6);
   if (arg.s0 != 0.f) load_panel(pA, arg.in_same, idx);   // the site's own panel travels while the last hop is computed
   FB_CP(B, 7);
+  }
 #undef FB_FENCE
 #undef FB_PIN
 #undef FB_LD
@@ -1447,6 +1509,20 @@ void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_o
       if (rel % panel) errorQuda("ghost zone not aligned with the panels of its field");
       arg.commMask = gh.mask;
       for (int d = 0; d < 4; d++) for (int k = 0; k < 2; k++) arg.ghostBase[d][k] = (int)(rel / panel) + gh.offset[d][k];
+    }
+  }
+  {
+    // the x / y tile variant (QUDA_AMD_BLOCK_FINE_XYTILE): 8 right-hand sides, no site matrices, planes that 8 x 4 tiles cover
+    static int xyEnv = -1;
+    if (xyEnv < 0) { const char *e = getenv("QUDA_AMD_BLOCK_FINE_XYTILE"); xyEnv = e ? atoi(e) : 0; }
+    if (xyEnv && nrhs == 8 && !tmat && !arg.tile && g.Xh % 8 == 0 && g.X[1] % 4 == 0) {
+      arg.tilesX = g.Xh / 8; arg.tilesY = g.X[1] / 4;
+      constexpr size_t ldsXY = (size_t)60 * 224 * sizeof(float);
+      static bool attr = false;
+      if (!attr) { HIP_CHECK(hipFuncSetAttribute((const void *)fine_block_kernel<8, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsXY)); attr = true; }
+      hipLaunchKernelGGL((fine_block_kernel<8, 0, 1>), dim3(nb), dim3(threads), ldsXY, computeStream(), arg);
+      HIP_CHECK(hipGetLastError());
+      return;
     }
   }
 #define FB_LAUNCH(N) \
