@@ -654,3 +654,16 @@ def test_lockstep_bicgstab_variants_agree():
             fa, fb = np.array(got["fingerprint"]), np.array(ref["fingerprint"])
             assert np.max(np.abs(fa - fb)) < 0.1 * np.max(np.abs(fb)), (action, name, np.max(np.abs(fa - fb)), np.max(np.abs(fb)))
         print(action, {n: (runs[n][action]["null_iters"], runs[n][action]["iters"], "%.2e" % max(runs[n][action]["quality"])) for n in runs})
+
+
+def test_opt_in_xy_tile_of_the_multi_rhs_stencil():
+    """QUDA_AMD_BLOCK_FINE_XYTILE=1 (dslash.hip fine_block_kernel<8, 0, 1>: the x / y neighbour panels of an 8 x 4 tile staged in LDS; measured slower, off by
+    default) stays correct: every right-hand side against the host tm_mat on lattices the tiles cover, unpartitioned and under partition masks whose x / y
+    faces come out of the ghost zone.  The switch is read once per process, hence a child process (tools/fine_block_xy_check.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fine_block_xy_check.py")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, QUDA_AMD_BLOCK_FINE_XYTILE="1"))
+    assert r.returncode == 0 and "XYCHECK ok" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
