@@ -536,20 +536,33 @@ def main():
         Xc = Xl
         g_cpu = gauge if dist is None else gauge
         inp = src_h.copy()
-        oracle.set_threads(1)
-        t0 = time.perf_counter()
-        oracle.tm_dslash(g_cpu, inp, Xc, kappa, mu, +1, 0, "ee", 0)
-        t1 = time.perf_counter() - t0
+        # protocol of SURVEY 8d / BASELINE.md 4.3: fields resident, >= 10 warm-up + >= 50 timed applications, wall clock.  All cores: the bench
+        # workload itself (same lattice, same inputs).  One thread (the reference's host path has no threading): the same operator on a
+        # 16^4 sample of the workload (60 applications of 32^4 would be a minute of one core; the loop nest is compute-bound, its rate does not
+        # depend on the volume: 0.86 / 0.89 GFLOP/s at 8^4 / 16^4 in BASELINE.md 3)
+        n_warm, n_timed = 10, 50
         oracle.set_threads(cores)
-        n_all = max(3, min(40, int(12.0 / max(t1 / cores, 1e-3))))
-        oracle.tm_dslash(g_cpu, inp, Xc, kappa, mu, +1, 0, "ee", 0)
-        t0 = time.perf_counter()
-        for _ in range(n_all):
+        for _ in range(n_warm):
             oracle.tm_dslash(g_cpu, inp, Xc, kappa, mu, +1, 0, "ee", 0)
-        tall = (time.perf_counter() - t0) / n_all
+        t0 = time.perf_counter()
+        for _ in range(n_timed):
+            oracle.tm_dslash(g_cpu, inp, Xc, kappa, mu, +1, 0, "ee", 0)
+        tall = (time.perf_counter() - t0) / n_timed
+        Xs = [min(16, v) for v in Xc]
+        Vh_s = int(np.prod(Xs)) // 2
+        g_s, inp_s = make_gauge(Xs), np.random.default_rng(77).random(Vh_s * 24)
+        oracle.set_threads(1)
+        for _ in range(n_warm):
+            oracle.tm_dslash(g_s, inp_s, Xs, kappa, mu, +1, 0, "ee", 0)
+        t0 = time.perf_counter()
+        for _ in range(n_timed):
+            oracle.tm_dslash(g_s, inp_s, Xs, kappa, mu, +1, 0, "ee", 0)
+        t1 = (time.perf_counter() - t0) / n_timed
         cpu = dict(value=round(1368.0 * Vh_local / tall * 1e-9, 3), unit="GFLOP/s", cores=cores, kind="port",
-                   sample="%d x tm_dslash fp64 on %s (oracle/liboracle.so, outer parallel-for over sites); 1 thread = %.3f GFLOP/s"
-                   % (n_all, "x".join(str(v) for v in Xc), 1368.0 * Vh_local / t1 * 1e-9))
+                   sample="%d warm-up + %d timed tm_dslash fp64 on %s (oracle/liboracle.so, outer parallel-for over sites, %d threads); 1 thread, same protocol on a %s sample = %.3f GFLOP/s"
+                   % (n_warm, n_timed, "x".join(str(v) for v in Xc), cores, "x".join(str(v) for v in Xs), 1368.0 * Vh_s / t1 * 1e-9),
+                   one_thread=dict(value=round(1368.0 * Vh_s / t1 * 1e-9, 3), unit="GFLOP/s", cores=1, lattice="x".join(str(v) for v in Xs), warmup=n_warm, timed=n_timed),
+                   warmup=n_warm, timed=n_timed)
         if g16 is not None:
             # the solver half of the metric on the host: the reference's restarted GCR(20) (lib/inv_gcr_quda.cpp, plainest configuration)
             # on the host tm_mat with lib/blas_cpu.cpp-style BLAS (oracle/qo_solver.c), fp64, on the SAME 16^4 problem (field, kappa, mu,
@@ -607,7 +620,7 @@ def main():
             "vs_baseline": None, "dtype": dtype_name[args.prec], "data": "synthetic",
             "config": {"workload": "%s even-odd Dslash (DiracTwistedMassPC::Dslash, kappa=%g mu=%g), %s lattice, recon-%d, fields resident in HBM"
                        % ({"tm": "twisted-mass", "tmc": "twisted-clover", "wilson": "Wilson"}[args.dslash], kappa, mu, "x".join(map(str, X)), args.recon),
-                       "local_lattice": Xl, "halo_transport": {1: "direct peer stores (IPC-mapped ghost zones over xGMI)", 0: "RCCL send/recv", -1: "none (single rank)"}[int(qa.lib().qudaAmdHaloTransport())], "halo_wire_format": {0: "flag-in-data", 1: "32-byte sectors"}[int(qa.lib().qudaAmdHaloWireFormat())] if dist else "none", "process_grid": dist.grid if dist else [1, 1, 1, 1], "flops_per_site": r["flops_site"],
+                       "local_lattice": Xl, "halo_transport": {1: "direct peer stores (IPC-mapped ghost zones over xGMI)", 0: "RCCL send/recv", -1: "none (single rank)"}[int(qa.lib().qudaAmdHaloTransport()) if int(qa.lib().qudaAmdCommSize()) > 1 else -1], "halo_wire_format": {0: "flag-in-data", 1: "32-byte sectors"}[int(qa.lib().qudaAmdHaloWireFormat())] if dist else "none", "process_grid": dist.grid if dist else [1, 1, 1, 1], "flops_per_site": r["flops_site"],
                        "ranks_in_communicator": int(qa.lib().qudaAmdCommSize()), "per_rank_kernel_us": {"slowest": round(1e6 * r["sec"], 2), "fastest": round(1e6 * r["sec_min"], 2)},
                        "per_rank": ranks_dslash,   # transport + exchange / global-sum counters of every rank after the Dslash measurement
                        "other_configs": "BASELINE configs[3] (32^3 x 64 over 8 GPUs): --lattice 32,32,32,64 (grid 1x2x2x2, local 32x16x16x32)"},

@@ -39,6 +39,8 @@ struct MGParam : SolverParam {
   MGParam(QudaMultigridParam &g, std::vector<ColorSpinorField *> &B, DiracMatrix &matResidual, DiracMatrix &matSmooth, int level, QudaTwistFlavorType flavor);
 };
 
+class CoarseCycle;   // coarse_cycle.h: the cycle below a coarse level as one persistent kernel
+
 class MG : public Solver {
   MGParam &mgp;
   Transfer *transfer;
@@ -53,6 +55,11 @@ class MG : public Solver {
   DiracM *matCoarse, *matCoarseSmoother;
   bool pcSmooth;
   bool ownCoarseSolver;
+  // levels >= 1 of a small (launch-latency-bound) sub-hierarchy run as ONE persistent kernel (coarse_cycle.h); created at the first cycle,
+  // checked once against the kernel-per-operation path below (cycleUnfused), dropped for good if the two disagree
+  CoarseCycle *fused = nullptr;
+  bool fusedTried = false, fusedVerified = false;
+  void cycleUnfused(ColorSpinorField &out, ColorSpinorField &in);
  public:
   // how generateNullVectors produced this level's vectors: 0 loaded / restricted / sequential BiCGstab solves (the reference's loop),
   // 1 lockstep block BiCGstab on the multi-right-hand-side fine stencil, 2 the same on the MFMA coarse operator; and the lockstep iteration count
@@ -80,6 +87,12 @@ class MG : public Solver {
   // level-0 smoothers re-created with `sloppy` as their inner (MR work-field) operator in its precision; nullptr: back to fp32
   void setSmootherSloppy(DiracMatrix *sloppy);
   const std::vector<ColorSpinorField *> &nullVectors() const { return mgp.B; }
+  // structure of the hierarchy, for the fused coarse cycle
+  const MGParam &params() const { return mgp; }
+  bool smootherIsPC() const { return pcSmooth; }
+  const SolverParam *preSmootherParam() const { return param_presmooth; }
+  const CoarseCycle *fusedCycle() const { return fused; }
+  void dropFusedCycle();   // hierarchy contents changed (half-precision mirrors switched on): rebuild or abandon at the next cycle
   DiracMatrix &residualMatrix() const { return mgp.matResidual; }
 };
 

@@ -89,7 +89,8 @@ void qudaAmdMultigridLevelInfo(void *mg_instance, int level, int info[18]); /* X
 void qudaAmdMultigridGetNullVector(void *mg_instance, int level, int k, float *h_out);
 void qudaAmdMultigridGetV(void *mg_instance, int level, float *h_out);
 void qudaAmdMultigridGetCoarseLinks(void *mg_instance, int level, float *h_Y, float *h_X);
-/* op 0: R (level -> level+1; lib/restrictor.cu), 1: P (level+1 -> level; lib/prolongator.cu), 2: M of `level` */
+/* op 0: R (level -> level+1; lib/restrictor.cu), 1: P (level+1 -> level; lib/prolongator.cu), 2: M of `level`,
+ * 3: one multigrid cycle of `level`, x = K b (MG::operator(), lib/multigrid.cpp:488-604) */
 void qudaAmdMultigridApply(void *mg_instance, int level, int op, float *h_out, const float *h_in);
 /* The operator of a COARSE level applied to nrhs (8, 16, 24 or 32) host vectors at once through the multi-right-hand-side kernel
  * on the matrix cores (v_mfma_f32_16x16x4_f32; the reference's multi-source coarse Dslash, lib/dslash_coarse.cu:294-333): the
@@ -117,6 +118,12 @@ void qudaAmdWriteSpinorFields(const char *filename, void *V[], QudaPrecision pre
 void qudaAmdReadSpinorFields(const char *filename, void *V[], QudaPrecision precision, const int *X, int nColor, int nSpin, int Nvec);
 void qudaAmdSetExitLine(const char *text, int status);
 double qudaAmdMultigridTimeApply(void *mg_instance, int level, int niter);
+/* The cycle from a coarse level down (smoothers, residual, R, coarsest-grid GCR, P) as ONE persistent kernel (include/coarse_cycle.h) where
+ * the sub-hierarchy qualifies; on by default (QUDA_AMD_MG_FUSED=0 / SetFused(0): the kernel-per-operation path).  FusedStats: returns 1 if
+ * `level` owns such a kernel and fills out[] with the last launch's device-wide barriers, coarsest-grid GCR iterations, its restarts,
+ * halo exchanges and the grid size. */
+void qudaAmdMultigridSetFused(int on);
+int qudaAmdMultigridFusedStats(void *mg_instance, int level, long long out[5]);
 /* seconds per application of the restrictor (what = 0) or prolongator (what = 1) between `level` and `level + 1` */
 double qudaAmdMultigridTimeTransfer(void *mg_instance, int level, int what, int niter);
 

@@ -119,7 +119,7 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
                  "qudaAmdMultigridVerify", "qudaAmdMultigridCycle", "qudaAmdTimeAxpy", "qudaAmdMultigridLevels", "qudaAmdMultigridLevelInfo",
                  "qudaAmdMultigridSetHalfStorage", "qudaAmdMultigridGetNullVector", "qudaAmdMultigridGetV", "qudaAmdMultigridGetCoarseLinks", "qudaAmdMultigridApply", "qudaAmdMultigridApplyBlock",
                  "qudaAmdMultigridTimeApply", "qudaAmdMultigridTimeTransfer", "qudaAmdSetExitLine", "qudaAmdDiracPrepare", "qudaAmdDiracReconstruct", "qudaAmdSpinorRawInfo", "qudaAmdGaugeRawInfo", "qudaAmdCloverRawInfo", "qudaAmdRawDeviceCopy",
-                 "qudaAmdSetSolutionSink", "qudaAmdCommStats", "qudaAmdDescribeHaloError", "qudaAmdMultigridOrthoFallbackBlocks", "qudaAmdProfileMarker", "qudaAmdAccountStart", "qudaAmdAccountDump", "qudaAmdWriteSpinorFields", "qudaAmdReadSpinorFields", "qudaAmdMultigridRefine"]
+                 "qudaAmdSetSolutionSink", "qudaAmdCommStats", "qudaAmdDescribeHaloError", "qudaAmdMultigridOrthoFallbackBlocks", "qudaAmdProfileMarker", "qudaAmdAccountStart", "qudaAmdAccountDump", "qudaAmdWriteSpinorFields", "qudaAmdReadSpinorFields", "qudaAmdMultigridRefine", "qudaAmdMultigridSetFused", "qudaAmdMultigridFusedStats"]
 
 _lib = None
 
@@ -205,6 +205,10 @@ def lib():
         L.qudaAmdMultigridGetV.argtypes = [_p, _i, _p]
         L.qudaAmdMultigridGetCoarseLinks.argtypes = [_p, _i, _p, _p]
         L.qudaAmdMultigridApply.argtypes = [_p, _i, _i, _p, _p]
+        L.qudaAmdMultigridSetFused.argtypes = [_i]
+        L.qudaAmdMultigridSetFused.restype = None
+        L.qudaAmdMultigridFusedStats.argtypes = [_p, _i, _p]
+        L.qudaAmdMultigridFusedStats.restype = _i
         L.qudaAmdMultigridApplyBlock.argtypes = [_p, _i, _i, _p, _p, _i]
         L.qudaAmdMultigridApplyBlock.restype = _d
         L.qudaAmdMultigridTimeApply.argtypes = [_p, _i, _i]
@@ -635,7 +639,7 @@ class Multigrid:
 
     def apply(self, level, op, h_in):
         """op 'R' (level -> level+1), 'P' (level+1 -> level), 'M' (operator of `level`); fields as (sites, spin, colour) complex64"""
-        i = self.level_info(level) if op != "M" or level < self.levels() - 1 else None
+        i = self.level_info(level) if op not in ("M", "K") or level < self.levels() - 1 else None
         if i is None:
             j = self.level_info(level - 1)
             fine_shape = (int(np.prod(j["Xc"])), 2, j["Nvec"])
@@ -643,11 +647,18 @@ class Multigrid:
         else:
             fine_shape = (int(np.prod(i["Xf"])), i["fineSpin"], i["fineColor"])
             coarse_shape = (int(np.prod(i["Xc"])), 2, i["Nvec"])
-        shape_in, shape_out = {"R": (fine_shape, coarse_shape), "P": (coarse_shape, fine_shape), "M": (fine_shape, fine_shape)}[op]
+        shape_in, shape_out = {"R": (fine_shape, coarse_shape), "P": (coarse_shape, fine_shape), "M": (fine_shape, fine_shape), "K": (fine_shape, fine_shape)}[op]
         h_in = np.ascontiguousarray(h_in, dtype=np.complex64).reshape(shape_in)
         out = np.zeros(shape_out, dtype=np.complex64)
-        lib().qudaAmdMultigridApply(self.h, level, {"R": 0, "P": 1, "M": 2}[op], _vp(out), _vp(h_in))
+        lib().qudaAmdMultigridApply(self.h, level, {"R": 0, "P": 1, "M": 2, "K": 3}[op], _vp(out), _vp(h_in))
         return out
+
+    def fused_stats(self, level):
+        """None if `level` does not run its cycle as one persistent kernel (coarse_cycle.h), else the last launch's counters"""
+        a = (C.c_longlong * 5)()
+        if not lib().qudaAmdMultigridFusedStats(self.h, int(level), a):
+            return None
+        return dict(barriers=int(a[0]), gcr_iters=int(a[1]), gcr_restarts=int(a[2]), halo_exchanges=int(a[3]), grid=int(a[4]))
 
     def free(self):
         if self.h:

@@ -11,6 +11,7 @@
 
 #include "interface_internal.h"
 #include "block.h"
+#include "coarse_cycle.h"
 #include "dslash.h"
 #include "multigrid.h"
 #include "quda_amd_ext.h"
@@ -163,7 +164,7 @@ void qudaAmdMultigridApply(void *mg_instance, int level, int op, float *h_out, c
   switch (op) {
     case 0: fin = fine(); fout = T->createCoarseField(); break;
     case 1: fin = T->createCoarseField(); fout = fine(); break;
-    case 2: fin = fine(); fout = fine(); break;
+    case 2: case 3: fin = fine(); fout = fine(); break;
     default: errorQuda("unknown op %d", op);
   }
   ColorSpinorField hin = hostView(*fin, const_cast<float *>(h_in)), hout = hostView(*fout, h_out);
@@ -171,9 +172,18 @@ void qudaAmdMultigridApply(void *mg_instance, int level, int op, float *h_out, c
   fin->twistFlavor = fout->twistFlavor = proto.twistFlavor;
   if (op == 0) T->R(*fout, *fin);
   else if (op == 1) T->P(*fout, *fin);
+  else if (op == 3) (*m)(*fout, *fin);   // one multigrid cycle of this level (MG::operator(): the fused persistent kernel where it qualifies)
   else m->residualMatrix()(*fout, *fin);
   hout = *fout;
   delete fin; delete fout;
+}
+
+// the cycle below a coarse level as one persistent kernel (coarse_cycle.h): process-wide switch and the statistics of the last launch of `level`
+void qudaAmdMultigridSetFused(int on) { coarseCycleSetEnabled(on); }
+int qudaAmdMultigridFusedStats(void *mg_instance, int level, long long out[5]) {
+  MG *m = levelOf(mg_instance, level);
+  coarseCycleStats(m->fusedCycle(), out);
+  return m->fusedCycle() ? 1 : 0;
 }
 
 // M of a COARSE level applied to nrhs host vectors at once through the multi-right-hand-side MFMA kernel (block.h): h_in / h_out

@@ -1,6 +1,8 @@
 // multigrid.cpp — MG setup and cycle (see multigrid.h).
 #include "multigrid.h"
 #include "block.h"
+#include "coarse_cycle.h"
+#include "p2p.h"
 
 #include <cmath>
 #include <sys/time.h>
@@ -182,7 +184,14 @@ MG::MG(MGParam &p)
   if (getVerbosity() >= QUDA_SUMMARIZE) printfQuda("MG level %d: setup completed\n", p.level + 1);
 }
 
+void MG::dropFusedCycle() {
+  coarseCycleDestroy(fused);
+  fused = nullptr; fusedTried = false; fusedVerified = false;
+  if (coarse) coarse->dropFusedCycle();
+}
+
 MG::~MG() {
+  coarseCycleDestroy(fused);
   if (ownCoarseSolver) delete coarse_solver;
   delete param_coarse_solver;
   delete coarse;
@@ -573,6 +582,43 @@ void MG::cycleParity(ColorSpinorField &x, ColorSpinorField &b, bool fullResidual
 
 void MG::operator()(ColorSpinorField &x, ColorSpinorField &b) {
   if (b.SiteSubset() != QUDA_FULL_SITE_SUBSET) { cycleParity(x, b, false); return; }
+  if (mgp.level >= 1 && coarseCycleEnabled() && !mgProfiling()) {
+    // the whole cycle from this level down in one launch (coarse_cycle.h); the first use is checked against the kernel-per-operation path
+    // on every rank, and any disagreement (or a wait that ran out) sends all ranks back to that path for good
+    if (!fusedTried) { fusedTried = true; fused = coarseCycleCreate(*this); }
+    if (fused && !fusedVerified) {
+      cycleUnfused(x, b);
+      ColorSpinorField ref(x);
+      double fail = coarseCycleApply(fused, x, b) ? 0.0 : 1.0;
+      HIP_CHECK(hipStreamSynchronize(computeStream()));
+      if (p2pTakeError()) fail = 1.0;
+      if (fail == 0.0) {
+        const bool wasGlobal = blas::globalReduction();
+        blas::setGlobalReduction(false);
+        const double n2 = blas::norm2(ref), d2 = blas::xmyNorm(x, ref);   // ref <- x - ref
+        blas::setGlobalReduction(wasGlobal);
+        if (!(d2 <= 1e-6 * n2)) fail = 1.0;
+        if (getVerbosity() >= QUDA_VERBOSE || getenv("QUDA_AMD_MG_FUSED_VERBOSE")) printfQuda("MG level %d: fused coarse cycle against the kernel-per-operation path: |dx|^2 / |x|^2 = %e\n", mgp.level + 1, n2 > 0 ? d2 / n2 : d2);
+      }
+      if (getenv("QUDA_AMD_MG_FUSED_VERIFY_FAIL")) fail = 1.0;
+      comm_allreduce(&fail, 1);
+      if (fail != 0.0) {
+        if (commGrid().rank == 0) warningQuda("MG level %d: the fused coarse cycle disagrees with the kernel-per-operation path on its first use: staying with the latter", mgp.level + 1);
+        coarseCycleDestroy(fused);
+        fused = nullptr;
+        cycleUnfused(x, b);
+      } else {
+        fusedVerified = true;
+      }
+      blas::setGlobalReduction(true);
+      return;
+    }
+    if (fused && coarseCycleApply(fused, x, b)) { blas::setGlobalReduction(true); return; }
+  }
+  cycleUnfused(x, b);
+}
+
+void MG::cycleUnfused(ColorSpinorField &x, ColorSpinorField &b) {
   const Dirac &dirac = *mgp.matSmooth.Expose();
   static int parityRoute = -1;
   if (parityRoute < 0) { const char *e = getenv("QUDA_AMD_MG_PARITY_CYCLE"); parityRoute = e ? atoi(e) : 1; }
@@ -660,6 +706,7 @@ void MG::setSmootherSloppy(DiracMatrix *sloppy) {
 }
 
 void MG::makeHalfMirrors() {
+  dropFusedCycle();
   if (transfer) transfer->makeHalf();
   if (diracCoarse) diracCoarse->Links().makeHalf();
   if (diracCoarseSmoother) diracCoarseSmoother->HatLinks().makeHalf();
@@ -832,6 +879,7 @@ void multigridSetHalfStorage(multigrid_solver &mgs, bool on) {
     HIP_CHECK(hipStreamSynchronize(computeStream()));
   } else {
     mgs.mg->setSmootherSloppy(nullptr);
+    mgs.mg->dropFusedCycle();   // fp32 storage again: the fused coarse cycle may come back
   }
   setCoarseHalfStorage(on);
 }

@@ -323,11 +323,13 @@ def test_partitioned_dslash_self_neighbour(qa, mask, fmt):
         qa.lib().qudaAmdSetDslashTune(b"halo_format", -1)
 
 
+@pytest.mark.parametrize("X", [(32, 16, 16, 16), (32, 16, 16, 32)], ids=["32^4-over-8", "configs3-32^3x64-over-8"])
 @pytest.mark.parametrize("fmt", [0, 1], ids=["flag-in-data", "sectors-128B-line"])
-def test_partitioned_dslash_at_the_8gpu_sublattice(qa, oracle, fmt):
-    """the local lattice of an 8-GPU split of 32^4 (32 x 16 x 16 x 16, y z t partitioned): many pack blocks, faces of different sizes,
-    pack blocks that straddle two (dimension, direction) ranges; all three precisions against the oracle, both wire formats"""
-    X, kappa, mu = (32, 16, 16, 16), 0.1, 0.01
+def test_partitioned_dslash_at_the_8gpu_sublattice(qa, oracle, fmt, X):
+    """the local lattice of an 8-GPU split (grid 1 x 2 x 2 x 2, y z t partitioned) of 32^4 (32 x 16 x 16 x 16) and of BASELINE configs[3],
+    32^3 x 64 (32 x 16 x 16 x 32): many pack blocks, faces of different sizes, pack blocks that straddle two (dimension, direction)
+    ranges; all three precisions against the oracle, both wire formats"""
+    kappa, mu = 0.1, 0.01
     gauge, spinor, _ = oracle.make_fields(list(X), clover=False)
     nh = spinor.size // 2
     oracle.set_threads(8)
