@@ -446,9 +446,10 @@ def main():
             halo = dict(local_lattice="x".join(map(str, Xs)), partitioned="y,z,t (self-neighbour emulation)")
             for prec in (8, 4, 2):
                 row = {}
-                # the partitioned kernel in both wire formats of the peer-store ghost zones: flag-in-data 16-byte vectors (default) and
-                # 32-byte sectors = one 128-byte line per fp64 face site (QUDA_AMD_HALO_FORMAT=sector): 2/3 of the bytes on the links
-                for mask, fmt, name in ((0, 0, "unpartitioned_us"), (0b1110, 0, "partitioned_us"), (0b1110, 1, "partitioned_sector_format_us")):
+                # the partitioned kernel in both wire formats of the peer-store ghost zones: flag-in-data {word, flag, word, flag} vectors and the
+                # compact self-validating 16-byte atoms {3 words, flag} = one 128-byte line per fp64 face site (QUDA_AMD_HALO_FORMAT=atom, the
+                # default between devices): 2/3 of the bytes on the links
+                for mask, fmt, name in ((0, 0, "unpartitioned_us"), (0b1110, 0, "partitioned_us"), (0b1110, 1, "partitioned_atom_format_us")):
                     qa.lib().qudaAmdSetPartitionMask(mask)
                     qa.lib().qudaAmdSetDslashTune(b"halo_format", fmt)
                     qa.load_gauge(gs, qa.gauge_param(Xs, cuda_prec=prec))
@@ -462,9 +463,9 @@ def main():
                         row["transport"] = {1: "direct peer stores", 0: "RCCL send/recv", -1: "none"}[int(qa.lib().qudaAmdHaloTransport())]
                     src.free(); dst.free(); d.free()
                 qa.lib().qudaAmdSetDslashTune(b"halo_format", -1)
-                site_bytes = {8: (192, 128), 4: (96, 64), 2: (64, 32)}[prec]
-                row["wire_bytes_per_face_site"] = {"flag_in_data": site_bytes[0], "sector_format": site_bytes[1], "payload": {8: 96, 4: 48, 2: 28}[prec]}
-                row["y_face_bytes"] = {"flag_in_data": site_bytes[0] * 32 * 16 * 16 // 2, "sector_format": site_bytes[1] * 32 * 16 * 16 // 2}
+                site_bytes = {8: (192, 128), 4: (96, 64), 2: (64, 48)}[prec]
+                row["wire_bytes_per_face_site"] = {"flag_in_data": site_bytes[0], "atom_format": site_bytes[1], "payload": {8: 96, 4: 48, 2: 28}[prec]}
+                row["y_face_bytes"] = {"flag_in_data": site_bytes[0] * 32 * 16 * 16 // 2, "atom_format": site_bytes[1] * 32 * 16 * 16 // 2}
                 # what an 8-GPU strong-scaling run would make of it if xGMI behaved like the emulation: the 32^4 kernel of this precision on
                 # one GPU over the partitioned sub-lattice kernel (8 = ideal)
                 one = {8: 1e6 * r["sec"] if (args.prec, args.recon, args.dslash) == (8, 18, "tm") else None,
@@ -472,7 +473,7 @@ def main():
                 if one:
                     row["one_gpu_32x4_us"] = round(one, 2)
                     row["projected_speedup_8_gpus"] = round(one / row["partitioned_us"], 2)
-                    row["projected_speedup_8_gpus_sector_format"] = round(one / row["partitioned_sector_format_us"], 2)
+                    row["projected_speedup_8_gpus_atom_format"] = round(one / row["partitioned_atom_format_us"], 2)
                 halo[dtype_name[prec].split("+")[0]] = row
             qa.lib().qudaAmdSetPartitionMask(0)
             extra["halo_8gpu_sublattice"] = halo
@@ -620,7 +621,7 @@ def main():
             "vs_baseline": None, "dtype": dtype_name[args.prec], "data": "synthetic",
             "config": {"workload": "%s even-odd Dslash (DiracTwistedMassPC::Dslash, kappa=%g mu=%g), %s lattice, recon-%d, fields resident in HBM"
                        % ({"tm": "twisted-mass", "tmc": "twisted-clover", "wilson": "Wilson"}[args.dslash], kappa, mu, "x".join(map(str, X)), args.recon),
-                       "local_lattice": Xl, "halo_transport": {1: "direct peer stores (IPC-mapped ghost zones over xGMI)", 0: "RCCL send/recv", -1: "none (single rank)"}[int(qa.lib().qudaAmdHaloTransport()) if int(qa.lib().qudaAmdCommSize()) > 1 else -1], "halo_wire_format": {0: "flag-in-data", 1: "32-byte sectors"}[int(qa.lib().qudaAmdHaloWireFormat())] if dist else "none", "process_grid": dist.grid if dist else [1, 1, 1, 1], "flops_per_site": r["flops_site"],
+                       "local_lattice": Xl, "halo_transport": {1: "direct peer stores (IPC-mapped ghost zones over xGMI)", 0: "RCCL send/recv", -1: "none (single rank)"}[int(qa.lib().qudaAmdHaloTransport()) if int(qa.lib().qudaAmdCommSize()) > 1 else -1], "halo_wire_format": {0: "flag-in-data", 1: "self-validating 16-byte atoms"}[int(qa.lib().qudaAmdHaloWireFormat())] if dist else "none", "process_grid": dist.grid if dist else [1, 1, 1, 1], "flops_per_site": r["flops_site"],
                        "ranks_in_communicator": int(qa.lib().qudaAmdCommSize()), "per_rank_kernel_us": {"slowest": round(1e6 * r["sec"], 2), "fastest": round(1e6 * r["sec_min"], 2)},
                        "per_rank": ranks_dslash,   # transport + exchange / global-sum counters of every rank after the Dslash measurement
                        "other_configs": "BASELINE configs[3] (32^3 x 64 over 8 GPUs): --lattice 32,32,32,64 (grid 1x2x2x2, local 32x16x16x32)"},

@@ -95,8 +95,9 @@ struct DslashTune {
   // peer-store halo launch: face packing folded into the site threads (-1: environment QUDA_AMD_P2P_FOLD, default OFF; the path is compiled out unless dslash.hip is built with -DQA_P2P_FOLD=1: it measured slower than pack blocks), start delay of
   // the site blocks and raised issue priority of the pack waves (measurement aids)
   int p2p_fold = -1, site_delay = 0, pack_prio = 0;
-  // wire format of the peer-store ghost zones: 0 flag-in-data 16-byte vectors, 1 32-byte sectors = one 128-byte line per fp64 face site,
-  // -1 automatic (sectors between devices, flag-in-data where ranks share one); QUDA_AMD_HALO_FORMAT=ll|sector; must be the same on every rank
+  // wire format of the peer-store ghost zones: 0 flag-in-data {word, flag, word, flag} vectors, 1 self-validating 16-byte atoms {3 words, flag} = one
+  // 128-byte line per fp64 face site, -1 automatic (atoms between devices, flag-in-data where ranks share one); QUDA_AMD_HALO_FORMAT=ll|atom; must be
+  // the same on every rank
   int halo_format = -1;
   int edge_first = 1;  // peer-store launch, plane-tiled order: every XCD starts with its boundary planes
 };

@@ -206,7 +206,7 @@ void qudaAmdDeviceSynchronize(void);
 /* halo transport in use: -1 not decided yet (no partitioned Dslash so far), 0 staged RCCL send/recv, 1 direct peer stores
  * into IPC-mapped ghost zones (the reference's "p2p" vs staged comms policies, lib/dslash_policy.cuh:838-998) */
 int qudaAmdHaloTransport(void);
-int qudaAmdHaloWireFormat(void);   /* wire format of the peer-store ghost zones in use: 0 flag-in-data, 1 32-byte sectors (dslash.h haloWireFormat) */
+int qudaAmdHaloWireFormat(void);   /* wire format of the peer-store ghost zones in use: 0 flag-in-data {word, flag} halves, 1 self-validating 16-byte atoms {3 words, flag} (dslash.h haloWireFormat) */
 /* launch geometry of the fine-grid stencil kernel, the counterpart of the reference's autotuner entries for the dslash kernels
  * (lib/tune.cpp, TuneParam block / grid): key = "block" (threads per block, 0 automatic), "remap" (XCD-aware block mapping),
  * "order" (legacy slab order), "tiled" / "nxz" / "tz" / "tt" (plane-tiled block order: XCDs along z, tile extents),

@@ -47,7 +47,7 @@ template <typename real> struct PackArg {
   int start[9];     // prefix offsets of the 8 (dim, dir) thread ranges
   // peer-store transport: send[][] point into the NEIGHBOURS' ghost zones; the last block to finish raises the flags there
   unsigned llFlag[4];      // flag-in-data value of this exchange per dimension (use count of the (dimension, buffer) zone)
-  int llFormat;            // wire format of the peer-store ghost zones: 0 flag-in-data 16-byte vectors (GhostLL), 1 32-byte sectors (GhostSector)
+  int llFormat;            // wire format of the peer-store ghost zones: 0 flag-in-data {word, flag, word, flag} vectors, 1 self-validating 16-byte atoms {3 words, flag} (GhostLL)
   unsigned long long *timeline;
 };
 
@@ -234,7 +234,7 @@ template <typename real> __device__ __forceinline__ void twist_inplace(real *p, 
 #endif
 template <typename T> struct GhostLL;
 template <> struct GhostLL<double> {
-  static constexpr int NV = 12, NS = 4;
+  static constexpr int NV = 12, NA = 8;
   static __device__ __forceinline__ void encode(unsigned *w, const double *h) {
 #pragma unroll
     for (int k = 0; k < 12; k++) { const unsigned long long b = __builtin_bit_cast(unsigned long long, h[k]); w[2 * k] = (unsigned)b; w[2 * k + 1] = (unsigned)(b >> 32); }
@@ -245,7 +245,7 @@ template <> struct GhostLL<double> {
   }
 };
 template <> struct GhostLL<float> {
-  static constexpr int NV = 6, NS = 2;
+  static constexpr int NV = 6, NA = 4;
   static __device__ __forceinline__ void encode(unsigned *w, const float *h) {
 #pragma unroll
     for (int k = 0; k < 12; k++) w[k] = __builtin_bit_cast(unsigned, h[k]);
@@ -256,7 +256,7 @@ template <> struct GhostLL<float> {
   }
 };
 template <> struct GhostLL<short> {   // 12 int16 + the fp32 scale of the site (same quantisation as Planar<short>::store)
-  static constexpr int NV = 4, NS = 1;
+  static constexpr int NV = 4, NA = 3;
   static __device__ __forceinline__ void encode(unsigned *w, const float *h) {
     float m = 0.f;
 #pragma unroll
@@ -290,36 +290,45 @@ template <typename T, typename real> __device__ __forceinline__ void ghost_ll_st
   }
 }
 // receiver: poll the site's own vectors (system-scope loads) until every half carries this exchange's flag; bounded by `ticks`
-// ---- the 32-byte-sector wire format (selectable next to flag-in-data: QUDA_AMD_HALO_FORMAT=sector, tune key "halo_format") ----
-// The flag-in-data vectors spend half of every byte on the wire on flags (786 KB per fp64 face of the 8-GPU split of 32^3 x 64, two
-// such faces sharing one xGMI link where a dimension has only two ranks).  Here a face site travels as NS sectors of 32 bytes =
-// 24 bytes of payload + the exchange's flag in the last 8 (16-bit storage: 24 + the 4-byte scale + a 4-byte flag) — fp64 4 sectors =
-// ONE 128-byte line per site (96 B payload + 4 x 8 B flags: the line of the collective libraries' 128-byte protocol, with its spare 32
-// bytes spent on a flag per sector instead of one per line), fp32 half a line, 16-bit a quarter: 128 / 64 / 32 bytes per site against
-// 192 / 96 / 64.  Plane-major [sector][faceCB].  What it assumes, and the 16-byte format does not: that a 32-byte sector written by ONE
-// store instruction (two adjacent lanes, 16 bytes each — the pack block transposes its sites through LDS for that, pack_body_sector)
-// becomes visible as a whole, i.e. that the flag in its second half never overtakes its first half.  True on every path of this
-// device a 1-GPU box can exercise; across xGMI it is what the first multi-GPU run has to show (the start-up probe and the first-use
-// comparison with the staged transport run in the selected format), which is why flag-in-data stays the default.
-template <typename T> __device__ __forceinline__ __amdgpu_buffer_rsrc_t ghost_sector_rsrc(const void *base, int faceCB) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)((unsigned)faceCB * (unsigned)(GhostLL<T>::NS * 32)), 0x00020000);
+// ---- the compact wire format: self-validating 16-byte atoms (QUDA_AMD_HALO_FORMAT=atom, tune key "halo_format" = 1) ----
+// The flag-in-data vectors above spend half of every byte on the wire on flags (786 KB per fp64 face of the 8-GPU split of 32^3 x 64,
+// two such faces sharing one xGMI link where a dimension has only two ranks).  Here a face site travels as NA atoms of 16 bytes =
+// three 32-bit payload words + the exchange's 32-bit flag: fp64 24 words = 8 atoms = ONE 128-byte line per site, fp32 4 atoms = 64 bytes,
+// 16-bit storage 6 packed words + the scale = 3 atoms = 48 bytes — 128 / 64 / 48 bytes per face site against 192 / 96 / 64.
+// Plane-major [atom][faceCB].  Every atom is written by ONE 16-byte store of ONE lane and validates itself: the format assumes nothing
+// about the order in which different stores, or different lanes of one store, become visible across xGMI — only that a naturally aligned
+// 16-byte store of a lane is not torn, the granularity the collective libraries' 128-byte protocol builds on as well.  (Round 3 had
+// 32-byte sectors written by two adjacent lanes with the flag in the second half: one assumption more, and an LDS transpose in the pack
+// blocks to arrange it; replaced.)  The sender is pack_emit as for flag-in-data — no LDS, and the receiver needs 8 instead of 12
+// sixteen-byte loads per fp64 site.
+template <typename T> __device__ __forceinline__ __amdgpu_buffer_rsrc_t ghost_atom_rsrc(const void *base, int faceCB) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)((unsigned)faceCB * (unsigned)(GhostLL<T>::NA * 16)), 0x00020000);
 }
-template <typename T> __device__ __forceinline__ bool ghost_sector_read(unsigned *w, const __amdgpu_buffer_rsrc_t &rs, int faceCB, int f, unsigned flag, unsigned &sy, unsigned &sw, int &sv) {
-  constexpr int NS = GhostLL<T>::NS;
+template <typename T, typename real> __device__ __forceinline__ void ghost_atom_store(const real *h, void *zone, int faceCB, int f, unsigned flag) {
+  constexpr int NV = GhostLL<T>::NV, NA = GhostLL<T>::NA;
+  unsigned w[3 * NA > 2 * NV ? 3 * NA : 2 * NV];
+  GhostLL<T>::encode(w, h);
+#pragma unroll
+  for (int k = 2 * NV; k < 3 * NA; k++) w[k] = 0u;
+  const __amdgpu_buffer_rsrc_t rs = ghost_atom_rsrc<T>(zone, faceCB);
+#pragma unroll
+  for (int v = 0; v < NA; v++) {
+    u32x4_t q; q.x = w[3 * v]; q.y = w[3 * v + 1]; q.z = w[3 * v + 2]; q.w = flag;
+    __builtin_amdgcn_raw_buffer_store_b128(q, rs, f * 16, v * faceCB * 16, QA_LL_STORE_AUX);
+  }
+}
+// one look at the atoms of face site f; false: some atom does not carry this exchange's flag yet (sy = the flag seen, sv = its atom)
+template <typename T> __device__ __forceinline__ bool ghost_atom_read(unsigned *w, const __amdgpu_buffer_rsrc_t &rs, int faceCB, int f, unsigned flag, unsigned &sy, unsigned &sw, int &sv) {
+  constexpr int NV = GhostLL<T>::NV, NA = GhostLL<T>::NA;
   bool ok = true;
 #pragma unroll
-  for (int s = 0; s < NS; s++) {
-    const u32x4_t q0 = __builtin_amdgcn_raw_buffer_load_b128(rs, f * 32, s * faceCB * 32, 17);
-    const u32x4_t q1 = __builtin_amdgcn_raw_buffer_load_b128(rs, f * 32 + 16, s * faceCB * 32, 17);
-    bool good;
-    if (sizeof(T) == 2) {
-      w[0] = q0.x; w[1] = q0.y; w[2] = q0.z; w[3] = q0.w; w[4] = q1.x; w[5] = q1.y; w[6] = q1.z; w[7] = 0u;
-      good = q1.w == flag;
-    } else {
-      w[6 * s] = q0.x; w[6 * s + 1] = q0.y; w[6 * s + 2] = q0.z; w[6 * s + 3] = q0.w; w[6 * s + 4] = q1.x; w[6 * s + 5] = q1.y;
-      good = q1.z == flag && q1.w == flag;
-    }
-    if (!good && ok) { sy = sizeof(T) == 2 ? q1.w : q1.z; sw = q1.w; sv = s; }
+  for (int v = 0; v < NA; v++) {
+    const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rs, f * 16, v * faceCB * 16, 17);
+    if (3 * v < 2 * NV) w[3 * v] = q.x;
+    if (3 * v + 1 < 2 * NV) w[3 * v + 1] = q.y;
+    if (3 * v + 2 < 2 * NV) w[3 * v + 2] = q.z;
+    const bool good = q.w == flag;
+    if (!good && ok) { sy = q.w; sw = q.w; sv = v; }
     ok = ok && good;
   }
   return ok;
@@ -330,11 +339,11 @@ __device__ __forceinline__ void ghost_ll_load(real *h, const void *zone, int fac
   constexpr int NV = GhostLL<T>::NV;
   unsigned w[2 * NV];
   if (fmt) {
-    const __amdgpu_buffer_rsrc_t rs = ghost_sector_rsrc<T>(zone, faceCB);
+    const __amdgpu_buffer_rsrc_t rs = ghost_atom_rsrc<T>(zone, faceCB);
     unsigned long long t0 = 0;
     for (;;) {
       unsigned sy = flag, sw = flag; int sv = -1;
-      if (ghost_sector_read<T>(w, rs, faceCB, f, flag, sy, sw, sv)) break;
+      if (ghost_atom_read<T>(w, rs, faceCB, f, flag, sy, sw, sv)) break;
       if (!t0) t0 = wall_clock64();
       else if (__hip_atomic_load(errWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
       else if (wall_clock64() - t0 > ticks) {
@@ -621,7 +630,10 @@ template <typename T, bool PRETWIST, bool P2P, typename real> __device__ __force
     default: spin_project<3>(h, psi, s); break;
   }
   char *sb = arg.send[d][to_fwd];
-  if (P2P) ghost_ll_store<T>(h, sb, arg.faceCB[d], f, arg.llFlag[d]);   // straight into the neighbour's zone, flag in the data
+  if (P2P) {   // straight into the neighbour's zone, flag in the data
+    if (arg.llFormat) ghost_atom_store<T>(h, sb, arg.faceCB[d], f, arg.llFlag[d]);
+    else ghost_ll_store<T>(h, sb, arg.faceCB[d], f, arg.llFlag[d]);
+  }
   else Planar<T, 12>::store(h, sb, arg.faceCB[d], f, reinterpret_cast<float *>(sb + arg.normOff[d]), f);
 }
 template <typename T, bool PRETWIST, bool P2P, typename real> __device__ __forceinline__ void pack_body(const PackArg<real> &arg, int bid, int chunk) {
@@ -643,57 +655,6 @@ template <typename T, bool PRETWIST, bool P2P, typename real> __device__ __force
     pack_emit<T, PRETWIST, P2P>(arg, psi, slot, f);
   }
   if (P2P && arg.timeline && threadIdx.x == 0) arg.timeline[1024 + bid] = wall_clock64();
-}
-
-// The pack block of the 32-byte-sector format (ghost_sector_read above): every thread builds the sectors of its face site in LDS —
-// [sector][site of the block][8 words] — and the block then copies them out with 16 bytes per lane, consecutive lanes on consecutive
-// addresses: lanes 2 i and 2 i + 1 of ONE store instruction write the two halves of one sector, and a wave instruction covers 32 whole
-// sectors of consecutive face sites.  Needs chunk * (NS * 32 + 8) bytes of dynamic LDS (launchDslash).
-template <typename T, bool PRETWIST, typename real> __device__ __forceinline__ void pack_body_sector(const PackArg<real> &arg, int bid, int chunk) {
-  constexpr int NV = GhostLL<T>::NV, NS = GhostLL<T>::NS;
-  extern __shared__ __attribute__((aligned(16))) unsigned char pack_lds[];
-  u32x4_t *sec = reinterpret_cast<u32x4_t *>(pack_lds);                                  // [NS][chunk][2]
-  int2 *meta = reinterpret_cast<int2 *>(pack_lds + (size_t)NS * chunk * 32);            // (slot, face index) per site, slot < 0: none
-  const int t = (int)threadIdx.x;
-  const int tid = t < chunk ? bid * chunk + t : arg.start[8];
-  if (t < chunk) meta[t] = make_int2(-1, 0);
-  if (tid < arg.start[8]) {
-    int slot, f;
-    const int idx = pack_locate(arg, tid, slot, f);
-    real psi[24], h[12];
-    Planar<T, 24>::load(psi, arg.in, arg.sp_stride, idx, arg.inNorm, idx);
-    const int d = slot >> 1, to_fwd = slot & 1;
-    if (PRETWIST) twist_inplace(psi, arg.a);
-    const real sgn = to_fwd ? -arg.sfwd : arg.sfwd;
-    switch (d) {
-      case 0: spin_project<0>(h, psi, sgn); break;
-      case 1: spin_project<1>(h, psi, sgn); break;
-      case 2: spin_project<2>(h, psi, sgn); break;
-      default: spin_project<3>(h, psi, sgn); break;
-    }
-    unsigned w[2 * NV];
-    GhostLL<T>::encode(w, h);
-    const unsigned flag = arg.llFlag[d];
-#pragma unroll
-    for (int s = 0; s < NS; s++) {
-      u32x4_t q0, q1;
-      if (sizeof(T) == 2) { q0.x = w[0]; q0.y = w[1]; q0.z = w[2]; q0.w = w[3]; q1.x = w[4]; q1.y = w[5]; q1.z = w[6]; q1.w = flag; }
-      else { q0.x = w[6 * s]; q0.y = w[6 * s + 1]; q0.z = w[6 * s + 2]; q0.w = w[6 * s + 3]; q1.x = w[6 * s + 4]; q1.y = w[6 * s + 5]; q1.z = flag; q1.w = flag; }
-      sec[((size_t)s * chunk + t) * 2] = q0;
-      sec[((size_t)s * chunk + t) * 2 + 1] = q1;
-    }
-    meta[t] = make_int2(slot, f);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int s = 0; s < NS; s++)
-    for (int j = t; j < 2 * chunk; j += (int)blockDim.x) {
-      const int2 m = meta[j >> 1];
-      if (m.x < 0) continue;
-      const int d = m.x >> 1;
-      const __amdgpu_buffer_rsrc_t rs = ghost_sector_rsrc<T>(arg.send[d][m.x & 1], arg.faceCB[d]);
-      __builtin_amdgcn_raw_buffer_store_b128(sec[(size_t)s * chunk * 2 + j], rs, m.y * 32 + (j & 1) * 16, s * arg.faceCB[d] * 32, QA_LL_STORE_AUX);
-    }
 }
 
 // VARIANT: 0 = Wilson / twist epilogues, 1 = twist applied to the neighbours first (TWIST_INV_DSLASH), 2 = clover epilogues.
@@ -844,8 +805,7 @@ __global__ void __launch_bounds__(256) dslash_kernel(const DslashArg<typename St
     // ghost words they need and add the off-node hops (stencil_site, KT == 3)
     if (b < arg.packBlocks) {
       if (arg.packPrio) __builtin_amdgcn_s_setprio(3);
-      if (arg.pack.llFormat) pack_body_sector<T, VARIANT == 1>(arg.pack, b, arg.packChunk);
-      else pack_body<T, VARIANT == 1, true>(arg.pack, b, arg.packChunk);
+      pack_body<T, VARIANT == 1, true>(arg.pack, b, arg.packChunk);
       return;
     }
     b -= arg.packBlocks;
@@ -1695,14 +1655,15 @@ DslashTune &dslashTune() {
     t.lds_pad = env("QUDA_AMD_DSLASH_LDS", 0);
     t.ygroups = env("QUDA_AMD_DSLASH_YGROUPS", -1);
     t.edge_first = env("QUDA_AMD_EDGE_FIRST", 1);
-    { const char *e = getenv("QUDA_AMD_HALO_FORMAT"); t.halo_format = !e ? -1 : ((!strcmp(e, "sector") || !strcmp(e, "line128") || !strcmp(e, "1")) ? 1 : 0); }
+    { const char *e = getenv("QUDA_AMD_HALO_FORMAT"); t.halo_format = !e ? -1 : ((!strcmp(e, "atom") || !strcmp(e, "atom16") || !strcmp(e, "sector") || !strcmp(e, "1")) ? 1 : 0); }
   }
   return t;
 }
-// automatic (-1): the sector format between DEVICES — two thirds of flag-in-data's bytes on the wire (fp64 / fp32; half for 16-bit), and in a 1 x 2 x 2 x 2
-// grid the +mu and -mu neighbour are the same GPU, so both faces of a dimension share one xGMI link: 1.57 MB per link and application in fp64
-// against 1.05 MB, i.e. ~26 against ~17 us at 60 GB/s next to a 20 us interior kernel — and flag-in-data where no link is crossed (ranks sharing a
-// device in a rehearsal, the self-neighbour emulation on one rank), where its packing is 1 us cheaper.  The same on every rank by construction.
+// automatic (-1): the compact atoms between DEVICES — two thirds of flag-in-data's bytes on the wire (fp64 / fp32; three quarters for 16-bit): in a
+// 1 x 2 x 2 x 2 grid the +mu and -mu neighbour are the same GPU, so both faces of a dimension share one xGMI link, 1.57 MB per link and application in
+// fp64 against 1.05 MB, ~26 against ~17 us at 60 GB/s next to a 20 us interior kernel — and flag-in-data where no link is crossed (ranks sharing a device in
+// a rehearsal, the self-neighbour emulation on one rank).  Both formats validate every single store by itself (8-byte halves resp. 16-byte atoms), neither
+// relies on the order in which stores become visible.  The same on every rank by construction.
 int haloWireFormat() {
   const int f = dslashTune().halo_format;
   if (f >= 0) return f ? 1 : 0;
@@ -2064,7 +2025,7 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
       static int foldEnv = -1;
       if (foldEnv < 0) { const char *e = getenv("QUDA_AMD_P2P_FOLD"); foldEnv = e ? atoi(e) : 0; }
       pa.llFormat = haloWireFormat();
-      const int fold = pa.llFormat ? 0 : (tune.p2p_fold >= 0 ? tune.p2p_fold : foldEnv);   // the sector format packs in whole blocks (LDS transpose)
+      const int fold = tune.p2p_fold >= 0 ? tune.p2p_fold : foldEnv;
       const int nbp = nb < 256 ? nb : 256;
       const int share = (nt + nbp - 1) / nbp;
       arg.packShare = 0; arg.packFoldBlocks = 0;
@@ -2079,7 +2040,7 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
         HIP_CHECK(hipStreamSynchronize(cs));
         memset(tl, 0, 16384 * sizeof(unsigned long long));
         pa.timeline = tl; arg.timeline = tl; arg.pack = pa;
-        hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 3>), dim3(arg.packBlocks + nb), dim3(bs), pa.llFormat ? (size_t)bs * (GhostLL<T>::NS * 32 + 8) : 0, cs, arg);
+        hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 3>), dim3(arg.packBlocks + nb), dim3(bs), 0, cs, arg);
         HIP_CHECK(hipStreamSynchronize(cs));
         unsigned long long t0 = ~0ull;
         for (int i = 0; i < 16384; i++) if ((i < 3072 || i >= 4096) && tl[i] && tl[i] < t0) t0 = tl[i];   // 3072..4095 hold placement words
@@ -2115,8 +2076,7 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
     }
     pa.timeline = nullptr; arg.timeline = nullptr;
     arg.pack = pa;
-    const size_t packLds = pa.llFormat ? (size_t)bs * (GhostLL<T>::NS * 32 + 8) : 0;   // LDS transpose of the sector pack blocks
-    hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 3>), dim3(arg.packBlocks + nb), dim3(bs), packLds, cs, arg);
+    hipLaunchKernelGGL((dslash_kernel<T, R, VARIANT, GAUX, 3>), dim3(arg.packBlocks + nb), dim3(bs), 0, cs, arg);
     HIP_CHECK(hipGetLastError());
     return;
   }

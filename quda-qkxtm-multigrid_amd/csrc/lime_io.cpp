@@ -131,13 +131,15 @@ bool scidacIsContainer(const char *fname) {
   return ok;
 }
 
-// vecs[i]: fp32 host field of the LOCAL lattice X, even-odd site order, nReal = 2 nSpin nColor reals per site
-void scidacWriteSpinors(const char *fname, const std::vector<const float *> &vecs, const int X[4], int nSpin, int nColor) {
+// vecs[i]: host field of the LOCAL lattice X in `prec` (fp32 -> 'F' records, fp64 -> 'D' records, as the reference's write_spinor_field picks
+// the file precision from the field, lib/qio_field.cpp:305-314), even-odd site order, nReal = 2 nSpin nColor reals per site
+void scidacWriteSpinorsPrec(const char *fname, const std::vector<const void *> &vecs, QudaPrecision prec, const int X[4], int nSpin, int nColor) {
   const CommGrid &g = commGrid();
   const int nvec = (int)vecs.size(), nReal = 2 * nSpin * nColor;
+  const size_t es = prec == QUDA_DOUBLE_PRECISION ? sizeof(double) : sizeof(float);
   int G[4], off[4];
   for (int d = 0; d < 4; d++) { G[d] = X[d] * g.dims[d]; off[d] = X[d] * g.coords[d]; }
-  const uint64_t gvol = (uint64_t)G[0] * G[1] * G[2] * G[3], siteBytes = (uint64_t)nvec * nReal * sizeof(float);
+  const uint64_t gvol = (uint64_t)G[0] * G[1] * G[2] * G[3], siteBytes = (uint64_t)nvec * nReal * es;
   long dataOffset = 0;
   if (g.rank == 0) {
     FILE *f = fopen(fname, "wb");
@@ -148,8 +150,8 @@ void scidacWriteSpinors(const char *fname, const std::vector<const float *> &vec
     const char *userFile = "Dummy user file XML";
     limeWriteRecord(f, "scidac-file-xml", userFile, strlen(userFile) + 1, false, true);
     snprintf(xml, sizeof(xml), "<?xml version=\"1.0\" encoding=\"UTF-8\"?><scidacRecord><version>1.1</version><date>unknown</date><recordtype>0</recordtype>"
-             "<datatype>QUDA_FNs%dNc%d_ColorSpinorField</datatype><precision>F</precision><colors>%d</colors><spins>%d</spins><typesize>%d</typesize><datacount>%d</datacount></scidacRecord>",
-             nSpin, nColor, nColor, nSpin, (int)(nReal * sizeof(float)), nvec);
+             "<datatype>QUDA_%cNs%dNc%d_ColorSpinorField</datatype><precision>%c</precision><colors>%d</colors><spins>%d</spins><typesize>%d</typesize><datacount>%d</datacount></scidacRecord>",
+             es == 8 ? 'D' : 'F', nSpin, nColor, es == 8 ? 'D' : 'F', nColor, nSpin, (int)(nReal * es), nvec);
     limeWriteRecord(f, "scidac-private-record-xml", xml, strlen(xml) + 1, true, false);
     const char *userRec = "Dummy user record XML for SU(N) field";
     limeWriteRecord(f, "scidac-record-xml", userRec, strlen(userRec) + 1, false, false);
@@ -164,7 +166,8 @@ void scidacWriteSpinors(const char *fname, const std::vector<const float *> &vec
   FILE *f = fopen(fname, "r+b");
   if (!f) errorQuda("cannot reopen %s", fname);
   const long Vh = (long)X[0] * X[1] * X[2] * X[3] / 2;
-  std::vector<float> row((size_t)X[0] * nvec * nReal);
+  const size_t rowReals = (size_t)X[0] * nvec * nReal;
+  std::vector<unsigned char> row(rowReals * es);
   const bool swap = !hostIsBigEndian();
   uint32_t suma = 0, sumb = 0;
   for (int t = 0; t < X[3]; t++)
@@ -173,17 +176,17 @@ void scidacWriteSpinors(const char *fname, const std::vector<const float *> &vec
         for (int x = 0; x < X[0]; x++) {
           const int par = (x + y + z + t) & 1;   // local parity (local extents are even, so it equals the global one)
           const long cb = ((((long)t * X[2] + z) * X[1] + y) * X[0] + x) >> 1;
-          for (int v = 0; v < nvec; v++) memcpy(&row[((size_t)x * nvec + v) * nReal], vecs[v] + ((size_t)par * Vh + cb) * nReal, nReal * sizeof(float));
+          for (int v = 0; v < nvec; v++) memcpy(&row[((size_t)x * nvec + v) * nReal * es], (const unsigned char *)vecs[v] + ((size_t)par * Vh + cb) * nReal * es, nReal * es);
         }
-        if (swap) swap4(row.data(), row.size());
+        if (swap) { if (es == 8) swap8((double *)row.data(), rowReals); else swap4((float *)row.data(), rowReals); }
         const uint64_t rank0 = (((uint64_t)(t + off[3]) * G[2] + (z + off[2])) * G[1] + (y + off[1])) * G[0] + off[0];
         for (int x = 0; x < X[0]; x++) {
-          const uint32_t c = crc32_bytes((const unsigned char *)&row[(size_t)x * nvec * nReal], siteBytes);
+          const uint32_t c = crc32_bytes(&row[(size_t)x * siteBytes], siteBytes);
           const unsigned r29 = (unsigned)((rank0 + x) % 29), r31 = (unsigned)((rank0 + x) % 31);
           suma ^= (c << r29) | (r29 ? c >> (32 - r29) : 0u);
           sumb ^= (c << r31) | (r31 ? c >> (32 - r31) : 0u);
         }
-        if (fseek(f, dataOffset + (long)(rank0 * siteBytes), SEEK_SET) != 0 || fwrite(row.data(), sizeof(float), row.size(), f) != row.size()) errorQuda("short write on %s", fname);
+        if (fseek(f, dataOffset + (long)(rank0 * siteBytes), SEEK_SET) != 0 || fwrite(row.data(), 1, row.size(), f) != row.size()) errorQuda("short write on %s", fname);
       }
   fclose(f);
   xorAllreduce(suma, sumb);
@@ -198,9 +201,13 @@ void scidacWriteSpinors(const char *fname, const std::vector<const float *> &vec
   }
   commBarrier();
 }
+void scidacWriteSpinors(const char *fname, const std::vector<const float *> &vecs, const int X[4], int nSpin, int nColor) {
+  std::vector<const void *> v(vecs.begin(), vecs.end());
+  scidacWriteSpinorsPrec(fname, v, QUDA_SINGLE_PRECISION, X, nSpin, nColor);
+}
 
 // fills vecs[0 .. n-1] (n <= datacount of the file) with this rank's sub-lattice; the file's lattice, site size and checksum are checked
-void scidacReadSpinors(const char *fname, const std::vector<float *> &vecs, const int X[4], int nSpin, int nColor) {
+void scidacReadSpinorsPrec(const char *fname, const std::vector<void *> &vecs, QudaPrecision memPrec, const int X[4], int nSpin, int nColor) {
   const CommGrid &g = commGrid();
   const int nvec = (int)vecs.size(), nReal = 2 * nSpin * nColor;
   int G[4], off[4];
@@ -235,36 +242,50 @@ void scidacReadSpinors(const char *fname, const std::vector<float *> &vecs, cons
   }
   if (payload < 0) errorQuda("%s: no scidac-binary-data record", fname);
   for (int d = 0; d < 4; d++) if (fd[d] != G[d]) errorQuda("%s holds a %d x %d x %d x %d lattice, this run has %d x %d x %d x %d", fname, fd[0], fd[1], fd[2], fd[3], G[0], G[1], G[2], G[3]);
-  if (prec != 'F' || typesize != (int)(nReal * sizeof(float))) errorQuda("%s: records of precision %c with %d bytes per site and vector (this level needs fp32, %d bytes)", fname, prec ? prec : '?', typesize, (int)(nReal * sizeof(float)));
+  // the file's precision comes from its record description, as the reference's read_field takes it (lib/qio_field.cpp:73-125): 'F' or 'D'
+  if ((prec != 'F' && prec != 'D') || typesize != (int)(nReal * (prec == 'D' ? sizeof(double) : sizeof(float))))
+    errorQuda("%s: records of precision %c with %d bytes per site and vector (expected F with %d or D with %d bytes)", fname, prec ? prec : '?', typesize, (int)(nReal * sizeof(float)), (int)(nReal * sizeof(double)));
+  const size_t es = prec == 'D' ? sizeof(double) : sizeof(float), ms = memPrec == QUDA_DOUBLE_PRECISION ? sizeof(double) : sizeof(float);
   if (fileCount < nvec) errorQuda("%s holds %d vectors, %d are needed", fname, fileCount, nvec);
   if (fileCount > nvec) warningQuda("%s holds %d vectors, this level uses the first %d", fname, fileCount, nvec);
-  const uint64_t siteBytes = (uint64_t)fileCount * nReal * sizeof(float);
+  const uint64_t siteBytes = (uint64_t)fileCount * nReal * es;
   const long Vh = (long)X[0] * X[1] * X[2] * X[3] / 2;
-  std::vector<float> row((size_t)X[0] * fileCount * nReal);
+  const size_t rowReals = (size_t)X[0] * fileCount * nReal;
+  std::vector<unsigned char> row(rowReals * es);
   const bool swap = !hostIsBigEndian();
   uint32_t suma = 0, sumb = 0;
   for (int t = 0; t < X[3]; t++)
     for (int z = 0; z < X[2]; z++)
       for (int y = 0; y < X[1]; y++) {
         const uint64_t rank0 = (((uint64_t)(t + off[3]) * G[2] + (z + off[2])) * G[1] + (y + off[1])) * G[0] + off[0];
-        if (fseek(f, payload + (long)(rank0 * siteBytes), SEEK_SET) != 0 || fread(row.data(), sizeof(float), row.size(), f) != row.size()) errorQuda("short read on %s", fname);
+        if (fseek(f, payload + (long)(rank0 * siteBytes), SEEK_SET) != 0 || fread(row.data(), 1, row.size(), f) != row.size()) errorQuda("short read on %s", fname);
         for (int x = 0; x < X[0]; x++) {
-          const uint32_t c = crc32_bytes((const unsigned char *)&row[(size_t)x * fileCount * nReal], siteBytes);
+          const uint32_t c = crc32_bytes(&row[(size_t)x * siteBytes], siteBytes);
           const unsigned r29 = (unsigned)((rank0 + x) % 29), r31 = (unsigned)((rank0 + x) % 31);
           suma ^= (c << r29) | (r29 ? c >> (32 - r29) : 0u);
           sumb ^= (c << r31) | (r31 ? c >> (32 - r31) : 0u);
         }
-        if (swap) swap4(row.data(), row.size());
+        if (swap) { if (es == 8) swap8((double *)row.data(), rowReals); else swap4((float *)row.data(), rowReals); }
         for (int x = 0; x < X[0]; x++) {
           const int par = (x + y + z + t) & 1;
           const long cb = ((((long)t * X[2] + z) * X[1] + y) * X[0] + x) >> 1;
-          for (int v = 0; v < nvec; v++) memcpy(vecs[v] + ((size_t)par * Vh + cb) * nReal, &row[((size_t)x * fileCount + v) * nReal], nReal * sizeof(float));
+          for (int v = 0; v < nvec; v++) {
+            const unsigned char *src = &row[((size_t)x * fileCount + v) * nReal * es];
+            unsigned char *dst = (unsigned char *)vecs[v] + ((size_t)par * Vh + cb) * nReal * ms;
+            if (es == ms) memcpy(dst, src, nReal * es);
+            else if (es == 8) for (int k = 0; k < nReal; k++) ((float *)dst)[k] = (float)((const double *)src)[k];
+            else for (int k = 0; k < nReal; k++) ((double *)dst)[k] = (double)((const float *)src)[k];
+          }
         }
       }
   fclose(f);
   xorAllreduce(suma, sumb);
   if (haveSum && (suma != wantA || sumb != wantB)) errorQuda("%s: checksum mismatch (file %x %x, data %x %x)", fname, wantA, wantB, suma, sumb);
   if (!haveSum) warningQuda("%s carries no scidac-checksum record", fname);
+}
+void scidacReadSpinors(const char *fname, const std::vector<float *> &vecs, const int X[4], int nSpin, int nColor) {
+  std::vector<void *> v(vecs.begin(), vecs.end());
+  scidacReadSpinorsPrec(fname, v, QUDA_SINGLE_PRECISION, X, nSpin, nColor);
 }
 
 }  // namespace quda
@@ -277,30 +298,13 @@ extern "C" {
 // local lattice X in even-odd site order, 2 nSpin nColor reals per site, fp32 or fp64 in memory; fp32 in the file
 void qudaAmdWriteSpinorFields(const char *filename, void *V[], QudaPrecision precision, const int *X, int nColor, int nSpin, int Nvec) {
   if (precision != QUDA_DOUBLE_PRECISION && precision != QUDA_SINGLE_PRECISION) errorQuda("Error, file_prec=%d not supported", precision);
-  const size_t n = (size_t)X[0] * X[1] * X[2] * X[3] * 2 * nSpin * nColor;
-  std::vector<std::vector<float>> tmp;
-  std::vector<const float *> ptrs(Nvec);
-  for (int i = 0; i < Nvec; i++) {
-    if (precision == QUDA_SINGLE_PRECISION) { ptrs[i] = (const float *)V[i]; continue; }
-    tmp.emplace_back(n);
-    const double *d = (const double *)V[i];
-    for (size_t k = 0; k < n; k++) tmp.back()[k] = (float)d[k];
-    ptrs[i] = tmp.back().data();
-  }
-  scidacWriteSpinors(filename, ptrs, X, nSpin, nColor);
+  std::vector<const void *> ptrs(V, V + Nvec);
+  scidacWriteSpinorsPrec(filename, ptrs, precision, X, nSpin, nColor);   // fp64 fields -> 'D' records (QUDA_DNs..), fp32 -> 'F'
 }
 void qudaAmdReadSpinorFields(const char *filename, void *V[], QudaPrecision precision, const int *X, int nColor, int nSpin, int Nvec) {
   if (precision != QUDA_DOUBLE_PRECISION && precision != QUDA_SINGLE_PRECISION) errorQuda("Error, cpu precision %d not supported", precision);
-  const size_t n = (size_t)X[0] * X[1] * X[2] * X[3] * 2 * nSpin * nColor;
-  std::vector<std::vector<float>> tmp(precision == QUDA_DOUBLE_PRECISION ? Nvec : 0);
-  std::vector<float *> ptrs(Nvec);
-  for (int i = 0; i < Nvec; i++) {
-    if (precision == QUDA_SINGLE_PRECISION) ptrs[i] = (float *)V[i];
-    else { tmp[i].resize(n); ptrs[i] = tmp[i].data(); }
-  }
-  scidacReadSpinors(filename, ptrs, X, nSpin, nColor);
-  if (precision == QUDA_DOUBLE_PRECISION)
-    for (int i = 0; i < Nvec; i++) { double *d = (double *)V[i]; for (size_t k = 0; k < n; k++) d[k] = (double)tmp[i][k]; }
+  std::vector<void *> ptrs(V, V + Nvec);
+  scidacReadSpinorsPrec(filename, ptrs, precision, X, nSpin, nColor);     // the record's precision ('F' or 'D') is converted to the caller's
 }
 
 

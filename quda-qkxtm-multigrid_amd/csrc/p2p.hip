@@ -154,16 +154,13 @@ __global__ void p2p_probe_send(ProbeWindow *const *peer, int rank, int round) {
     probe_u32x4 q; q.x = probe_token(rank, s, v, round); q.y = 0xf1a60000u + round; q.z = ~probe_token(rank, s, v, round); q.w = 0xf1a60000u + round;
     __builtin_amdgcn_raw_buffer_store_b128(q, rs, v * 16, 0, 17);
   }
-  // the 32-byte-sector format (dslash.hip ghost_sector_read): 6 payload words + the flag twice, the two 16-byte halves of a sector
-  // written by two ADJACENT lanes of one store instruction (16 lanes of slot s = 8 sectors per instruction, 4 instructions)
+  // the compact format (dslash.hip ghost_atom_store): self-validating 16-byte atoms {3 payload words, flag}, each one 16-byte store of one lane
   for (int v4 = 0; v4 < 4; v4++) {
-    const int sct = v4 * 8 + (k >> 1), half = k & 1;
+    const int at = v4 * 16 + k;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)w->sec[s], 0, (int)sizeof(w->sec[s]), 0x00020000);
-    const unsigned tk = probe_token(rank, s, sct, round);
-    probe_u32x4 q;
-    if (!half) { q.x = tk; q.y = ~tk; q.z = tk + 1u; q.w = tk + 2u; }
-    else { q.x = tk + 3u; q.y = tk + 4u; q.z = 0x5ec70000u + round; q.w = 0x5ec70000u + round; }
-    __builtin_amdgcn_raw_buffer_store_b128(q, rs, sct * 32 + half * 16, 0, 17);
+    const unsigned tk = probe_token(rank, s, at, round);
+    probe_u32x4 q; q.x = tk; q.y = ~tk; q.z = tk + 1u; q.w = 0x5ec70000u + round;
+    __builtin_amdgcn_raw_buffer_store_b128(q, rs, at * 16, 0, 17);
   }
 }
 __global__ void p2p_probe_recv(ProbeWindow *mine, const int *fromRank, unsigned long long ticks, int *result, int round) {
@@ -189,11 +186,11 @@ __global__ void p2p_probe_recv(ProbeWindow *mine, const int *fromRank, unsigned 
     }
   }
   const __amdgpu_buffer_rsrc_t rsec = __builtin_amdgcn_make_buffer_rsrc((void *)mine->sec[s], 0, (int)sizeof(mine->sec[s]), 0x00020000);
-  for (int v = 0; v < 32 && ok; v++) {
+  for (int v = 0; v < 64 && ok; v++) {
     const unsigned flag = 0x5ec70000u + round, tk = probe_token(fromRank[s], s, v, round);
     for (;;) {
-      const probe_u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rsec, v * 32, 0, 17), q1 = __builtin_amdgcn_raw_buffer_load_b128(rsec, v * 32 + 16, 0, 17);
-      if (q1.z == flag && q1.w == flag) { ok = q0.x == tk && q0.y == ~tk && q0.z == tk + 1u && q0.w == tk + 2u && q1.x == tk + 3u && q1.y == tk + 4u; break; }
+      const probe_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsec, v * 16, 0, 17);
+      if (q.w == flag) { ok = q.x == tk && q.y == ~tk && q.z == tk + 1u; break; }
       if (wall_clock64() - t0 > ticks) { ok = false; break; }
       __builtin_amdgcn_s_sleep(1);
     }

@@ -296,14 +296,14 @@ def test_twisted_clover_at_full_size_against_the_oracle(qa, oracle):
             assert qc.rel_err(qa.mat(x_h.copy(), ip), want_m) < 2 * TOL[prec], prec
 
 
-@pytest.mark.parametrize("fmt", [0, 1], ids=["flag-in-data", "sectors-128B-line"])
+@pytest.mark.parametrize("fmt", [0, 1], ids=["flag-in-data", "atoms-16B"])
 @pytest.mark.parametrize("mask", [1, 2, 4, 8, 6, 9, 15])
 def test_partitioned_dslash_self_neighbour(qa, mask, fmt):
     """The reference's own way of testing the halo path without a cluster (tests/test_util.cpp:2047-2065 --partition):
     a single process treats dimension d as partitioned and talks to itself — pack kernel, ghost-zone exchange,
     interior + exterior kernels — and must reproduce the golden vectors exactly like the unpartitioned kernel.
-    fmt: wire format of the peer-store ghost zones — flag-in-data 16-byte vectors, or 32-byte sectors with a flag each (one 128-byte
-    line per fp64 face site), selected at run time through the tune key the environment variable sets."""
+    fmt: wire format of the peer-store ghost zones — flag-in-data {word, flag, word, flag} vectors, or self-validating 16-byte atoms {3 words, flag} (one 128-byte
+    line per fp64 face site; ADVICE r3: every 16 bytes validate themselves), selected at run time through the tune key the environment variable sets."""
     qa.lib().qudaAmdSetDslashTune(b"halo_format", fmt)
     z, X, kappa, mu, gauge = qc.load(qc.FILES[1])  # 6x4x2x8: includes an extent-2 dimension
     names = ["wil_dslash_p0_d0", "wil_dslash_p1_d1", "tm_dslash_fp_ee_d0_p0", "tm_dslash_fm_oo_d1_p0", "tm_dslash_fp_ee_d1_p0",
@@ -324,7 +324,7 @@ def test_partitioned_dslash_self_neighbour(qa, mask, fmt):
 
 
 @pytest.mark.parametrize("X", [(32, 16, 16, 16), (32, 16, 16, 32)], ids=["32^4-over-8", "configs3-32^3x64-over-8"])
-@pytest.mark.parametrize("fmt", [0, 1], ids=["flag-in-data", "sectors-128B-line"])
+@pytest.mark.parametrize("fmt", [0, 1], ids=["flag-in-data", "atoms-16B"])
 def test_partitioned_dslash_at_the_8gpu_sublattice(qa, oracle, fmt, X):
     """the local lattice of an 8-GPU split (grid 1 x 2 x 2 x 2, y z t partitioned) of 32^4 (32 x 16 x 16 x 16) and of BASELINE configs[3],
     32^3 x 64 (32 x 16 x 16 x 32): many pack blocks, faces of different sizes, pack blocks that straddle two (dimension, direction)

@@ -149,3 +149,47 @@ def test_scidac_vector_file_records_and_round_trip(qa, tmp_path, X, nspin, ncolo
     qa.lib().qudaAmdReadSpinorFields(path, bptrs, 8, Xc, ncolor, nspin, nvec - 1)
     for v in range(nvec - 1):
         assert np.array_equal(back[v], fields[v].astype(np.float64))
+
+
+def test_scidac_double_precision_records(qa, tmp_path):
+    """fp64 fields are written as 'D' records (datatype QUDA_DNs.., typesize 8 * reals: reference lib/qio_field.cpp:305-314) and a 'D' file
+    — also one assembled here byte by byte — loads into fp32 or fp64 memory (the file's precision comes from its record, :73-125)"""
+    import ctypes as C
+    X, nspin, ncolor, nvec = (4, 4, 2, 4), 4, 3, 2
+    nreal = 2 * nspin * ncolor
+    V = int(np.prod(X))
+    fields32, lex, eo = _vectors(X, nvec, nreal, 0.25)
+    fields = [f.astype(np.float64) + 1e-9 * (1 + i) for i, f in enumerate(fields32)]   # not representable in fp32
+    path = str(tmp_path / "dvecs").encode()
+    Xc = (C.c_int * 4)(*X)
+    ptrs = (C.c_void_p * nvec)(*[f.ctypes.data for f in fields])
+    qa.lib().qudaAmdWriteSpinorFields(path, ptrs, 8, Xc, ncolor, nspin, nvec)
+    recs = _walk(open(path, "rb").read())
+    assert ("<datatype>QUDA_DNs%dNc%d_ColorSpinorField</datatype><precision>D</precision><colors>%d</colors><spins>%d</spins><typesize>%d</typesize><datacount>%d</datacount>"
+            % (nspin, ncolor, ncolor, nspin, 8 * nreal, nvec)).encode() in recs[2][1]
+    want = np.zeros((V, nvec, nreal), dtype=">f8")
+    for v in range(nvec):
+        want[lex, v] = fields[v][eo]
+    assert recs[4][1] == want.tobytes()
+    back = [np.zeros((V, nreal)) for _ in range(nvec)]
+    bptrs = (C.c_void_p * nvec)(*[f.ctypes.data for f in back])
+    qa.lib().qudaAmdReadSpinorFields(path, bptrs, 8, Xc, ncolor, nspin, nvec)
+    for v in range(nvec):
+        assert np.array_equal(back[v], fields[v])          # bit-exact in fp64
+    back32 = [np.zeros((V, nreal), dtype=np.float32) for _ in range(nvec)]
+    bptrs = (C.c_void_p * nvec)(*[f.ctypes.data for f in back32])
+    qa.lib().qudaAmdReadSpinorFields(path, bptrs, 4, Xc, ncolor, nspin, nvec)
+    for v in range(nvec):
+        assert np.array_equal(back32[v], fields[v].astype(np.float32))
+    # the same file put together here from the format description, without the library's writer
+    hand = str(tmp_path / "dvecs_by_hand").encode()
+    with open(hand, "wb") as f:
+        for name, data, mb, me in [("scidac-private-file-xml", recs[0][1], True, False), ("scidac-file-xml", b"user\0", False, True),
+                                   ("scidac-private-record-xml", recs[2][1], True, False), ("scidac-record-xml", b"rec\0", False, False),
+                                   ("scidac-binary-data", want.tobytes(), False, False), ("scidac-checksum", recs[5][1], False, True)]:
+            f.write(lime_record(name, data, mb, me))
+    back = [np.zeros((V, nreal)) for _ in range(nvec)]
+    bptrs = (C.c_void_p * nvec)(*[f.ctypes.data for f in back])
+    qa.lib().qudaAmdReadSpinorFields(hand, bptrs, 8, Xc, ncolor, nspin, nvec)
+    for v in range(nvec):
+        assert np.array_equal(back[v], fields[v])
