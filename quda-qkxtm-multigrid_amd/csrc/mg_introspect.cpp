@@ -157,7 +157,7 @@ void qudaAmdMultigridGetCoarseLinks(void *mg_instance, int level, float *h_Y, fl
 void qudaAmdMultigridApply(void *mg_instance, int level, int op, float *h_out, const float *h_in) {
   MG *m = levelOf(mg_instance, level);
   const Transfer *T = m->getTransfer();
-  if (op != 2 && !T) errorQuda("level %d is the coarsest level: no transfer", level);
+  if (op < 2 && !T) errorQuda("level %d is the coarsest level: no transfer", level);
   ColorSpinorField *fin = nullptr, *fout = nullptr;
   const ColorSpinorField &proto = *m->nullVectors()[0];
   auto fine = [&]() { ColorSpinorParam p = proto.param(); p.create = QUDA_ZERO_FIELD_CREATE; return new ColorSpinorField(p); };

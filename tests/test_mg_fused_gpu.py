@@ -26,8 +26,8 @@ BLOCKS3 = [(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)]
 
 
 @pytest.mark.parametrize("mask", [0, 14, 15, 9], ids=["unpartitioned", "self-neighbour-yzt", "self-neighbour-xyzt", "self-neighbour-xt"])
-@pytest.mark.parametrize("X,levels,blocks,nvec", [((16, 8, 8, 16), 3, BLOCKS3, 8), ((16, 16, 16, 16), 3, BLOCKS3, 24), ((8, 8, 8, 16), 2, (4, 4, 4, 4), 16)],
-                         ids=["3-levels-n16", "3-levels-n48", "2-levels-n32"])
+@pytest.mark.parametrize("X,levels,blocks,nvec", [((16, 8, 8, 16), 3, BLOCKS3, 8), ((16, 16, 16, 16), 3, BLOCKS3, 24), ((8, 8, 8, 16), 2, (4, 4, 4, 4), 32)],
+                         ids=["3-levels-n16", "3-levels-n48", "2-levels-n64"])
 def test_fused_coarse_cycle_matches_the_kernel_per_operation_path(qa, oracle, X, levels, blocks, nvec, mask):
     kappa, mu = 0.124, 0.005
     qa.lib().qudaAmdSetPartitionMask(mask)
@@ -99,11 +99,11 @@ def test_fused_cycle_falls_back_when_its_first_use_check_fails(qa, oracle, monke
 def test_fused_coarsest_gcr_through_restarts(qa, oracle, mask):
     """a tight coarsest-grid tolerance drives the in-kernel GCR through full Krylov spaces, restarts and true-residual updates (reference
     lib/inv_gcr_quda.cpp:300-470): same solution as the host-driven GCR of the kernel-per-operation path"""
-    X, kappa, mu, nvec = (8, 8, 8, 16), 0.124, 0.005, 16
+    X, kappa, mu, nvec = (8, 8, 8, 16), 0.124, 0.005, 8
     qa.lib().qudaAmdSetPartitionMask(mask)
     try:
         gauge, ip = _setup(qa, X, kappa, mu)
-        mp = qa.multigrid_param(ip, n_level=2, geo_block=(4, 4, 4, 4), n_vec=nvec, setup_maxiter=300, setup_tol=1e-5, smoother_pc=True, cycle=qa.QUDA_MG_CYCLE_VCYCLE, smoother_tol=1e-6)
+        mp = qa.multigrid_param(ip, n_level=2, geo_block=(4, 4, 4, 4), n_vec=nvec, setup_maxiter=300, setup_tol=1e-5, smoother_pc=True, cycle=qa.QUDA_MG_CYCLE_VCYCLE, smoother_tol=1e-9)
         mg = qa.Multigrid(mp)
         try:
             Vc = int(np.prod(mg.level_info(0)["Xc"]))
@@ -119,7 +119,7 @@ def test_fused_coarsest_gcr_through_restarts(qa, oracle, mask):
             # both are solutions of the coarsest system to 1e-6: compare through the operator, |M x - b| / |b|
             for x in (got, want):
                 r = mg.apply(1, "M", x) - bc
-                assert np.linalg.norm(r) < 5e-6 * np.linalg.norm(bc), (np.linalg.norm(r) / np.linalg.norm(bc), st)
+                assert np.linalg.norm(r) < 1e-5 * np.linalg.norm(bc), (np.linalg.norm(r) / np.linalg.norm(bc), st)
             assert np.linalg.norm(got - want) < 1e-4 * np.linalg.norm(want), st
             print("fused coarsest GCR mask %d: %s" % (mask, st))
         finally:

@@ -667,3 +667,65 @@ def test_opt_in_xy_tile_of_the_multi_rhs_stencil():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fine_block_xy_check.py")], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, QUDA_AMD_BLOCK_FINE_XYTILE="1"))
     assert r.returncode == 0 and "XYCHECK ok" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_hierarchy_from_a_scidac_vector_file_built_by_hand(qa, oracle, tmp_path):
+    """f4 (reference MG::loadVectors -> read_spinor_field, lib/multigrid.cpp:639-691, lib/qio_field.cpp:198-260): the null vectors arrive in a
+    SciDAC / QIO single-file container that THIS TEST assembles byte by byte from the format description — LIME records (144-byte
+    big-endian headers, data padded to 8 bytes), one field record with datacount = Nvec, global lexicographic sites, per site vector 0 ..
+    Nvec-1, big-endian fp32, QIO's rotated-CRC checksum pair — not with the library's writer.  The hierarchy built from it (compute_null_vector
+    = NO) must restrict and prolongate like the oracle's R / P (lib/restrictor.cu:51-125, lib/prolongator.cu:42-116) built from the SAME
+    vectors through the oracle's block Gram-Schmidt (lib/transfer_util.cu:328-363)."""
+    import struct
+    import zlib
+    X, kappa, mu, nvec, bs = (8, 8, 8, 8), 0.124, 0.005, 8, (4, 4, 4, 4)
+    _, ip = _setup(qa, X, kappa, mu)
+    V4 = int(np.prod(X))
+    rng = np.random.default_rng(91)
+    B = [(rng.standard_normal((V4, 4, 3)) + 1j * rng.standard_normal((V4, 4, 3))).astype(np.complex64) for _ in range(nvec)]   # even-odd host order
+    c = np.indices(X[::-1]).reshape(4, -1)[::-1]
+    lex = ((c[3] * X[2] + c[2]) * X[1] + c[1]) * X[0] + c[0]
+    eo = ((c[0] + c[1] + c[2] + c[3]) & 1) * (V4 // 2) + lex // 2
+    payload = np.zeros((V4, nvec, 24), dtype=">f4")
+    for v in range(nvec):
+        payload[lex, v] = B[v].reshape(V4, 12).view(np.float32).reshape(V4, 24)[eo]
+    suma = sumb = 0
+    for s in range(V4):
+        crc = zlib.crc32(payload[s].tobytes()) & 0xFFFFFFFF
+        r29, r31 = s % 29, s % 31
+        suma ^= ((crc << r29) | (crc >> (32 - r29))) & 0xFFFFFFFF
+        sumb ^= ((crc << r31) | (crc >> (32 - r31))) & 0xFFFFFFFF
+
+    def rec(rtype, data, mb, me):
+        head = struct.pack(">IHHQ", 0x456789AB, 1, (0x8000 if mb else 0) | (0x4000 if me else 0), len(data)) + rtype.encode().ljust(128, b"\0")
+        return head + data + b"\0" * (-len(data) % 8)
+
+    blob = (rec("scidac-private-file-xml", ("<?xml version=\"1.0\" encoding=\"UTF-8\"?><scidacFile><version>1.1</version><spacetime>4</spacetime><dims>%d %d %d %d </dims><volfmt>0</volfmt></scidacFile>" % X).encode() + b"\0", True, False)
+            + rec("scidac-file-xml", b"assembled by tests/test_mg_gpu.py\0", False, True)
+            + rec("scidac-private-record-xml", ("<?xml version=\"1.0\" encoding=\"UTF-8\"?><scidacRecord><version>1.1</version><date>today</date><recordtype>0</recordtype><datatype>QUDA_FNs4Nc3_ColorSpinorField</datatype>"
+                                               "<precision>F</precision><colors>3</colors><spins>4</spins><typesize>96</typesize><datacount>%d</datacount></scidacRecord>" % nvec).encode() + b"\0", True, False)
+            + rec("scidac-record-xml", b"null vectors\0", False, False)
+            + rec("scidac-binary-data", payload.tobytes(), False, False)
+            + rec("scidac-checksum", ("<?xml version=\"1.0\" encoding=\"UTF-8\"?><scidacChecksum><version>1.0</version><suma>%x</suma><sumb>%x</sumb></scidacChecksum>" % (suma, sumb)).encode() + b"\0", False, True))
+    base = str(tmp_path / "handmade")
+    with open(base + "_level_0", "wb") as f:
+        f.write(blob)
+    mp = qa.multigrid_param(ip, n_level=2, geo_block=bs, n_vec=nvec)
+    mp.compute_null_vector = qa.QUDA_COMPUTE_NULL_VECTOR_NO
+    mp.vec_infile = base.encode()
+    mg = qa.Multigrid(mp)
+    try:
+        for k in range(nvec):   # the device holds exactly the vectors of the file
+            assert np.array_equal(mg.null_vector(0, k).reshape(V4, 4, 3), B[k]), k
+        Bd = np.stack([b.astype(np.complex128) for b in B], axis=-1)
+        Vo = oracle.mg_block_orthogonalize(Bd, list(X), list(bs), 4, 3, nvec, 2)
+        Vc = V4 // int(np.prod(bs))
+        fine = (rng.standard_normal((V4, 4, 3)) + 1j * rng.standard_normal((V4, 4, 3))).astype(np.complex64)
+        coarse = (rng.standard_normal((Vc, 2, nvec)) + 1j * rng.standard_normal((Vc, 2, nvec))).astype(np.complex64)
+        r_dev, p_dev = mg.apply(0, "R", fine), mg.apply(0, "P", coarse)
+        r_ref = oracle.mg_restrict(fine.astype(np.complex128), Vo, list(X), list(bs), 4, 3, nvec, 2)
+        p_ref = oracle.mg_prolongate(coarse.astype(np.complex128), Vo, list(X), list(bs), 4, 3, nvec, 2)
+        assert float(np.max(np.abs(r_dev.reshape(r_ref.shape) - r_ref)) / np.max(np.abs(r_ref))) < 2e-5
+        assert float(np.max(np.abs(p_dev.reshape(p_ref.shape) - p_ref)) / np.max(np.abs(p_ref))) < 2e-5
+    finally:
+        mg.free()
