@@ -123,6 +123,14 @@ double qudaAmdMultigridTimeApply(void *mg_instance, int level, int niter);
  * `level` owns such a kernel and fills out[] with the last launch's device-wide barriers, coarsest-grid GCR iterations, its restarts,
  * halo exchanges and the grid size. */
 void qudaAmdMultigridSetFused(int on);
+/* Launch-parameter cache (include/tune.h; reference lib/tune.cpp:213-355): tunecache.tsv under QUDA_RESOURCE_PATH in the reference's text
+ * format.  Load re-reads the file and returns the number of entries; Store / Lookup address one entry by the reference's key triple,
+ * param = block.x y z, grid.x y z, shared_bytes, aux.x y z w; Sweeps = sweeps this process has run (0 when everything came from the file). */
+int qudaAmdTuneCacheLoad(void);
+void qudaAmdTuneCacheSave(void);
+void qudaAmdTuneCacheStore(const char *volume, const char *name, const char *aux, const int param[11], float time, const char *comment);
+int qudaAmdTuneCacheLookup(const char *volume, const char *name, const char *aux, int param[11], float *time);
+long qudaAmdTuneSweeps(void);
 int qudaAmdMultigridFusedStats(void *mg_instance, int level, long long out[5]);
 /* seconds per application of the restrictor (what = 0) or prolongator (what = 1) between `level` and `level + 1` */
 double qudaAmdMultigridTimeTransfer(void *mg_instance, int level, int what, int niter);

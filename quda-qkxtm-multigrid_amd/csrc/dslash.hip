@@ -29,6 +29,7 @@
 #include "device_io.h"
 #include "halo.h"
 #include "block.h"
+#include "tune.h"
 
 namespace quda {
 
@@ -1816,6 +1817,79 @@ template <typename T, int R, int VARIANT, int GAUX, typename Arg> static void la
   HIP_CHECK(hipGetLastError());
 }
 
+// ---- launch-parameter sweep (tune.h) ----
+static const DslashTune *g_sweepTune = nullptr;   // candidate being timed: launchDslash takes its knobs from here and leaves the cache alone
+static TuneKey dslashTuneKey(const LatticeGeom &g, int precBytes, int recon, int variant, const DslashParam &p, int pmask) {
+  char vol[32], aux[256];
+  snprintf(vol, sizeof(vol), "%dx%dx%dx%d", g.X[0], g.X[1], g.X[2], g.X[3]);
+  snprintf(aux, sizeof(aux), "prec=%d,recon=%d,mode=%d,xpay=%d,dagger=%d,comm=%d%d%d%d", precBytes, recon, (int)p.mode, p.x ? 1 : 0, p.dagger ? 1 : 0, pmask & 1, (pmask >> 1) & 1, (pmask >> 2) & 1,
+           (pmask >> 3) & 1);
+  return TuneKey(vol, variant == 2 ? "dslash_kernel<clover>" : (variant == 1 ? "dslash_kernel<twist-first>" : "dslash_kernel"), aux);
+}
+template <typename T, int R, int VARIANT>
+static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, const DslashParam &p);
+// Times the candidate knob settings of one key INTERLEAVED (A B C ... three rounds, minimum per candidate: consecutive runs of one candidate
+// share the device's placement / clock state, tools/policy_interleaved.sh) with device events on the compute stream and stores the fastest.
+// Every launch is the caller's own application (`out` is simply produced several times); on a grid-decomposed lattice every rank runs the
+// same number of launches, so the exchanges pair up.
+template <typename T, int R, int VARIANT>
+static void sweepDslash(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, const DslashParam &p, const TuneKey &key, int pmask) {
+  std::vector<DslashTune> cand;
+  const DslashTune &user = dslashTune();
+  const LatticeGeom &g = U.geom;
+  for (int yg : {1, 2})
+    for (int st : {0, 2})
+      for (int lk : {0, 2})
+        for (int ef : {1, 0}) {
+          if (user.ygroups >= 0 && yg != (user.ygroups > 1 ? user.ygroups : 1)) continue;
+          if (user.store_aux >= 0 && st != user.store_aux) continue;
+          if ((sizeof(T) != 2 || pmask) && lk != 0) continue;                 // the link policy is a knob of the 16-bit unpartitioned kernel only
+          if (sizeof(T) == 2 && user.link_aux >= 0 && lk != user.link_aux) continue;
+          if (pmask && (st != 0 || yg != 1)) continue;                       // partitioned launch: boundary-first or interior-first order
+          if (!pmask && ef != 1) continue;
+          DslashTune t;
+          t.ygroups = yg; t.store_aux = st; t.link_aux = sizeof(T) == 2 && !pmask ? lk : -1; t.edge_first = pmask ? ef : -1;
+          cand.push_back(t);
+        }
+  if (cand.empty()) return;
+  const int reps = 10, rounds = 3;
+  std::vector<float> best(cand.size(), 1e30f);
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+  hipStream_t cs = computeStream();
+  for (int round = 0; round < rounds; round++)
+    for (size_t c = 0; c < cand.size(); c++) {
+      g_sweepTune = &cand[c];
+      launchDslash<T, R, VARIANT>(out, in, U, p);   // warm-up of this candidate
+      HIP_CHECK(hipEventRecord(e0, cs));
+      for (int i = 0; i < reps; i++) launchDslash<T, R, VARIANT>(out, in, U, p);
+      HIP_CHECK(hipEventRecord(e1, cs));
+      HIP_CHECK(hipEventSynchronize(e1));
+      float ms = 0;
+      HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+      best[c] = std::min(best[c], ms / reps);
+    }
+  g_sweepTune = nullptr;
+  HIP_CHECK(hipEventDestroy(e0)); HIP_CHECK(hipEventDestroy(e1));
+  size_t w = 0;
+  for (size_t c = 1; c < cand.size(); c++) if (best[c] < best[w]) w = c;
+  TuneParam tp;
+  const int plane = g.Xh * g.X[1];
+  int bs = 256;
+  for (int c : {256, 192, 128, 64}) if (plane % c == 0) { bs = c; break; }
+  tp.block[0] = bs; tp.grid[0] = (g.Vh + bs - 1) / bs;
+  tp.aux[0] = cand[w].ygroups; tp.aux[1] = cand[w].link_aux < 0 ? 0 : cand[w].link_aux; tp.aux[2] = cand[w].store_aux; tp.aux[3] = cand[w].edge_first < 0 ? 1 : cand[w].edge_first;
+  tp.time = 1e-3f * best[w];
+  char text[160];
+  int n = snprintf(text, sizeof(text), "# %.2f us;", 1e3 * best[w]);
+  for (size_t c = 0; c < cand.size() && n < (int)sizeof(text) - 24; c++) n += snprintf(text + n, sizeof(text) - n, " yg%d st%d lk%d ef%d=%.2f", cand[c].ygroups, cand[c].store_aux, cand[c].link_aux, cand[c].edge_first, 1e3 * best[c]);
+  tp.comment = text;
+  tuneStore(key, tp);
+  tuneCountSweep();
+  saveTuneCache();
+  if (getVerbosity() >= QUDA_SUMMARIZE) printfQuda("Tuned %s %s %s: y groups %d, link policy %d, store policy %d, boundary-first %d (%s)\n", key.volume, key.name, key.aux, tp.aux[0], tp.aux[1], tp.aux[2], tp.aux[3], text);
+}
+
 template <typename T, int R, int VARIANT>
 static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, const DslashParam &p) {
   using real = typename Store<T>::real;
@@ -1843,7 +1917,32 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
   const bool first_t = commGrid().coords[3] == 0, last_t = commGrid().coords[3] == commGrid().dims[3] - 1;
   arg.tsign_fwd = (R == 12 && U.t_boundary == QUDA_ANTI_PERIODIC_T && last_t) ? -1 : 1;
   arg.tsign_bwd = (R == 12 && U.t_boundary == QUDA_ANTI_PERIODIC_T && first_t) ? -1 : 1;
-  const DslashTune &tune = dslashTune();
+  DslashTune tune = dslashTune();
+  {
+    // launch-parameter cache (tune.h; reference lib/tune.cpp): where the caller left a knob automatic, the value a sweep found for this
+    // (lattice, kernel, precision, reconstruct, epilogue, partition mask) is used; with tuning enabled the first launch of a key runs the sweep
+    int pmask = 0;
+    for (int d = 0; d < 4; d++) if (commGrid().partitioned(d)) pmask |= 1 << d;
+    if (g_sweepTune) {
+      if (g_sweepTune->ygroups >= 0) tune.ygroups = g_sweepTune->ygroups;
+      if (g_sweepTune->link_aux >= 0) tune.link_aux = g_sweepTune->link_aux;
+      if (g_sweepTune->store_aux >= 0) tune.store_aux = g_sweepTune->store_aux;
+      if (g_sweepTune->edge_first >= 0) tune.edge_first = g_sweepTune->edge_first;
+    } else if (tuningEnabled() || tuneCacheSize() > 0) {
+      const TuneKey key = dslashTuneKey(g, (int)sizeof(T), R, VARIANT, p, pmask);
+      const TuneParam *tp = tuneLookup(key);
+      if (!tp && tuningEnabled() && !(pmask && haloBuffers(g, in.Precision()).verified == 0)) {   // (a partitioned launch is first verified, then tuned)
+        sweepDslash<T, R, VARIANT>(out, in, U, p, key, pmask);
+        tp = tuneLookup(key);
+      }
+      if (tp) {
+        if (tune.ygroups < 0) tune.ygroups = tp->aux[0];
+        if (tune.link_aux < 0) tune.link_aux = tp->aux[1];
+        if (tune.store_aux < 0) tune.store_aux = tp->aux[2];
+        if (pmask) tune.edge_first = tp->aux[3];
+      }
+    }
+  }
   // block size: the largest of 256 / 192 / 128 / 64 threads that cuts an (x, y) plane into whole blocks (needed by the
   // plane-tiled order), 256 otherwise; QUDA_AMD_DSLASH_BLOCK overrides
   const int plane = g.Xh * g.X[1];

@@ -9,6 +9,7 @@
 #include "blas.h"
 #include "dirac.h"
 #include "interface_internal.h"
+#include "tune.h"
 #include "halo.h"
 #include "p2p.h"
 #include "quda_amd_ext.h"
@@ -102,6 +103,9 @@ ColorSpinorParam deviceSpinorParam(QudaPrecision prec, QudaSiteSubset subset, Qu
 
 }  // namespace quda
 
+QudaTune getTuning();   // include/util_quda.h (global namespace; that header's logging macros clash with qa_core.h's here)
+void setTuning(QudaTune tune);
+
 using namespace quda;
 
 // ================================================================================================
@@ -130,6 +134,7 @@ void initQudaMemory(void) {
   }
   createStreams();
   blas::init();
+  loadTuneCache();   // reference initQudaMemory: loadTuneCache() (lib/interface_quda.cpp:468)
   g_initialized = true;
 }
 
@@ -144,6 +149,8 @@ void initQuda(int device) {
 
 void endQuda(void) {
   if (!g_initialized) return;
+  saveTuneCache();   // reference endQuda: saveTuneCache() (lib/interface_quda.cpp:1069)
+  tuneCacheClear();
   freeGaugeQuda();
   freeCloverQuda();
   freeStagingBuffer();
@@ -410,6 +417,7 @@ static void meetRanksBeforeOperator() {
 
 void dslashQuda(void *h_out, void *h_in, QudaInvertParam *inv, QudaParity parity) {
   checkResident(inv);
+  if (inv->tune == QUDA_TUNE_YES || inv->tune == QUDA_TUNE_NO) setTuning(inv->tune);   // reference dslashQuda: setTuning(inv_param->tune)
   ColorSpinorParam cpuParam(h_in, *inv, g_geom.X, true);
   ColorSpinorField in_h(cpuParam);
   ColorSpinorParam dp = deviceSpinorParam(inv->cuda_prec, QUDA_PARITY_SITE_SUBSET, inv->twist_flavor);
@@ -447,6 +455,7 @@ static void normalizeMat(ColorSpinorField &out, const QudaInvertParam *inv, bool
 
 static void applyMat(void *h_out, void *h_in, QudaInvertParam *inv, bool dagmat) {
   checkResident(inv);
+  if (inv->tune == QUDA_TUNE_YES || inv->tune == QUDA_TUNE_NO) setTuning(inv->tune);
   const bool pc = inv->solution_type == QUDA_MATPC_SOLUTION || inv->solution_type == QUDA_MATPCDAG_MATPC_SOLUTION;
   ColorSpinorParam cpuParam(h_in, *inv, g_geom.X, pc);
   ColorSpinorField in_h(cpuParam);

@@ -10,6 +10,8 @@
 #include "quda_amd_ext.h"
 #include "solver.h"
 
+void setTuning(QudaTune tune);   // include/util_quda.h
+
 using namespace quda;
 
 namespace quda {
@@ -42,6 +44,7 @@ extern "C" {
 
 void invertQuda(void *hp_x, void *hp_b, QudaInvertParam *param) {
   if (!gaugePrecise) errorQuda("Gauge field not allocated");
+  if (param->tune == QUDA_TUNE_YES || param->tune == QUDA_TUNE_NO) setTuning(param->tune);   // reference invertQuda: setTuning(param->tune)
   if (!cloverPrecise && param->dslash_type == QUDA_TWISTED_CLOVER_DSLASH) errorQuda("Clover field not allocated");
   const bool pc_solution = param->solution_type == QUDA_MATPC_SOLUTION || param->solution_type == QUDA_MATPCDAG_MATPC_SOLUTION;
   const bool pc_solve = param->solve_type == QUDA_DIRECT_PC_SOLVE || param->solve_type == QUDA_NORMOP_PC_SOLVE;

@@ -7,6 +7,7 @@ Tolerances (BASELINE.json north_star: 1e-5 relative in double, 1e-2 in 16-bit, p
     fp32  2e-5
     16-bit 1e-2
 """
+import ctypes as C
 import importlib
 import json
 import os
@@ -497,3 +498,59 @@ def test_peer_store_halo_is_verified_on_first_use(forced_failure):
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-1500:]
     assert ("transport 0" if forced_failure else "transport 1") in out, out[-1500:]
+
+
+def test_tune_cache_is_filled_by_a_sweep_and_read_back(qa, oracle, tmp_path):
+    """f4, the launch-parameter half (reference lib/tune.cpp:213-355): with QudaInvertParam.tune = QUDA_TUNE_YES the first application of a
+    (lattice, kernel, precision, reconstruct, epilogue, partition mask) key times the candidate knob settings interleaved and keeps the
+    fastest; the table lands in $QUDA_RESOURCE_PATH/tunecache.tsv in the reference's text format; a second library start reads it and
+    sweeps nothing.  The operator's result is the oracle's while tuning and with the cached parameters."""
+    X, kappa, mu = (16, 16, 16, 16), 0.1, 0.01
+    gauge, spinor, _ = oracle.make_fields(list(X), clover=False)
+    nh = spinor.size // 2
+    oracle.set_threads(8)
+    try:
+        want = oracle.tm_dslash(gauge, spinor[:nh].copy(), list(X), kappa, mu, +1, 0, "ee", 0)
+    finally:
+        oracle.set_threads(1)
+    L = qa.lib()
+    L.qudaAmdTuneSweeps.restype = C.c_long
+    qa.end()
+    os.environ["QUDA_RESOURCE_PATH"] = str(tmp_path)
+    try:
+        qa.init(0)
+        s0 = L.qudaAmdTuneSweeps()
+        for prec in (8, 2):
+            qa.load_gauge(gauge, qa.gauge_param(X, cuda_prec=prec))
+            ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=prec)
+            ip.tune = 1   # QUDA_TUNE_YES
+            for _ in range(2):
+                assert qc.rel_err(qa.dslash(spinor[:nh].copy(), ip, 0), want) < TOL[prec]
+        assert L.qudaAmdTuneSweeps() - s0 == 2          # one sweep per key, none for the repeated application
+        L.qudaAmdSetPartitionMask(0b1010)
+        qa.load_gauge(gauge, qa.gauge_param(X, cuda_prec=4))
+        ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=4)
+        ip.tune = 1
+        for _ in range(3):   # first use of the peer-store transport is verified, the next application is tuned, the third runs from the table
+            assert qc.rel_err(qa.dslash(spinor[:nh].copy(), ip, 0), want) < TOL[4]
+        L.qudaAmdSetPartitionMask(0)
+        assert L.qudaAmdTuneSweeps() - s0 == 3
+        text = (tmp_path / "tunecache.tsv").read_text()
+        rows = [ln.split("\t") for ln in text.split("\n")[3:] if ln]
+        assert text.startswith("tunecache\t") and len(rows) == 3
+        assert sorted(r[2].split(",")[0] for r in rows) == ["prec=2", "prec=4", "prec=8"] and all(r[0].strip() == "16x16x16x16" and r[1] == "dslash_kernel" for r in rows)
+        assert [r for r in rows if r[2].startswith("prec=4")][0][2].endswith("comm=0101")
+        # second start: the table comes from the file, nothing is swept
+        qa.end()
+        qa.init(0)
+        s1 = L.qudaAmdTuneSweeps()
+        qa.load_gauge(gauge, qa.gauge_param(X, cuda_prec=8))
+        ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=8)
+        ip.tune = 1
+        assert qc.rel_err(qa.dslash(spinor[:nh].copy(), ip, 0), want) < TOL[8]
+        assert L.qudaAmdTuneSweeps() == s1
+    finally:
+        L.qudaAmdSetPartitionMask(0)
+        qa.end()
+        del os.environ["QUDA_RESOURCE_PATH"]
+        qa.init(0)
