@@ -143,7 +143,7 @@ def run_mg_ranks(qa, dist, X, kappa=0.124, mu=0.005):
 
 
 def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)), gauge=None, extras=True, kappa=0.124, mu=0.005, plain_maxiter=5000,
-           coarse_bench=True, setup_repeats=1, dslash="tm", csw=1.57551, cycle="V", refine=0, recon_sloppy=None):
+           coarse_bench=True, setup_repeats=1, dslash="tm", csw=1.57551, cycle="V", refine=0, recon_sloppy=None, recon_precondition=None):
     """MG-preconditioned GCR to |r|/|b| <= 1e-10 (the second half of the metric) on one GPU: 3-level K-cycle, 24 null
     vectors, 4^4 then 2^4 aggregates, even-odd preconditioned MR smoother — the reference harness' shape (tests/multigrid_invert_test.cpp:224-286)
     with the plain V-cycle BASELINE.json configs[4] names (cycle="K": the harness' default K-cycle, reported next to it) on a smooth synthetic gauge field (synth.smooth_gauge: far easier than a production
@@ -152,7 +152,7 @@ def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2,
     qa.lib().freeCloverQuda()
     if gauge is None:
         gauge = smooth_gauge(X, 0.35)
-    gp = qa.gauge_param(X, cuda_prec=8, prec_sloppy=4, prec_precondition=4, t_boundary=qa.QUDA_PERIODIC_T, recon_sloppy=recon_sloppy)   # recon_sloppy: also the preconditioner links'
+    gp = qa.gauge_param(X, cuda_prec=8, prec_sloppy=4, prec_precondition=4, t_boundary=qa.QUDA_PERIODIC_T, recon_sloppy=recon_sloppy, recon_precondition=recon_precondition)   # recon_sloppy: also the preconditioner links' unless given
     qa.load_gauge(gauge, gp)
     del gauge
     ip = qa.invert_param(qa.QUDA_TWISTED_CLOVER_DSLASH if dslash == "tmc" else qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=8, prec_sloppy=4,
@@ -323,7 +323,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--prec", type=int, default=8, choices=[8, 4, 2])
-    ap.add_argument("--recon", type=int, default=18, choices=[18, 12])
+    ap.add_argument("--recon", type=int, default=18, choices=[18, 12, 8])
     ap.add_argument("--dslash", default="tm", choices=["tm", "tmc", "wilson"])
     ap.add_argument("--lattice", default="32,32,32,32")
     ap.add_argument("--fast-gauge", action="store_true", help="links = periodic repetition of 65536 random SU(3) matrices (profiling of big lattices)")
@@ -423,7 +423,7 @@ def main():
 
     extra = {}
     if not args.no_extra and rank == 0 and world == 1:
-        for prec, recon, kind in ((4, 18, "tm"), (4, 12, "tm"), (2, 18, "tm"), (8, 18, "tmc"), (4, 18, "tmc"), (2, 18, "tmc")):
+        for prec, recon, kind in ((8, 12, "tm"), (4, 18, "tm"), (4, 12, "tm"), (4, 8, "tm"), (2, 18, "tm"), (2, 8, "tm"), (8, 18, "tmc"), (4, 18, "tmc"), (2, 18, "tmc")):
             e = run(prec, recon, kind, max(20, args.steps // 2), 5)
             extra["%s_%s_r%d" % (kind, dtype_name[prec].split("+")[0], recon)] = dict(
                 gflops=round(e["flops_site"] * Vh_global / e["sec"] * 1e-9, 1), hbm_gbs=round(e["bytes_site"] * Vh_local / e["sec"] * 1e-9, 1),
@@ -501,6 +501,9 @@ def main():
         # the precise links stay at 18): every fp32 stencil of the cycle moves 576 instead of 768 B per site
         r12 = run_mg(qa, Xc5, blocks=((4, 4, 4, 4), (2, 2, 2, 4), (2, 2, 2, 2)), gauge=gc5, extras=False, coarse_bench=False, recon_sloppy=qa.QUDA_RECONSTRUCT_12)
         extra["mg_gcr_c5_one_gpu"]["recon12_sloppy_links"] = {k: r12[k] for k in ("setup_secs", "solve_secs", "solver_secs", "iters", "true_res")}
+        # ... and with 8-real sloppy links (reconstruct_sloppy = 8: the fp32 operator of the outer GCR moves 448 B per site; the hierarchy keeps 12)
+        r8 = run_mg(qa, Xc5, blocks=((4, 4, 4, 4), (2, 2, 2, 4), (2, 2, 2, 2)), gauge=gc5, extras=False, coarse_bench=False, recon_sloppy=qa.QUDA_RECONSTRUCT_8, recon_precondition=qa.QUDA_RECONSTRUCT_12)
+        extra["mg_gcr_c5_one_gpu"]["recon8_sloppy_links"] = {k: r8[k] for k in ("setup_secs", "solve_secs", "solver_secs", "iters", "true_res")}
         # ... and with the production action (twisted clover, clover term built on the device) at the production volume
         extra["mg_gcr_c5_tmc_one_gpu"] = run_mg(qa, Xc5, blocks=((4, 4, 4, 4), (2, 2, 2, 4), (2, 2, 2, 2)), gauge=gc5, dslash="tmc", extras=False, coarse_bench=False)
         # the stencil at that production volume (Vh = 5.3 M sites: one time slice is 10.6 MB, the fields no longer sit in the 256 MB
@@ -508,8 +511,8 @@ def main():
         Vh5 = int(np.prod(Xc5)) // 2
         h5 = np.random.default_rng(3).random(Vh5 * 24)
         row5 = {}
-        for prec in (8, 4, 2):
-            qa.load_gauge(gc5, qa.gauge_param(list(Xc5), cuda_prec=prec))
+        for prec, recon5 in ((8, 18), (4, 18), (2, 18), (8, 12), (4, 12), (4, 8), (2, 8)):
+            qa.load_gauge(gc5, qa.gauge_param(list(Xc5), cuda_prec=prec, recon=recon5))
             ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=prec)
             src, dst = qa.Spinor(prec), qa.Spinor(prec)
             src.load(h5, ip)
@@ -517,7 +520,7 @@ def main():
             d.time_dslash(dst, src, 0, 5)
             sec = min(d.time_dslash(dst, src, 0, 30) for _ in range(2))
             bs = qa.lib().qudaAmdDslashBytesPerSite(ip, 0, 0)
-            row5["tm_%s_r18" % dtype_name[prec].split("+")[0]] = dict(us=round(1e6 * sec, 1), hbm_gbs=round(bs * Vh5 / sec * 1e-9, 1), frac=round(bs * Vh5 / sec * 1e-9 / HBM_PEAK_GBS, 4),
+            row5["tm_%s_r%d" % (dtype_name[prec].split("+")[0], recon5)] = dict(us=round(1e6 * sec, 1), hbm_gbs=round(bs * Vh5 / sec * 1e-9, 1), frac=round(bs * Vh5 / sec * 1e-9 / HBM_PEAK_GBS, 4),
                                                                     gflops=round(qa.lib().qudaAmdDslashFlopsPerSite(ip, 0) * Vh5 / sec * 1e-9, 1), bytes_per_site=bs)
             src.free(); dst.free(); d.free()
         extra["dslash_48x48x48x96"] = row5

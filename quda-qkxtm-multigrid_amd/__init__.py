@@ -19,7 +19,7 @@ INCLUDE_DIR = os.path.join(os.path.dirname(_HERE), "include")
 QUDA_INVALID_ENUM = -(2**31)
 QUDA_CPU_FIELD_LOCATION, QUDA_CUDA_FIELD_LOCATION = 1, 2
 QUDA_HALF_PRECISION, QUDA_SINGLE_PRECISION, QUDA_DOUBLE_PRECISION = 2, 4, 8
-QUDA_RECONSTRUCT_NO, QUDA_RECONSTRUCT_12 = 18, 12
+QUDA_RECONSTRUCT_NO, QUDA_RECONSTRUCT_12, QUDA_RECONSTRUCT_8 = 18, 12, 8
 QUDA_WILSON_LINKS = 0
 QUDA_QDP_GAUGE_ORDER = 5
 QUDA_ANTI_PERIODIC_T, QUDA_PERIODIC_T = -1, 1

@@ -227,14 +227,66 @@ template <typename T> __host__ __device__ constexpr size_t storeSize() { return 
 // ---- SU(3) link: 18 reals row-major (row*6 + col*2 + re/im); R = 18 stored fully, R = 12 rows 0,1 stored,
 // row 2 = conj(row0 x row1) * sign (sign carries a folded anti-periodic boundary, reference
 // tests/test_util.cpp:283-296 / lib/read_gauge.h) ----
+// R = 8 (reference Reconstruct<8>, include/gauge_field_order.h:516-585; lib/read_gauge.h RECONSTRUCT_8 macros): stored are
+//   [arg U00, arg U20, U01.re, U01.im, U02.re, U02.im, U10.re, U10.im]   (16-bit: the two phases in units of pi)
+// and the matrix M = u0 V, V in SU(3), u0 = +-1 the folded anti-periodic boundary sign, comes back from the unit length of row 0 and
+// column 0 and the SU(2) rotation of the lower-right block.  The same for the pre-daggered backward links of this library's layout
+// (U^dagger is as much an SU(3) matrix as U).  37 % of the link bytes of R = 18 for ~110 flops, two sincos, two sqrt and one reciprocal.
+__device__ __forceinline__ void qa_sincos(float x, float *s, float *c) { *s = __sinf(x); *c = __cosf(x); }   // v_sin_f32 / v_cos_f32 (|x| <= pi: ~1e-6)
+__device__ __forceinline__ void qa_sincos(double x, double *s, double *c) { sincos(x, s, c); }
+template <typename real> __device__ __forceinline__ void su3_reconstruct8(real *U, const real *in, real u0, real phaseUnit) {
+  const real a2r = in[2], a2i = in[3], a3r = in[4], a3i = in[5], b1r = in[6], b1i = in[7];
+  const real row_sum = a2r * a2r + a2i * a2i + a3r * a3r + a3i * a3i;
+  const real d0 = (real)1 - row_sum;
+  const real m0 = sqrt(d0 >= (real)0 ? d0 : (real)0);
+  real s0, c0, s1, c1;
+  qa_sincos(in[0] * phaseUnit, &s0, &c0);
+  qa_sincos(in[1] * phaseUnit, &s1, &c1);
+  const real a1r = m0 * c0, a1i = m0 * s0;
+  const real d1 = (real)1 - (m0 * m0 + b1r * b1r + b1i * b1i);
+  const real m1 = sqrt(d1 >= (real)0 ? d1 : (real)0);
+  const real c1r = m1 * c1, c1i = m1 * s1;
+  const real rinv = u0 / row_sum;                 // 1 / (u0 row_sum), u0 = +-1
+  // A = conj(a1) b1 ; A2 = conj(a1) c1, both times u0
+  const real Ar = u0 * (a1r * b1r + a1i * b1i), Ai = u0 * (a1r * b1i - a1i * b1r);
+  const real Br = u0 * (a1r * c1r + a1i * c1i), Bi = u0 * (a1r * c1i - a1i * c1r);
+  // conj(c1) conj(a3) etc.: conj(x) conj(y) = conj(x y)
+  const real c1a3r = c1r * a3r - c1i * a3i, c1a3i = -(c1r * a3i + c1i * a3r);
+  const real c1a2r = c1r * a2r - c1i * a2i, c1a2i = -(c1r * a2i + c1i * a2r);
+  const real b1a3r = b1r * a3r - b1i * a3i, b1a3i = -(b1r * a3i + b1i * a3r);
+  const real b1a2r = b1r * a2r - b1i * a2i, b1a2i = -(b1r * a2i + b1i * a2r);
+  U[0] = a1r; U[1] = a1i; U[2] = a2r; U[3] = a2i; U[4] = a3r; U[5] = a3i;
+  U[6] = b1r; U[7] = b1i;
+  U[8] = -(c1a3r + (Ar * a2r - Ai * a2i)) * rinv;  U[9] = -(c1a3i + (Ar * a2i + Ai * a2r)) * rinv;    // U11
+  U[10] = (c1a2r - (Ar * a3r - Ai * a3i)) * rinv;  U[11] = (c1a2i - (Ar * a3i + Ai * a3r)) * rinv;    // U12
+  U[12] = c1r; U[13] = c1i;
+  U[14] = (b1a3r - (Br * a2r - Bi * a2i)) * rinv;  U[15] = (b1a3i - (Br * a2i + Bi * a2r)) * rinv;    // U21
+  U[16] = -(b1a2r + (Br * a3r - Bi * a3i)) * rinv; U[17] = -(b1a2i + (Br * a3i + Bi * a3r)) * rinv;   // U22
+}
+// the inverse: the 8 stored reals of M = u0 V (reference Reconstruct<8>::Pack)
+template <typename real> __device__ __forceinline__ void su3_pack8(real *out, const real *U, real phaseUnitInv) {
+  out[0] = atan2(U[1], U[0]) * phaseUnitInv;
+  out[1] = atan2(U[13], U[12]) * phaseUnitInv;
+#pragma unroll
+  for (int i = 2; i < 8; i++) out[i] = U[i];
+}
+template <typename T> struct PhaseUnit { static constexpr double value = 1.0; };
+template <> struct PhaseUnit<short> { static constexpr double value = 3.14159265358979323846; };   // 16-bit storage holds phase / pi in [-1, 1]
+
 template <typename T, int R> struct Link {
   using real = typename Store<T>::real;
   using Raw = RawBlock<T, R>;
   // request / finish pair for the fenced stencil pipeline (RawBlock): finish converts and, for R = 12, rebuilds the third row
   template <int AUX = 0> static __device__ __forceinline__ void request(Raw &raw, const void *blk, int stride, int x) { raw.template load<AUX>(blk, stride, x, nullptr, 0); }
   static __device__ __forceinline__ void finish(real *U, const Raw &raw, real sign) {
-    raw.unpack(U);
-    if (R == 12) third_row(U, sign);
+    if constexpr (R == 8) {
+      real in[8];
+      raw.unpack(in);
+      su3_reconstruct8(U, in, sign, (real)PhaseUnit<T>::value);
+    } else {
+      raw.unpack(U);
+      if (R == 12) third_row(U, sign);
+    }
   }
   static __device__ __forceinline__ void third_row(real *U, real sign) {
     // c = conj(a x b)
@@ -249,6 +301,12 @@ template <typename T, int R> struct Link {
 #undef QA_CROSS
   }
   template <int AUX = 0> static __device__ __forceinline__ void load(real *U, const void *blk, int stride, int x, real sign) {
+    if constexpr (R == 8) {
+      real in[8];
+      Planar<T, 8>::template load<AUX>(in, blk, stride, x, nullptr, 0);
+      su3_reconstruct8(U, in, sign, (real)PhaseUnit<T>::value);
+      return;
+    }
     Planar<T, R>::template load<AUX>(U, blk, stride, x, nullptr, 0);
     if (R == 12) {
       // c = conj(a x b)

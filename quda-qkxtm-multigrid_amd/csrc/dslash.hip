@@ -454,9 +454,16 @@ __device__ __forceinline__ void hop_compute(real *acc, const RawBlock<T, 24> &ps
     // 16-bit: the hop is linear in the neighbour and in the link, so the integers go through it as they are and the product of
     // the two scales is applied inside the reconstruction (conversion: one v_cvt per operand instead of v_cvt + v_mul)
     psiRaw.unpack_unscaled(psi);
-    URaw.unpack_unscaled(U);
-    if (R == 12) Link<T, R>::third_row(U, sign * kShortInv);   // row 3 = conj(row 1 x row 2): back to the units of the stored rows
-    hop_arith<DIR, PRETWIST, GH, true>(acc, psi, U, arg, off_node, psiRaw.scale() * kShortInv);
+    if constexpr (R == 8) {
+      // 8-real links: the reconstruction is not linear in the stored values, so the link comes back in its own units and only the
+      // neighbour's integers and scale go through the hop
+      Link<T, R>::finish(U, URaw, sign);
+      hop_arith<DIR, PRETWIST, GH, true>(acc, psi, U, arg, off_node, psiRaw.scale());
+    } else {
+      URaw.unpack_unscaled(U);
+      if (R == 12) Link<T, R>::third_row(U, sign * kShortInv);   // row 3 = conj(row 1 x row 2): back to the units of the stored rows
+      hop_arith<DIR, PRETWIST, GH, true>(acc, psi, U, arg, off_node, psiRaw.scale() * kShortInv);
+    }
   } else {
     psiRaw.unpack(psi);
     Link<T, R>::finish(U, URaw, sign);
@@ -1913,10 +1920,10 @@ static void launchDslash(ColorSpinorField &out, const ColorSpinorField &in, cons
   arg.parity = p.parity; arg.mode = p.mode; arg.xpay = p.x ? 1 : 0;
   arg.sfwd = p.dagger ? -1 : 1;
   arg.a = (real)p.a; arg.b = (real)p.b; arg.k = (real)p.k;
-  // recon-12: the reconstructed row of boundary t-links carries the (folded) boundary sign
+  // recon-12: the reconstructed row of boundary t-links carries the (folded) boundary sign; recon-8: u0 of the reconstruction is that sign
   const bool first_t = commGrid().coords[3] == 0, last_t = commGrid().coords[3] == commGrid().dims[3] - 1;
-  arg.tsign_fwd = (R == 12 && U.t_boundary == QUDA_ANTI_PERIODIC_T && last_t) ? -1 : 1;
-  arg.tsign_bwd = (R == 12 && U.t_boundary == QUDA_ANTI_PERIODIC_T && first_t) ? -1 : 1;
+  arg.tsign_fwd = (R != 18 && U.t_boundary == QUDA_ANTI_PERIODIC_T && last_t) ? -1 : 1;
+  arg.tsign_bwd = (R != 18 && U.t_boundary == QUDA_ANTI_PERIODIC_T && first_t) ? -1 : 1;
   DslashTune tune = dslashTune();
   {
     // launch-parameter cache (tune.h; reference lib/tune.cpp): where the caller left a knob automatic, the value a sweep found for this
@@ -2228,8 +2235,12 @@ template <typename T> static void dispatchRecon(ColorSpinorField &out, const Col
     if (variant == 2) launchDslash<T, 12, 2>(out, in, U, p);
     else if (variant == 1) launchDslash<T, 12, 1>(out, in, U, p);
     else launchDslash<T, 12, 0>(out, in, U, p);
+  } else if (U.reconstruct == QUDA_RECONSTRUCT_8) {   // reference: the RECONSTRUCT_8 variants of every Wilson-type stencil, lib/dslash_quda.cuh:16-52
+    if (variant == 2) launchDslash<T, 8, 2>(out, in, U, p);
+    else if (variant == 1) launchDslash<T, 8, 1>(out, in, U, p);
+    else launchDslash<T, 8, 0>(out, in, U, p);
   } else {
-    errorQuda("reconstruct %d not supported (18 and 12 only)", U.reconstruct);
+    errorQuda("reconstruct %d not supported (18, 12 and 8)", U.reconstruct);
   }
 }
 
@@ -2301,8 +2312,8 @@ template <typename T, int R> static void launchHopDir(ColorSpinorField &out, con
   arg.parity = parity; arg.sfwd = 1;
   if (x) { arg.x = x->V(); arg.xNorm = (const float *)x->Norm(); arg.xpay = 1; arg.k = (real)xcoef; }
   const bool first_t = commGrid().coords[3] == 0, last_t = commGrid().coords[3] == commGrid().dims[3] - 1;
-  arg.tsign_fwd = (R == 12 && U.t_boundary == QUDA_ANTI_PERIODIC_T && last_t) ? -1 : 1;
-  arg.tsign_bwd = (R == 12 && U.t_boundary == QUDA_ANTI_PERIODIC_T && first_t) ? -1 : 1;
+  arg.tsign_fwd = (R != 18 && U.t_boundary == QUDA_ANTI_PERIODIC_T && last_t) ? -1 : 1;
+  arg.tsign_bwd = (R != 18 && U.t_boundary == QUDA_ANTI_PERIODIC_T && first_t) ? -1 : 1;
   const int mu = dir >> 1;
   const void *ghost = nullptr;
   if (commGrid().partitioned(mu)) {
@@ -2335,10 +2346,10 @@ void applyCovariantShift(ColorSpinorField &out, const ColorSpinorField &in, cons
   if (in.VolumeCB() != U.geom.Vh || out.VolumeCB() != U.geom.Vh) errorQuda("volume mismatch");
   if (x && (x->Precision() != out.Precision() || x->Stride() != out.Stride())) errorQuda("accumulation field does not match the output");
   if (in.Stride() != out.Stride()) errorQuda("stride mismatch");
-  const bool r12 = U.reconstruct == QUDA_RECONSTRUCT_12;
+  const int rr = (int)U.reconstruct;
   switch (in.Precision()) {
-    case QUDA_DOUBLE_PRECISION: r12 ? launchHopDir<double, 12>(out, in, U, parity, dir, coef, true, x, xcoef) : launchHopDir<double, 18>(out, in, U, parity, dir, coef, true, x, xcoef); break;
-    case QUDA_SINGLE_PRECISION: r12 ? launchHopDir<float, 12>(out, in, U, parity, dir, coef, true, x, xcoef) : launchHopDir<float, 18>(out, in, U, parity, dir, coef, true, x, xcoef); break;
+    case QUDA_DOUBLE_PRECISION: rr == 12 ? launchHopDir<double, 12>(out, in, U, parity, dir, coef, true, x, xcoef) : (rr == 8 ? launchHopDir<double, 8>(out, in, U, parity, dir, coef, true, x, xcoef) : launchHopDir<double, 18>(out, in, U, parity, dir, coef, true, x, xcoef)); break;
+    case QUDA_SINGLE_PRECISION: rr == 12 ? launchHopDir<float, 12>(out, in, U, parity, dir, coef, true, x, xcoef) : (rr == 8 ? launchHopDir<float, 8>(out, in, U, parity, dir, coef, true, x, xcoef) : launchHopDir<float, 18>(out, in, U, parity, dir, coef, true, x, xcoef)); break;
     default: errorQuda("covariant shift: fp64/fp32 only");
   }
 }
@@ -2470,10 +2481,10 @@ void galerkinLocalUV(float *Lout, const float *V, const CloverField &C, double a
 void applyHopDir(ColorSpinorField &out, const ColorSpinorField &in, const GaugeField &U, int parity, int dir, double coef) {
   if (in.Precision() != out.Precision() || in.Precision() != U.precision) errorQuda("precision mismatch");
   if (in.VolumeCB() != U.geom.Vh) errorQuda("volume mismatch");
-  const bool r12 = U.reconstruct == QUDA_RECONSTRUCT_12;
+  const int rr = (int)U.reconstruct;
   switch (in.Precision()) {
-    case QUDA_DOUBLE_PRECISION: r12 ? launchHopDir<double, 12>(out, in, U, parity, dir, coef) : launchHopDir<double, 18>(out, in, U, parity, dir, coef); break;
-    case QUDA_SINGLE_PRECISION: r12 ? launchHopDir<float, 12>(out, in, U, parity, dir, coef) : launchHopDir<float, 18>(out, in, U, parity, dir, coef); break;
+    case QUDA_DOUBLE_PRECISION: rr == 12 ? launchHopDir<double, 12>(out, in, U, parity, dir, coef) : (rr == 8 ? launchHopDir<double, 8>(out, in, U, parity, dir, coef) : launchHopDir<double, 18>(out, in, U, parity, dir, coef)); break;
+    case QUDA_SINGLE_PRECISION: rr == 12 ? launchHopDir<float, 12>(out, in, U, parity, dir, coef) : (rr == 8 ? launchHopDir<float, 8>(out, in, U, parity, dir, coef) : launchHopDir<float, 18>(out, in, U, parity, dir, coef)); break;
     default: errorQuda("single-direction hop: fp64/fp32 only");
   }
 }

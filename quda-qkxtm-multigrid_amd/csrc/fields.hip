@@ -375,7 +375,7 @@ void copyColorSpinor(ColorSpinorField &dst, const ColorSpinorField &src) {
 // ================================================================================================
 GaugeField::GaugeField(const LatticeGeom &g, QudaPrecision prec, QudaReconstructType recon, QudaTboundary tb, double aniso)
     : geom(g), precision(prec), reconstruct(recon), t_boundary(tb), anisotropy(aniso), stride(g.Vh + gaugePadSites()), data(nullptr), tbc_folded(true) {
-  if (recon != QUDA_RECONSTRUCT_NO && recon != QUDA_RECONSTRUCT_12) errorQuda("reconstruct %d not supported (18, 12)", recon);
+  if (recon != QUDA_RECONSTRUCT_NO && recon != QUDA_RECONSTRUCT_12 && recon != QUDA_RECONSTRUCT_8) errorQuda("reconstruct %d not supported (18, 12, 8)", recon);
   if (prec == QUDA_HALF_PRECISION && aniso != 1.0) errorQuda("16-bit links need anisotropy 1 (fixed-point range)");
   link_bytes = alignUp((size_t)stride * (int)recon * (int)prec, 1024);
   bytes = 16 * link_bytes;
@@ -407,6 +407,17 @@ __global__ void gauge_face_pack_kernel(THost *out, const THost *h, LatticeGeom g
 // one thread per (parity, site): builds the 8 matrices the stencil needs at that site.  ghost[d] != nullptr: the
 // backward link of a site on the x_d = 0 face lives on the -d neighbour rank and is taken from its packed last slice.
 template <typename THost> struct GhostLinks { const THost *g[4]; };
+
+// store one link in the device's reconstruct type: 18 / 12 the leading reals as they are, 8 the packed form of device_io.h su3_pack8
+template <typename TDev, int R, typename real> __device__ __forceinline__ void store_link(const real *U, void *blk, int stride, int idx) {
+  if constexpr (R == 8) {
+    real o[8];
+    su3_pack8(o, U, (real)(1.0 / PhaseUnit<TDev>::value));
+    Planar<TDev, 8>::store(o, blk, stride, idx, nullptr, 0);
+  } else {
+    Planar<TDev, R>::store(U, blk, stride, idx, nullptr, 0);
+  }
+}
 
 template <typename TDev, int R, typename THost>
 __global__ void gauge_load_kernel(char *data, size_t link_bytes, int stride, const THost *h0, const THost *h1, const THost *h2, const THost *h3,
@@ -442,7 +453,7 @@ __global__ void gauge_load_kernel(char *data, size_t link_bytes, int stride, con
     const THost *f = h[mu] + ((size_t)parity * g.Vh + idx) * 18;
 #pragma unroll
     for (int k = 0; k < 18; k++) U[k] = (real)f[k];
-    Planar<TDev, R>::store(U, base + (size_t)(2 * mu) * link_bytes, stride, idx, nullptr, 0);
+    store_link<TDev, R>(U, base + (size_t)(2 * mu) * link_bytes, stride, idx);
     const THost *bk = (ghost.g[mu] && coord[mu] == 0) ? ghost.g[mu] + ((size_t)(1 - parity) * g.faceCB[mu] + face[mu]) * 18
                                                        : h[mu] + ((size_t)(1 - parity) * g.Vh + nb[mu]) * 18;
 #pragma unroll
@@ -452,7 +463,7 @@ __global__ void gauge_load_kernel(char *data, size_t link_bytes, int stride, con
         U[r * 6 + c * 2] = (real)bk[c * 6 + r * 2];
         U[r * 6 + c * 2 + 1] = -(real)bk[c * 6 + r * 2 + 1];
       }
-    Planar<TDev, R>::store(U, base + (size_t)(2 * mu + 1) * link_bytes, stride, idx, nullptr, 0);
+    store_link<TDev, R>(U, base + (size_t)(2 * mu + 1) * link_bytes, stride, idx);
   }
 }
 
@@ -496,6 +507,7 @@ void GaugeField::loadQDP(void *const h_gauge[4], QudaPrecision cpu_prec) {
   if (cpu_prec == QUDA_DOUBLE_PRECISION) gaugeLoad<TD, RR, double>(*this, h_gauge); \
   else gaugeLoad<TD, RR, float>(*this, h_gauge);
   if (reconstruct == QUDA_RECONSTRUCT_NO) { QA_DISPATCH_DEV(precision, QA_GL(TD, 18)); }
+  else if (reconstruct == QUDA_RECONSTRUCT_8) { QA_DISPATCH_DEV(precision, QA_GL(TD, 8)); }
   else { QA_DISPATCH_DEV(precision, QA_GL(TD, 12)); }
 #undef QA_GL
 }
@@ -512,6 +524,10 @@ __global__ void gauge_convert_kernel(char *out, size_t out_link_bytes, const cha
   typename Store<TOut>::real v[R];
 #pragma unroll
   for (int k = 0; k < R; k++) v[k] = (typename Store<TOut>::real)u[k];
+  if (R == 8) {   // the two phases are stored in the unit of their precision (16-bit: phase / pi)
+    const typename Store<TOut>::real f = (typename Store<TOut>::real)(PhaseUnit<TIn>::value / PhaseUnit<TOut>::value);
+    v[0] *= f; v[1] *= f;
+  }
   Planar<TOut, R>::store(v, out + (size_t)blk * out_link_bytes, stride, idx, nullptr, 0);
 }
 void GaugeField::copyFrom(const GaugeField &src) {
@@ -520,6 +536,8 @@ void GaugeField::copyFrom(const GaugeField &src) {
   const int bs = 256, nb = (16 * geom.Vh + bs - 1) / bs;
   if (reconstruct == QUDA_RECONSTRUCT_12)
     hipLaunchKernelGGL((gauge_convert_kernel<short, float, 12>), dim3(nb), dim3(bs), 0, computeStream(), (char *)data, link_bytes, (const char *)src.data, src.link_bytes, stride, geom.Vh);
+  else if (reconstruct == QUDA_RECONSTRUCT_8)
+    hipLaunchKernelGGL((gauge_convert_kernel<short, float, 8>), dim3(nb), dim3(bs), 0, computeStream(), (char *)data, link_bytes, (const char *)src.data, src.link_bytes, stride, geom.Vh);
   else
     hipLaunchKernelGGL((gauge_convert_kernel<short, float, 18>), dim3(nb), dim3(bs), 0, computeStream(), (char *)data, link_bytes, (const char *)src.data, src.link_bytes, stride, geom.Vh);
   HIP_CHECK(hipGetLastError());
@@ -689,7 +707,7 @@ template <typename T, int R> __device__ __forceinline__ void load_link(M3 &U, co
   real u[18];
   // the host links carry the anti-periodic sign on the last time slice; recon-12 stores rows 0,1 as given and has to put the
   // sign back on the reconstructed third row (in the plaquette the two boundary links of a leaf then cancel their signs)
-  const real sign = (R == 12 && mu == 3 && x[3] == g.X[3] - 1) ? (real)g.tsign : (real)1;
+  const real sign = (R != 18 && mu == 3 && x[3] == g.X[3] - 1) ? (real)g.tsign : (real)1;   // (recon-8: u0 of the reconstruction)
   Link<T, R>::load(u, g.data + ((size_t)par * 8 + 2 * mu) * g.link_bytes, g.stride, idx, sign);
 #pragma unroll
   for (int k = 0; k < 9; k++) { U.re[k] = u[2 * k]; U.im[k] = u[2 * k + 1]; }
@@ -802,7 +820,7 @@ __device__ __forceinline__ void mf_store(const M3 &m, const MatField &f, int par
 template <typename T, int R> __device__ __forceinline__ void load_w(M3 &U, const GaugeView &g, int par, int idx, int slot, int t) {
   using real = typename Store<T>::real;
   real sign = 1;
-  if (R == 12 && (slot >> 1) == 3) sign = (slot & 1) ? (t == 0 ? (real)g.tsign_bwd : (real)1) : (t == g.X[3] - 1 ? (real)g.tsign : (real)1);
+  if (R != 18 && (slot >> 1) == 3) sign = (slot & 1) ? (t == 0 ? (real)g.tsign_bwd : (real)1) : (t == g.X[3] - 1 ? (real)g.tsign : (real)1);
   real u[18];
   Link<T, R>::load(u, g.data + ((size_t)par * 8 + slot) * g.link_bytes, g.stride, idx, sign);
 #pragma unroll
@@ -968,9 +986,9 @@ void CloverField::computeFromGauge(const GaugeField &U, double coeff) {
   g.tsign = (U.t_boundary == QUDA_ANTI_PERIODIC_T && last_t) ? -1 : 1;
   g.tsign_bwd = (U.t_boundary == QUDA_ANTI_PERIODIC_T && first_t) ? -1 : 1;
   const int bs = 128, nb = (2 * geom.Vh + bs - 1) / bs;
-  const bool r12 = U.reconstruct == QUDA_RECONSTRUCT_12;
+  const bool r12 = U.reconstruct == QUDA_RECONSTRUCT_12, r8 = U.reconstruct == QUDA_RECONSTRUCT_8;
   if (decomposed) {
-#define QA_CD(T) { if (r12) cloverFromGaugeDecomposed<T, 12>(stage, U, g, coeff); else cloverFromGaugeDecomposed<T, 18>(stage, U, g, coeff); }
+#define QA_CD(T) { if (r12) cloverFromGaugeDecomposed<T, 12>(stage, U, g, coeff); else if (r8) cloverFromGaugeDecomposed<T, 8>(stage, U, g, coeff); else cloverFromGaugeDecomposed<T, 18>(stage, U, g, coeff); }
     switch (U.precision) {
       case QUDA_DOUBLE_PRECISION: QA_CD(double) break;
       case QUDA_SINGLE_PRECISION: QA_CD(float) break;
@@ -981,6 +999,7 @@ void CloverField::computeFromGauge(const GaugeField &U, double coeff) {
   } else {
 #define QA_CG(T) \
   if (r12) hipLaunchKernelGGL((clover_from_gauge_kernel<T, 12>), dim3(nb), dim3(bs), 0, computeStream(), stage, g, coeff, geom.Vh); \
+  else if (r8) hipLaunchKernelGGL((clover_from_gauge_kernel<T, 8>), dim3(nb), dim3(bs), 0, computeStream(), stage, g, coeff, geom.Vh); \
   else hipLaunchKernelGGL((clover_from_gauge_kernel<T, 18>), dim3(nb), dim3(bs), 0, computeStream(), stage, g, coeff, geom.Vh);
   switch (U.precision) {
     case QUDA_DOUBLE_PRECISION: QA_CG(double) break;
@@ -1227,8 +1246,9 @@ static GaugeView viewOf(const GaugeField &U) {
 static void extractForwardLinks(MatField F, const GaugeField &U, int mu) {
   const GaugeView g = viewOf(U);
   const int Vh = U.geom.Vh, bs = 128, nb = (2 * Vh + bs - 1) / bs;
-  const bool r12 = U.reconstruct == QUDA_RECONSTRUCT_12;
+  const bool r12 = U.reconstruct == QUDA_RECONSTRUCT_12, r8 = U.reconstruct == QUDA_RECONSTRUCT_8;
 #define QA_EX(T) { if (r12) hipLaunchKernelGGL((cl_extract_kernel<T, 12>), dim3(nb), dim3(bs), 0, computeStream(), F, g, mu, Vh); \
+                   else if (r8) hipLaunchKernelGGL((cl_extract_kernel<T, 8>), dim3(nb), dim3(bs), 0, computeStream(), F, g, mu, Vh); \
                    else hipLaunchKernelGGL((cl_extract_kernel<T, 18>), dim3(nb), dim3(bs), 0, computeStream(), F, g, mu, Vh); }
   switch (U.precision) {
     case QUDA_DOUBLE_PRECISION: QA_EX(double) break;

@@ -273,7 +273,7 @@ static void checkGaugeParam(const QudaGaugeParam *p) {
   if (p->t_boundary != QUDA_ANTI_PERIODIC_T && p->t_boundary != QUDA_PERIODIC_T) errorQuda("Parameter t_boundary undefined");
   if (p->cpu_prec != QUDA_DOUBLE_PRECISION && p->cpu_prec != QUDA_SINGLE_PRECISION) errorQuda("Parameter cpu_prec = %d undefined", p->cpu_prec);
   if (p->cuda_prec != QUDA_DOUBLE_PRECISION && p->cuda_prec != QUDA_SINGLE_PRECISION && p->cuda_prec != QUDA_HALF_PRECISION) errorQuda("Parameter cuda_prec = %d undefined", p->cuda_prec);
-  if (p->reconstruct != QUDA_RECONSTRUCT_NO && p->reconstruct != QUDA_RECONSTRUCT_12) errorQuda("Parameter reconstruct = %d: this library implements 18 and 12", p->reconstruct);
+  if (p->reconstruct != QUDA_RECONSTRUCT_NO && p->reconstruct != QUDA_RECONSTRUCT_12 && p->reconstruct != QUDA_RECONSTRUCT_8) errorQuda("Parameter reconstruct = %d: this library implements 18, 12 and 8", p->reconstruct);
   if (p->gauge_order != QUDA_QDP_GAUGE_ORDER) errorQuda("Parameter gauge_order = %d: only QUDA_QDP_GAUGE_ORDER host fields are supported", p->gauge_order);
   if (p->type != QUDA_WILSON_LINKS) errorQuda("Parameter type = %d: only Wilson (SU(3)) links are on this path", p->type);
 }
@@ -290,7 +290,7 @@ void loadGaugeQuda(void *h_gauge, QudaGaugeParam *param) {
   double gib = gaugePrecise->GiB();
   auto valid = [](QudaPrecision p) { return p == QUDA_DOUBLE_PRECISION || p == QUDA_SINGLE_PRECISION || p == QUDA_HALF_PRECISION; };
   if (valid(param->cuda_prec_sloppy) && (param->cuda_prec_sloppy != param->cuda_prec || param->reconstruct_sloppy != param->reconstruct)) {
-    QudaReconstructType r = (param->reconstruct_sloppy == QUDA_RECONSTRUCT_12) ? QUDA_RECONSTRUCT_12 : QUDA_RECONSTRUCT_NO;
+    QudaReconstructType r = (param->reconstruct_sloppy == QUDA_RECONSTRUCT_12 || param->reconstruct_sloppy == QUDA_RECONSTRUCT_8) ? param->reconstruct_sloppy : QUDA_RECONSTRUCT_NO;
     gaugeSloppy = new GaugeField(g_geom, param->cuda_prec_sloppy, r, param->t_boundary, param->anisotropy);
     loadGaugeWithHalo(*gaugeSloppy, links, param->cpu_prec);
     gib += gaugeSloppy->GiB();
@@ -298,7 +298,7 @@ void loadGaugeQuda(void *h_gauge, QudaGaugeParam *param) {
   const QudaPrecision sp = gaugeSloppy ? gaugeSloppy->precision : gaugePrecise->precision;
   const QudaReconstructType sr = gaugeSloppy ? gaugeSloppy->reconstruct : gaugePrecise->reconstruct;
   if (valid(param->cuda_prec_precondition) && (param->cuda_prec_precondition != sp || (param->reconstruct_precondition != sr && param->reconstruct_precondition != QUDA_RECONSTRUCT_INVALID))) {
-    QudaReconstructType r = (param->reconstruct_precondition == QUDA_RECONSTRUCT_12) ? QUDA_RECONSTRUCT_12 : QUDA_RECONSTRUCT_NO;
+    QudaReconstructType r = (param->reconstruct_precondition == QUDA_RECONSTRUCT_12 || param->reconstruct_precondition == QUDA_RECONSTRUCT_8) ? param->reconstruct_precondition : QUDA_RECONSTRUCT_NO;
     gaugePrecondition = new GaugeField(g_geom, param->cuda_prec_precondition, r, param->t_boundary, param->anisotropy);
     loadGaugeWithHalo(*gaugePrecondition, links, param->cpu_prec);
     gib += gaugePrecondition->GiB();

@@ -41,7 +41,7 @@ def _load_fields(qa, gauge, clover, X, kappa, mu, prec, recon, host_dtype=np.flo
 
 
 @pytest.mark.parametrize("path", qc.FILES, ids=[os.path.basename(f) for f in qc.FILES])
-@pytest.mark.parametrize("prec,recon", [(8, 18), (8, 12), (4, 18), (4, 12), (2, 18), (2, 12)])
+@pytest.mark.parametrize("prec,recon", [(8, 18), (8, 12), (8, 8), (4, 18), (4, 12), (4, 8), (2, 18), (2, 12), (2, 8)])
 def test_all_golden_cases_through_c_abi(qa, path, prec, recon):
     z, X, kappa, mu, gauge = qc.load(path)
     _load_fields(qa, gauge, z["clover"], X, kappa, mu, prec, recon)
