@@ -41,6 +41,11 @@ constexpr int kKrylovMax = 20;
 constexpr int kRedMax = 2 * kKrylovMax + 4;   // sums of one grid reduction
 constexpr int kMaxRanks = 16;
 constexpr int kThreads = 256;
+// Halo zones are buffered FOUR deep (exchange number mod 4).  A face is pushed either by the phase that reads it (after the barrier in front of
+// that phase) or — matpc's intermediate vector, the residual of MR / GCR — already by the phase that PRODUCES it, so that it is on its way
+// while the barrier is still being crossed (3.5 us per hop phase).  With producer-side pushes a rank in the phase that consumes exchange k + 1
+// may push exchange k + 2 while a neighbour is still reading exchange k - 1: live exchanges span at most 4 numbers.
+constexpr int kHaloBufs = 4;
 
 struct CcVec { float2 *p[2]; int stride; };
 
@@ -50,6 +55,7 @@ struct CcLevel {
   const float4 *links, *hat;   // [site][9][n/2][n] float4: Y (slot 8 = X) and Xinv Y (slot 8 = Xinv)
   int solvePar;                // parity of the even-odd preconditioned system (reference matpc_type of DiracCoarsePC)
   int nuPre, nuPost, mrGlobal;
+  int ntLinks;                 // links streamed with non-temporal loads (levels whose links exceed what the L2s hold between two phases)
   float omega;
   // transfer to the next coarser level (absent on the coarsest one)
   const float4 *V; const int *b2f; int blockVol, GS, nAgg;
@@ -58,8 +64,8 @@ struct CcLevel {
   float2 *bt, *r, *Ar, *t;     // parity fields, [component][Vh]: bt, r, Ar on solvePar, t on the other parity
   // halo of partitioned dimensions
   int commMask, faceCB[4];
-  u32x4_t *ghost[4][2][2];     // [dim][0: from the -dim neighbour (its x = L-1 face), 1: from the +dim neighbour (its x = 0 face)][buffer]
-  u32x4_t *peer[4][2][2];      // [dim][my face 0 / L-1][buffer]: where that face lands in the neighbour's window
+  u32x4_t *ghost[4][2][kHaloBufs];   // [dim][0: from the -dim neighbour (its x = L-1 face), 1: from the +dim neighbour (its x = 0 face)][buffer]
+  u32x4_t *peer[4][2][kHaloBufs];    // [dim][my face 0 / L-1][buffer]: where that face lands in the neighbour's window
 };
 
 struct CcArg {
@@ -111,6 +117,12 @@ struct CcCtx {
 // Pointers come out of the argument block as generic pointers, and a load through a generic pointer is a FLAT load — which the compiler
 // can only wait for with vmcnt(0), i.e. behind every link load in flight.  Everything outside LDS is therefore accessed through an
 // explicitly GLOBAL pointer.
+__device__ __forceinline__ float4 cc_ld(const float4 *p) {   // cached global load (links of a level small enough to stay in the L2s)
+  typedef float f32x4_g __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(1))) f32x4_g *gptr;
+  const f32x4_g t = *(gptr)(unsigned long long)p;
+  return make_float4(t.x, t.y, t.z, t.w);
+}
 template <typename T> __device__ __forceinline__ __attribute__((address_space(1))) T *gp(T *p) { return (__attribute__((address_space(1))) T *)(unsigned long long)p; }
 __device__ __forceinline__ float4 cc_ld_nt(const float4 *p) {
   typedef float f32x4_nt __attribute__((ext_vector_type(4)));
@@ -290,7 +302,7 @@ __device__ __forceinline__ void cc_coords(const CcLevel &L, int par, int xcb, in
 
 // push the faces of `v` (parities in pmask) of every partitioned dimension into the neighbours' windows; flag = c.seq (already advanced)
 __device__ __forceinline__ void cc_push(const CcArg &a, const CcLevel &L, const CcCtx &c, const CcVec &v, int pmask) {
-  const int buf = (int)(c.seq & 1);
+  const int buf = (int)(c.seq & (kHaloBufs - 1));
   const unsigned flag = c.seq;
   const int npar = (pmask == 3) ? 2 : 1, p0 = (pmask == 2) ? 1 : 0;
 #pragma unroll
@@ -353,7 +365,7 @@ __device__ __forceinline__ void cc_neighbour(const CcLevel &L, const int c[4], i
 // ghost zone.  Thread (wave w, lane j) owns component j of the matrices w, w + 4, w + 8: it works out their neighbours itself and requests
 // all its loads back to back (one round trip for the whole staging), then polls whatever ghost words have not arrived yet.
 __device__ __forceinline__ void cc_stage(const CcArg &a, const CcLevel &L, CcShared &s, CcCtx &c, const CcVec &in, int par, int xcb, int mmask) {
-  const int buf = (int)(c.seq & 1);
+  const int buf = (int)(c.seq & (kHaloBufs - 1));
   const unsigned flag = c.seq;
   const int wave = threadIdx.x >> 6, j = threadIdx.x & 63;
   int cs[4];
@@ -415,7 +427,7 @@ template <int N, int M0, int M1> struct LinkRegs {
   static constexpr int B0 = (NM * CH > 48) ? (NM + 1) / 2 : NM;   // matrices of the first batch
   float4 w[B0][CH];
 };
-template <int N, int M0, int M1> __device__ __forceinline__ void cc_links_issue(LinkRegs<N, M0, M1> &r, const float4 *G, size_t site) {
+template <int N, int M0, int M1> __device__ __forceinline__ void cc_links_issue(LinkRegs<N, M0, M1> &r, const float4 *G, size_t site, int nt) {
   using R = LinkRegs<N, M0, M1>;
   static_assert(R::NH % 4 == 0, "column pairs must split evenly over the four waves");
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -424,10 +436,10 @@ template <int N, int M0, int M1> __device__ __forceinline__ void cc_links_issue(
   for (int i = 0; i < R::B0; i++) {
     const float4 *g = G + ((site * 9 + (M0 + i)) * R::NH + wave * R::CH) * N + row;
 #pragma unroll
-    for (int q = 0; q < R::CH; q++) r.w[i][q] = cc_ld_nt(g + (size_t)q * N);
+    for (int q = 0; q < R::CH; q++) r.w[i][q] = nt ? cc_ld_nt(g + (size_t)q * N) : cc_ld(g + (size_t)q * N);
   }
 }
-template <int N, int M0, int M1> __device__ __forceinline__ void cc_links_finish(CcShared &s, const LinkRegs<N, M0, M1> &r, const float4 *G, size_t site) {
+template <int N, int M0, int M1> __device__ __forceinline__ void cc_links_finish(CcShared &s, const LinkRegs<N, M0, M1> &r, const float4 *G, size_t site, int nt) {
   using R = LinkRegs<N, M0, M1>;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = lane < N ? lane : 0;
@@ -438,7 +450,7 @@ template <int N, int M0, int M1> __device__ __forceinline__ void cc_links_finish
     for (int i = R::B0; i < R::NM; i++) {
       const float4 *g = G + ((site * 9 + (M0 + i)) * R::NH + wave * R::CH) * N + row;
 #pragma unroll
-      for (int q = 0; q < R::CH; q++) w2[i - R::B0][q] = cc_ld_nt(g + (size_t)q * N);
+      for (int q = 0; q < R::CH; q++) w2[i - R::B0][q] = nt ? cc_ld_nt(g + (size_t)q * N) : cc_ld(g + (size_t)q * N);
     }
   }
 #pragma unroll
@@ -467,6 +479,32 @@ __device__ __forceinline__ CcVec cc_parity_vec(float2 *p, int par, int Vh) {
 __device__ __forceinline__ CcVec cc_parity_of(const CcVec &full, int par) {
   CcVec v; v.p[par] = full.p[par]; v.p[1 - par] = nullptr; v.stride = full.stride; return v;
 }
+// producer-side push: component j of the site with coordinates cs (parity par) goes into the neighbours' zones of exchange number `seq`
+// wherever the site lies on a partitioned face (the consumer's cc_exchange_begin is then told that the faces are on their way)
+__device__ __forceinline__ void cc_push_site(const CcLevel &L, unsigned seq, int par, const int cs[4], int j, float2 val) {
+  const int buf = (int)(seq & (kHaloBufs - 1));
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    if (!((L.commMask >> d) & 1)) continue;
+    const bool lo = cs[d] == 0, hi = cs[d] == L.Xc[d] - 1;
+    if (!lo && !hi) continue;
+    int l = 0, mul = 1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (k != d) { l += cs[k] * mul; mul *= L.Xc[k]; }
+    const int f = l >> 1, nf = L.faceCB[d];
+    const unsigned long long w0 = (unsigned long long)__builtin_bit_cast(unsigned, val.x) | ((unsigned long long)seq << 32), w1 = (unsigned long long)__builtin_bit_cast(unsigned, val.y) | ((unsigned long long)seq << 32);
+    if (lo) {
+      unsigned long long *dst = reinterpret_cast<unsigned long long *>(L.peer[d][0][buf] + ((size_t)par * L.n + j) * nf + f);
+      __hip_atomic_store(gp(dst), w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(gp(dst + 1), w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (hi) {
+      unsigned long long *dst = reinterpret_cast<unsigned long long *>(L.peer[d][1][buf] + ((size_t)par * L.n + j) * nf + f);
+      __hip_atomic_store(gp(dst), w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(gp(dst + 1), w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
 __device__ __forceinline__ void cc_exchange_begin(const CcArg &a, const CcLevel &L, CcCtx &c, const CcVec &v, int pmask) {
   if (L.commMask) { c.seq++; cc_push(a, L, c, v, pmask); }
 }
@@ -486,10 +524,10 @@ template <int N> __device__ __forceinline__ void cc_prepare(const CcArg &a, cons
   const int p = L.solvePar, q = 1 - p;
   for (int t = blockIdx.x; t < L.Vh; t += gridDim.x) {
     LinkRegs<N, 8, 9> lk;
-    cc_links_issue(lk, L.hat, (size_t)q * L.Vh + t);
+    cc_links_issue(lk, L.hat, (size_t)q * L.Vh + t, L.ntLinks);
     if (threadIdx.x < N) s.xin[8][threadIdx.x] = cc_ldb(a, L, L.b.p[q] + (size_t)threadIdx.x * L.b.stride + t);
     __syncthreads();
-    cc_links_finish(s, lk, L.hat, (size_t)q * L.Vh + t);
+    cc_links_finish(s, lk, L.hat, (size_t)q * L.Vh + t, L.ntLinks);
     if (threadIdx.x < N) stc(a, L.x.p[q] + (size_t)threadIdx.x * L.x.stride + t, s.yout[threadIdx.x]);
   }
   cc_barrier(a, s, c);
@@ -498,16 +536,16 @@ template <int N> __device__ __forceinline__ void cc_prepare(const CcArg &a, cons
   for (int t = blockIdx.x; t < L.Vh; t += gridDim.x) {
     LinkRegs<N, 0, 8> lk;
     LinkRegs<N, 8, 9> lk2;
-    cc_links_issue(lk, L.links, (size_t)p * L.Vh + t);
-    cc_links_issue(lk2, L.hat, (size_t)p * L.Vh + t);
+    cc_links_issue(lk, L.links, (size_t)p * L.Vh + t, L.ntLinks);
+    cc_links_issue(lk2, L.hat, (size_t)p * L.Vh + t, L.ntLinks);
     cc_stage(a, L, s, c, L.x, p, t, 0xff);
-    cc_links_finish(s, lk, L.links, (size_t)p * L.Vh + t);
+    cc_links_finish(s, lk, L.links, (size_t)p * L.Vh + t, L.ntLinks);
     if (threadIdx.x < N) {
       const float2 bv = cc_ldb(a, L, L.b.p[p] + (size_t)threadIdx.x * L.b.stride + t), h = s.yout[threadIdx.x];
       s.xin[8][threadIdx.x] = make_float2(bv.x - h.x, bv.y - h.y);
     }
     __syncthreads();
-    cc_links_finish(s, lk2, L.hat, (size_t)p * L.Vh + t);
+    cc_links_finish(s, lk2, L.hat, (size_t)p * L.Vh + t, L.ntLinks);
     if (threadIdx.x < 64) {
       double v = 0.0;
       if (threadIdx.x < N) {
@@ -527,16 +565,16 @@ template <int N> __device__ __forceinline__ void cc_reconstruct(const CcArg &a, 
   for (int t = blockIdx.x; t < L.Vh; t += gridDim.x) {
     LinkRegs<N, 0, 8> lk;
     LinkRegs<N, 8, 9> lk2;
-    cc_links_issue(lk, L.links, (size_t)q * L.Vh + t);
-    cc_links_issue(lk2, L.hat, (size_t)q * L.Vh + t);
+    cc_links_issue(lk, L.links, (size_t)q * L.Vh + t, L.ntLinks);
+    cc_links_issue(lk2, L.hat, (size_t)q * L.Vh + t, L.ntLinks);
     cc_stage(a, L, s, c, L.x, q, t, 0xff);
-    cc_links_finish(s, lk, L.links, (size_t)q * L.Vh + t);
+    cc_links_finish(s, lk, L.links, (size_t)q * L.Vh + t, L.ntLinks);
     if (threadIdx.x < N) {
       const float2 bv = cc_ldb(a, L, L.b.p[q] + (size_t)threadIdx.x * L.b.stride + t), h = s.yout[threadIdx.x];
       s.xin[8][threadIdx.x] = make_float2(bv.x - h.x, bv.y - h.y);
     }
     __syncthreads();
-    cc_links_finish(s, lk2, L.hat, (size_t)q * L.Vh + t);
+    cc_links_finish(s, lk2, L.hat, (size_t)q * L.Vh + t, L.ntLinks);
     if (threadIdx.x < N) stc(a, L.x.p[q] + (size_t)threadIdx.x * L.x.stride + t, s.yout[threadIdx.x]);
   }
 }
@@ -544,26 +582,31 @@ template <int N> __device__ __forceinline__ void cc_reconstruct(const CcArg &a, 
 // w = Yhat_pq Yhat_qp in_p in two phases (Mhat in = in - w: reference DiracCoarsePC::M, lib/dirac_coarse.cpp:332-350):
 //   phase 1: t_q = Yhat_qp in_p (ends with a barrier);  phase 2: w at every p site, handed to epi(site, row, w, in(site)[row], row < N) on
 //   the first wave.  No barrier at the end.
-template <int N, typename Epi> __device__ __forceinline__ void cc_matpc(const CcArg &a, const CcLevel &L, CcShared &s, CcCtx &c, const CcVec &vin, Epi epi) {
+template <int N, typename Epi> __device__ __forceinline__ void cc_matpc(const CcArg &a, const CcLevel &L, CcShared &s, CcCtx &c, const CcVec &vin, Epi epi, bool pushed = false) {
   const int p = L.solvePar, q = 1 - p;
-  cc_exchange_begin(a, L, c, vin, 1 << p);
+  if (!pushed) cc_exchange_begin(a, L, c, vin, 1 << p);   // pushed: the faces of vin went out when it was produced (exchange number c.seq)
+  const unsigned seqT = c.seq + 1;                         // exchange number of the intermediate vector t, pushed by the sites that produce it
   for (int t = blockIdx.x; t < L.Vh; t += gridDim.x) {
     LinkRegs<N, 0, 8> lk;
-    cc_links_issue(lk, L.hat, (size_t)q * L.Vh + t);
+    cc_links_issue(lk, L.hat, (size_t)q * L.Vh + t, L.ntLinks);
     cc_stage(a, L, s, c, vin, q, t, 0xff);
-    cc_links_finish(s, lk, L.hat, (size_t)q * L.Vh + t);
-    if (threadIdx.x < N) stc(a, L.t + (size_t)threadIdx.x * L.Vh + t, s.yout[threadIdx.x]);
+    cc_links_finish(s, lk, L.hat, (size_t)q * L.Vh + t, L.ntLinks);
+    if (threadIdx.x < N) {
+      const float2 v = s.yout[threadIdx.x];
+      stc(a, L.t + (size_t)threadIdx.x * L.Vh + t, v);
+      if (L.commMask) { int cs[4]; cc_coords(L, q, t, cs); cc_push_site(L, seqT, q, cs, (int)threadIdx.x, v); }
+    }
   }
   cc_barrier(a, s, c);
   const CcVec vt = cc_parity_vec(L.t, q, L.Vh);
-  cc_exchange_begin(a, L, c, vt, 1 << q);
+  if (L.commMask) c.seq = seqT;
   for (int t = blockIdx.x; t < L.Vh; t += gridDim.x) {
     LinkRegs<N, 0, 8> lk;
-    cc_links_issue(lk, L.hat, (size_t)p * L.Vh + t);
+    cc_links_issue(lk, L.hat, (size_t)p * L.Vh + t, L.ntLinks);
     float2 iv = make_float2(0.f, 0.f);   // the site's own input: requested with the links, used in the epilogue
     if (threadIdx.x < N) iv = ldc(a, vin.p[p] + (size_t)threadIdx.x * vin.stride + t);
     cc_stage(a, L, s, c, vt, p, t, 0xff);
-    cc_links_finish(s, lk, L.hat, (size_t)p * L.Vh + t);
+    cc_links_finish(s, lk, L.hat, (size_t)p * L.Vh + t, L.ntLinks);
     if (threadIdx.x < 64) {
       const bool on = threadIdx.x < N;
       float2 w = make_float2(0.f, 0.f);
@@ -580,10 +623,19 @@ template <int N> __device__ __forceinline__ void cc_mr(const CcArg &a, const CcL
   const int p = L.solvePar, Vh = L.Vh, nel = N * Vh;
   const CcVec xp = cc_parity_of(L.x, p), vbt = cc_parity_vec(L.bt, p, Vh), vr = cc_parity_vec(L.r, p, Vh);
   bool fresh = !guess;
+  bool pushed = false;   // the residual's faces went out when it was produced (exchange number c.seq)
   if (guess) {
+    const bool pushR = L.commMask && nu > 0;
+    const unsigned seqR = c.seq + 3;   // (the matpc below uses c.seq + 1 for x and + 2 for t)
     cc_matpc<N>(a, L, s, c, xp, [&](int t, int j, float2 w, float2 iv, bool on) {
-      if (on) { const float2 b = ldc(a, L.bt + (size_t)j * Vh + t); stc(a, L.r + (size_t)j * Vh + t, make_float2(b.x - iv.x + w.x, b.y - iv.y + w.y)); }
+      if (on) {
+        const float2 b = ldc(a, L.bt + (size_t)j * Vh + t);
+        const float2 r = make_float2(b.x - iv.x + w.x, b.y - iv.y + w.y);
+        stc(a, L.r + (size_t)j * Vh + t, r);
+        if (pushR) { int cs[4]; cc_coords(L, p, t, cs); cc_push_site(L, seqR, p, cs, j, r); }
+      }
     });
+    if (pushR) { c.seq = seqR; pushed = true; }
     cc_barrier(a, s, c);
   } else if (nu == 0) {
     for (int e = blockIdx.x * kThreads + threadIdx.x; e < nel; e += gridDim.x * kThreads) {
@@ -601,24 +653,31 @@ template <int N> __device__ __forceinline__ void cc_mr(const CcArg &a, const CcL
       double re = on ? (double)Ar.x * iv.x + (double)Ar.y * iv.y : 0.0, im = on ? (double)Ar.x * iv.y - (double)Ar.y * iv.x : 0.0, nn = on ? (double)Ar.x * Ar.x + (double)Ar.y * Ar.y : 0.0;
       re = wave_sum(re); im = wave_sum(im); nn = wave_sum(nn);
       if (j == 0) { s.dacc[0] += re; s.dacc[1] += im; s.dacc[2] += nn; }
-    });
+    }, pushed);
     cc_reduce(a, s, c, 3, L.mrGlobal != 0);
     const double z = s.red[2], sc = z > 0.0 ? (double)L.omega / z : 0.0;
     const float ar = (float)(sc * s.red[0]), ai = (float)(sc * s.red[1]);
+    const bool pushR = L.commMask && it + 1 < nu;   // the next iteration hops the new residual: its faces leave with the update
+    const unsigned seqR = c.seq + 1;
     for (int e = blockIdx.x * kThreads + threadIdx.x; e < nel; e += gridDim.x * kThreads) {
       const int j = e / Vh, t = e - j * Vh;
       float2 *xe = L.x.p[p] + (size_t)j * L.x.stride + t;
       const float2 Ar = ldc(a, L.Ar + e);
+      float2 rn;
       if (fresh) {
         const float2 b = ldc(a, L.bt + e);
         stc(a, xe, make_float2(ar * b.x - ai * b.y, ar * b.y + ai * b.x));
-        stc(a, L.r + e, make_float2(b.x - (ar * Ar.x - ai * Ar.y), b.y - (ar * Ar.y + ai * Ar.x)));
+        rn = make_float2(b.x - (ar * Ar.x - ai * Ar.y), b.y - (ar * Ar.y + ai * Ar.x));
       } else {
         const float2 r = ldc(a, L.r + e), x0 = ldc(a, xe);
         stc(a, xe, make_float2(x0.x + ar * r.x - ai * r.y, x0.y + ar * r.y + ai * r.x));
-        stc(a, L.r + e, make_float2(r.x - (ar * Ar.x - ai * Ar.y), r.y - (ar * Ar.y + ai * Ar.x)));
+        rn = make_float2(r.x - (ar * Ar.x - ai * Ar.y), r.y - (ar * Ar.y + ai * Ar.x));
       }
+      stc(a, L.r + e, rn);
+      if (pushR) { int cs[4]; cc_coords(L, p, t, cs); cc_push_site(L, seqR, p, cs, j, rn); }
     }
+    pushed = pushR;
+    if (pushR) c.seq = seqR;
     fresh = false;
     cc_barrier(a, s, c);
   }
@@ -630,9 +689,9 @@ template <int N> __device__ __forceinline__ void cc_residual(const CcArg &a, con
   for (int A = blockIdx.x; A < 2 * L.Vh; A += gridDim.x) {
     const int par = A >= L.Vh, t = A - par * L.Vh;
     LinkRegs<N, 0, 9> lk;
-    cc_links_issue(lk, L.links, (size_t)A);
+    cc_links_issue(lk, L.links, (size_t)A, L.ntLinks);
     cc_stage(a, L, s, c, L.x, par, t, 0x1ff);
-    cc_links_finish(s, lk, L.links, (size_t)A);
+    cc_links_finish(s, lk, L.links, (size_t)A, L.ntLinks);
     if (threadIdx.x < N) {
       const float2 bv = cc_ldb(a, L, L.b.p[par] + (size_t)threadIdx.x * L.b.stride + t), h = s.yout[threadIdx.x];
       stc(a, L.rf.p[par] + (size_t)threadIdx.x * L.rf.stride + t, make_float2(bv.x - h.x, bv.y - h.y));
@@ -756,7 +815,15 @@ template <int N> __device__ __forceinline__ void cc_gcr(const CcArg &a, const Cc
     return;
   }
   const double stop = a.tol * a.tol * b2;
-  for (int e = e0; e < nel; e += estep) { stc(a, L.r + e, ldc(a, L.bt + e)); stc(a, a.y + e, make_float2(0.f, 0.f)); }
+  // (the faces of every new residual leave with the phase that produces it: pushR / `pushed`, see cc_matpc)
+  auto pushElem = [&](unsigned seq, int e, float2 v) { const int j = e / Vh, t = e - j * Vh; int cs[4]; cc_coords(L, p, t, cs); cc_push_site(L, seq, p, cs, j, v); };
+  const bool comm = L.commMask != 0;
+  {
+    const unsigned seqR = c.seq + 1;
+    for (int e = e0; e < nel; e += estep) { const float2 v = ldc(a, L.bt + e); stc(a, L.r + e, v); stc(a, a.y + e, make_float2(0.f, 0.f)); if (comm) pushElem(seqR, e, v); }
+    if (comm) c.seq = seqR;
+  }
+  bool pushed = comm;
   cc_barrier(a, s, c);
   const CcVec vr = cc_parity_vec(L.r, p, Vh), vy = cc_parity_vec(a.y, p, Vh);
   double r2 = b2, r2_old = b2;
@@ -785,7 +852,8 @@ template <int N> __device__ __forceinline__ void cc_gcr(const CcArg &a, const Cc
       double re = on ? (double)Ap.x * iv.x + (double)Ap.y * iv.y : 0.0, im = on ? (double)Ap.x * iv.y - (double)Ap.y * iv.x : 0.0, nn = on ? (double)Ap.x * Ap.x + (double)Ap.y * Ap.y : 0.0;
       re = wave_sum(re); im = wave_sum(im); nn = wave_sum(nn);
       if (j == 0) { s.dacc[2 * k] += re; s.dacc[2 * k + 1] += im; s.dacc[2 * k + 2] += nn; }
-    });
+    }, pushed);
+    pushed = false;
     cc_reduce(a, s, c, K, true);
     const double apn = s.red[2 * k + 2];
     double g2 = apn;
@@ -806,6 +874,7 @@ template <int N> __device__ __forceinline__ void cc_gcr(const CcArg &a, const Cc
       cc_clear_acc(s, 1);
       const float ig = (float)(1.0 / gamma), alr = (float)(apr / gamma), ali = (float)(api / gamma);
       double nn = 0.0;
+      const unsigned seqR = c.seq + 1;
       for (int e = e0; e < nel; e += estep) {
         float2 v = ldc(a, APk + e);
         for (int i = 0; i < k; i++) {
@@ -818,8 +887,10 @@ template <int N> __device__ __forceinline__ void cc_gcr(const CcArg &a, const Cc
         float2 r = ldc(a, L.r + e);
         r.x -= alr * v.x - ali * v.y; r.y -= alr * v.y + ali * v.x;
         stc(a, L.r + e, r);
+        if (comm) pushElem(seqR, e, r);
         nn += (double)r.x * r.x + (double)r.y * r.y;
       }
+      if (comm) { c.seq = seqR; pushed = true; }
       cc_block_add(s, 0, nn);
       cc_reduce(a, s, c, 1, true);
       r2 = s.red[0];
@@ -852,11 +923,14 @@ template <int N> __device__ __forceinline__ void cc_gcr(const CcArg &a, const Cc
       cc_clear_acc(s, 1);
       const float ig = (float)(1.0 / gamma), alr = (float)(apr / gamma), ali = (float)(api / gamma);
       double n2 = 0.0;
+      const unsigned seqR = c.seq + 1;
       for (int e = e0; e < nel; e += estep) {
         float2 v = ldc(a, APk + e); v.x *= ig; v.y *= ig; stc(a, APk + e, v);
         float2 r = ldc(a, L.r + e); r.x -= alr * v.x - ali * v.y; r.y -= alr * v.y + ali * v.x; stc(a, L.r + e, r);
+        if (comm) pushElem(seqR, e, r);
         n2 += (double)r.x * r.x + (double)r.y * r.y;
       }
+      if (comm) { c.seq = seqR; pushed = true; }
       cc_block_add(s, 0, n2);
       cc_reduce(a, s, c, 1, true);
       r2 = s.red[0];
@@ -884,14 +958,19 @@ template <int N> __device__ __forceinline__ void cc_gcr(const CcArg &a, const Cc
       }
       cc_barrier(a, s, c);
       cc_clear_acc(s, 1);
+      const unsigned seqR2 = c.seq + 3;   // (the matpc below: + 1 for y, + 2 for t)
       cc_matpc<N>(a, L, s, c, vy, [&](int t, int j, float2 w, float2 iv, bool on) {
         const size_t o = (size_t)j * Vh + t;
         float2 rr = make_float2(0.f, 0.f);
-        if (on) { const float2 b = ldc(a, L.bt + o); rr = make_float2(b.x - iv.x + w.x, b.y - iv.y + w.y); stc(a, L.r + o, rr); }
+        if (on) {
+          const float2 b = ldc(a, L.bt + o); rr = make_float2(b.x - iv.x + w.x, b.y - iv.y + w.y); stc(a, L.r + o, rr);
+          if (comm) { int cs[4]; cc_coords(L, p, t, cs); cc_push_site(L, seqR2, p, cs, j, rr); }
+        }
         double nn = (double)rr.x * rr.x + (double)rr.y * rr.y;
         nn = wave_sum(nn);
         if (j == 0) s.dacc[0] += nn;
       });
+      if (comm) { c.seq = seqR2; pushed = true; }
       cc_reduce(a, s, c, 1, true);
       r2 = s.red[0];
       if (r2 > r2_old) {
@@ -1029,7 +1108,8 @@ CoarseCycle *coarseCycleCreate(MG &top) {
   if (tp.level < 1) return nullptr;
   const int nl = tp.Nlevel - tp.level;
   if (nl < 1 || nl > kMaxLevels) return nullptr;
-  if (coarseHalfStorage()) return nullptr;
+  // (half-precision storage of the hierarchy: the fused cycle keeps reading the fp32 masters of the coarse links — below level 0 a phase is
+  // bound by latency, not by bytes — while R / P of level 0 and its smoother use the fp16 / 16-bit mirrors)
   const CommGrid &g = commGrid();
   if (g.size > kMaxRanks) return nullptr;
   if (commReductionsNeeded() && g.size == 1) return nullptr;          // RCCL self-test mode: sums must go through the collective
@@ -1065,6 +1145,7 @@ CoarseCycle *coarseCycleCreate(MG &top) {
     else ok = false;
     L.omega = (float)p.omega;
     L.mrGlobal = p.global_reduction && commReductionsNeeded() ? 1 : 0;
+    L.ntLinks = (size_t)2 * Y.nSites * 9 * Y.n * Y.n * 8 > ((size_t)24 << 20) ? 1 : 0;   // links + preconditioned links against the 8 x 4 MB of L2
     L.commMask = 0;
     for (int d = 0; d < 4; d++) { L.faceCB[d] = L.Vh / L.Xc[d]; if (g.partitioned(d)) L.commMask |= 1 << d; }
     if (L.commMask) anyComm = true;
@@ -1090,7 +1171,7 @@ CoarseCycle *coarseCycleCreate(MG &top) {
     const size_t pv = (size_t)L.n * L.Vh;
     elems += 6 * pv + 2 * pv + (l > 0 ? 2 * pv : 0) + (coarsest ? (size_t)(2 * a.nKrylov + 1) * pv : 0);
     if (L.commMask)
-      for (int d = 0; d < 4; d++) if ((L.commMask >> d) & 1) winBytes += (size_t)4 * 2 * L.n * L.faceCB[d] * sizeof(u32x4_t);
+      for (int d = 0; d < 4; d++) if ((L.commMask >> d) & 1) winBytes += (size_t)2 * kHaloBufs * 2 * L.n * L.faceCB[d] * sizeof(u32x4_t);
   }
   if (ok && anyComm && !p2pHaloEnabled()) ok = false;   // staged (RCCL) transport: no peer windows to push into
   if (!ok) { delete cc; return nullptr; }
@@ -1159,7 +1240,7 @@ CoarseCycle *coarseCycleCreate(MG &top) {
           // zone k = 0: filled by the -d neighbour with its x_d = L-1 face; zone k = 1: by the +d neighbour with its x_d = 0 face
           const int face = k == 0 ? 1 : 0;          // which of MY faces goes into the neighbour's zone k
           const int slot = 2 * d + (face ? 1 : 0);  // face L-1 travels to the +d neighbour, face 0 to the -d neighbour
-          for (int buf = 0; buf < 2; buf++) {
+          for (int buf = 0; buf < kHaloBufs; buf++) {
             L.ghost[d][k][buf] = (u32x4_t *)(cc->window + off);
             L.peer[d][face][buf] = (u32x4_t *)((char *)cc->map->peer[slot] + off);
             off += zone;

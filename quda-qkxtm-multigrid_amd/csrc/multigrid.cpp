@@ -587,7 +587,11 @@ void MG::operator()(ColorSpinorField &x, ColorSpinorField &b) {
     // on every rank, and any disagreement (or a wait that ran out) sends all ranks back to that path for good
     if (!fusedTried) { fusedTried = true; fused = coarseCycleCreate(*this); }
     if (fused && !fusedVerified) {
+      // (the fused cycle reads the fp32 coarse links whatever the storage switch says: the reference cycle of this check does the same)
+      const bool half = coarseHalfStorage();
+      if (half) setCoarseHalfStorage(false);
       cycleUnfused(x, b);
+      if (half) setCoarseHalfStorage(true);
       ColorSpinorField ref(x);
       double fail = coarseCycleApply(fused, x, b) ? 0.0 : 1.0;
       HIP_CHECK(hipStreamSynchronize(computeStream()));
@@ -706,7 +710,6 @@ void MG::setSmootherSloppy(DiracMatrix *sloppy) {
 }
 
 void MG::makeHalfMirrors() {
-  dropFusedCycle();
   if (transfer) transfer->makeHalf();
   if (diracCoarse) diracCoarse->Links().makeHalf();
   if (diracCoarseSmoother) diracCoarseSmoother->HatLinks().makeHalf();
@@ -879,7 +882,6 @@ void multigridSetHalfStorage(multigrid_solver &mgs, bool on) {
     HIP_CHECK(hipStreamSynchronize(computeStream()));
   } else {
     mgs.mg->setSmootherSloppy(nullptr);
-    mgs.mg->dropFusedCycle();   // fp32 storage again: the fused coarse cycle may come back
   }
   setCoarseHalfStorage(on);
 }

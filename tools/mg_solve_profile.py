@@ -47,6 +47,10 @@ mp = qa.multigrid_param(ip, n_level=3, geo_block=blocks, n_vec=24, setup_maxiter
 t0 = time.perf_counter()
 mg = qa.Multigrid(mp)
 setup = time.perf_counter() - t0
+if os.environ.get("QA_PROFILE_HALF"):      # fp16 V + 16-bit level-0 smoother (qudaAmdMultigridSetHalfStorage)
+    mg.set_half_storage(True)
+if os.environ.get("QA_PROFILE_FUSED") is not None:   # 0: the kernel-per-operation coarse cycle
+    qa.lib().qudaAmdMultigridSetFused(int(os.environ["QA_PROFILE_FUSED"]))
 ip.inv_type_precondition, ip.preconditioner = qa.QUDA_MG_INVERTER, mg.h
 ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
 b = np.random.default_rng(5).random(int(np.prod(X)) * 24)
