@@ -479,6 +479,40 @@ __global__ void __launch_bounds__(256) blas_kernel(BlasArg<F> arg) {
   const long total = arg.n * arg.nseg;
   F f = arg.f;
   blas_prepare(f, 0);
+  if constexpr (!SITE) {
+    // Four chunks per thread and trip, all their loads requested before the first is used: a streaming kernel needs ~64 KB in flight per CU
+    // to cover the HBM latency at 8 TB/s (Little), and two 16-byte loads per lane in 8 waves per CU are 16 KB — the one-chunk loop ran
+    // axpy at 4.65 TB/s where the copy rate of the device is 6.3.  The loads cannot be hoisted by the compiler (the stores of a chunk may
+    // alias the next chunk's loads for all it knows), hence by hand.
+    constexpr int UN = 4;
+    using V = Chunk<real, M>;
+    const long step = (long)gridDim.x * blockDim.x;
+    for (long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x; i0 < total; i0 += step * UN) {
+      V xv[UN], yv[UN], zv[UN], wv[UN];
+      int seg[UN]; long jj[UN]; bool ok[UN];
+#pragma unroll
+      for (int u = 0; u < UN; u++) {
+        const long i = i0 + u * step;
+        ok[u] = i < total;
+        const long ic = ok[u] ? i : i0;
+        seg[u] = ic >= arg.n ? 1 : 0;
+        jj[u] = ic - seg[u] * arg.n;
+        if (F::rx) xv[u] = reinterpret_cast<const V *>(arg.x.v[seg[u]])[jj[u]];
+        if (F::ry) yv[u] = reinterpret_cast<const V *>(arg.y.v[seg[u]])[jj[u]];
+        if (F::rz) zv[u] = reinterpret_cast<const V *>(arg.z.v[seg[u]])[jj[u]];
+        if (F::rw) wv[u] = reinterpret_cast<const V *>(arg.w.v[seg[u]])[jj[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < UN; u++) {
+        if (!ok[u]) continue;
+        f.template operator()<real, M>(xv[u].v, yv[u].v, zv[u].v, wv[u].v, red);
+        if (F::wx) reinterpret_cast<V *>(arg.x.v[seg[u]])[jj[u]] = xv[u];
+        if (F::wy) reinterpret_cast<V *>(arg.y.v[seg[u]])[jj[u]] = yv[u];
+        if (F::wz) reinterpret_cast<V *>(arg.z.v[seg[u]])[jj[u]] = zv[u];
+        if (F::ww) reinterpret_cast<V *>(arg.w.v[seg[u]])[jj[u]] = wv[u];
+      }
+    }
+  } else {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int seg = i >= arg.n ? 1 : 0;
     const long j = i - seg * arg.n;
@@ -486,31 +520,16 @@ __global__ void __launch_bounds__(256) blas_kernel(BlasArg<F> arg) {
     alignas(16) real y[M];
     alignas(16) real z[M];
     alignas(16) real w[M];
-    if (SITE) {
-      if (F::rx) Planar<T, M>::load(x, arg.x.v[seg], arg.stride, (int)j, arg.x.norm[seg], (int)j);
-      if (F::ry) Planar<T, M>::load(y, arg.y.v[seg], arg.stride, (int)j, arg.y.norm[seg], (int)j);
-      if (F::rz) Planar<T, M>::load(z, arg.z.v[seg], arg.stride, (int)j, arg.z.norm[seg], (int)j);
-      if (F::rw) Planar<T, M>::load(w, arg.w.v[seg], arg.stride, (int)j, arg.w.norm[seg], (int)j);
-    } else {
-      using V = Chunk<real, M>;
-      if (F::rx) *reinterpret_cast<V *>(x) = reinterpret_cast<const V *>(arg.x.v[seg])[j];
-      if (F::ry) *reinterpret_cast<V *>(y) = reinterpret_cast<const V *>(arg.y.v[seg])[j];
-      if (F::rz) *reinterpret_cast<V *>(z) = reinterpret_cast<const V *>(arg.z.v[seg])[j];
-      if (F::rw) *reinterpret_cast<V *>(w) = reinterpret_cast<const V *>(arg.w.v[seg])[j];
-    }
+    if (F::rx) Planar<T, M>::load(x, arg.x.v[seg], arg.stride, (int)j, arg.x.norm[seg], (int)j);
+    if (F::ry) Planar<T, M>::load(y, arg.y.v[seg], arg.stride, (int)j, arg.y.norm[seg], (int)j);
+    if (F::rz) Planar<T, M>::load(z, arg.z.v[seg], arg.stride, (int)j, arg.z.norm[seg], (int)j);
+    if (F::rw) Planar<T, M>::load(w, arg.w.v[seg], arg.stride, (int)j, arg.w.norm[seg], (int)j);
     f.template operator()<real, M>(x, y, z, w, red);
-    if (SITE) {
-      if (F::wx) Planar<T, M>::store(x, arg.x.v[seg], arg.stride, (int)j, arg.x.norm[seg], (int)j);
-      if (F::wy) Planar<T, M>::store(y, arg.y.v[seg], arg.stride, (int)j, arg.y.norm[seg], (int)j);
-      if (F::wz) Planar<T, M>::store(z, arg.z.v[seg], arg.stride, (int)j, arg.z.norm[seg], (int)j);
-      if (F::ww) Planar<T, M>::store(w, arg.w.v[seg], arg.stride, (int)j, arg.w.norm[seg], (int)j);
-    } else {
-      using V = Chunk<real, M>;
-      if (F::wx) reinterpret_cast<V *>(arg.x.v[seg])[j] = *reinterpret_cast<V *>(x);
-      if (F::wy) reinterpret_cast<V *>(arg.y.v[seg])[j] = *reinterpret_cast<V *>(y);
-      if (F::wz) reinterpret_cast<V *>(arg.z.v[seg])[j] = *reinterpret_cast<V *>(z);
-      if (F::ww) reinterpret_cast<V *>(arg.w.v[seg])[j] = *reinterpret_cast<V *>(w);
-    }
+    if (F::wx) Planar<T, M>::store(x, arg.x.v[seg], arg.stride, (int)j, arg.x.norm[seg], (int)j);
+    if (F::wy) Planar<T, M>::store(y, arg.y.v[seg], arg.stride, (int)j, arg.y.norm[seg], (int)j);
+    if (F::wz) Planar<T, M>::store(z, arg.z.v[seg], arg.stride, (int)j, arg.z.norm[seg], (int)j);
+    if (F::ww) Planar<T, M>::store(w, arg.w.v[seg], arg.stride, (int)j, arg.w.norm[seg], (int)j);
+  }
   }
   if (F::nred > 0) {
     RedCtl c;

@@ -822,6 +822,10 @@ multigrid_solver::multigrid_solver(QudaMultigridParam &mg_param)
 void multigrid_solver::refine(int passes, int cycles) {
   if (passes <= 0) return;
   const double t0 = now();
+  // half-precision storage is a property of the hierarchy objects that are rebuilt below: remember it and put it back (a refined
+  // hierarchy silently lost its fp16 mirrors and 16-bit smoother while the process-wide switch stayed on)
+  const bool hadHalf = coarseHalfStorage() && mSmoothHalf != nullptr;
+  if (hadHalf) multigridSetHalfStorage(*this, false);
   ColorSpinorField *y = likeField(*B[0]);
   const QudaTwistFlavorType flavor = B[0]->TwistFlavor();
   y->twistFlavor = flavor;
@@ -845,6 +849,7 @@ void multigrid_solver::refine(int passes, int cycles) {
     if (getVerbosity() >= QUDA_SUMMARIZE || mgProfiling()) printfQuda("MG set-up refinement pass %d of %d done (%.3f s so far)\n", pass + 1, passes, now() - t0);
   }
   delete y;
+  if (hadHalf) multigridSetHalfStorage(*this, true);
   mg_param_copy.secs += now() - t0;
 }
 

@@ -437,6 +437,7 @@ void GCR::operator()(ColorSpinorField &x, ColorSpinorField &b) {
   bool l2_converge = false;
   const int pipeline = param.pipeline > 1 ? 1 : (param.pipeline == 0 ? 1 : param.pipeline);
   int k = 0;
+  bool blockedOrthoOk = true;   // cleared for the rest of a Krylov cycle once the blocked orthogonalisation has shown a loss of orthogonality
   PrintStats("GCR", total_iter + k, r2, b2, 0.0);
   while (!convergence(r2, 0.0, stop, param.tol_hq) && total_iter < param.maxiter) {
     for (int m = 0; m < param.precondition_cycle; m++) {
@@ -460,7 +461,7 @@ void GCR::operator()(ColorSpinorField &x, ColorSpinorField &b) {
     // difference loses more than two digits (the new direction lies almost in the span of the old ones) the iteration falls back to
     // the sequential chain, which measures the norm instead of inferring it.
     bool blocked = false;
-    if (blas::multiSupported(*Ap[k], k)) {
+    if (blockedOrthoOk && blas::multiSupported(*Ap[k], k)) {
       std::vector<Complex> bk(k > 0 ? k : 1);
       Complex apr; double apn;
       blas::multiDot(bk.data(), apr, apn, Ap, k, *Ap[k], rSloppy);
@@ -474,6 +475,17 @@ void GCR::operator()(ColorSpinorField &x, ColorSpinorField &b) {
         double y2;
         blas::multiCaxpyResidual(r2, y2, bk.data(), Ap, k, 1.0 / gamma[k], *Ap[k], alpha[k], rSloppy);   // Ap_k = (Ap_k - sum beta_i Ap_i) / gamma ; r -= alpha Ap_k
         blocked = true;
+        // y2 is the MEASURED |Ap_k|^2 after the normalisation with the inferred gamma: 1 up to round-off while the old directions are
+        // orthonormal.  Where it is not (single-pass classical Gram-Schmidt in fp32 over up to 20 directions), the direction is put right
+        // with the measured norm — Ap_k, gamma and alpha rescaled consistently, r untouched: alpha Ap_k is invariant under that rescaling
+        // — and the rest of this Krylov cycle goes through the sequential chain, which measures instead of inferring.
+        if (k > 0 && std::fabs(y2 - 1.0) > 1e-3 && y2 > 0.0) {
+          const double s = sqrt(y2);
+          blas::ax(1.0 / s, *Ap[k]);
+          gamma[k] *= s;
+          alpha[k] *= s;
+          blockedOrthoOk = false;
+        }
       }
     }
     if (!blocked) {
@@ -505,6 +517,7 @@ void GCR::operator()(ColorSpinorField &x, ColorSpinorField &b) {
         resIncrease = 0;
       }
       k = 0;
+      blockedOrthoOk = true;
       if (!convergence(r2, 0.0, stop, param.tol_hq)) {
         restart++;
         PrintStats("GCR (restart)", restart, r2, b2, 0.0);
