@@ -992,6 +992,9 @@ template <int N> __device__ __forceinline__ void cc_gcr(const CcArg &a, const Cc
   cc_barrier(a, s, c);
 }
 
+}  // namespace
+
+// (outside the anonymous namespace, so that profilers print a plain kernel name)
 // The argument block lives in device memory (the levels are indexed at run time: a by-value kernel argument would be copied to scratch)
 template <int N> __global__ void __launch_bounds__(kThreads) coarse_cycle_kernel(const CcArg *__restrict__ ap) {
   // The argument block is copied into LDS first: the phases read its fields (extents, pointers, strides) all the time, and read from global
@@ -1060,7 +1063,6 @@ template <int N> __global__ void __launch_bounds__(kThreads) coarse_cycle_kernel
   }
 }
 
-}  // namespace
 
 // ================================================================================================
 // host side
