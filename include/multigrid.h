@@ -40,6 +40,7 @@ struct MGParam : SolverParam {
 };
 
 class CoarseCycle;   // coarse_cycle.h: the cycle below a coarse level as one persistent kernel
+struct MGBlockState;  // block_solver.cpp: per-source smoothers / work fields and the block-field cycle below the fine level (invertMultiSrcQuda)
 
 class MG : public Solver {
   MGParam &mgp;
@@ -60,6 +61,9 @@ class MG : public Solver {
   CoarseCycle *fused = nullptr;
   bool fusedTried = false, fusedVerified = false;
   void cycleUnfused(ColorSpinorField &out, ColorSpinorField &in);
+  MGBlockState *blockState = nullptr;
+  bool blockPrepare(int nsrc);
+  void cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorField *> &b, const std::vector<char> &active, bool fullResidual);
  public:
   // how generateNullVectors produced this level's vectors: 0 loaded / restricted / sequential BiCGstab solves (the reference's loop),
   // 1 lockstep block BiCGstab on the multi-right-hand-side fine stencil, 2 the same on the MFMA coarse operator; and the lockstep iteration count
@@ -92,7 +96,12 @@ class MG : public Solver {
   bool smootherIsPC() const { return pcSmooth; }
   const SolverParam *preSmootherParam() const { return param_presmooth; }
   const CoarseCycle *fusedCycle() const { return fused; }
-  void dropFusedCycle();   // hierarchy contents changed (half-precision mirrors switched on): rebuild or abandon at the next cycle
+  void dropFusedCycle();
+  // x_i = K b_i for several sources at once (level 0 only): smoothing / R / P per source, everything below the fine level on block fields through
+  // the multi-right-hand-side MFMA coarse operator (block_solver.cpp).  false: this hierarchy does not qualify, the caller applies K per source.
+  // active[i] = 0: source i is left alone.  blockRelease frees the per-source state.
+  bool cycleBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorField *> &b, const std::vector<char> &active);
+  void blockRelease();   // hierarchy contents changed (half-precision mirrors switched on): rebuild or abandon at the next cycle
   DiracMatrix &residualMatrix() const { return mgp.matResidual; }
 };
 

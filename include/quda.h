@@ -178,6 +178,9 @@ void loadCloverQuda(void *h_clover, void *h_clovinv, QudaInvertParam *inv_param)
 void freeCloverQuda(void);                                 /* ref quda.h:613 */
 
 void invertQuda(void *h_x, void *h_b, QudaInvertParam *param);       /* ref quda.h:636; interface_quda.cpp:2276 */
+/* param->num_src sources through ONE lockstep solve (GCR, optionally MG-preconditioned: the cycle below the fine level runs on block fields
+ * through the multi-right-hand-side MFMA coarse operator); ref quda.h:647, whose own implementation "cannot work" (interface_quda.cpp:2546-2549) */
+void invertMultiSrcQuda(void **_hp_x, void **_hp_b, QudaInvertParam *param);
 void *newMultigridQuda(QudaMultigridParam *param);                   /* ref quda.h:666; interface_quda.cpp:2257 */
 void destroyMultigridQuda(void *mg_instance);                        /* ref quda.h:671 */
 

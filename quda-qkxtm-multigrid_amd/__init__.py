@@ -107,7 +107,7 @@ class QudaMultigridParam(C.Structure):
 # every extern "C" symbol include/quda.h and include/quda_amd_ext.h declare
 QUDA_H_SYMBOLS = ["setVerbosityQuda", "initCommsGridQuda", "initQudaDevice", "initQudaMemory", "initQuda", "endQuda",
                   "newQudaGaugeParam", "newQudaInvertParam", "newQudaMultigridParam", "printQudaGaugeParam", "printQudaInvertParam",
-                  "printQudaMultigridParam", "loadGaugeQuda", "freeGaugeQuda", "loadCloverQuda", "freeCloverQuda", "invertQuda",
+                  "printQudaMultigridParam", "loadGaugeQuda", "freeGaugeQuda", "loadCloverQuda", "freeCloverQuda", "invertQuda", "invertMultiSrcQuda",
                   "newMultigridQuda", "destroyMultigridQuda", "dslashQuda", "cloverQuda", "MatQuda", "MatDagMatQuda", "openMagma",
                   "closeMagma"]
 EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLoad", "qudaAmdSpinorSave", "qudaAmdSpinorCopy",
@@ -175,6 +175,8 @@ def lib():
         L.MatQuda.argtypes = [_p, _p, C.POINTER(QudaInvertParam)]
         L.MatDagMatQuda.argtypes = [_p, _p, C.POINTER(QudaInvertParam)]
         L.invertQuda.argtypes = [_p, _p, C.POINTER(QudaInvertParam)]
+        L.invertMultiSrcQuda.argtypes = [_p, _p, C.POINTER(QudaInvertParam)]
+        L.invertMultiSrcQuda.restype = None
         L.cloverQuda.argtypes = [_p, _p, C.POINTER(QudaInvertParam), C.POINTER(_i), _i]
         L.loadGaugeQuda.argtypes = [_p, C.POINTER(QudaGaugeParam)]
         L.loadCloverQuda.argtypes = [_p, _p, C.POINTER(QudaInvertParam)]
@@ -365,6 +367,18 @@ def invert(h_b, ip, out=None):
     x = np.zeros_like(h_b) if out is None else out
     lib().invertQuda(_vp(x), _vp(h_b), C.byref(ip))
     return x
+
+
+def invert_multi_src(h_bs, ip):
+    """invertMultiSrcQuda: the sources h_bs[i] through one lockstep solve; returns the list of solutions (ip.num_src is set here)"""
+    bs = [np.ascontiguousarray(b) for b in h_bs]
+    xs = [np.zeros_like(b) for b in bs]
+    n = len(bs)
+    ip.num_src = n
+    pb = (_p * n)(*[_vp(b) for b in bs])
+    px = (_p * n)(*[_vp(x) for x in xs])
+    lib().invertMultiSrcQuda(px, pb, C.byref(ip))
+    return xs
 
 
 def read_lime_gauge(fname, gp, grid=(1, 1, 1, 1), ip=None, local_volume=None):

@@ -1,0 +1,592 @@
+// block_solver.cpp — several right-hand sides through MG-preconditioned GCR in lockstep (invertMultiSrcQuda).
+//
+// The reference declares the entry point (include/quda.h:647, QudaInvertParam::num_src) and carries a multi-source fifth dimension through
+// its coarse-grid kernel (lib/dslash_coarse.cu:278, :294-333), but its invertMultiSrcQuda "is just a copy of invertQuda and cannot work"
+// (lib/interface_quda.cpp:2546-2549).  The consumer is there all the same: calcMG_threepTwop_EvenOdd solves twelve spin-colour sources per
+// flavour with one operator and one hierarchy (lib/interface_quda.cpp:6018-6531).  Here the sources go through the solver TOGETHER:
+//   * outer solver: restarted flexible GCR per source with a shared Krylov index (reference lib/inv_gcr_quda.cpp:235-516 per source; a source
+//     that has converged simply stops being updated), mixed precision and true-residual restarts as the single-source GCR of solver.cpp;
+//   * preconditioner: ONE multigrid cycle for all sources (MG::cycleBlock): smoothing, restriction and prolongation on the fine level per
+//     source with the kernels of the single-source cycle, and everything below the fine level on BLOCK FIELDS (block.h: site-major, right-
+//     hand side fastest) — the coarse operators read their dense link matrices once for all sources and run on the matrix cores
+//     (coarse_block_kernel, v_mfma_f32_16x16x4_f32).
+// The even-odd preconditioned coarse operator on block fields needs no kernel of its own: the full block operator applied to a field whose
+// other parity is zero IS the parity-restricted hop (sites of one parity only have neighbours of the other), at 2.25 x the necessary flops —
+// which the matrix cores have to spare — and the local terms Xinv come out of the same application (slot 8 of the preconditioned links).
+#include <cmath>
+#include <cstring>
+#include <sys/time.h>
+
+#include "block.h"
+#include "interface_internal.h"
+#include "multigrid.h"
+
+void setTuning(QudaTune tune);   // include/util_quda.h
+
+namespace quda {
+
+void massRescale(ColorSpinorField &b, QudaInvertParam &param);   // solve_interface.cpp
+
+static double nowSec() {
+  timeval t;
+  gettimeofday(&t, nullptr);
+  return t.tv_sec + 1e-6 * t.tv_usec;
+}
+
+// ================================================================================================
+// the cycle below the fine level on block fields
+// ================================================================================================
+struct BlockLevel {
+  const CoarseGauge *Y = nullptr, *H = nullptr;   // links (slot 8 = X) and preconditioned links Xinv Y (slot 8 = Xinv)
+  const Transfer *T = nullptr;                    // to the next coarser level (nullptr on the coarsest)
+  int p = 0;                                      // parity of the even-odd preconditioned system
+  int nuPre = 0, nuPost = 0;
+  double omega = 1.0;
+  BlockField *b = nullptr, *x = nullptr, *bt = nullptr, *r = nullptr, *Ar = nullptr, *t = nullptr, *w1 = nullptr, *w2 = nullptr;
+  std::vector<ColorSpinorField *> fine, coarse;   // per right-hand side staging fields of the transfer to the next level
+};
+
+class BlockCoarseCycle {
+ public:
+  int nl = 0, nb = 0;   // levels, right-hand sides of the block (a multiple of 8)
+  std::vector<BlockLevel> L;
+  // coarsest-grid GCR
+  int nKrylov = 20, maxiter = 1000;
+  double tol = 0.25;
+  std::vector<BlockField *> P, AP;
+  BlockField *y = nullptr;
+  long applies = 0, gcrIters = 0;
+
+  ~BlockCoarseCycle() {
+    for (BlockLevel &l : L) {
+      for (BlockField *f : {l.b, l.x, l.bt, l.r, l.Ar, l.t, l.w1, l.w2}) delete f;
+      for (ColorSpinorField *f : l.fine) delete f;
+      for (ColorSpinorField *f : l.coarse) delete f;
+    }
+    for (BlockField *f : P) delete f;
+    for (BlockField *f : AP) delete f;
+    delete y;
+  }
+
+  static void zeroParity(BlockField &f, int par) {
+    const size_t half = (size_t)f.Vh * f.ncomp * f.nrhs;
+    HIP_CHECK(hipMemsetAsync(f.v + (size_t)par * half, 0, half * sizeof(float2), computeStream()));
+  }
+  static void copyParity(BlockField &dst, const BlockField &src, int par) {
+    const size_t half = (size_t)src.Vh * src.ncomp * src.nrhs;
+    HIP_CHECK(hipMemcpyAsync(dst.v + (size_t)par * half, src.v + (size_t)par * half, half * sizeof(float2), hipMemcpyDeviceToDevice, computeStream()));
+  }
+  void apply(BlockField &out, BlockField &in, const CoarseGauge &G) { applyCoarseBlock(out, in, G); applies++; }
+  // y = x - y
+  void xmy(const BlockField &x, BlockField &yv) {
+    blockblas::negate(yv);
+    std::vector<Complex> one(nb, Complex(1.0, 0.0));
+    blockblas::caxpy(one.data(), x, yv);
+  }
+
+  // out_p = in_p - Yhat_pq Yhat_qp in_p   (in: other parity zero; out: other parity zero)   reference DiracCoarsePC::M, lib/dirac_coarse.cpp:332-350
+  void matpc(BlockLevel &l, BlockField &out, BlockField &in) {
+    apply(*l.t, in, *l.H);
+    zeroParity(*l.t, l.p);
+    apply(out, *l.t, *l.H);
+    zeroParity(out, 1 - l.p);
+    xmy(in, out);
+  }
+  // Schur prepare (reference DiracCoarsePC::prepare, :296-330): bt_p = Xinv (b_p - D_pq Xinv b_q)
+  void prepare(BlockLevel &l) {
+    const int p = l.p, q = 1 - p;
+    blockblas::copy(*l.w1, *l.b);
+    zeroParity(*l.w1, p);
+    apply(*l.w2, *l.w1, *l.H);          // parity q: Xinv b_q
+    zeroParity(*l.w2, p);
+    apply(*l.w1, *l.w2, *l.Y);          // parity p: D_pq (Xinv b_q)
+    xmy(*l.b, *l.w1);                   // b - ...
+    zeroParity(*l.w1, q);
+    apply(*l.bt, *l.w1, *l.H);          // parity p: Xinv ( . )
+    zeroParity(*l.bt, q);
+  }
+  // x_q = Xinv (b_q - D_qp x_p)   (reference DiracCoarsePC::reconstruct, :352-372); x_q is overwritten
+  void reconstruct(BlockLevel &l) {
+    const int p = l.p, q = 1 - p;
+    zeroParity(*l.x, q);
+    apply(*l.w1, *l.x, *l.Y);           // parity q: D_qp x_p
+    xmy(*l.b, *l.w1);
+    zeroParity(*l.w1, p);
+    apply(*l.w2, *l.w1, *l.H);          // parity q: Xinv ( . )
+    copyParity(*l.x, *l.w2, q);
+  }
+  // MR on the preconditioned system, per right-hand side alpha (reference lib/inv_mr_quda.cpp:40-200)
+  void mr(BlockLevel &l, int nu, bool guess) {
+    std::vector<Complex> dot(nb), al(nb), mal(nb);
+    std::vector<double> nrm(nb);
+    if (guess) {
+      blockblas::copy(*l.w1, *l.x);
+      zeroParity(*l.w1, 1 - l.p);
+      matpc(l, *l.r, *l.w1);
+      xmy(*l.bt, *l.r);                 // r = bt - Mhat x_p
+    } else {
+      zeroParity(*l.x, l.p);
+      blockblas::copy(*l.r, *l.bt);
+    }
+    for (int it = 0; it < nu; it++) {
+      matpc(l, *l.Ar, *l.r);
+      blockblas::cDotNormA(dot.data(), nrm.data(), *l.Ar, *l.r);
+      for (int i = 0; i < nb; i++) { al[i] = nrm[i] > 0.0 ? l.omega * dot[i] / nrm[i] : Complex(0.0); mal[i] = -al[i]; }
+      blockblas::caxpy(al.data(), *l.r, *l.x);     // x_p += alpha r   (r is zero on the other parity)
+      blockblas::caxpy(mal.data(), *l.Ar, *l.r);   // r -= alpha Ar
+    }
+  }
+  // restarted GCR(nKrylov) on Mhat x_p = bt to |r| <= tol |bt| per right-hand side, in lockstep (reference lib/inv_gcr_quda.cpp:235-516)
+  void gcr(BlockLevel &l) {
+    std::vector<double> b2(nb), r2(nb), stop(nb), nrm(nb);
+    std::vector<Complex> dot(nb), c(nb);
+    blockblas::norm2(b2.data(), *l.bt);
+    blockblas::copy(*l.r, *l.bt);
+    blockblas::zero(*y);
+    bool any = false;
+    for (int i = 0; i < nb; i++) { stop[i] = tol * tol * b2[i]; r2[i] = b2[i]; any = any || b2[i] > 0.0; }
+    // coefficients per right-hand side
+    std::vector<std::vector<Complex>> alpha(nKrylov, std::vector<Complex>(nb));
+    std::vector<std::vector<double>> gamma(nKrylov, std::vector<double>(nb));
+    std::vector<std::vector<std::vector<Complex>>> beta(nKrylov, std::vector<std::vector<Complex>>(nKrylov, std::vector<Complex>(nb)));
+    auto open = [&]() { for (int i = 0; i < nb; i++) if (r2[i] > stop[i]) return true; return false; };
+    int k = 0, total = 0;
+    while (any && open() && total < maxiter) {
+      blockblas::copy(*P[k], *l.r);
+      matpc(l, *AP[k], *P[k]);
+      for (int j = 0; j < k; j++) {
+        blockblas::cDot(dot.data(), *AP[j], *AP[k]);
+        for (int i = 0; i < nb; i++) { beta[j][k][i] = dot[i]; c[i] = -dot[i]; }
+        blockblas::caxpy(c.data(), *AP[j], *AP[k]);
+      }
+      blockblas::cDotNormA(dot.data(), nrm.data(), *AP[k], *l.r);
+      for (int i = 0; i < nb; i++) {
+        gamma[k][i] = sqrt(nrm[i]);
+        alpha[k][i] = gamma[k][i] > 0.0 ? dot[i] / gamma[k][i] : Complex(0.0);
+        c[i] = gamma[k][i] > 0.0 ? Complex(1.0 / gamma[k][i] - 1.0) : Complex(0.0);   // AP_k *= 1 / gamma  (y += c x with x = y)
+      }
+      blockblas::caxpy(c.data(), *AP[k], *AP[k]);
+      for (int i = 0; i < nb; i++) c[i] = -alpha[k][i];
+      blockblas::caxpy(c.data(), *AP[k], *l.r);
+      blockblas::norm2(r2.data(), *l.r);
+      k++; total++;
+      if (k == nKrylov || total == maxiter || !open()) {
+        // solution update by back substitution per right-hand side (reference :125-157), then the true residual
+        std::vector<std::vector<Complex>> delta(k, std::vector<Complex>(nb));
+        for (int i = 0; i < nb; i++)
+          for (int a = k - 1; a >= 0; a--) {
+            Complex d = alpha[a][i];
+            for (int j = a + 1; j < k; j++) d -= beta[a][j][i] * delta[j][i];
+            delta[a][i] = gamma[a][i] > 0.0 ? d / gamma[a][i] : Complex(0.0);
+          }
+        for (int a = 0; a < k; a++) blockblas::caxpy(delta[a].data(), *P[a], *y);
+        matpc(l, *l.r, *y);
+        xmy(*l.bt, *l.r);
+        blockblas::norm2(r2.data(), *l.r);
+        k = 0;
+      }
+    }
+    gcrIters += total;
+    // x_p = y (other parity of x is rebuilt by reconstruct)
+    copyParity(*l.x, *y, l.p);
+  }
+
+  // x = cycle(b) on level 0 of the sub-hierarchy; fields of L[0].b / L[0].x are filled / read by the caller
+  void cycle(int lev = 0) {
+    BlockLevel &l = L[lev];
+    if (lev == nl - 1) {
+      prepare(l);
+      gcr(l);
+      reconstruct(l);
+      return;
+    }
+    prepare(l);
+    mr(l, l.nuPre, false);
+    reconstruct(l);
+    apply(*l.r, *l.x, *l.Y);            // r = b - M x on every site
+    xmy(*l.b, *l.r);
+    // restrict / prolongate per right-hand side with the single-vector kernels of the level (aggregates of the coarse levels are tiny)
+    BlockLevel &c = L[lev + 1];
+    blockUnpack(l.fine, *l.r);
+    for (int i = 0; i < nb; i++) l.T->R(*l.coarse[i], *l.fine[i]);
+    blockPack(*c.b, l.coarse);
+    cycle(lev + 1);
+    blockUnpack(l.coarse, *c.x);
+    for (int i = 0; i < nb; i++) l.T->P(*l.fine[i], *l.coarse[i]);
+    blockPack(*l.w1, l.fine);
+    std::vector<Complex> one(nb, Complex(1.0, 0.0));
+    blockblas::caxpy(one.data(), *l.w1, *l.x);
+    mr(l, l.nuPost, true);
+    reconstruct(l);
+  }
+};
+
+static BlockCoarseCycle *blockCoarseCreate(MG &top, int nb) {
+  const MGParam &tp = top.params();
+  if (tp.level < 1) return nullptr;
+  BlockCoarseCycle *bc = new BlockCoarseCycle;
+  bc->nl = tp.Nlevel - tp.level;
+  bc->nb = nb;
+  bc->L.resize(bc->nl);
+  MG *m = &top;
+  for (int l = 0; l < bc->nl; l++, m = m->getCoarse()) {
+    if (!m) { delete bc; return nullptr; }
+    const MGParam &p = m->params();
+    const bool coarsest = p.level == p.Nlevel - 1;
+    const DiracCoarse *dc = dynamic_cast<const DiracCoarse *>(p.matResidual.Expose());
+    const DiracCoarsePC *ds = dynamic_cast<const DiracCoarsePC *>(p.matSmooth.Expose());
+    if (!dc || !ds || !m->smootherIsPC() || !blockCoarseSupported(dc->Links(), nb)) { delete bc; return nullptr; }
+    if (!coarsest && !(p.cycle_type == QUDA_MG_CYCLE_VCYCLE || p.level == p.Nlevel - 2)) { delete bc; return nullptr; }
+    BlockLevel &L = bc->L[l];
+    L.Y = &dc->Links(); L.H = &ds->HatLinks();
+    const QudaMatPCType pc = ds->getMatPCType();
+    L.p = (pc == QUDA_MATPC_ODD_ODD) ? 1 : 0;
+    L.nuPre = p.nu_pre; L.nuPost = p.nu_post; L.omega = p.omega;
+    const int nGhost = blockGhost(L.Y->Xc, false).nGhost;
+    for (BlockField **f : {&L.b, &L.x, &L.bt, &L.r, &L.Ar, &L.t, &L.w1, &L.w2}) { *f = new BlockField(L.Y->nSites, L.Y->n, nb, nGhost); blockblas::zero(**f); }
+    if (!coarsest) {
+      L.T = m->getTransfer();
+      if (!L.T) { delete bc; return nullptr; }
+      for (int i = 0; i < nb; i++) { L.fine.push_back(L.T->createFineField()); L.coarse.push_back(L.T->createCoarseField()); }
+    } else {
+      const SolverParam *sp = m->preSmootherParam();
+      bc->nKrylov = sp->Nkrylov; bc->maxiter = sp->maxiter; bc->tol = sp->tol;
+      for (int k = 0; k < bc->nKrylov; k++) {
+        bc->P.push_back(new BlockField(L.Y->nSites, L.Y->n, nb, nGhost)); bc->AP.push_back(new BlockField(L.Y->nSites, L.Y->n, nb, nGhost));
+        blockblas::zero(*bc->P.back()); blockblas::zero(*bc->AP.back());
+      }
+      bc->y = new BlockField(L.Y->nSites, L.Y->n, nb, nGhost);
+      blockblas::zero(*bc->y);
+    }
+  }
+  return bc;
+}
+
+// ================================================================================================
+// the multigrid cycle for several sources at once (level 0: per source; below: block fields)
+// ================================================================================================
+struct MGBlockState {
+  int nsrc = 0, nb = 0;
+  std::vector<Solver *> pre, post;
+  std::vector<SolverParam *> prePar, postPar;
+  std::vector<ColorSpinorField *> r, rc, xc, btilde;
+  BlockCoarseCycle *coarse = nullptr;
+  ~MGBlockState() {
+    for (Solver *s : pre) delete s;
+    for (Solver *s : post) delete s;
+    for (SolverParam *s : prePar) delete s;
+    for (SolverParam *s : postPar) delete s;
+    for (ColorSpinorField *f : r) delete f;
+    for (ColorSpinorField *f : rc) delete f;
+    for (ColorSpinorField *f : xc) delete f;
+    for (ColorSpinorField *f : btilde) delete f;
+    delete coarse;
+  }
+};
+
+void MG::blockRelease() { delete blockState; blockState = nullptr; }
+
+bool MG::blockPrepare(int nsrc) {
+  if (blockState && blockState->nsrc == nsrc) return true;
+  blockRelease();
+  if (mgp.level != 0 || mgp.level == mgp.Nlevel - 1 || !pcSmooth || !coarse) return false;
+  const int nb = (nsrc + 7) / 8 * 8;
+  if (nb > kMaxBlockRhs) return false;
+  MGBlockState *st = new MGBlockState;
+  st->nsrc = nsrc; st->nb = nb;
+  st->coarse = blockCoarseCreate(*coarse, nb);
+  if (!st->coarse) { delete st; return false; }
+  for (int i = 0; i < nsrc; i++) {
+    st->prePar.push_back(new SolverParam(*param_presmooth));
+    st->postPar.push_back(new SolverParam(*param_postsmooth));
+    st->pre.push_back(Solver::create(*st->prePar.back(), mgp.matSmooth, mgp.matSmooth, mgp.matSmooth));
+    st->post.push_back(Solver::create(*st->postPar.back(), mgp.matSmooth, mgp.matSmooth, mgp.matSmooth));
+    ColorSpinorParam cp = r->param();
+    cp.create = QUDA_ZERO_FIELD_CREATE;
+    st->r.push_back(new ColorSpinorField(cp));
+    ColorSpinorParam bp = r->Even().param();
+    bp.create = QUDA_ZERO_FIELD_CREATE;
+    st->btilde.push_back(new ColorSpinorField(bp));
+  }
+  for (int i = 0; i < nb; i++) { st->rc.push_back(transfer->createCoarseField()); st->xc.push_back(transfer->createCoarseField()); }
+  blockState = st;
+  return true;
+}
+
+// the parity cycle of MG::cycleParity for all sources: x_i = K b_i (single-parity fields)
+void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorField *> &b, const std::vector<char> &active, bool fullResidual) {
+  MGBlockState &st = *blockState;
+  const int nsrc = st.nsrc;
+  const Dirac &dirac = *mgp.matSmooth.Expose();
+  const bool odd = dirac.getMatPCType() == QUDA_MATPC_ODD_ODD || dirac.getMatPCType() == QUDA_MATPC_ODD_ODD_ASYMMETRIC;
+  const bool symmetric = dirac.getMatPCType() == QUDA_MATPC_EVEN_EVEN || dirac.getMatPCType() == QUDA_MATPC_ODD_ODD;
+  std::vector<const ColorSpinorField *> rin(nsrc, nullptr);
+  for (int i = 0; i < nsrc; i++) {
+    if (!active[i]) continue;
+    x[i]->twistFlavor = b[i]->twistFlavor;
+    ColorSpinorField &rp = odd ? st.r[i]->Odd() : st.r[i]->Even();
+    st.r[i]->twistFlavor = rp.twistFlavor = b[i]->twistFlavor;
+    (*st.pre[i])(*x[i], *b[i]);
+    const ColorSpinorField *res = mgp.nu_pre > 0 ? st.pre[i]->lastResidual() : nullptr;
+    if (res && res->Precision() == QUDA_SINGLE_PRECISION && !(fullResidual && symmetric)) {
+      rin[i] = res;
+    } else if (res) {
+      if (fullResidual && symmetric && res->Precision() == QUDA_SINGLE_PRECISION) dirac.localTermParity(rp, *res, odd ? 1 : 0);
+      else { blas::copy(rp, *res); if (fullResidual && symmetric) dirac.localTermParity(rp, rp, odd ? 1 : 0); }
+      rin[i] = &rp;
+    } else {
+      mgp.matSmooth(rp, *x[i]);
+      blas::axpby(1.0, *b[i], -1.0, rp);
+      if (fullResidual && symmetric) dirac.localTermParity(rp, rp, odd ? 1 : 0);
+      rin[i] = &rp;
+    }
+  }
+  transfer->setSiteSubset(QUDA_PARITY_SITE_SUBSET, odd ? QUDA_ODD_PARITY : QUDA_EVEN_PARITY);
+  for (int i = 0; i < st.nb; i++) {
+    if (i < nsrc && active[i]) transfer->R(*st.rc[i], *rin[i]);
+    else blas::zero(*st.rc[i]);
+  }
+  // everything below the fine level for all sources at once, on the matrix cores
+  blockPack(*st.coarse->L[0].b, st.rc);
+  st.coarse->cycle();
+  blockUnpack(st.xc, *st.coarse->L[0].x);
+  for (int i = 0; i < nsrc; i++) {
+    if (!active[i]) continue;
+    ColorSpinorField &rp = odd ? st.r[i]->Odd() : st.r[i]->Even();
+    transfer->P(rp, *st.xc[i]);
+    blas::xpy(rp, *x[i]);
+  }
+  transfer->setSiteSubset(QUDA_FULL_SITE_SUBSET, QUDA_INVALID_PARITY);
+  for (int i = 0; i < nsrc; i++) if (active[i]) (*st.post[i])(*x[i], *b[i]);
+  blas::setGlobalReduction(true);
+}
+
+// x_i = K b_i for all sources (full fields: Schur prepare, parity cycle, reconstruct, as MG::operator(); parity fields: the parity cycle)
+bool MG::cycleBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorField *> &b, const std::vector<char> &active) {
+  const int nsrc = (int)x.size();
+  if (!blockPrepare(nsrc)) return false;
+  if (b[0]->SiteSubset() != QUDA_FULL_SITE_SUBSET) { cycleParityBlock(x, b, active, false); return true; }
+  MGBlockState &st = *blockState;
+  const Dirac &dirac = *mgp.matSmooth.Expose();
+  const bool matpc = mgp.mg_global.coarse_grid_solution_type[0] == QUDA_MATPC_SOLUTION;
+  std::vector<ColorSpinorField *> in(nsrc, nullptr), out(nsrc, nullptr);
+  for (int i = 0; i < nsrc; i++) {
+    if (!active[i]) continue;
+    st.r[i]->twistFlavor = x[i]->twistFlavor = b[i]->twistFlavor;
+    blas::copy(*st.r[i], *b[i]);
+    ColorSpinorField *pin = nullptr, *pout = nullptr;
+    dirac.prepare(pin, pout, *x[i], *st.r[i], QUDA_MAT_SOLUTION);
+    st.btilde[i]->twistFlavor = b[i]->twistFlavor;
+    blas::copy(*st.btilde[i], *pin);
+    in[i] = st.btilde[i]; out[i] = pout;
+  }
+  for (int i = 0; i < nsrc; i++) if (!active[i]) { in[i] = st.btilde[i]; out[i] = st.btilde[i]; }
+  cycleParityBlock(out, in, active, !matpc);
+  for (int i = 0; i < nsrc; i++) if (active[i]) dirac.reconstruct(*x[i], *b[i], QUDA_MAT_SOLUTION);
+  return true;
+}
+
+// ================================================================================================
+// lockstep GCR (reference lib/inv_gcr_quda.cpp:235-516 per source; host form solver.cpp GCR::operator())
+// ================================================================================================
+static ColorSpinorField *likeF(const ColorSpinorField &x, QudaPrecision prec) {
+  ColorSpinorParam p = x.param();
+  p.location = QUDA_CUDA_FIELD_LOCATION;
+  p.precision = prec;
+  p.create = QUDA_ZERO_FIELD_CREATE;
+  return new ColorSpinorField(p);
+}
+
+struct BlockGcrResult { int iter = 0; std::vector<double> r2, b2; double secs = 0; bool blockCycle = false; };
+
+static BlockGcrResult blockGCR(std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorField *> &b, DiracMatrix &mat, DiracMatrix &matSloppy, MG *K, SolverParam &param) {
+  const int ns = (int)x.size(), nK = param.Nkrylov;
+  BlockGcrResult res;
+  res.r2.assign(ns, 0.0); res.b2.assign(ns, 0.0);
+  const bool mixed = param.precision_sloppy != x[0]->Precision();
+  const QudaPrecision ps = param.precision_sloppy;
+  std::vector<ColorSpinorField *> r(ns), y(ns), xS(ns), rS(ns);
+  std::vector<std::vector<ColorSpinorField *>> p(ns), Ap(ns);
+  for (int i = 0; i < ns; i++) {
+    r[i] = likeF(*x[i], x[i]->Precision()); y[i] = likeF(*x[i], x[i]->Precision());
+    xS[i] = mixed ? likeF(*x[i], ps) : x[i]; rS[i] = mixed ? likeF(*x[i], ps) : r[i];
+    for (int k = 0; k < nK; k++) { p[i].push_back(likeF(*x[i], ps)); Ap[i].push_back(likeF(*x[i], ps)); }
+    for (ColorSpinorField *f : {r[i], y[i], xS[i], rS[i]}) f->twistFlavor = b[i]->twistFlavor;
+    for (int k = 0; k < nK; k++) { p[i][k]->twistFlavor = b[i]->twistFlavor; Ap[i][k]->twistFlavor = b[i]->twistFlavor; }
+  }
+  std::vector<std::vector<Complex>> alpha(ns, std::vector<Complex>(nK));
+  std::vector<std::vector<double>> gamma(ns, std::vector<double>(nK));
+  std::vector<std::vector<std::vector<Complex>>> beta(ns, std::vector<std::vector<Complex>>(nK, std::vector<Complex>(nK)));
+  std::vector<double> stop(ns), r2(ns), r2_old(ns);
+  std::vector<char> open(ns, 1);
+  blas::setGlobalReduction(param.global_reduction);
+  const double t0 = nowSec();
+  for (int i = 0; i < ns; i++) {
+    res.b2[i] = blas::norm2(*b[i]);
+    if (res.b2[i] == 0.0) errorQuda("Source %d has zero norm", i);
+    blas::copy(*r[i], *b[i]);
+    r2[i] = r2_old[i] = res.b2[i];
+    blas::zero(*x[i]);
+    if (mixed) { blas::zero(*xS[i]); blas::copy(*rS[i], *r[i]); }
+    stop[i] = Solver::stopping(param.tol, res.b2[i], param.residual_type);
+  }
+  auto anyOpen = [&]() { for (int i = 0; i < ns; i++) if (open[i]) return true; return false; };
+  int k = 0, total = 0;
+  std::vector<ColorSpinorField *> pk(ns), rk(ns);
+  while (anyOpen() && total < param.maxiter) {
+    // p_k = K r for every open source: one block cycle
+    for (int i = 0; i < ns; i++) { pk[i] = p[i][k]; rk[i] = rS[i]; }
+    bool done = false;
+    if (K) { done = K->cycleBlock(pk, rk, open); res.blockCycle = res.blockCycle || done; }
+    for (int i = 0; i < ns; i++) {
+      if (!open[i]) continue;
+      if (!done) { if (K) (*K)(*p[i][k], *rS[i]); else blas::copy(*p[i][k], *rS[i]); }
+      blas::setGlobalReduction(param.global_reduction);
+      matSloppy(*Ap[i][k], *p[i][k]);
+      // orthogonalisation against the source's own directions: the blocked two-sweep form where it applies (solver.cpp), else the chain
+      bool blocked = false;
+      if (blas::multiSupported(*Ap[i][k], k)) {
+        std::vector<Complex> bk(k > 0 ? k : 1);
+        Complex apr; double apn;
+        blas::multiDot(bk.data(), apr, apn, Ap[i], k, *Ap[i][k], *rS[i]);
+        double g2 = apn;
+        for (int j = 0; j < k; j++) g2 -= std::norm(bk[j]);
+        if (apn == 0.0) errorQuda("GCR breakdown");
+        if (g2 > 1e-2 * apn) {
+          for (int j = 0; j < k; j++) { beta[i][j][k] = bk[j]; bk[j] = -bk[j]; }
+          gamma[i][k] = sqrt(g2);
+          alpha[i][k] = apr / gamma[i][k];
+          double y2;
+          blas::multiCaxpyResidual(r2[i], y2, bk.data(), Ap[i], k, 1.0 / gamma[i][k], *Ap[i][k], alpha[i][k], *rS[i]);
+          blocked = true;
+        }
+      }
+      if (!blocked) {
+        for (int j = 0; j < k; j++) {
+          beta[i][j][k] = blas::cDotProduct(*Ap[i][j], *Ap[i][k]);
+          blas::caxpy(-beta[i][j][k], *Ap[i][j], *Ap[i][k]);
+        }
+        const double3_t Apr = blas::cDotProductNormA(*Ap[i][k], *rS[i]);
+        gamma[i][k] = sqrt(Apr.z);
+        if (gamma[i][k] == 0.0) errorQuda("GCR breakdown");
+        alpha[i][k] = Complex(Apr.x, Apr.y) / gamma[i][k];
+        r2[i] = blas::cabxpyAxNorm(1.0 / gamma[i][k], -alpha[i][k], *Ap[i][k], *rS[i]);
+      }
+    }
+    k++; total++;
+    // reliable update / restart for ALL sources when the Krylov space is full or every open source has reached its sloppy target
+    bool allSloppy = true, anyDelta = false;
+    for (int i = 0; i < ns; i++) if (open[i]) { allSloppy = allSloppy && r2[i] < stop[i]; anyDelta = anyDelta || sqrt(r2[i] / r2_old[i]) < param.delta; }
+    if (k == nK || total == param.maxiter || allSloppy || anyDelta) {
+      for (int i = 0; i < ns; i++) {
+        if (!open[i]) continue;
+        std::vector<Complex> delta(k);
+        for (int a = k - 1; a >= 0; a--) {
+          delta[a] = alpha[i][a];
+          for (int j = a + 1; j < k; j++) delta[a] -= beta[i][a][j] * delta[j];
+          delta[a] /= gamma[i][a];
+        }
+        if (blas::multiSupported(*xS[i], k)) blas::multiCaxpy(delta.data(), p[i], k, *xS[i]);
+        else for (int a = 0; a < k; a++) blas::caxpy(delta[a], *p[i][a], *xS[i]);
+        if (mixed) blas::copy(*x[i], *xS[i]);
+        blas::xpy(*x[i], *y[i]);
+        mat(*r[i], *y[i]);
+        r2[i] = blas::xmyNorm(*b[i], *r[i]);
+        if (r2[i] <= stop[i]) {
+          open[i] = 0;
+        } else {
+          if (mixed) blas::copy(*rS[i], *r[i]);
+          blas::zero(*xS[i]);
+          if (!mixed) blas::zero(*x[i]);
+        }
+        r2_old[i] = r2[i];
+      }
+      k = 0;
+    }
+  }
+  for (int i = 0; i < ns; i++) { blas::copy(*x[i], *y[i]); res.r2[i] = r2[i]; }
+  res.iter = total;
+  res.secs = nowSec() - t0;
+  for (int i = 0; i < ns; i++) {
+    delete r[i]; delete y[i];
+    if (mixed) { delete xS[i]; delete rS[i]; }
+    for (int kk = 0; kk < nK; kk++) { delete p[i][kk]; delete Ap[i][kk]; }
+  }
+  blas::setGlobalReduction(true);
+  return res;
+}
+
+}  // namespace quda
+
+using namespace quda;
+
+extern "C" {
+
+// reference include/quda.h:647 (lib/interface_quda.cpp:2546: "currently that code is just a copy of invertQuda and cannot work"): param->num_src
+// sources _hp_b[i] -> solutions _hp_x[i], one operator, one preconditioner.  GCR (optionally MG-preconditioned) direct solves; iter / secs
+// are those of the lockstep solve, true_res the worst source's.
+void invertMultiSrcQuda(void **_hp_x, void **_hp_b, QudaInvertParam *param) {
+  if (!gaugePrecise) errorQuda("Gauge field not allocated");
+  if (param->tune == QUDA_TUNE_YES || param->tune == QUDA_TUNE_NO) setTuning(param->tune);
+  if (!cloverPrecise && param->dslash_type == QUDA_TWISTED_CLOVER_DSLASH) errorQuda("Clover field not allocated");
+  const int ns = param->num_src;
+  if (ns < 1 || ns > kMaxBlockRhs) errorQuda("num_src = %d outside 1 .. %d", ns, kMaxBlockRhs);
+  const bool pc_solution = param->solution_type == QUDA_MATPC_SOLUTION;
+  const bool pc_solve = param->solve_type == QUDA_DIRECT_PC_SOLVE;
+  if (param->solve_type != QUDA_DIRECT_SOLVE && param->solve_type != QUDA_DIRECT_PC_SOLVE) errorQuda("invertMultiSrcQuda: direct solves only");
+  if (param->solution_type != QUDA_MAT_SOLUTION && param->solution_type != QUDA_MATPC_SOLUTION) errorQuda("invertMultiSrcQuda: MAT / MATPC solutions only");
+  if (param->inv_type != QUDA_GCR_INVERTER) errorQuda("invertMultiSrcQuda: the lockstep solver is GCR (inv_type %d)", param->inv_type);
+  if (pc_solution && !pc_solve) errorQuda("Preconditioned (PC) solution_type requires a PC solve_type");
+  param->secs = 0; param->gflops = 0; param->iter = 0;
+
+  DiracParam dp, dpSloppy, dpPre;
+  setDiracParam(dp, param, pc_solve);
+  setDiracSloppyParam(dpSloppy, param, pc_solve);
+  setDiracPreParam(dpPre, param, pc_solve);
+  Dirac *d = Dirac::create(dp), *dSloppy = Dirac::create(dpSloppy), *dPre = Dirac::create(dpPre);
+  const LatticeGeom &geom = residentGeom();
+  std::vector<ColorSpinorField *> b(ns), x(ns), in(ns), out(ns);
+  std::vector<double> nb(ns);
+  for (int i = 0; i < ns; i++) {
+    ColorSpinorParam cpuParam(_hp_b[i], *param, geom.X, pc_solution);
+    ColorSpinorField h_b(cpuParam);
+    ColorSpinorParam cp = deviceSpinorParam(param->cuda_prec, pc_solution ? QUDA_PARITY_SITE_SUBSET : QUDA_FULL_SITE_SUBSET, param->twist_flavor);
+    cp.create = QUDA_ZERO_FIELD_CREATE;
+    b[i] = new ColorSpinorField(cp); x[i] = new ColorSpinorField(cp);
+    *b[i] = h_b;
+    nb[i] = blas::norm2(*b[i]);
+    if (nb[i] == 0.0) errorQuda("Source %d has zero norm", i);
+    if (param->solver_normalization == QUDA_SOURCE_NORMALIZATION) blas::ax(1.0 / sqrt(nb[i]), *b[i]);
+    massRescale(*b[i], *param);
+    d->prepare(in[i], out[i], *x[i], *b[i], param->solution_type);
+  }
+  {
+    DiracM m(*d), mSloppy(*dSloppy);
+    SolverParam sp(*param);
+    MG *K = nullptr;
+    if (param->inv_type_precondition == QUDA_MG_INVERTER) {
+      if (!param->preconditioner) errorQuda("GCR with multigrid preconditioner: param.preconditioner is NULL");
+      K = static_cast<multigrid_solver *>(param->preconditioner)->mg;
+    } else if (param->inv_type_precondition != QUDA_INVALID_INVERTER) {
+      errorQuda("invertMultiSrcQuda: preconditioner %d not supported (none or QUDA_MG_INVERTER)", param->inv_type_precondition);
+    }
+    const BlockGcrResult res = blockGCR(out, in, m, mSloppy, K, sp);
+    param->iter = res.iter;
+    param->secs = res.secs;
+    double worst = 0;
+    for (int i = 0; i < ns; i++) worst = std::max(worst, sqrt(res.r2[i] / res.b2[i]));
+    param->true_res = worst;
+    if (K) K->blockRelease();
+  }
+  for (int i = 0; i < ns; i++) {
+    d->reconstruct(*x[i], *b[i], param->solution_type);
+    if (param->solver_normalization == QUDA_SOURCE_NORMALIZATION) blas::ax(sqrt(nb[i]), *x[i]);
+    ColorSpinorParam cpuParam(_hp_x[i], *param, geom.X, pc_solution);
+    ColorSpinorField h_x(cpuParam);
+    h_x = *x[i];
+    delete b[i]; delete x[i];
+  }
+  delete d; delete dSloppy; delete dPre;
+}
+
+}

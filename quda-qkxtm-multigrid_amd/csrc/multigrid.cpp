@@ -191,6 +191,7 @@ void MG::dropFusedCycle() {
 }
 
 MG::~MG() {
+  blockRelease();
   coarseCycleDestroy(fused);
   if (ownCoarseSolver) delete coarse_solver;
   delete param_coarse_solver;

@@ -17,7 +17,7 @@ using namespace quda;
 namespace quda {
 
 // reference massRescale :1412-1480 (Wilson-type branch)
-static void massRescale(ColorSpinorField &b, QudaInvertParam &param) {
+void massRescale(ColorSpinorField &b, QudaInvertParam &param) {
   const double kappa = param.kappa;
   switch (param.solution_type) {
     case QUDA_MAT_SOLUTION:

@@ -1,0 +1,70 @@
+"""invertMultiSrcQuda (reference include/quda.h:647; lib/interface_quda.cpp:2546: declared, "cannot work" there): several sources through ONE
+lockstep MG-GCR solve — outer GCR per source with a shared Krylov index, one multigrid cycle for all sources whose coarse levels run on block
+fields through the multi-right-hand-side MFMA coarse operator (csrc/block_solver.cpp).  Every column is a solution in its own right: host
+residual with the oracle's tm_mat (as tests/multigrid_invert_test.cpp:529-577), agreement with the single-source invertQuda, the same
+iteration count within one."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qa():
+    mod = importlib.import_module("quda-qkxtm-multigrid_amd")
+    mod.init(0)
+    yield mod
+    mod.end()
+
+
+from test_mg_gpu import _setup, _true_residual  # noqa: E402
+
+
+@pytest.mark.parametrize("outer_pc", [False, True], ids=["full-system", "even-odd-outer"])
+@pytest.mark.parametrize("X,levels,blocks,nvec,nsrc,mask", [((16, 8, 8, 16), 3, [(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)], 8, 5, 0), ((16, 16, 16, 16), 3, [(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)], 24, 12, 0),
+                                                    ((16, 8, 8, 16), 2, (4, 4, 4, 4), 8, 3, 9)], ids=["5-sources-n16", "12-sources-n48", "3-sources-partitioned-xt"])
+def test_multi_source_mg_gcr_matches_single_source_solves(qa, oracle, X, levels, blocks, nvec, nsrc, mask, outer_pc):
+    kappa, mu = 0.124, 0.005
+    qa.lib().qudaAmdSetPartitionMask(mask)
+    try:
+        gauge, ip = _setup(qa, X, kappa, mu)
+        mp = qa.multigrid_param(ip, n_level=levels, geo_block=blocks, n_vec=nvec, setup_maxiter=300, setup_tol=1e-5, smoother_pc=True, cycle=qa.QUDA_MG_CYCLE_VCYCLE)
+        mg = qa.Multigrid(mp)
+        try:
+            V = int(np.prod(X))
+            rng = np.random.default_rng(41)
+            bs = [rng.random(V * 24) for _ in range(nsrc)]
+            ip.inv_type_precondition, ip.preconditioner = qa.QUDA_MG_INVERTER, mg.h
+            ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
+            if outer_pc:
+                ip.solve_type = qa.QUDA_DIRECT_PC_SOLVE
+            singles, iters = [], []
+            for b in bs:
+                singles.append(qa.invert(b, ip))
+                iters.append(ip.iter)
+            xs = qa.invert_multi_src(bs, ip)
+            it_block = ip.iter
+            assert abs(it_block - max(iters)) <= 1, (it_block, iters)
+            for i in range(nsrc):
+                res = _true_residual(oracle, gauge, X, kappa, mu, xs[i], bs[i])
+                assert res < 1e-10, (i, res)
+                assert np.linalg.norm(xs[i] - singles[i]) < 1e-7 * np.linalg.norm(singles[i]), i
+            print("multi-source MG-GCR %s %d sources: %d lockstep iterations (single-source %s), worst residual reported %.2e" % (X, nsrc, it_block, iters, ip.true_res))
+        finally:
+            mg.free()
+    finally:
+        qa.lib().qudaAmdSetPartitionMask(0)
+
+
+def test_multi_source_plain_gcr(qa, oracle):
+    """without a preconditioner the lockstep solver is nsrc independent GCR(20) solves sharing their Krylov index"""
+    X, kappa, mu = (8, 8, 8, 8), 0.124, 0.005
+    gauge, ip = _setup(qa, X, kappa, mu)
+    ip.inv_type_precondition = qa.QUDA_INVALID_ENUM
+    rng = np.random.default_rng(43)
+    bs = [rng.random(int(np.prod(X)) * 24) for _ in range(3)]
+    xs = qa.invert_multi_src(bs, ip)
+    for x, b in zip(xs, bs):
+        assert _true_residual(oracle, gauge, X, kappa, mu, x, b) < 1e-10
