@@ -44,6 +44,10 @@ class Transfer {
   // outside the site's own aggregate contribute (used by the Galerkin coarse-operator construction).
   void R(ColorSpinorField &coarse, const ColorSpinorField &fine, int dir = -1, int boundary = 0) const;
   void P(ColorSpinorField &fine, const ColorSpinorField &coarse) const;
+  // FOUR sources per pass over V (the multi-source cycle of invertMultiSrcQuda; fine level, fp32 V, aggregates of 64 .. 256 sites)
+  bool canQuad() const;
+  void R4(ColorSpinorField *const coarse[4], const ColorSpinorField *const fine[4]) const;
+  void P4(ColorSpinorField *const fine[4], const ColorSpinorField *const coarse[4]) const;
   // both halves of the Galerkin split in one pass over V: `leaving` = R over the fine sites whose dir-neighbour lies outside
   // their aggregate, `staying` = R over the others (equal to R(.., dir, 1) and R(.., dir, 0))
   void RSplit(ColorSpinorField &leaving, ColorSpinorField &staying, const ColorSpinorField &fine, int dir) const;

@@ -369,10 +369,13 @@ def invert(h_b, ip, out=None):
     return x
 
 
-def invert_multi_src(h_bs, ip):
-    """invertMultiSrcQuda: the sources h_bs[i] through one lockstep solve; returns the list of solutions (ip.num_src is set here)"""
+def invert_multi_src(h_bs, ip, out=None):
+    """invertMultiSrcQuda: the sources h_bs[i] through one lockstep solve; returns the list of solutions (ip.num_src is set here).
+    out: a list of arrays to receive the solutions (as invert(..., out=))"""
     bs = [np.ascontiguousarray(b) for b in h_bs]
-    xs = [np.zeros_like(b) for b in bs]
+    xs = out if out is not None else [np.zeros_like(b) for b in bs]
+    if len(xs) != len(bs) or any(x.shape != b.shape or x.dtype != b.dtype or not x.flags.c_contiguous for x, b in zip(xs, bs)):
+        raise ValueError("out must hold one contiguous array per source, of the source's shape and type")
     n = len(bs)
     ip.num_src = n
     pb = (_p * n)(*[_vp(b) for b in bs])

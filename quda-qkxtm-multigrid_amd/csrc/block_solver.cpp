@@ -284,6 +284,13 @@ struct MGBlockState {
   }
 };
 
+// QUDA_AMD_MULTISRC_QUAD=0: restrict / prolong the sources one at a time (the comparison leg of tools/multisrc_timing.py)
+static bool blockQuadTransfer() {
+  static int on = -1;
+  if (on < 0) { const char *e = getenv("QUDA_AMD_MULTISRC_QUAD"); on = (e && !atoi(e)) ? 0 : 1; }
+  return on != 0;
+}
+
 void MG::blockRelease() { delete blockState; blockState = nullptr; }
 
 bool MG::blockPrepare(int nsrc) {
@@ -342,19 +349,45 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
     }
   }
   transfer->setSiteSubset(QUDA_PARITY_SITE_SUBSET, odd ? QUDA_ODD_PARITY : QUDA_EVEN_PARITY);
-  for (int i = 0; i < st.nb; i++) {
+  // V (2304 B per fine site) is the traffic of the restrictor and the prolongator: groups of four active sources share one pass over it
+  const bool quad = transfer->canQuad() && blockQuadTransfer();
+  auto quadGroup = [&](int i) {
+    if (!quad || i + 4 > nsrc) return false;
+    for (int s = 0; s < 4; s++) if (!active[i + s] || rin[i + s]->Precision() != QUDA_SINGLE_PRECISION) return false;
+    return true;
+  };
+  for (int i = 0; i < st.nb;) {
+    if (quadGroup(i)) {
+      ColorSpinorField *c4[4] = {st.rc[i], st.rc[i + 1], st.rc[i + 2], st.rc[i + 3]};
+      const ColorSpinorField *f4[4] = {rin[i], rin[i + 1], rin[i + 2], rin[i + 3]};
+      transfer->R4(c4, f4);
+      i += 4;
+      continue;
+    }
     if (i < nsrc && active[i]) transfer->R(*st.rc[i], *rin[i]);
     else blas::zero(*st.rc[i]);
+    i++;
   }
   // everything below the fine level for all sources at once, on the matrix cores
   blockPack(*st.coarse->L[0].b, st.rc);
   st.coarse->cycle();
   blockUnpack(st.xc, *st.coarse->L[0].x);
-  for (int i = 0; i < nsrc; i++) {
-    if (!active[i]) continue;
-    ColorSpinorField &rp = odd ? st.r[i]->Odd() : st.r[i]->Even();
-    transfer->P(rp, *st.xc[i]);
-    blas::xpy(rp, *x[i]);
+  for (int i = 0; i < nsrc;) {
+    if (quadGroup(i)) {
+      ColorSpinorField *f4[4];
+      const ColorSpinorField *c4[4] = {st.xc[i], st.xc[i + 1], st.xc[i + 2], st.xc[i + 3]};
+      for (int s = 0; s < 4; s++) f4[s] = odd ? &st.r[i + s]->Odd() : &st.r[i + s]->Even();
+      transfer->P4(f4, c4);
+      for (int s = 0; s < 4; s++) blas::xpy(*f4[s], *x[i + s]);
+      i += 4;
+      continue;
+    }
+    if (active[i]) {
+      ColorSpinorField &rp = odd ? st.r[i]->Odd() : st.r[i]->Even();
+      transfer->P(rp, *st.xc[i]);
+      blas::xpy(rp, *x[i]);
+    }
+    i++;
   }
   transfer->setSiteSubset(QUDA_FULL_SITE_SUBSET, QUDA_INVALID_PARITY);
   for (int i = 0; i < nsrc; i++) if (active[i]) (*st.post[i])(*x[i], *b[i]);
@@ -389,11 +422,11 @@ bool MG::cycleBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorF
 // ================================================================================================
 // lockstep GCR (reference lib/inv_gcr_quda.cpp:235-516 per source; host form solver.cpp GCR::operator())
 // ================================================================================================
-static ColorSpinorField *likeF(const ColorSpinorField &x, QudaPrecision prec) {
+static ColorSpinorField *likeF(const ColorSpinorField &x, QudaPrecision prec, bool zeroed = true) {
   ColorSpinorParam p = x.param();
   p.location = QUDA_CUDA_FIELD_LOCATION;
   p.precision = prec;
-  p.create = QUDA_ZERO_FIELD_CREATE;
+  p.create = zeroed ? QUDA_ZERO_FIELD_CREATE : QUDA_NULL_FIELD_CREATE;
   return new ColorSpinorField(p);
 }
 
@@ -410,10 +443,16 @@ static BlockGcrResult blockGCR(std::vector<ColorSpinorField *> &x, std::vector<C
   for (int i = 0; i < ns; i++) {
     r[i] = likeF(*x[i], x[i]->Precision()); y[i] = likeF(*x[i], x[i]->Precision());
     xS[i] = mixed ? likeF(*x[i], ps) : x[i]; rS[i] = mixed ? likeF(*x[i], ps) : r[i];
-    for (int k = 0; k < nK; k++) { p[i].push_back(likeF(*x[i], ps)); Ap[i].push_back(likeF(*x[i], ps)); }
+    p[i].assign(nK, nullptr); Ap[i].assign(nK, nullptr);   // the Krylov space grows with the iteration count (12 sources x 40 fields otherwise)
     for (ColorSpinorField *f : {r[i], y[i], xS[i], rS[i]}) f->twistFlavor = b[i]->twistFlavor;
-    for (int k = 0; k < nK; k++) { p[i][k]->twistFlavor = b[i]->twistFlavor; Ap[i][k]->twistFlavor = b[i]->twistFlavor; }
   }
+  auto grow = [&](int k) {   // direction k of every source: written in full before it is read, so not cleared
+    for (int i = 0; i < ns; i++) {
+      if (p[i][k]) continue;
+      p[i][k] = likeF(*x[i], ps, false); Ap[i][k] = likeF(*x[i], ps, false);
+      p[i][k]->twistFlavor = Ap[i][k]->twistFlavor = b[i]->twistFlavor;
+    }
+  };
   std::vector<std::vector<Complex>> alpha(ns, std::vector<Complex>(nK));
   std::vector<std::vector<double>> gamma(ns, std::vector<double>(nK));
   std::vector<std::vector<std::vector<Complex>>> beta(ns, std::vector<std::vector<Complex>>(nK, std::vector<Complex>(nK)));
@@ -435,6 +474,7 @@ static BlockGcrResult blockGCR(std::vector<ColorSpinorField *> &x, std::vector<C
   std::vector<ColorSpinorField *> pk(ns), rk(ns);
   while (anyOpen() && total < param.maxiter) {
     // p_k = K r for every open source: one block cycle
+    grow(k);
     for (int i = 0; i < ns; i++) { pk[i] = p[i][k]; rk[i] = rS[i]; }
     bool done = false;
     if (K) { done = K->cycleBlock(pk, rk, open); res.blockCycle = res.blockCycle || done; }
@@ -510,7 +550,7 @@ static BlockGcrResult blockGCR(std::vector<ColorSpinorField *> &x, std::vector<C
   for (int i = 0; i < ns; i++) {
     delete r[i]; delete y[i];
     if (mixed) { delete xS[i]; delete rS[i]; }
-    for (int kk = 0; kk < nK; kk++) { delete p[i][kk]; delete Ap[i][kk]; }
+    for (int kk = 0; kk < nK; kk++) { delete p[i][kk]; delete Ap[i][kk]; }   // nullptr beyond the directions used
   }
   blas::setGlobalReduction(true);
   return res;
@@ -576,7 +616,8 @@ void invertMultiSrcQuda(void **_hp_x, void **_hp_b, QudaInvertParam *param) {
     double worst = 0;
     for (int i = 0; i < ns; i++) worst = std::max(worst, sqrt(res.r2[i] / res.b2[i]));
     param->true_res = worst;
-    if (K) K->blockRelease();
+    // the hierarchy keeps its multi-source work space (solvers, residuals, block fields of the coarse levels) for the next call with the same
+    // number of sources — a propagator is 12 of these calls' worth; released with the hierarchy or when num_src changes
   }
   for (int i = 0; i < ns; i++) {
     d->reconstruct(*x[i], *b[i], param->solution_type);

@@ -304,6 +304,166 @@ __global__ void __launch_bounds__(256) restrict_stream_kernel(CoarseVec out, Fin
   }
 }
 
+// ---- FOUR SOURCES per pass over V (invertMultiSrcQuda, block_solver.cpp): the restrictor / prolongator of the fine level are pure streams of V
+// (2304 B per fine site against 96 B of vector), so a lockstep multi-source cycle that restricts its sources one after the other reads V once per
+// source.  Same structure as restrict_stream_kernel / prolong_kernel — three steps of V requests in flight per thread, fenced — with the V entries
+// of a step meeting the site's components of four sources; the reduce-scatter butterfly that summed four STEPS of one source there sums one step
+// of four SOURCES here (16 values -> lanes 0..15). ----
+struct Src4 { FineVec f[4]; CoarseVec c[4]; };
+template <int NCF, int NVEC, int NV>
+__global__ void __launch_bounds__(256) restrict_stream4_kernel(Src4 a, const void *V, const int *block_to_fine, int blockVol, MaskArg mask, AggMap amap) {
+  constexpr int K = 4 * NCF, KH = K / 2, NVP = NVEC / 2, NST = 2 * NVP;
+  typedef typename VRaw<false>::type raw_t;
+  __shared__ float4 part[4][NST][4];   // [wave][chirality * NVP + vector pair][source]
+  const int A = aggregate_of_block(amap), b = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  float2 r[4][K];
+#pragma unroll
+  for (int s = 0; s < 4; s++)
+#pragma unroll
+    for (int k = 0; k < K; k++) r[s][k] = make_float2(0.f, 0.f);
+  bool have = false;
+  if (b < blockVol && mask_keep(mask, b)) {
+    const int f = block_to_fine[(size_t)A * blockVol + b];
+    const int parity = f >= a.f[0].Vh, x = f - parity * a.f[0].Vh;
+    if (a.f[0].v[parity]) {
+      have = true;
+#pragma unroll
+      for (int s = 0; s < 4; s++) load_fine_site<NV, K>(r[s], a.f[s].v[parity], a.f[s].stride, x);
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(have) == 0) {   // wave-uniform
+    for (int e = lane; e < NST * 4; e += 64) part[wave][e >> 2][e & 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    const int bl = b < blockVol ? b : 0;
+#pragma unroll
+    for (int chi = 0; chi < 2; chi++) {
+      raw_t w0[KH], w1[KH], w2[KH];
+      auto vload = [&](raw_t *dst, int vpl) {
+        if (vpl >= NVP) return;
+#pragma unroll
+        for (int kk = 0; kk < KH; kk++) dst[kk] = load_v_raw<false>(V, (((size_t)A * K + chi * KH + kk) * NVP + vpl) * blockVol + bl);
+      };
+      vload(w0, 0); vload(w1, 1); vload(w2, 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int vp = 0; vp < NVP; vp++) {
+        const int ph = vp % 3;
+        float w[16];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int kk = 0; kk < KH; kk++) {
+            const float4 v = v_unpack(ph == 0 ? w0[kk] : (ph == 1 ? w1[kk] : w2[kk]));
+            const float2 rr = r[s][chi * KH + kk];
+            acc.x += v.x * rr.x + v.y * rr.y; acc.y += v.x * rr.y - v.y * rr.x;   // conj(V) r
+            acc.z += v.z * rr.x + v.w * rr.y; acc.w += v.z * rr.y - v.w * rr.x;
+          }
+          w[4 * s] = acc.x; w[4 * s + 1] = acc.y; w[4 * s + 2] = acc.z; w[4 * s + 3] = acc.w;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ph == 0) vload(w0, vp + 3); else if (ph == 1) vload(w1, vp + 3); else vload(w2, vp + 3);   // the buffer just used: three steps ahead
+        __builtin_amdgcn_sched_barrier(0);
+#define QA_BFLY(HALFN, M)                                                                  \
+        {                                                                                  \
+          const bool up = (lane & M) != 0;                                                 \
+          _Pragma("unroll") for (int j = 0; j < HALFN; j++) {                              \
+            const float keep = up ? w[HALFN + j] : w[j], give = up ? w[j] : w[HALFN + j]; \
+            w[j] = keep + __shfl_xor(give, M, 64);                                         \
+          }                                                                                \
+        }
+        QA_BFLY(8, 1) QA_BFLY(4, 2) QA_BFLY(2, 4) QA_BFLY(1, 8)
+#undef QA_BFLY
+        w[0] += __shfl_xor(w[0], 16, 64);
+        w[0] += __shfl_xor(w[0], 32, 64);
+        if (lane < 16) {   // lane l holds the total of value index (bit-reversed l) = 4 * source + component
+          const int vi = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+          reinterpret_cast<float *>(&part[wave][chi * NVP + vp][0])[vi] = w[0];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < NST * 4; e += blockDim.x) {
+    const int it = e >> 2, s = e & 3;
+    float4 t = part[0][it][s];
+    for (int w2 = 1; w2 < nw; w2++) { const float4 u = part[w2][it][s]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    const CoarseVec &o = a.c[s];
+    const int cpar = A >= o.Vh, xc = A - cpar * o.Vh, c0 = 2 * it;   // = chi * NVEC + 2 * vp
+    float *ob = o.v[cpar];
+    ob[((size_t)c0 * o.stride + xc) * 2] = t.x; ob[((size_t)c0 * o.stride + xc) * 2 + 1] = t.y;
+    ob[((size_t)(c0 + 1) * o.stride + xc) * 2] = t.z; ob[((size_t)(c0 + 1) * o.stride + xc) * 2 + 1] = t.w;
+  }
+}
+template <int NCF, int NVEC, int NV>
+__global__ void __launch_bounds__(256) prolong4_kernel(Src4 a, const void *V, const int *block_to_fine, int blockVol, AggMap amap) {
+  constexpr int K = 4 * NCF, KH = K / 2, NVP = NVEC / 2;
+  typedef typename VRaw<false>::type raw_t;
+  __shared__ float2 xc_s[4][2 * NVEC];
+  const int A = aggregate_of_block(amap), b = threadIdx.x;
+  for (int e = threadIdx.x; e < 4 * 2 * NVEC; e += blockDim.x) {
+    const int s = e / (2 * NVEC), j = e - s * 2 * NVEC;
+    const CoarseVec &in = a.c[s];
+    const int cpar = A >= in.Vh, xc = A - cpar * in.Vh;
+    const float *p = in.v[cpar] + ((size_t)j * in.stride + xc) * 2;
+    xc_s[s][j] = make_float2(p[0], p[1]);
+  }
+  __syncthreads();
+  if (b >= blockVol) return;
+  const int f = block_to_fine[(size_t)A * blockVol + b];
+  const int parity = f >= a.f[0].Vh, x = f - parity * a.f[0].Vh;
+  if (!a.f[0].v[parity]) return;   // this parity is absent from single-parity output fields
+  float2 acc[4][K];
+#pragma unroll
+  for (int s = 0; s < 4; s++)
+#pragma unroll
+    for (int k = 0; k < K; k++) acc[s][k] = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int chi = 0; chi < 2; chi++) {
+    raw_t w0[KH], w1[KH], w2[KH];
+    auto vload = [&](raw_t *dst, int vpl) {
+      if (vpl >= NVP) return;
+#pragma unroll
+      for (int kk = 0; kk < KH; kk++) dst[kk] = load_v_raw<false>(V, (((size_t)A * K + chi * KH + kk) * NVP + vpl) * blockVol + b);
+    };
+    vload(w0, 0); vload(w1, 1); vload(w2, 2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int vp = 0; vp < NVP; vp++) {
+      const int ph = vp % 3;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const float2 c0 = xc_s[s][chi * NVEC + 2 * vp], c1 = xc_s[s][chi * NVEC + 2 * vp + 1];
+#pragma unroll
+        for (int kk = 0; kk < KH; kk++) {
+          const float4 w = v_unpack(ph == 0 ? w0[kk] : (ph == 1 ? w1[kk] : w2[kk]));
+          acc[s][chi * KH + kk].x += w.x * c0.x - w.y * c0.y + w.z * c1.x - w.w * c1.y;
+          acc[s][chi * KH + kk].y += w.x * c0.y + w.y * c0.x + w.z * c1.y + w.w * c1.x;
+        }
+      }
+      // pin the sums here (as prolong_kernel): without it the multiply-adds sink below the last fence and every load stays live
+#pragma unroll
+      for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int kk = 0; kk < KH; kk++) asm volatile("" : "+v"(acc[s][chi * KH + kk].x), "+v"(acc[s][chi * KH + kk].y));
+      __builtin_amdgcn_sched_barrier(0);
+      if (ph == 0) vload(w0, vp + 3); else if (ph == 1) vload(w1, vp + 3); else vload(w2, vp + 3);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+    float *base = a.f[s].v[parity];
+    if (NV == 4) {
+#pragma unroll
+      for (int k = 0; k < K; k += 2) *reinterpret_cast<float4 *>(base + fidx<NV>(a.f[s].stride, x, k)) = make_float4(acc[s][k].x, acc[s][k].y, acc[s][k + 1].x, acc[s][k + 1].y);
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; k++) *reinterpret_cast<float2 *>(base + fidx<NV>(a.f[s].stride, x, k)) = acc[s][k];
+    }
+  }
+}
+
 // ---- four right-hand sides per pass over V (Galerkin construction of the first coarse level: the 8 single-direction hops of
 // one probe are restricted in two launches instead of eight; V is the whole cost of a restriction) ----
 struct Multi4 {
@@ -1377,6 +1537,61 @@ void Transfer::P(ColorSpinorField &fine, const ColorSpinorField &coarse) const {
 #undef QA_P
   HIP_CHECK(hipGetLastError());
   flops_ += 8ull * fineSpin * fineColor * Nvec * fineVol;  // reference lib/prolongator.cu:228
+}
+
+// four sources per pass over V (fine level, fp32 V): see restrict_stream4_kernel / prolong4_kernel
+bool Transfer::canQuad() const { return fineSpin == 4 && fineColor == 3 && spin_bs == 2 && blockVol > 32 && blockVol <= 256 && (Nvec == 8 || Nvec == 24 || Nvec == 32); }
+void Transfer::R4(ColorSpinorField *const coarse[4], const ColorSpinorField *const fine[4]) const {
+  if (!canQuad()) errorQuda("four-source restrictor: fine level with 4^4-type aggregates only");
+  const bool sub = fine[0]->SiteSubset() == QUDA_PARITY_SITE_SUBSET;
+  if (sub && site_subset != QUDA_PARITY_SITE_SUBSET) errorQuda("single-parity fine field but the transfer is set to full fields");
+  Src4 a;
+  for (int s = 0; s < 4; s++) {
+    if (fine[s]->Nspin() != fineSpin || fine[s]->Ncolor() != fineColor || (long)fine[s]->VolumeCB() * 2 != fineVol || fine[s]->SiteSubset() != fine[0]->SiteSubset() || fine[s]->Precision() != QUDA_SINGLE_PRECISION)
+      errorQuda("fine field %d does not match the transfer operator", s);
+    a.f[s] = fineVec(*fine[s], sub ? (int)subset_parity : -1);
+    a.c[s] = coarseVec(*coarse[s]);
+  }
+  MaskArg m;
+  m.dir = -1; m.boundary = 0; m.pm = parityMajor ? 1 : 0;
+  for (int d = 0; d < 4; d++) { m.bs[d] = geo_bs[d]; m.single[d] = Xc[d] == 1; }
+  const int threads = (blockVol + 63) / 64 * 64;
+  if (g_acctOn) {
+    const double frac = sub ? 0.5 : 1.0;
+    acct("restrict_stream4_kernel", frac * fineVol * ((double)fineSpin * fineColor * Nvec * 8 + 4.0 * fineSpin * fineColor * 8.0) + 4.0 * nAgg * 2 * Nvec * 8, "level 0 -> coarse, 4 sources");
+  }
+  switch (Nvec) {
+    case 8: hipLaunchKernelGGL((restrict_stream4_kernel<3, 8, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, m, aggMapOf(*this)); break;
+    case 24: hipLaunchKernelGGL((restrict_stream4_kernel<3, 24, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, m, aggMapOf(*this)); break;
+    default: hipLaunchKernelGGL((restrict_stream4_kernel<3, 32, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, m, aggMapOf(*this)); break;
+  }
+  HIP_CHECK(hipGetLastError());
+  flops_ += 4 * 8ull * fineSpin * fineColor * Nvec * fineVol;
+}
+void Transfer::P4(ColorSpinorField *const fine[4], const ColorSpinorField *const coarse[4]) const {
+  if (!canQuad()) errorQuda("four-source prolongator: fine level with 4^4-type aggregates only");
+  const bool sub = fine[0]->SiteSubset() == QUDA_PARITY_SITE_SUBSET;
+  if (sub && site_subset != QUDA_PARITY_SITE_SUBSET) errorQuda("single-parity fine field but the transfer is set to full fields");
+  Src4 a;
+  for (int s = 0; s < 4; s++) {
+    if (fine[s]->Nspin() != fineSpin || fine[s]->Ncolor() != fineColor || (long)fine[s]->VolumeCB() * 2 != fineVol || fine[s]->SiteSubset() != fine[0]->SiteSubset() || fine[s]->Precision() != QUDA_SINGLE_PRECISION)
+      errorQuda("fine field %d does not match the transfer operator", s);
+    a.f[s] = fineVec(*fine[s], sub ? (int)subset_parity : -1);
+    a.c[s] = coarseVec(*coarse[s]);
+  }
+  const int threads = (blockVol + 63) / 64 * 64;
+  const AggMap amap = aggMapOf(*this);
+  if (g_acctOn) {
+    const double frac = sub ? 0.5 : 1.0;
+    acct("prolong4_kernel", frac * fineVol * ((double)fineSpin * fineColor * Nvec * 8 + 4.0 * fineSpin * fineColor * 8.0) + 4.0 * nAgg * 2 * Nvec * 8, "coarse -> level 0, 4 sources");
+  }
+  switch (Nvec) {
+    case 8: hipLaunchKernelGGL((prolong4_kernel<3, 8, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, amap); break;
+    case 24: hipLaunchKernelGGL((prolong4_kernel<3, 24, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, amap); break;
+    default: hipLaunchKernelGGL((prolong4_kernel<3, 32, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, amap); break;
+  }
+  HIP_CHECK(hipGetLastError());
+  flops_ += 4 * 8ull * fineSpin * fineColor * Nvec * fineVol;
 }
 
 void Transfer::column(ColorSpinorField &fine, int j) const {
