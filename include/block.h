@@ -41,6 +41,10 @@ struct BlockField {
 // parity >= 0: the block holds only that parity half of the fields (nSites = VolumeCB)
 void blockPack(BlockField &dst, const std::vector<ColorSpinorField *> &src, int parity = -1);
 void blockUnpack(const std::vector<ColorSpinorField *> &dst, const BlockField &src, int parity = -1);
+// n <= nrhs single-parity fp32 fine fields (nSpin 4) <-> the columns of one 12-component block field of VolumeCB sites; f[i] == nullptr: a
+// column of zeros (pack) / left alone (unpack); accumulate: dst += the fields
+void blockPackParity(BlockField &dst, const ColorSpinorField *const *f, int n, bool accumulate = false);
+void blockUnpackParity(ColorSpinorField *const *f, int n, const BlockField &src);
 
 // Ghost zone of a block field on a grid-decomposed lattice (reference: the ghost of a multi-source coarse field is a full coarse
 // spinor per face site and source, lib/dslash_coarse.cu:68-137; here the same for the multi-right-hand-side fine stencil): per
@@ -92,6 +96,8 @@ void cxpaypbz(const BlockField &r, const Complex *a, const BlockField &v, const 
 void bicgstabDots(Complex *ts, double *tt, Complex *r0s, Complex *r0t, const BlockField &t, const BlockField &s, const BlockField &r0);
 // x_i += a_i p_i + w_i s_i ; r_i = s_i - w_i t_i (in place of s) ; p_i = r_i + b_i (p_i - w_i v_i) ; r2_i = |r_i|^2   (one pass: 5 reads, 3 writes)
 void bicgstabFused(double *r2, const Complex *a, const Complex *w, const Complex *b, BlockField &p, BlockField &r, BlockField &x, const BlockField &t, const BlockField &v);
+// minimal-residual step, coefficient from device sums [Re (Ar, r) | Im (Ar, r) | |Ar|^2][nrhs]: x = [x +] alpha rin, r = rin - alpha Ar, alpha = omega (Ar, r) / |Ar|^2
+void mrUpdateDev(BlockField &x, BlockField &r, const BlockField &rin, const BlockField &Ar, const double *d_sums, double omega, bool fresh);
 void negate(BlockField &x);                                                           // x = -x
 }  // namespace blockblas
 

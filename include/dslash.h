@@ -60,6 +60,9 @@ void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_o
                           double a1, const float *tmat = nullptr, int tmode = 0, float2 *ghost = nullptr, const FineBlockDots *dots = nullptr);
 bool fineBlockDotsSupported(int nrhs);
 void fineBlockDotsFinish(double *sums, int nrhs, int mode);
+// mode 3 (4 or 8 right-hand sides): (out, in_same), |out|^2 only — the sums of a minimal-residual step, no further field read (a unused).
+// fineBlockDotsFinishDev: the sums stay in DEVICE memory (rank-local), no host round trip — the update kernel that follows reads them
+void fineBlockDotsFinishDev(double *d_sums, int nrhs, int mode);
 void freeFineBlockDots();
 // ghost: on a grid-decomposed lattice the ghost zone of in_other (blockGhost(X, true).nGhost panels, a whole number of panels away from
 // in_other); it is filled here (pack + grouped exchange) before the launch

@@ -96,6 +96,88 @@ void blockUnpack(const std::vector<ColorSpinorField *> &dst, const BlockField &s
   HIP_CHECK(hipGetLastError());
 }
 
+// ---- single-parity fp32 fine fields (FLOAT4 planes) <-> one block field, through LDS: both sides move whole lines (a wave reads / writes 64
+// consecutive sites of one plane of one field, the block side is one contiguous chunk of 64 panels); the generic kernel above touches 8 bytes per
+// line on the field side.  A nullptr field is a column of zeros (pack) / is skipped (unpack): sources that have converged, padding columns. ----
+struct FinePtrs { float *v[kMaxBlockRhs]; };
+template <int MODE> __global__ void __launch_bounds__(256) block_fine_pack_kernel(float2 *blk, FinePtrs f, int stride, int Vh, int nrhs) {   // MODE 0 pack, 1 pack and add, 2 unpack
+  extern __shared__ float2 pk_lds[];   // [64 sites][12 nrhs + 1]: the odd stride spreads the sites of a wave over the banks
+  const int SS = 12 * nrhs + 1;
+  const int x0 = blockIdx.x * 64, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nloc = Vh - x0 < 64 ? Vh - x0 : 64;
+  float4 *chunk = reinterpret_cast<float4 *>(blk + (size_t)x0 * 12 * nrhs);
+  const int nq = nloc * 6 * nrhs;   // 16-byte words of the chunk
+  if (MODE != 2) {
+    for (int i = wave; i < nrhs; i += 4) {
+      const float4 *base = reinterpret_cast<const float4 *>(f.v[i]);
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const float4 v = (base && lane < nloc) ? base[(size_t)k * stride + x0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+        pk_lds[lane * SS + (2 * k) * nrhs + i] = make_float2(v.x, v.y);
+        pk_lds[lane * SS + (2 * k + 1) * nrhs + i] = make_float2(v.z, v.w);
+      }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < nq; q += 256) {
+      const int e = 2 * q, site = e / (12 * nrhs), c = e - site * 12 * nrhs;
+      const float2 a = pk_lds[site * SS + c], b = pk_lds[site * SS + c + 1];
+      float4 o = make_float4(a.x, a.y, b.x, b.y);
+      if (MODE == 1) { const float4 w = chunk[q]; o.x += w.x; o.y += w.y; o.z += w.z; o.w += w.w; }
+      chunk[q] = o;
+    }
+  } else {
+    for (int q = threadIdx.x; q < nq; q += 256) {
+      const int e = 2 * q, site = e / (12 * nrhs), c = e - site * 12 * nrhs;
+      const float4 w = chunk[q];
+      pk_lds[site * SS + c] = make_float2(w.x, w.y);
+      pk_lds[site * SS + c + 1] = make_float2(w.z, w.w);
+    }
+    __syncthreads();
+    for (int i = wave; i < nrhs; i += 4) {
+      float4 *base = reinterpret_cast<float4 *>(f.v[i]);
+      if (!base || lane >= nloc) continue;
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const float2 a = pk_lds[lane * SS + (2 * k) * nrhs + i], b = pk_lds[lane * SS + (2 * k + 1) * nrhs + i];
+        base[(size_t)k * stride + x0 + lane] = make_float4(a.x, a.y, b.x, b.y);
+      }
+    }
+  }
+}
+static FinePtrs finePtrs(const ColorSpinorField *const *f, int n, const BlockField &b, int &stride) {
+  if (n > b.nrhs || b.ncomp != 12 || b.nrhs % 2) errorQuda("%d fine fields for a block of %d right-hand sides x %d components", n, b.nrhs, b.ncomp);
+  FinePtrs p;
+  memset(&p, 0, sizeof(p));
+  stride = 0;
+  for (int i = 0; i < n; i++) {
+    if (!f[i]) continue;
+    const ColorSpinorField &g = *f[i];
+    if (g.Precision() != QUDA_SINGLE_PRECISION || g.SiteSubset() != QUDA_PARITY_SITE_SUBSET || g.Location() != QUDA_CUDA_FIELD_LOCATION || g.Nspin() != 4 || g.Ncolor() != 3 ||
+        g.VolumeCB() != b.nSites || (stride && g.Stride() != stride))
+      errorQuda("field %d does not match the block (single-parity fp32 fine fields of %d sites)", i, b.nSites);
+    stride = g.Stride();
+    p.v[i] = (float *)g.V();
+  }
+  return p;
+}
+void blockPackParity(BlockField &dst, const ColorSpinorField *const *f, int n, bool accumulate) {
+  int stride;
+  const FinePtrs p = finePtrs(f, n, dst, stride);
+  const size_t lds = (size_t)64 * (12 * dst.nrhs + 1) * sizeof(float2);
+  const unsigned grid = (unsigned)((dst.nSites + 63) / 64);
+  if (accumulate) hipLaunchKernelGGL((block_fine_pack_kernel<1>), dim3(grid), dim3(256), lds, computeStream(), dst.v, p, stride, dst.nSites, dst.nrhs);
+  else hipLaunchKernelGGL((block_fine_pack_kernel<0>), dim3(grid), dim3(256), lds, computeStream(), dst.v, p, stride, dst.nSites, dst.nrhs);
+  HIP_CHECK(hipGetLastError());
+}
+void blockUnpackParity(ColorSpinorField *const *f, int n, const BlockField &src) {
+  int stride;
+  const FinePtrs p = finePtrs(f, n, src, stride);
+  if (!stride) return;   // nothing to write
+  const size_t lds = (size_t)64 * (12 * src.nrhs + 1) * sizeof(float2);
+  hipLaunchKernelGGL((block_fine_pack_kernel<2>), dim3((unsigned)((src.nSites + 63) / 64)), dim3(256), lds, computeStream(), src.v, p, stride, src.nSites, src.nrhs);
+  HIP_CHECK(hipGetLastError());
+}
+
 // ================================================================================================
 // ghost zone of a block field (block.h BlockGhost)
 // ================================================================================================
@@ -740,6 +822,35 @@ void bicgstabFused(double *r2, const Complex *al, const Complex *om, const Compl
   setCoef(a.c.a, al, p.nrhs); setCoef(a.c.b, om, p.nrhs); setCoef(a.c.c, be, p.nrhs);
   run<8, 1>(a, p);
   for (int i = 0; i < p.nrhs; i++) r2[i] = h_res[i];
+}
+// one minimal-residual step with the coefficient taken from DEVICE sums (fineBlockDotsFinishDev, mode 3: Re / Im (Ar, r), |Ar|^2 per right-hand
+// side): alpha_i = omega (Ar_i, r_i) / |Ar_i|^2 (0 for a column of zeros);  x = [x +] alpha rin ;  r = rin - alpha Ar — no host round trip
+__global__ void __launch_bounds__(256) mr_update_kernel(float4 *x, float4 *r, const float4 *rin, const float4 *Ar, const double *sums, float omega, int nrhs, long n4, int fresh) {
+  const int half = nrhs >> 1, pr = threadIdx.x % half;
+  float2 al[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int i = 2 * pr + h;
+    const double n = sums[2 * nrhs + i];
+    al[h] = n > 0.0 ? make_float2((float)(omega * sums[i] / n), (float)(omega * sums[nrhs + i] / n)) : make_float2(0.f, 0.f);
+  }
+  for (long q = blockIdx.x * 256l + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+    const float4 rv = rin[q], av = Ar[q];
+    const float2 p0 = cmul(al[0], make_float2(rv.x, rv.y)), p1 = cmul(al[1], make_float2(rv.z, rv.w));
+    const float2 q0 = cmul(al[0], make_float2(av.x, av.y)), q1 = cmul(al[1], make_float2(av.z, av.w));
+    float4 xv = fresh ? make_float4(0.f, 0.f, 0.f, 0.f) : x[q];
+    xv.x += p0.x; xv.y += p0.y; xv.z += p1.x; xv.w += p1.y;
+    x[q] = xv;
+    r[q] = make_float4(rv.x - q0.x, rv.y - q0.y, rv.z - q1.x, rv.w - q1.y);
+  }
+}
+void mrUpdateDev(BlockField &x, BlockField &r, const BlockField &rin, const BlockField &Ar, const double *d_sums, double omega, bool fresh) {
+  check(x, r); check(x, rin); check(x, Ar);
+  if (x.nrhs % 2 || 256 % (x.nrhs / 2)) errorQuda("minimal-residual update: %d right-hand sides", x.nrhs);
+  const long n4 = (long)x.elems() / 2;
+  const unsigned grid = (unsigned)std::min<long>((n4 + 255) / 256, 8192);
+  hipLaunchKernelGGL(mr_update_kernel, dim3(grid), dim3(256), 0, computeStream(), (float4 *)x.v, (float4 *)r.v, (const float4 *)rin.v, (const float4 *)Ar.v, d_sums, (float)omega, x.nrhs, n4, fresh ? 1 : 0);
+  HIP_CHECK(hipGetLastError());
 }
 void negate(BlockField &x) {
   BArg a = {};

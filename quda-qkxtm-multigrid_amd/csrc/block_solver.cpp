@@ -263,6 +263,119 @@ static BlockCoarseCycle *blockCoarseCreate(MG &top, int nb) {
 }
 
 // ================================================================================================
+// the smoother of the fine level for all sources: MR on the even-odd preconditioned operator, on block fields
+// ================================================================================================
+// The per-source smoother streams the gauge links once per source and step (384 - 576 B per site against 192 B of spinor), and every step is a
+// chain of five launches per source.  Here groups of 8 (or 4) sources share one pass over the links (fine_block_kernel: dslash.h
+// applyFineBlockParity), the two sums of the MR step come out of the second launch's epilogue where `A r` and `r` already sit in registers
+// (mode 3), and the coefficient never leaves the device (fineBlockDotsFinishDev -> blockblas::mrUpdateDev) — the same arithmetic as MR of
+// solver.cpp with device-side scalars (fp32 fields, fp64 sums, rank-local), reference lib/inv_mr_quda.cpp:40-200.
+struct FineGroup {
+  int first = 0, n = 0, nrhs = 0;   // sources [first, first + n) are the first n columns of blocks with nrhs columns
+  BlockField *B = nullptr, *X = nullptr, *R = nullptr, *AR = nullptr, *T = nullptr;
+  double *d_sums = nullptr;
+};
+class BlockFineSmoother {
+ public:
+  const GaugeField *U = nullptr;
+  double kappa = 0, a = 0, binv = 1, omega = 1;
+  int par = 0;                         // parity of the preconditioned system
+  int nuPre = 0, nuPost = 0;
+  float *tmat[2] = {nullptr, nullptr};   // twisted clover: dense (A + i a g5)^-1 per parity
+  size_t tmatBytes = 0;
+  std::vector<FineGroup> groups;
+
+  ~BlockFineSmoother() {
+    for (FineGroup &g : groups) {
+      for (BlockField *f : {g.B, g.X, g.R, g.AR, g.T}) delete f;
+      if (g.d_sums) poolDeviceFree(g.d_sums, 0);
+    }
+    for (int p = 0; p < 2; p++) if (tmat[p]) poolDeviceFree(tmat[p], tmatBytes);
+  }
+  static float2 *ghostOf(BlockField &f) { return f.nGhost ? f.v + f.elems() : nullptr; }
+  // out = in - kappa^2 A^-1 D_pq A^-1 D_qp in     (reference DiracTwistedMassPC::M / DiracTwistedCloverPC::M, symmetric preconditioning);
+  // dots: (out, in) and |out|^2 per right-hand side into g.d_sums
+  void matpc(FineGroup &g, BlockField &out, BlockField &in, bool dots) {
+    const FineBlockDots d = {nullptr, 3};
+    const int p = par, q = 1 - par;
+    if (tmat[0]) {
+      applyFineBlockParity(g.T->v, nullptr, in.v, in.nrhs, *U, q, 0.0, 0.0, 1.0, 0.0, tmat[q], 1, ghostOf(in));
+      applyFineBlockParity(out.v, in.v, g.T->v, in.nrhs, *U, p, 1.0, 0.0, -kappa * kappa, 0.0, tmat[p], 1, ghostOf(*g.T), dots ? &d : nullptr);
+    } else {
+      applyFineBlockParity(g.T->v, nullptr, in.v, in.nrhs, *U, q, 0.0, 0.0, binv, -a, nullptr, 0, ghostOf(in));
+      applyFineBlockParity(out.v, in.v, g.T->v, in.nrhs, *U, p, 1.0, 0.0, -kappa * kappa * binv, -a, nullptr, 0, ghostOf(*g.T), dots ? &d : nullptr);
+    }
+    if (dots) fineBlockDotsFinishDev(g.d_sums, in.nrhs, 3);
+  }
+  // nu MR steps on (X, R); fresh: X is not defined yet and the residual is `first` (the source itself), not R
+  void mr(FineGroup &g, int nu, BlockField *first) {
+    for (int k = 0; k < nu; k++) {
+      BlockField &rin = (k == 0 && first) ? *first : *g.R;
+      matpc(g, *g.AR, rin, true);
+      blockblas::mrUpdateDev(*g.X, *g.R, rin, *g.AR, g.d_sums, omega, k == 0 && first);
+    }
+  }
+  // R = B - M X
+  void residual(FineGroup &g) {
+    matpc(g, *g.AR, *g.X, false);
+    std::vector<Complex> zero(g.nrhs, Complex(0.0, 0.0)), mone(g.nrhs, Complex(-1.0, 0.0));
+    blockblas::cxpaypbz(*g.B, zero.data(), *g.B, mone.data(), *g.AR);   // AR = B - AR
+    std::swap(g.R, g.AR);
+  }
+};
+
+static bool blockFineSmootherOn() {
+  static int on = -1;
+  if (on < 0) { const char *e = getenv("QUDA_AMD_MULTISRC_BLOCK_SMOOTHER"); on = (e && !atoi(e)) ? 0 : 1; }
+  return on != 0;
+}
+
+// nullptr: this fine level keeps the per-source smoother (asymmetric preconditioning, a smoother other than MR, 16-bit smoothing, links the
+// multi-right-hand-side stencil does not read, sums that have to cross ranks)
+static BlockFineSmoother *blockFineCreate(const Dirac &dirac, const SolverParam &pre, const SolverParam &post, int flavor, int nsrc) {
+  if (!blockFineSmootherOn()) return nullptr;
+  const QudaDiracType ty = dirac.getDiracType();
+  if (ty != QUDA_TWISTED_MASSPC_DIRAC && ty != QUDA_WILSONPC_DIRAC && ty != QUDA_TWISTED_CLOVERPC_DIRAC) return nullptr;
+  const QudaMatPCType mt = dirac.getMatPCType();
+  if (mt != QUDA_MATPC_EVEN_EVEN && mt != QUDA_MATPC_ODD_ODD) return nullptr;
+  if (pre.inv_type != QUDA_MR_INVERTER || post.inv_type != QUDA_MR_INVERTER) return nullptr;
+  if (pre.precision_sloppy != QUDA_SINGLE_PRECISION || post.precision_sloppy != QUDA_SINGLE_PRECISION) return nullptr;
+  if (pre.global_reduction && commReductionsNeeded()) return nullptr;
+  const GaugeField *U = dirac.Gauge();
+  if (!U || !fineBlockSupported(*U, 8) || !fineBlockSupported(*U, 4) || !fineBlockDotsSupported(8) || !fineBlockDotsSupported(4)) return nullptr;
+  const bool tmc = ty == QUDA_TWISTED_CLOVERPC_DIRAC;
+  if (tmc && !(dirac.Clover() && dirac.Clover()->precision == QUDA_SINGLE_PRECISION)) return nullptr;
+  BlockFineSmoother *f = new BlockFineSmoother;
+  f->U = U;
+  f->kappa = dirac.Kappa();
+  f->a = ty == QUDA_WILSONPC_DIRAC ? 0.0 : 2.0 * dirac.Kappa() * (double)flavor * dirac.Mu();
+  f->binv = 1.0 / (1.0 + f->a * f->a);
+  f->omega = pre.omega;
+  f->par = mt == QUDA_MATPC_ODD_ODD ? 1 : 0;
+  f->nuPre = pre.maxiter; f->nuPost = post.maxiter;
+  const int Vh = U->geom.Vh;
+  if (tmc) {
+    f->tmatBytes = (size_t)Vh * 144 * sizeof(float);
+    for (int p = 0; p < 2; p++) {
+      f->tmat[p] = (float *)poolDeviceMalloc(f->tmatBytes);
+      cloverTwistDense(f->tmat[p], *dirac.Clover(), p, f->a, true);
+    }
+  }
+  const int nGhost = blockGhost(U->geom.X, true).nGhost;
+  for (int first = 0; first < nsrc;) {
+    FineGroup g;
+    const int left = nsrc - first;
+    g.first = first; g.n = left >= 8 ? 8 : left; g.nrhs = g.n > 4 ? 8 : 4;
+    g.B = new BlockField(Vh, 12, g.nrhs, nGhost); g.X = new BlockField(Vh, 12, g.nrhs, nGhost); g.R = new BlockField(Vh, 12, g.nrhs, nGhost);
+    g.AR = new BlockField(Vh, 12, g.nrhs, nGhost); g.T = new BlockField(Vh, 12, g.nrhs, nGhost);
+    g.d_sums = (double *)poolDeviceMalloc(3 * 8 * sizeof(double));
+    f->groups.push_back(g);
+    first += g.n;
+  }
+  return f;
+}
+
+// ================================================================================================
 // the multigrid cycle for several sources at once (level 0: per source; below: block fields)
 // ================================================================================================
 struct MGBlockState {
@@ -271,7 +384,9 @@ struct MGBlockState {
   std::vector<SolverParam *> prePar, postPar;
   std::vector<ColorSpinorField *> r, rc, xc, btilde;
   BlockCoarseCycle *coarse = nullptr;
+  BlockFineSmoother *fine = nullptr;   // nullptr: the per-source smoothers above
   ~MGBlockState() {
+    delete fine;
     for (Solver *s : pre) delete s;
     for (Solver *s : post) delete s;
     for (SolverParam *s : prePar) delete s;
@@ -316,6 +431,7 @@ bool MG::blockPrepare(int nsrc) {
     st->btilde.push_back(new ColorSpinorField(bp));
   }
   for (int i = 0; i < nb; i++) { st->rc.push_back(transfer->createCoarseField()); st->xc.push_back(transfer->createCoarseField()); }
+  st->fine = blockFineCreate(*mgp.matSmooth.Expose(), *param_presmooth, *param_postsmooth, (int)mgp.fineFlavor, nsrc);
   blockState = st;
   return true;
 }
@@ -328,7 +444,46 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
   const bool odd = dirac.getMatPCType() == QUDA_MATPC_ODD_ODD || dirac.getMatPCType() == QUDA_MATPC_ODD_ODD_ASYMMETRIC;
   const bool symmetric = dirac.getMatPCType() == QUDA_MATPC_EVEN_EVEN || dirac.getMatPCType() == QUDA_MATPC_ODD_ODD;
   std::vector<const ColorSpinorField *> rin(nsrc, nullptr);
-  for (int i = 0; i < nsrc; i++) {
+  // smoothing of all sources on block fields where the fine level allows it (BlockFineSmoother), else source by source
+  bool blockSmooth = st.fine != nullptr;
+  for (int i = 0; i < nsrc && blockSmooth; i++)
+    if (active[i] && (b[i]->Precision() != QUDA_SINGLE_PRECISION || x[i]->Precision() != QUDA_SINGLE_PRECISION || (int)b[i]->twistFlavor != (int)mgp.fineFlavor)) blockSmooth = false;
+  if (blockSmooth) {
+    BlockFineSmoother &F = *st.fine;
+    for (FineGroup &g : F.groups) {
+      const ColorSpinorField *src[8];
+      ColorSpinorField *dst[8];
+      for (int j = 0; j < g.n; j++) {
+        const int i = g.first + j;
+        src[j] = active[i] ? b[i] : nullptr;
+        dst[j] = nullptr;
+        if (!active[i]) continue;
+        x[i]->twistFlavor = b[i]->twistFlavor;
+        ColorSpinorField &rp = odd ? st.r[i]->Odd() : st.r[i]->Even();
+        st.r[i]->twistFlavor = rp.twistFlavor = b[i]->twistFlavor;
+        dst[j] = &rp;
+      }
+      blockPackParity(*g.B, src, g.n);
+      if (F.nuPre > 0) {
+        F.mr(g, F.nuPre, g.B);
+        blockUnpackParity(dst, g.n, *g.R);
+      }
+      for (int j = 0; j < g.n; j++) {
+        const int i = g.first + j;
+        if (!active[i]) continue;
+        if (F.nuPre > 0) {
+          if (fullResidual && symmetric) dirac.localTermParity(*dst[j], *dst[j], odd ? 1 : 0);
+          rin[i] = dst[j];
+        } else if (fullResidual && symmetric) {
+          dirac.localTermParity(*dst[j], *b[i], odd ? 1 : 0);
+          rin[i] = dst[j];
+        } else {
+          rin[i] = b[i];
+        }
+      }
+    }
+  }
+  for (int i = 0; i < nsrc && !blockSmooth; i++) {
     if (!active[i]) continue;
     x[i]->twistFlavor = b[i]->twistFlavor;
     ColorSpinorField &rp = odd ? st.r[i]->Odd() : st.r[i]->Even();
@@ -378,19 +533,38 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
       const ColorSpinorField *c4[4] = {st.xc[i], st.xc[i + 1], st.xc[i + 2], st.xc[i + 3]};
       for (int s = 0; s < 4; s++) f4[s] = odd ? &st.r[i + s]->Odd() : &st.r[i + s]->Even();
       transfer->P4(f4, c4);
-      for (int s = 0; s < 4; s++) blas::xpy(*f4[s], *x[i + s]);
+      if (!blockSmooth) for (int s = 0; s < 4; s++) blas::xpy(*f4[s], *x[i + s]);
       i += 4;
       continue;
     }
     if (active[i]) {
       ColorSpinorField &rp = odd ? st.r[i]->Odd() : st.r[i]->Even();
       transfer->P(rp, *st.xc[i]);
-      blas::xpy(rp, *x[i]);
+      if (!blockSmooth) blas::xpy(rp, *x[i]);
     }
     i++;
   }
   transfer->setSiteSubset(QUDA_FULL_SITE_SUBSET, QUDA_INVALID_PARITY);
-  for (int i = 0; i < nsrc; i++) if (active[i]) (*st.post[i])(*x[i], *b[i]);
+  if (blockSmooth) {
+    BlockFineSmoother &F = *st.fine;
+    for (FineGroup &g : F.groups) {
+      const ColorSpinorField *corr[8];
+      ColorSpinorField *dst[8];
+      for (int j = 0; j < g.n; j++) {
+        const int i = g.first + j;
+        corr[j] = active[i] ? (odd ? &st.r[i]->Odd() : &st.r[i]->Even()) : nullptr;
+        dst[j] = active[i] ? x[i] : nullptr;
+      }
+      blockPackParity(*g.X, corr, g.n, F.nuPre > 0);   // X (+)= P e
+      if (F.nuPost > 0) {
+        F.residual(g);
+        F.mr(g, F.nuPost, nullptr);
+      }
+      blockUnpackParity(dst, g.n, *g.X);
+    }
+  } else {
+    for (int i = 0; i < nsrc; i++) if (active[i]) (*st.post[i])(*x[i], *b[i]);
+  }
   blas::setGlobalReduction(true);
 }
 

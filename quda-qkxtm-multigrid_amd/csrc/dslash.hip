@@ -1240,16 +1240,26 @@ template <int NRHS, int CL = 0, int XY = 0> __global__ void __launch_bounds__(25
       outv[2 * j] = re; outv[2 * j + 1] = im;
     }
   }
-  if (NRHS == 8 && arg.dotMode) {   // uniform
+  if (NRHS <= 8 && arg.dotMode) {   // uniform
     // the two dot products of a BiCGstab half step where their operands already are: `out` and the site's own input panel in registers, one more
-    // panel (a = r0) loaded — instead of separate passes over the fields (blockblas::cDot / bicgstabDots: 2 resp. 3 field reads)
-    float4 ra[6];
-    load_panel(ra, arg.dotA, idx);
+    // panel (a = r0) loaded — instead of separate passes over the fields (blockblas::cDot / bicgstabDots: 2 resp. 3 field reads); mode 3: the
+    // two sums of a minimal-residual step, (out, same) and |out|^2, nothing loaded at all
     float av[24];
-    unpack_panel(av, ra);
-    const int ns = arg.dotMode == 1 ? 2 : 7;
+    if (arg.dotMode != 3) {
+      float4 ra[6];
+      load_panel(ra, arg.dotA, idx);
+      unpack_panel(av, ra);
+    }
+    const int ns = arg.dotMode == 1 ? 2 : (arg.dotMode == 3 ? 3 : 7);
     float sm[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (arg.dotMode == 1) {
+    if (arg.dotMode == 3) {
+#pragma unroll
+      for (int j = 0; j < 12; j++) {
+        const float orr = outv[2 * j], oi = outv[2 * j + 1], sr = same[2 * j], si = same[2 * j + 1];
+        sm[0] += orr * sr + oi * si; sm[1] += orr * si - oi * sr;    // conj(out) same
+        sm[2] += orr * orr + oi * oi;
+      }
+    } else if (arg.dotMode == 1) {
 #pragma unroll
       for (int j = 0; j < 12; j++) {
         sm[0] += av[2 * j] * outv[2 * j] + av[2 * j + 1] * outv[2 * j + 1];       // conj(a) out
@@ -1350,7 +1360,7 @@ void cloverTwistDense(float *out, const CloverField &C, int parity, double a, bo
 
 bool fineBlockSupported(const GaugeField &U, int nrhs) {
   if (U.precision != QUDA_SINGLE_PRECISION || (U.reconstruct != QUDA_RECONSTRUCT_NO && U.reconstruct != QUDA_RECONSTRUCT_12)) return false;
-  if (nrhs != 8 && nrhs != 16 && nrhs != 24 && nrhs != 32) return false;
+  if (nrhs != 4 && nrhs != 8 && nrhs != 16 && nrhs != 24 && nrhs != 32) return false;
   static int off = -1;
   if (off < 0) { const char *e = getenv("QUDA_AMD_BLOCK_FINE"); off = (e && !atoi(e)) ? 1 : 0; }
   return !off;
@@ -1394,25 +1404,32 @@ void freeFineBlockDots() {
 bool fineBlockDotsSupported(int nrhs) {
   static int off = -1;
   if (off < 0) { const char *e = getenv("QUDA_AMD_BLOCK_FINE_DOTS"); off = (e && !atoi(e)) ? 1 : 0; }
-  return !off && nrhs == 8;
+  return !off && (nrhs == 8 || nrhs == 4);
 }
+static int fbDotSums(int mode) { return mode == 1 ? 2 : (mode == 3 ? 3 : 7); }
 // after a launch with dots: sums[k * nrhs + i], k as in FineBlockArg::dotMode; a global sum on a grid-decomposed lattice
-void fineBlockDotsFinish(double *sums, int nrhs, int mode) {
-  const int ns = mode == 1 ? 2 : 7, nval = ns * nrhs;
+static void fbDotsReduce(double *dst, int nrhs, int mode) {
+  const int ns = fbDotSums(mode), nval = ns * nrhs;
   if (!g_fbBlocks || g_fbVals != nval) errorQuda("no multi-right-hand-side stencil launch with inner products (mode %d) to finish", mode);
   const int threads = 512 / nval * nval;
   hipLaunchKernelGGL(fine_block_dots_reduce, dim3(kFbChunks), dim3(threads), 0, computeStream(), g_fbPart2, (const double *)g_fbPart, g_fbBlocks, nval);
-  hipLaunchKernelGGL(fine_block_dots_finish, dim3(nval), dim3(64), 0, computeStream(), g_fbResDev, (const double *)g_fbPart2, kFbChunks, nval);
+  hipLaunchKernelGGL(fine_block_dots_finish, dim3(nval), dim3(64), 0, computeStream(), dst, (const double *)g_fbPart2, kFbChunks, nval);
   HIP_CHECK(hipGetLastError());
+  g_fbBlocks = 0;
+}
+void fineBlockDotsFinish(double *sums, int nrhs, int mode) {
+  const int nval = fbDotSums(mode) * nrhs;
+  fbDotsReduce(g_fbResDev, nrhs, mode);
   HIP_CHECK(hipStreamSynchronize(computeStream()));
   for (int q = 0; q < nval; q++) sums[q] = g_fbRes[q];
   if (commReductionsNeeded()) comm_allreduce(sums, nval);
-  g_fbBlocks = 0;
 }
+// the same into DEVICE memory, rank-local, no host round trip: the next kernel on the stream reads the sums (blockblas::mrUpdateDev)
+void fineBlockDotsFinishDev(double *d_sums, int nrhs, int mode) { fbDotsReduce(d_sums, nrhs, mode); }
 
 void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_other, int nrhs, const GaugeField &U, int parity, double s0, double a0, double k1,
                           double a1, const float *tmat, int tmode, float2 *ghost, const FineBlockDots *dots) {
-  if (!fineBlockSupported(U, nrhs)) errorQuda("multi-right-hand-side fine operator: fp32 links (18 or 12 reals), 8/16/24/32 right-hand sides");
+  if (!fineBlockSupported(U, nrhs)) errorQuda("multi-right-hand-side fine operator: fp32 links (18 or 12 reals), 4/8/16/24/32 right-hand sides");
   if (s0 != 0.0 && !in_same) errorQuda("same-parity input missing");
   if (tmat && (tmode != 1 && tmode != 2)) errorQuda("site-matrix mode %d (1: on the hop sum, 2: on the same-parity input)", tmode);
   if (tmat && tmode == 2 && s0 == 0.0) errorQuda("site matrix on the same-parity input, but that input is switched off");
@@ -1446,10 +1463,10 @@ void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_o
   }
   arg.dotA = nullptr; arg.dotPart = nullptr; arg.dotMode = 0;
   if (dots) {
-    if (!fineBlockDotsSupported(nrhs)) errorQuda("inner products in the stencil epilogue: 8 right-hand sides only");
-    if (dots->mode != 1 && dots->mode != 2) errorQuda("inner-product mode %d", dots->mode);
-    if (dots->mode == 2 && s0 == 0.0) errorQuda("inner products with the same-parity input, but that input is switched off");
-    const int ns = dots->mode == 1 ? 2 : 7;
+    if (!fineBlockDotsSupported(nrhs)) errorQuda("inner products in the stencil epilogue: 4 or 8 right-hand sides only");
+    if (dots->mode < 1 || dots->mode > 3) errorQuda("inner-product mode %d", dots->mode);
+    if (dots->mode >= 2 && s0 == 0.0) errorQuda("inner products with the same-parity input, but that input is switched off");
+    const int ns = fbDotSums(dots->mode);
     const size_t need = (size_t)nb * ns * nrhs * sizeof(double);
     if (need > g_fbPartBytes) {
       if (g_fbPart) poolDeviceFree(g_fbPart, 0);
@@ -1498,6 +1515,7 @@ void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_o
   else if (tmode == 1) hipLaunchKernelGGL((fine_block_kernel<N, 1>), dim3(nb), dim3(threads), 0, computeStream(), arg); \
   else hipLaunchKernelGGL((fine_block_kernel<N, 2>), dim3(nb), dim3(threads), 0, computeStream(), arg)
   switch (nrhs) {
+    case 4: FB_LAUNCH(4); break;
     case 8: FB_LAUNCH(8); break;
     case 16: FB_LAUNCH(16); break;
     case 24: FB_LAUNCH(24); break;
