@@ -132,6 +132,10 @@ void qudaAmdTuneCacheStore(const char *volume, const char *name, const char *aux
 int qudaAmdTuneCacheLookup(const char *volume, const char *name, const char *aux, int param[11], float *time);
 long qudaAmdTuneSweeps(void);
 int qudaAmdMultigridFusedStats(void *mg_instance, int level, long long out[5]);
+/* counters of invertMultiSrcQuda since start-up: [0] multigrid cycles run for all sources at once (coarse levels on block fields), [1] those of
+ * them whose fine-level smoothing also ran on block fields (multi-right-hand-side stencil; QUDA_AMD_MULTISRC_BLOCK_SMOOTHER=0 switches it off),
+ * [2] four-source restrictor / prolongator launches (QUDA_AMD_MULTISRC_QUAD=0), [3] lockstep solves */
+void qudaAmdMultiSrcStats(long long out[4]);
 /* seconds per application of the restrictor (what = 0) or prolongator (what = 1) between `level` and `level + 1` */
 double qudaAmdMultigridTimeTransfer(void *mg_instance, int level, int what, int niter);
 

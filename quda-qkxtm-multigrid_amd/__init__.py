@@ -119,7 +119,7 @@ EXT_H_SYMBOLS = ["qudaAmdSpinorCreate", "qudaAmdSpinorDestroy", "qudaAmdSpinorLo
                  "qudaAmdMultigridVerify", "qudaAmdMultigridCycle", "qudaAmdTimeAxpy", "qudaAmdMultigridLevels", "qudaAmdMultigridLevelInfo",
                  "qudaAmdMultigridSetHalfStorage", "qudaAmdMultigridGetNullVector", "qudaAmdMultigridGetV", "qudaAmdMultigridGetCoarseLinks", "qudaAmdMultigridApply", "qudaAmdMultigridApplyBlock",
                  "qudaAmdMultigridTimeApply", "qudaAmdMultigridTimeTransfer", "qudaAmdSetExitLine", "qudaAmdDiracPrepare", "qudaAmdDiracReconstruct", "qudaAmdSpinorRawInfo", "qudaAmdGaugeRawInfo", "qudaAmdCloverRawInfo", "qudaAmdRawDeviceCopy",
-                 "qudaAmdSetSolutionSink", "qudaAmdCommStats", "qudaAmdDescribeHaloError", "qudaAmdMultigridOrthoFallbackBlocks", "qudaAmdProfileMarker", "qudaAmdAccountStart", "qudaAmdAccountDump", "qudaAmdWriteSpinorFields", "qudaAmdReadSpinorFields", "qudaAmdMultigridRefine", "qudaAmdMultigridSetFused", "qudaAmdMultigridFusedStats"]
+                 "qudaAmdSetSolutionSink", "qudaAmdCommStats", "qudaAmdDescribeHaloError", "qudaAmdMultigridOrthoFallbackBlocks", "qudaAmdProfileMarker", "qudaAmdAccountStart", "qudaAmdAccountDump", "qudaAmdWriteSpinorFields", "qudaAmdReadSpinorFields", "qudaAmdMultigridRefine", "qudaAmdMultigridSetFused", "qudaAmdMultigridFusedStats", "qudaAmdMultiSrcStats"]
 
 _lib = None
 
@@ -367,6 +367,13 @@ def invert(h_b, ip, out=None):
     x = np.zeros_like(h_b) if out is None else out
     lib().invertQuda(_vp(x), _vp(h_b), C.byref(ip))
     return x
+
+
+def multi_src_stats():
+    """qudaAmdMultiSrcStats: counters of the lockstep multi-source path since start-up"""
+    a = (C.c_longlong * 4)()
+    lib().qudaAmdMultiSrcStats(a)
+    return dict(block_cycles=int(a[0]), block_smoothed=int(a[1]), quad_transfers=int(a[2]), solves=int(a[3]))
 
 
 def invert_multi_src(h_bs, ip, out=None):

@@ -27,6 +27,8 @@ namespace quda {
 
 void massRescale(ColorSpinorField &b, QudaInvertParam &param);   // solve_interface.cpp
 
+static long long g_msStats[4] = {0, 0, 0, 0};   // qudaAmdMultiSrcStats
+
 static double nowSec() {
   timeval t;
   gettimeofday(&t, nullptr);
@@ -448,6 +450,8 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
   bool blockSmooth = st.fine != nullptr;
   for (int i = 0; i < nsrc && blockSmooth; i++)
     if (active[i] && (b[i]->Precision() != QUDA_SINGLE_PRECISION || x[i]->Precision() != QUDA_SINGLE_PRECISION || (int)b[i]->twistFlavor != (int)mgp.fineFlavor)) blockSmooth = false;
+  g_msStats[0]++;
+  if (blockSmooth) g_msStats[1]++;
   if (blockSmooth) {
     BlockFineSmoother &F = *st.fine;
     for (FineGroup &g : F.groups) {
@@ -516,6 +520,7 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
       ColorSpinorField *c4[4] = {st.rc[i], st.rc[i + 1], st.rc[i + 2], st.rc[i + 3]};
       const ColorSpinorField *f4[4] = {rin[i], rin[i + 1], rin[i + 2], rin[i + 3]};
       transfer->R4(c4, f4);
+      g_msStats[2]++;
       i += 4;
       continue;
     }
@@ -533,6 +538,7 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
       const ColorSpinorField *c4[4] = {st.xc[i], st.xc[i + 1], st.xc[i + 2], st.xc[i + 3]};
       for (int s = 0; s < 4; s++) f4[s] = odd ? &st.r[i + s]->Odd() : &st.r[i + s]->Even();
       transfer->P4(f4, c4);
+      g_msStats[2]++;
       if (!blockSmooth) for (int s = 0; s < 4; s++) blas::xpy(*f4[s], *x[i + s]);
       i += 4;
       continue;
@@ -739,6 +745,8 @@ extern "C" {
 // reference include/quda.h:647 (lib/interface_quda.cpp:2546: "currently that code is just a copy of invertQuda and cannot work"): param->num_src
 // sources _hp_b[i] -> solutions _hp_x[i], one operator, one preconditioner.  GCR (optionally MG-preconditioned) direct solves; iter / secs
 // are those of the lockstep solve, true_res the worst source's.
+void qudaAmdMultiSrcStats(long long out[4]) { for (int i = 0; i < 4; i++) out[i] = g_msStats[i]; }
+
 void invertMultiSrcQuda(void **_hp_x, void **_hp_b, QudaInvertParam *param) {
   if (!gaugePrecise) errorQuda("Gauge field not allocated");
   if (param->tune == QUDA_TUNE_YES || param->tune == QUDA_TUNE_NO) setTuning(param->tune);
@@ -785,6 +793,7 @@ void invertMultiSrcQuda(void **_hp_x, void **_hp_b, QudaInvertParam *param) {
       errorQuda("invertMultiSrcQuda: preconditioner %d not supported (none or QUDA_MG_INVERTER)", param->inv_type_precondition);
     }
     const BlockGcrResult res = blockGCR(out, in, m, mSloppy, K, sp);
+    g_msStats[3]++;
     param->iter = res.iter;
     param->secs = res.secs;
     double worst = 0;

@@ -58,6 +58,57 @@ def test_multi_source_mg_gcr_matches_single_source_solves(qa, oracle, X, levels,
         qa.lib().qudaAmdSetPartitionMask(0)
 
 
+@pytest.mark.parametrize("action,matpc,nu_pre,nsrc,mask", [("tm", "oo", 0, 9, 14), ("tmc", "ee", 2, 12, 0), ("tm", "ee", 2, 4, 15), ("tm", "eeasym", 2, 3, 0)],
+                         ids=["odd-odd-no-presmoothing-9-sources-yzt", "twisted-clover-12-sources", "4-sources-xyzt", "asymmetric-falls-back"])
+def test_fine_level_block_smoother(qa, oracle, action, matpc, nu_pre, nsrc, mask):
+    """the fine-level smoothing of all sources on block fields (groups of 8 / 4 through the multi-right-hand-side stencil, MR sums in its epilogue,
+    coefficient on the device): same outer iteration count and the same solutions as the single-source solves — odd-odd preconditioning, no
+    pre-smoothing, twisted clover (dense site matrices), padded groups, partitioned dimensions; the asymmetric preconditioning is outside it
+    and must run source by source"""
+    X, kappa, mu = (16, 8, 8, 16), 0.124, 0.005
+    qa.lib().qudaAmdSetPartitionMask(mask)
+    try:
+        gauge, ip = _setup(qa, X, kappa, mu)
+        if action == "tmc":
+            ip.dslash_type = qa.QUDA_TWISTED_CLOVER_DSLASH
+            ip.clover_cpu_prec, ip.clover_cuda_prec, ip.clover_cuda_prec_sloppy, ip.clover_cuda_prec_precondition = 8, 8, 4, 4
+            ip.clover_order = qa.QUDA_PACKED_CLOVER_ORDER
+            ip.clover_coeff = kappa * 1.57551
+            qa.load_clover(None, None, ip)
+        ip.matpc_type = qa.MATPC[matpc]
+        mp = qa.multigrid_param(ip, n_level=3, geo_block=[(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)], n_vec=8, nu_pre=nu_pre, setup_maxiter=300, setup_tol=1e-5, smoother_pc=True,
+                                cycle=qa.QUDA_MG_CYCLE_VCYCLE)
+        mg = qa.Multigrid(mp)
+        try:
+            rng = np.random.default_rng(47)
+            bs = [rng.random(int(np.prod(X)) * 24) for _ in range(nsrc)]
+            ip.inv_type_precondition, ip.preconditioner = qa.QUDA_MG_INVERTER, mg.h
+            ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
+            ip.solve_type = qa.QUDA_DIRECT_PC_SOLVE
+            singles, iters = [], []
+            for b in bs:
+                singles.append(qa.invert(b, ip))
+                iters.append(ip.iter)
+            s0 = qa.multi_src_stats()
+            xs = qa.invert_multi_src(bs, ip)
+            s1 = qa.multi_src_stats()
+            assert abs(ip.iter - max(iters)) <= 1, (ip.iter, iters)
+            cycles, smoothed = s1["block_cycles"] - s0["block_cycles"], s1["block_smoothed"] - s0["block_smoothed"]
+            assert cycles >= ip.iter and smoothed == (0 if matpc == "eeasym" else cycles), (s0, s1)
+            ip.solve_type = qa.QUDA_DIRECT_SOLVE
+            for i in range(nsrc):
+                assert np.linalg.norm(bs[i] - qa.mat(xs[i], ip)) < 1e-9 * np.linalg.norm(bs[i]), i
+                if action == "tm":
+                    assert _true_residual(oracle, gauge, X, kappa, mu, xs[i], bs[i]) < 1e-10, i
+                assert np.linalg.norm(xs[i] - singles[i]) < 1e-7 * np.linalg.norm(singles[i]), i
+            print("block smoother %s %s nu_pre %d, %d sources, mask %d: %d lockstep iterations (single-source %s), %s" % (action, matpc, nu_pre, nsrc, mask, ip.iter, iters, s1))
+        finally:
+            mg.free()
+    finally:
+        qa.lib().qudaAmdSetPartitionMask(0)
+        qa.lib().freeCloverQuda()
+
+
 def test_multi_source_plain_gcr(qa, oracle):
     """without a preconditioner the lockstep solver is nsrc independent GCR(20) solves sharing their Krylov index"""
     X, kappa, mu = (8, 8, 8, 8), 0.124, 0.005
