@@ -143,7 +143,7 @@ def run_mg_ranks(qa, dist, X, kappa=0.124, mu=0.005):
 
 
 def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)), gauge=None, extras=True, kappa=0.124, mu=0.005, plain_maxiter=5000,
-           coarse_bench=True, setup_repeats=1, dslash="tm", csw=1.57551, cycle="V", refine=0, recon_sloppy=None, recon_precondition=None):
+           coarse_bench=True, setup_repeats=1, dslash="tm", csw=1.57551, cycle="V", refine=0, recon_sloppy=None, recon_precondition=None, multi_src=0):
     """MG-preconditioned GCR to |r|/|b| <= 1e-10 (the second half of the metric) on one GPU: 3-level K-cycle, 24 null
     vectors, 4^4 then 2^4 aggregates, even-odd preconditioned MR smoother — the reference harness' shape (tests/multigrid_invert_test.cpp:224-286)
     with the plain V-cycle BASELINE.json configs[4] names (cycle="K": the harness' default K-cycle, reported next to it) on a smooth synthetic gauge field (synth.smooth_gauge: far easier than a production
@@ -262,6 +262,39 @@ def run_mg(qa, X=(16, 16, 16, 16), blocks=((4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2,
     ip.solve_type = qa.QUDA_DIRECT_SOLVE
     out["outer_even_odd"] = dict(solve_secs=round(wall, 4), solver_secs=round(inner, 4), iters=iters,
                                  true_res=float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b)))
+    # a propagator's worth of sources through ONE lockstep solve (invertMultiSrcQuda, csrc/block_solver.cpp) against the same sources through
+    # invertQuda one after the other: even-odd outer solve as the QKXTM drivers run it, best of 3 passes each, solver seconds (the GCR loops) and
+    # wall seconds (with the host transfers) side by side
+    try:
+        nsrc = multi_src
+        if not nsrc:
+            raise RuntimeError("not requested for this leg")
+        rng = np.random.default_rng(7)
+        bs = [rng.random(int(np.prod(X)) * 24) for _ in range(nsrc)]
+        xs = [np.zeros_like(v) for v in bs]
+        ip.solve_type = qa.QUDA_DIRECT_PC_SOLVE
+        qa.invert_multi_src(bs, ip, out=xs)
+        seq, blk = [], []
+        for _ in range(3):
+            sw, ss, its = 0.0, 0.0, []
+            for v in bs:
+                t0 = time.perf_counter(); qa.invert(v, ip, out=xbuf); sw += time.perf_counter() - t0
+                ss += ip.secs; its.append(ip.iter)
+            seq.append((ss, sw))
+            t0 = time.perf_counter(); qa.invert_multi_src(bs, ip, out=xs); bw = time.perf_counter() - t0
+            blk.append((ip.secs, bw))
+        blk_iters = ip.iter
+        ip.solve_type = qa.QUDA_DIRECT_SOLVE
+        worst = max(float(np.linalg.norm(v - qa.mat(x, ip)) / np.linalg.norm(v)) for x, v in zip(xs, bs))
+        st = qa.multi_src_stats()
+        out["multi_src"] = dict(sources=nsrc, outer="even-odd (QUDA_DIRECT_PC_SOLVE)", sequential=dict(solver_secs=round(min(seq)[0], 4), wall_secs=round(min(seq)[1], 4), iters=its),
+                                lockstep=dict(solver_secs=round(min(blk)[0], 4), wall_secs=round(min(blk)[1], 4), iters=blk_iters, worst_true_res=worst,
+                                              fine_smoother="block fields (multi-rhs stencil)" if st["block_smoothed"] else "per source", quad_transfers=st["quad_transfers"] > 0),
+                                speedup_solver=round(min(seq)[0] / min(blk)[0], 3), speedup_wall=round(min(seq)[1] / min(blk)[1], 3))
+        del bs, xs
+    except Exception as e:
+        ip.solve_type = qa.QUDA_DIRECT_SOLVE
+        out["multi_src"] = dict(skipped=str(e)[:200])
     # opt-in half-precision storage inside the cycle: fp16 V and coarse links, 16-bit level-0 smoother (the outer solve is unchanged)
     mg.set_half_storage(True)
     wall, inner, iters, x = timed_solve()
@@ -481,7 +514,7 @@ def main():
     g16 = None
     if not args.no_extra and rank == 0 and world == 1:
         g32 = smooth_gauge((32, 32, 32, 32), 0.35)
-        extra["mg_gcr"] = run_mg(qa, (32, 32, 32, 32), gauge=g32)
+        extra["mg_gcr"] = run_mg(qa, (32, 32, 32, 32), gauge=g32, multi_src=12)
         # the same problem with the production action (twisted CLOVER): lockstep set-up on the clover variant of the multi-rhs stencil
         extra["mg_gcr_tmc"] = run_mg(qa, (32, 32, 32, 32), gauge=g32, dslash="tmc", coarse_bench=False)
         # where multigrid matters: the same field at its critical kappa (tools/mg_kappa_scan.py, profiles/r02_mg_kappa_scan_32x4_c.json:
@@ -496,7 +529,7 @@ def main():
         from synth import smooth_gauge_cayley
         Xc5 = (48, 48, 48, 96)
         gc5 = smooth_gauge_cayley(Xc5, 0.35, workers=min(16, os.cpu_count() or 8))
-        extra["mg_gcr_c5_one_gpu"] = run_mg(qa, Xc5, blocks=((4, 4, 4, 4), (2, 2, 2, 4), (2, 2, 2, 2)), gauge=gc5, setup_repeats=2)
+        extra["mg_gcr_c5_one_gpu"] = run_mg(qa, Xc5, blocks=((4, 4, 4, 4), (2, 2, 2, 4), (2, 2, 2, 2)), gauge=gc5, setup_repeats=2, multi_src=8)
         # ... with the sloppy and preconditioner links stored as 12 reals (reconstruct_sloppy = reconstruct_precondition = 12, the usual production choice;
         # the precise links stay at 18): every fp32 stencil of the cycle moves 576 instead of 768 B per site
         r12 = run_mg(qa, Xc5, blocks=((4, 4, 4, 4), (2, 2, 2, 4), (2, 2, 2, 2)), gauge=gc5, extras=False, coarse_bench=False, recon_sloppy=qa.QUDA_RECONSTRUCT_12)
