@@ -11,6 +11,11 @@
 //     v[((parity * Vh + x_cb) * ncomp + j) * nrhs + i]   (float2, j = spin * Ncolor + colour, i = right-hand side)
 // so the ncomp x nrhs panel of a site is one contiguous chunk (9 KB for 48 x 24): the operator stages a neighbour's panel with
 // full-line 16-byte loads, and a BLAS thread always meets the same pair of right-hand sides.
+// 12-component fields (the fine level's spin-colour vectors, read by fine_block_kernel) are PAIR-MAJOR inside the panel —
+//     v[(((x * 6 + j / 2) * nrhs + i) * 2 + j % 2]
+// so that the 16-byte word a lane loads is two components of ITS right-hand side (the stencil thread of (site, right-hand side) gets its 12
+// components in six loads that still cover whole 128-byte lines across the 8 right-hand sides, with no exchange between lanes: the
+// rhs-fastest order needed a DPP transposition per word, a third of the kernel's vector instructions).
 #pragma once
 
 #include <vector>
@@ -28,6 +33,7 @@ struct BlockField {
   // grid-decomposed lattices: nGhost further panels behind the nSites local ones, the faces of the neighbour ranks (BlockGhost below);
   // BLAS and pack / unpack never touch them
   int nGhost = 0;
+  bool pairMajor = false;   // ncomp == 12: see above
   size_t bytes = 0;
   BlockField() {}
   BlockField(int nSites, int ncomp, int nrhs, int nGhost = 0);

@@ -37,7 +37,7 @@
 
 namespace quda {
 
-BlockField::BlockField(int nSites_, int ncomp_, int nrhs_, int nGhost_) : nSites(nSites_), Vh(nSites_ / 2), ncomp(ncomp_), nrhs(nrhs_), nGhost(nGhost_) {
+BlockField::BlockField(int nSites_, int ncomp_, int nrhs_, int nGhost_) : nSites(nSites_), Vh(nSites_ / 2), ncomp(ncomp_), nrhs(nrhs_), nGhost(nGhost_), pairMajor(ncomp_ == 12) {
   if (nrhs < 1 || nrhs > kMaxBlockRhs) errorQuda("block field with %d right-hand sides (1..%d supported)", nrhs, kMaxBlockRhs);
   bytes = (elems() + (size_t)nGhost * ncomp * nrhs) * sizeof(float2);
   // From the size-bucketed pool (qa_core.h): the solver's six work fields have the same size in every batch of right-hand sides and
@@ -52,7 +52,7 @@ BlockField::~BlockField() { if (v) poolDeviceFree(v, bytes); }
 // ---- gather / scatter ----
 struct BlockPtrs { float *v[2][kMaxBlockRhs]; };
 // NV: reals per plane entry of the ordinary fields (2: FLOAT2 order of the coarse levels, 4: FLOAT4 order of fp32 nSpin = 4 fields)
-template <bool PACK, int NV> __global__ void __launch_bounds__(256) block_pack_kernel(float2 *blk, BlockPtrs f, int stride, int Vh, int ncomp, int nrhs, long total) {
+template <bool PACK, int NV> __global__ void __launch_bounds__(256) block_pack_kernel(float2 *blk, BlockPtrs f, int stride, int Vh, int ncomp, int nrhs, long total, int pairMajor) {
   const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
   if (t >= total) return;
   const int i = (int)(t % nrhs);
@@ -61,8 +61,9 @@ template <bool PACK, int NV> __global__ void __launch_bounds__(256) block_pack_k
   const int A = (int)(u / ncomp);
   const int par = A >= Vh, x = A - par * Vh;
   float2 *p = reinterpret_cast<float2 *>(f.v[par][i] + ((size_t)((2 * j) / NV) * stride + x) * NV + (2 * j) % NV);
-  if (PACK) blk[t] = *p;
-  else *p = blk[t];
+  const long b = pairMajor ? (((long)A * (ncomp >> 1) + (j >> 1)) * nrhs + i) * 2 + (j & 1) : t;
+  if (PACK) blk[b] = *p;
+  else *p = blk[b];
 }
 static BlockPtrs blockPtrs(const std::vector<ColorSpinorField *> &f, const BlockField &b, int &stride, int parity, int &Vh) {
   if ((int)f.size() < b.nrhs) errorQuda("%zu fields for a block of %d right-hand sides", f.size(), b.nrhs);
@@ -83,16 +84,16 @@ void blockPack(BlockField &dst, const std::vector<ColorSpinorField *> &src, int 
   int stride, Vh;
   const BlockPtrs p = blockPtrs(src, dst, stride, parity, Vh);
   const long total = (long)dst.elems();
-  if (src[0]->Nspin() == 4) hipLaunchKernelGGL((block_pack_kernel<true, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), dst.v, p, stride, Vh, dst.ncomp, dst.nrhs, total);
-  else hipLaunchKernelGGL((block_pack_kernel<true, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), dst.v, p, stride, Vh, dst.ncomp, dst.nrhs, total);
+  if (src[0]->Nspin() == 4) hipLaunchKernelGGL((block_pack_kernel<true, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), dst.v, p, stride, Vh, dst.ncomp, dst.nrhs, total, dst.pairMajor ? 1 : 0);
+  else hipLaunchKernelGGL((block_pack_kernel<true, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), dst.v, p, stride, Vh, dst.ncomp, dst.nrhs, total, dst.pairMajor ? 1 : 0);
   HIP_CHECK(hipGetLastError());
 }
 void blockUnpack(const std::vector<ColorSpinorField *> &dst, const BlockField &src, int parity) {
   int stride, Vh;
   const BlockPtrs p = blockPtrs(dst, src, stride, parity, Vh);
   const long total = (long)src.elems();
-  if (dst[0]->Nspin() == 4) hipLaunchKernelGGL((block_pack_kernel<false, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), src.v, p, stride, Vh, src.ncomp, src.nrhs, total);
-  else hipLaunchKernelGGL((block_pack_kernel<false, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), src.v, p, stride, Vh, src.ncomp, src.nrhs, total);
+  if (dst[0]->Nspin() == 4) hipLaunchKernelGGL((block_pack_kernel<false, 4>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), src.v, p, stride, Vh, src.ncomp, src.nrhs, total, src.pairMajor ? 1 : 0);
+  else hipLaunchKernelGGL((block_pack_kernel<false, 2>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, computeStream(), src.v, p, stride, Vh, src.ncomp, src.nrhs, total, src.pairMajor ? 1 : 0);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -100,52 +101,44 @@ void blockUnpack(const std::vector<ColorSpinorField *> &dst, const BlockField &s
 // consecutive sites of one plane of one field, the block side is one contiguous chunk of 64 panels); the generic kernel above touches 8 bytes per
 // line on the field side.  A nullptr field is a column of zeros (pack) / is skipped (unpack): sources that have converged, padding columns. ----
 struct FinePtrs { float *v[kMaxBlockRhs]; };
-template <int MODE> __global__ void __launch_bounds__(256) block_fine_pack_kernel(float2 *blk, FinePtrs f, int stride, int Vh, int nrhs) {   // MODE 0 pack, 1 pack and add, 2 unpack
-  extern __shared__ float2 pk_lds[];   // [64 sites][12 nrhs + 1]: the odd stride spreads the sites of a wave over the banks
-  const int SS = 12 * nrhs + 1;
+template <int MODE> __global__ void __launch_bounds__(256) block_fine_pack_kernel(float4 *blk, FinePtrs f, int stride, int Vh, int nrhs) {   // MODE 0 pack, 1 pack and add, 2 unpack
+  // a 16-byte word of a field plane (components 2k, 2k + 1 of one site) IS a word of the pair-major panel: only the order of the words changes
+  extern __shared__ float4 pk_lds[];   // [64 sites][6 nrhs + 1]: the odd stride spreads the sites of a wave over the banks
+  const int S4 = 6 * nrhs + 1;
   const int x0 = blockIdx.x * 64, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nloc = Vh - x0 < 64 ? Vh - x0 : 64;
-  float4 *chunk = reinterpret_cast<float4 *>(blk + (size_t)x0 * 12 * nrhs);
-  const int nq = nloc * 6 * nrhs;   // 16-byte words of the chunk
+  float4 *chunk = blk + (size_t)x0 * 6 * nrhs;
+  const int nq = nloc * 6 * nrhs;
   if (MODE != 2) {
     for (int i = wave; i < nrhs; i += 4) {
       const float4 *base = reinterpret_cast<const float4 *>(f.v[i]);
 #pragma unroll
-      for (int k = 0; k < 6; k++) {
-        const float4 v = (base && lane < nloc) ? base[(size_t)k * stride + x0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-        pk_lds[lane * SS + (2 * k) * nrhs + i] = make_float2(v.x, v.y);
-        pk_lds[lane * SS + (2 * k + 1) * nrhs + i] = make_float2(v.z, v.w);
-      }
+      for (int k = 0; k < 6; k++)
+        pk_lds[lane * S4 + k * nrhs + i] = (base && lane < nloc) ? base[(size_t)k * stride + x0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     for (int q = threadIdx.x; q < nq; q += 256) {
-      const int e = 2 * q, site = e / (12 * nrhs), c = e - site * 12 * nrhs;
-      const float2 a = pk_lds[site * SS + c], b = pk_lds[site * SS + c + 1];
-      float4 o = make_float4(a.x, a.y, b.x, b.y);
+      const int site = q / (6 * nrhs), c = q - site * 6 * nrhs;
+      float4 o = pk_lds[site * S4 + c];
       if (MODE == 1) { const float4 w = chunk[q]; o.x += w.x; o.y += w.y; o.z += w.z; o.w += w.w; }
       chunk[q] = o;
     }
   } else {
     for (int q = threadIdx.x; q < nq; q += 256) {
-      const int e = 2 * q, site = e / (12 * nrhs), c = e - site * 12 * nrhs;
-      const float4 w = chunk[q];
-      pk_lds[site * SS + c] = make_float2(w.x, w.y);
-      pk_lds[site * SS + c + 1] = make_float2(w.z, w.w);
+      const int site = q / (6 * nrhs), c = q - site * 6 * nrhs;
+      pk_lds[site * S4 + c] = chunk[q];
     }
     __syncthreads();
     for (int i = wave; i < nrhs; i += 4) {
       float4 *base = reinterpret_cast<float4 *>(f.v[i]);
       if (!base || lane >= nloc) continue;
 #pragma unroll
-      for (int k = 0; k < 6; k++) {
-        const float2 a = pk_lds[lane * SS + (2 * k) * nrhs + i], b = pk_lds[lane * SS + (2 * k + 1) * nrhs + i];
-        base[(size_t)k * stride + x0 + lane] = make_float4(a.x, a.y, b.x, b.y);
-      }
+      for (int k = 0; k < 6; k++) base[(size_t)k * stride + x0 + lane] = pk_lds[lane * S4 + k * nrhs + i];
     }
   }
 }
 static FinePtrs finePtrs(const ColorSpinorField *const *f, int n, const BlockField &b, int &stride) {
-  if (n > b.nrhs || b.ncomp != 12 || b.nrhs % 2) errorQuda("%d fine fields for a block of %d right-hand sides x %d components", n, b.nrhs, b.ncomp);
+  if (n > b.nrhs || b.ncomp != 12 || !b.pairMajor) errorQuda("%d fine fields for a block of %d right-hand sides x %d components", n, b.nrhs, b.ncomp);
   FinePtrs p;
   memset(&p, 0, sizeof(p));
   stride = 0;
@@ -163,18 +156,18 @@ static FinePtrs finePtrs(const ColorSpinorField *const *f, int n, const BlockFie
 void blockPackParity(BlockField &dst, const ColorSpinorField *const *f, int n, bool accumulate) {
   int stride;
   const FinePtrs p = finePtrs(f, n, dst, stride);
-  const size_t lds = (size_t)64 * (12 * dst.nrhs + 1) * sizeof(float2);
+  const size_t lds = (size_t)64 * (6 * dst.nrhs + 1) * sizeof(float4);
   const unsigned grid = (unsigned)((dst.nSites + 63) / 64);
-  if (accumulate) hipLaunchKernelGGL((block_fine_pack_kernel<1>), dim3(grid), dim3(256), lds, computeStream(), dst.v, p, stride, dst.nSites, dst.nrhs);
-  else hipLaunchKernelGGL((block_fine_pack_kernel<0>), dim3(grid), dim3(256), lds, computeStream(), dst.v, p, stride, dst.nSites, dst.nrhs);
+  if (accumulate) hipLaunchKernelGGL((block_fine_pack_kernel<1>), dim3(grid), dim3(256), lds, computeStream(), (float4 *)dst.v, p, stride, dst.nSites, dst.nrhs);
+  else hipLaunchKernelGGL((block_fine_pack_kernel<0>), dim3(grid), dim3(256), lds, computeStream(), (float4 *)dst.v, p, stride, dst.nSites, dst.nrhs);
   HIP_CHECK(hipGetLastError());
 }
 void blockUnpackParity(ColorSpinorField *const *f, int n, const BlockField &src) {
   int stride;
   const FinePtrs p = finePtrs(f, n, src, stride);
   if (!stride) return;   // nothing to write
-  const size_t lds = (size_t)64 * (12 * src.nrhs + 1) * sizeof(float2);
-  hipLaunchKernelGGL((block_fine_pack_kernel<2>), dim3((unsigned)((src.nSites + 63) / 64)), dim3(256), lds, computeStream(), src.v, p, stride, src.nSites, src.nrhs);
+  const size_t lds = (size_t)64 * (6 * src.nrhs + 1) * sizeof(float4);
+  hipLaunchKernelGGL((block_fine_pack_kernel<2>), dim3((unsigned)((src.nSites + 63) / 64)), dim3(256), lds, computeStream(), (float4 *)src.v, p, stride, src.nSites, src.nrhs);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -623,13 +616,16 @@ __device__ __forceinline__ void cacc(double &re, double &im, float2 x, float2 y)
 // OP: 0 norm2(x) | 1 cDot(x,y) | 2 y += a x | 3 (x,y) + |x|^2 | 4 bicgstab update | 5 z = x + a y + b z | 6 x = -x
 //     7 the five sums of a BiCGstab half step | 8 solution, residual and search direction of a BiCGstab iteration in one sweep
 // fields: x, y, z, w, u (meaning per op, see the wrappers)
-struct BArg { const float4 *x, *y, *w, *u; float4 *yo, *zo, *xo; long n4; int half; double *part; Coef c; };
+// half: threads with the same (threadIdx.x % half) meet the same right-hand sides — the pair (2 pr, 2 pr + 1) in the rhs-fastest order (half = nrhs / 2),
+// the single right-hand side pr in both halves of the word in the pair-major order of 12-component fields (pm = 1, half = nrhs)
+struct BArg { const float4 *x, *y, *w, *u; float4 *yo, *zo, *xo; long n4; int half, pm; double *part; Coef c; };
 
 template <int OP, int NSUM> __global__ void __launch_bounds__(kBS) block_blas_kernel(const BArg arg) {
   const int pr = threadIdx.x % arg.half;           // pair of right-hand sides (2 pr, 2 pr + 1) this thread owns
   double s[NSUM > 0 ? NSUM : 1][2] = {};
   float2 a0, a1, b0, b1;
-  a0 = arg.c.a[2 * pr]; a1 = arg.c.a[2 * pr + 1]; b0 = arg.c.b[2 * pr]; b1 = arg.c.b[2 * pr + 1];
+  const int i0 = arg.pm ? pr : 2 * pr, i1 = arg.pm ? pr : 2 * pr + 1;
+  a0 = arg.c.a[i0]; a1 = arg.c.a[i1]; b0 = arg.c.b[i0]; b1 = arg.c.b[i1];
   for (long q = blockIdx.x * (long)kBS + threadIdx.x; q < arg.n4; q += (long)gridDim.x * kBS) {
     if (OP == 0) {
       const float4 x = arg.x[q];
@@ -682,7 +678,7 @@ template <int OP, int NSUM> __global__ void __launch_bounds__(kBS) block_blas_ke
     } else if (OP == 8) {
       // x = p (in, out xo), y = s (in, out yo = r), zo = solution (in / out), w = t, u = v;  a = alpha, b = omega, c = beta:
       //   solution += alpha p + omega s ;  r = s - omega t ;  p = r + beta (p - omega v) ;  |r|^2 [0]
-      const float2 c0 = arg.c.c[2 * pr], c1 = arg.c.c[2 * pr + 1];
+      const float2 c0 = arg.c.c[i0], c1 = arg.c.c[i1];
       const float4 p = arg.x[q], t = arg.w[q], v = arg.u[q];
       float4 r = arg.y[q], z = arg.zo[q];
       const float2 ap0 = cmul(a0, make_float2(p.x, p.y)), ap1 = cmul(a1, make_float2(p.z, p.w));
@@ -710,8 +706,12 @@ template <int OP, int NSUM> __global__ void __launch_bounds__(kBS) block_blas_ke
       for (int k = 0; k < NSUM; k++) {
         double t0 = 0, t1 = 0;
         for (int j = threadIdx.x; j < kBS; j += arg.half) { t0 += red[j][k][0]; t1 += red[j][k][1]; }
-        double *o = arg.part + ((size_t)blockIdx.x * NSUM + k) * (2 * arg.half);
-        o[2 * threadIdx.x] = t0; o[2 * threadIdx.x + 1] = t1;
+        if (arg.pm) {
+          arg.part[((size_t)blockIdx.x * NSUM + k) * arg.half + threadIdx.x] = t0 + t1;
+        } else {
+          double *o = arg.part + ((size_t)blockIdx.x * NSUM + k) * (2 * arg.half);
+          o[2 * threadIdx.x] = t0; o[2 * threadIdx.x + 1] = t1;
+        }
       }
     }
   }
@@ -735,10 +735,11 @@ static void check(const BlockField &a, const BlockField &b) {
   if (a.nSites != b.nSites || a.ncomp != b.ncomp || a.nrhs != b.nrhs) errorQuda("block BLAS: field shapes differ");
 }
 template <int OP, int NSUM> static void run(BArg &arg, const BlockField &shape) {
-  if (shape.nrhs % 2 || kBS % (shape.nrhs / 2)) errorQuda("block BLAS: %d right-hand sides (need an even divisor pattern of %d threads)", shape.nrhs, kBS);
+  if (shape.nrhs % 2 || kBS % (shape.pairMajor ? shape.nrhs : shape.nrhs / 2)) errorQuda("block BLAS: %d right-hand sides (need an even divisor pattern of %d threads)", shape.nrhs, kBS);
   ensureBuffers();
   arg.n4 = (long)(shape.elems() / 2);
-  arg.half = shape.nrhs / 2;
+  arg.pm = shape.pairMajor ? 1 : 0;
+  arg.half = shape.pairMajor ? shape.nrhs : shape.nrhs / 2;
   arg.part = d_part;
   const int nb = gridFor(arg.n4);
   hipLaunchKernelGGL((block_blas_kernel<OP, NSUM>), dim3(nb), dim3(kBS), 0, computeStream(), arg);
@@ -826,13 +827,12 @@ void bicgstabFused(double *r2, const Complex *al, const Complex *om, const Compl
 // one minimal-residual step with the coefficient taken from DEVICE sums (fineBlockDotsFinishDev, mode 3: Re / Im (Ar, r), |Ar|^2 per right-hand
 // side): alpha_i = omega (Ar_i, r_i) / |Ar_i|^2 (0 for a column of zeros);  x = [x +] alpha rin ;  r = rin - alpha Ar — no host round trip
 __global__ void __launch_bounds__(256) mr_update_kernel(float4 *x, float4 *r, const float4 *rin, const float4 *Ar, const double *sums, float omega, int nrhs, long n4, int fresh) {
-  const int half = nrhs >> 1, pr = threadIdx.x % half;
+  // 12-component fields are pair-major (block.h): both halves of a 16-byte word belong to right-hand side (word index % nrhs)
+  const int i = threadIdx.x % nrhs;
   float2 al[2];
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    const int i = 2 * pr + h;
+  {
     const double n = sums[2 * nrhs + i];
-    al[h] = n > 0.0 ? make_float2((float)(omega * sums[i] / n), (float)(omega * sums[nrhs + i] / n)) : make_float2(0.f, 0.f);
+    al[0] = al[1] = n > 0.0 ? make_float2((float)(omega * sums[i] / n), (float)(omega * sums[nrhs + i] / n)) : make_float2(0.f, 0.f);
   }
   for (long q = blockIdx.x * 256l + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
     const float4 rv = rin[q], av = Ar[q];
@@ -846,7 +846,7 @@ __global__ void __launch_bounds__(256) mr_update_kernel(float4 *x, float4 *r, co
 }
 void mrUpdateDev(BlockField &x, BlockField &r, const BlockField &rin, const BlockField &Ar, const double *d_sums, double omega, bool fresh) {
   check(x, r); check(x, rin); check(x, Ar);
-  if (x.nrhs % 2 || 256 % (x.nrhs / 2)) errorQuda("minimal-residual update: %d right-hand sides", x.nrhs);
+  if (!x.pairMajor || 256 % x.nrhs) errorQuda("minimal-residual update: 12-component fields with 4 or 8 right-hand sides (got %d x %d)", x.ncomp, x.nrhs);
   const long n4 = (long)x.elems() / 2;
   const unsigned grid = (unsigned)std::min<long>((n4 + 255) / 256, 8192);
   hipLaunchKernelGGL(mr_update_kernel, dim3(grid), dim3(256), 0, computeStream(), (float4 *)x.v, (float4 *)r.v, (const float4 *)rin.v, (const float4 *)Ar.v, d_sums, (float)omega, x.nrhs, n4, fresh ? 1 : 0);

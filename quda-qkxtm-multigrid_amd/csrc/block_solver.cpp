@@ -283,6 +283,7 @@ class BlockFineSmoother {
   double kappa = 0, a = 0, binv = 1, omega = 1;
   int par = 0;                         // parity of the preconditioned system
   int nuPre = 0, nuPost = 0;
+  bool globalSums = false;             // the MR sums cross ranks
   float *tmat[2] = {nullptr, nullptr};   // twisted clover: dense (A + i a g5)^-1 per parity
   size_t tmatBytes = 0;
   std::vector<FineGroup> groups;
@@ -307,7 +308,13 @@ class BlockFineSmoother {
       applyFineBlockParity(g.T->v, nullptr, in.v, in.nrhs, *U, q, 0.0, 0.0, binv, -a, nullptr, 0, ghostOf(in));
       applyFineBlockParity(out.v, in.v, g.T->v, in.nrhs, *U, p, 1.0, 0.0, -kappa * kappa * binv, -a, nullptr, 0, ghostOf(*g.T), dots ? &d : nullptr);
     }
-    if (dots) fineBlockDotsFinishDev(g.d_sums, in.nrhs, 3);
+    if (!dots) return;
+    if (!globalSums) { fineBlockDotsFinishDev(g.d_sums, in.nrhs, 3); return; }
+    // sums over all ranks (smoother with global_reduction on a grid-decomposed lattice): through the host, one round trip per step and group
+    double sums[3 * 8];
+    fineBlockDotsFinish(sums, in.nrhs, 3);
+    HIP_CHECK(hipMemcpyAsync(g.d_sums, sums, 3 * in.nrhs * sizeof(double), hipMemcpyHostToDevice, computeStream()));
+    HIP_CHECK(hipStreamSynchronize(computeStream()));
   }
   // nu MR steps on (X, R); fresh: X is not defined yet and the residual is `first` (the source itself), not R
   void mr(FineGroup &g, int nu, BlockField *first) {
@@ -333,7 +340,7 @@ static bool blockFineSmootherOn() {
 }
 
 // nullptr: this fine level keeps the per-source smoother (asymmetric preconditioning, a smoother other than MR, 16-bit smoothing, links the
-// multi-right-hand-side stencil does not read, sums that have to cross ranks)
+// multi-right-hand-side stencil does not read)
 static BlockFineSmoother *blockFineCreate(const Dirac &dirac, const SolverParam &pre, const SolverParam &post, int flavor, int nsrc) {
   if (!blockFineSmootherOn()) return nullptr;
   const QudaDiracType ty = dirac.getDiracType();
@@ -342,7 +349,6 @@ static BlockFineSmoother *blockFineCreate(const Dirac &dirac, const SolverParam 
   if (mt != QUDA_MATPC_EVEN_EVEN && mt != QUDA_MATPC_ODD_ODD) return nullptr;
   if (pre.inv_type != QUDA_MR_INVERTER || post.inv_type != QUDA_MR_INVERTER) return nullptr;
   if (pre.precision_sloppy != QUDA_SINGLE_PRECISION || post.precision_sloppy != QUDA_SINGLE_PRECISION) return nullptr;
-  if (pre.global_reduction && commReductionsNeeded()) return nullptr;
   const GaugeField *U = dirac.Gauge();
   if (!U || !fineBlockSupported(*U, 8) || !fineBlockSupported(*U, 4) || !fineBlockDotsSupported(8) || !fineBlockDotsSupported(4)) return nullptr;
   const bool tmc = ty == QUDA_TWISTED_CLOVERPC_DIRAC;
@@ -355,6 +361,7 @@ static BlockFineSmoother *blockFineCreate(const Dirac &dirac, const SolverParam 
   f->omega = pre.omega;
   f->par = mt == QUDA_MATPC_ODD_ODD ? 1 : 0;
   f->nuPre = pre.maxiter; f->nuPost = post.maxiter;
+  f->globalSums = pre.global_reduction && commReductionsNeeded();
   const int Vh = U->geom.Vh;
   if (tmc) {
     f->tmatBytes = (size_t)Vh * 144 * sizeof(float);

@@ -1122,26 +1122,19 @@ template <int NRHS, int CL = 0, int XY = 0> __global__ void __launch_bounds__(25
   // Same register discipline as stencil_site: two panel buffers, the loads of hop d + 1 issued before the arithmetic of hop d,
   // fenced so the compiler neither hoists all 108 loads to the top (256 registers, one wave per SIMD: 12.7 ms per launch at
   // 48^3 x 96, four times the bandwidth bound) nor serialises them.
-  // The panels travel as 16-byte words: lane pair (i, i ^ 1) of a site shares its loads — the even lane fetches the even components of
-  // right-hand sides (i, i + 1), the odd lane the odd components, one 128-byte line per site and instruction (8-byte-per-lane loads
-  // run at 0.54-0.70 of the 16-byte rate on gfx950, and the kernel is bound by its L2 -> L1 requests); the 2 x 2 transposition
-  // between the two lanes is a DPP quad permute on the loaded data, in the compute phase behind the fence.
-  const int io = i & 1, ipr = i & ~1;
+  // The panels travel as 16-byte words, and the block field is PAIR-MAJOR (block.h): word ((site 6 + k) NRHS + i) holds components 2k, 2k + 1 of
+  // right-hand side i, so a lane's six loads are its own 12 components and the NRHS lanes of a site still read whole 128-byte lines (8-byte
+  // loads run at 0.54-0.70 of the 16-byte rate on gfx950, and the kernel is bound by its L2 -> L1 requests).  History: with the rhs-fastest
+  // order the lane pair (i, i ^ 1) shared its loads and transposed 2 x 2 by DPP — 620 of the kernel's ~1950 vector instructions.
   float4 pA[6], pB[6];
   auto load_panel = [&](float4 *raw, const float2 *base, int site) {
-    const float4 *p = reinterpret_cast<const float4 *>(base + ((long)site * 12 + io) * NRHS + ipr);
+    const float4 *p = reinterpret_cast<const float4 *>(base) + (long)site * 6 * NRHS + i;
 #pragma unroll
-    for (int k = 0; k < 6; k++) raw[k] = p[k * NRHS];   // component 2k + io, right-hand sides ipr and ipr + 1
+    for (int k = 0; k < 6; k++) raw[k] = p[k * NRHS];
   };
-  auto swap1 = [](float v) -> float { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)); };   // quad_perm [1,0,3,2]
   auto unpack_panel = [&](float *psi, const float4 *raw) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-      const float4 v = raw[k];
-      const float kx = io ? v.z : v.x, ky = io ? v.w : v.y;          // this lane's right-hand side of the component it loaded
-      const float rx = swap1(io ? v.x : v.z), ry = swap1(io ? v.y : v.w);   // ... and of the component the partner loaded
-      psi[4 * k] = io ? rx : kx; psi[4 * k + 1] = io ? ry : ky; psi[4 * k + 2] = io ? kx : rx; psi[4 * k + 3] = io ? ky : ry;
-    }
+    for (int k = 0; k < 6; k++) { psi[4 * k] = raw[k].x; psi[4 * k + 1] = raw[k].y; psi[4 * k + 2] = raw[k].z; psi[4 * k + 3] = raw[k].w; }
   };
   auto hop = [&](auto DIRC, const float4 *raw) {
     constexpr int DIR = decltype(DIRC)::value, MU = DIR / 2;
@@ -1164,9 +1157,9 @@ template <int NRHS, int CL = 0, int XY = 0> __global__ void __launch_bounds__(25
     float4 pC[6];
     const int r0 = (s >> 3) + 1, c0 = (s & 7) + 1;
     auto load_lds = [&](float4 *raw, int slot) {
-      const float *b = &plds[slot * PSTR + (io * NRHS + ipr) * 2];
+      const float *b = &plds[slot * PSTR + 4 * i];
 #pragma unroll
-      for (int k = 0; k < 6; k++) raw[k] = *reinterpret_cast<const float4 *>(b + k * 4 * NRHS);   // component 2k + io: (2k + io) NRHS + ipr complex numbers into the panel
+      for (int k = 0; k < 6; k++) raw[k] = *reinterpret_cast<const float4 *>(b + k * 4 * NRHS);   // word k NRHS + i of the panel
     };
     FB_LD(A, 4); FB_LD(B, 5);
     load_lds(pC, r0 * 10 + c0 + (xodd ? 1 : 0)); FB_CP(C, 0);
@@ -1288,14 +1281,9 @@ template <int NRHS, int CL = 0, int XY = 0> __global__ void __launch_bounds__(25
       arg.dotPart[((size_t)blockIdx.x * ns + k) * NRHS + ii] = t;
     }
   }
-  // store as the panels were loaded: the lane pair exchanges one component each and writes 16-byte words, a full line per site
-  float4 *o = reinterpret_cast<float4 *>(arg.out + ((size_t)idx * 12 + io) * NRHS + ipr);
+  float4 *o = reinterpret_cast<float4 *>(arg.out) + (size_t)idx * 6 * NRHS + i;
 #pragma unroll
-  for (int k = 0; k < 6; k++) {
-    const float kx = io ? outv[4 * k + 2] : outv[4 * k], ky = io ? outv[4 * k + 3] : outv[4 * k + 1];   // component 2k + io, this lane's right-hand side
-    const float rx = swap1(io ? outv[4 * k] : outv[4 * k + 2]), ry = swap1(io ? outv[4 * k + 1] : outv[4 * k + 3]);   // the same component of the partner's
-    o[k * NRHS] = io ? make_float4(rx, ry, kx, ky) : make_float4(kx, ky, rx, ry);
-  }
+  for (int k = 0; k < 6; k++) o[k * NRHS] = make_float4(outv[4 * k], outv[4 * k + 1], outv[4 * k + 2], outv[4 * k + 3]);
 }
 
 // Dense clover-twist matrices for fine_block_kernel: per site of one parity and chirality the 6 x 6 complex matrix
