@@ -158,6 +158,7 @@ void blockPackParity(BlockField &dst, const ColorSpinorField *const *f, int n, b
   const FinePtrs p = finePtrs(f, n, dst, stride);
   const size_t lds = (size_t)64 * (6 * dst.nrhs + 1) * sizeof(float4);
   const unsigned grid = (unsigned)((dst.nSites + 63) / 64);
+  acct("block_fine_pack_kernel", (double)dst.nSites * 96.0 * (n + dst.nrhs * (accumulate ? 2 : 1)), accumulate ? "fields -> block (+=)" : "fields -> block");
   if (accumulate) hipLaunchKernelGGL((block_fine_pack_kernel<1>), dim3(grid), dim3(256), lds, computeStream(), (float4 *)dst.v, p, stride, dst.nSites, dst.nrhs);
   else hipLaunchKernelGGL((block_fine_pack_kernel<0>), dim3(grid), dim3(256), lds, computeStream(), (float4 *)dst.v, p, stride, dst.nSites, dst.nrhs);
   HIP_CHECK(hipGetLastError());
@@ -167,6 +168,7 @@ void blockUnpackParity(ColorSpinorField *const *f, int n, const BlockField &src)
   const FinePtrs p = finePtrs(f, n, src, stride);
   if (!stride) return;   // nothing to write
   const size_t lds = (size_t)64 * (6 * src.nrhs + 1) * sizeof(float4);
+  acct("block_fine_pack_kernel", (double)src.nSites * 96.0 * (n + src.nrhs), "block -> fields");
   hipLaunchKernelGGL((block_fine_pack_kernel<2>), dim3((unsigned)((src.nSites + 63) / 64)), dim3(256), lds, computeStream(), (float4 *)src.v, p, stride, src.nSites, src.nrhs);
   HIP_CHECK(hipGetLastError());
 }
@@ -568,6 +570,10 @@ void applyCoarseBlock(BlockField &out, BlockField &in, const CoarseGauge &G) {
   }
   for (int d = 0; d < 4; d++) arg.Xc[d] = G.Xc[d];
   arg.nbr = coarseNeighbourTable(G.Xc);
+  if (g_acctOn) {   // the 9 link matrices of a site once, input and output panels once
+    char tag[64]; snprintf(tag, sizeof(tag), "coarse %dx%dx%dx%d n %d, %d rhs", G.Xc[0], G.Xc[1], G.Xc[2], G.Xc[3], G.n, in.nrhs);
+    acct("coarse_block_kernel", (double)G.nSites * (9.0 * G.n * G.n * 8 + 2.0 * G.n * in.nrhs * 8), tag);
+  }
 #define QA_CASE(NN, RR) if (G.n == NN && in.nrhs == RR) { launchCoarseBlock<NN, RR>(arg, G.nSites); return; }
   QA_CASE(48, 24) QA_CASE(48, 8) QA_CASE(48, 16) QA_CASE(48, 32)
   QA_CASE(16, 8) QA_CASE(16, 16) QA_CASE(16, 24) QA_CASE(16, 32)
@@ -849,6 +855,7 @@ void mrUpdateDev(BlockField &x, BlockField &r, const BlockField &rin, const Bloc
   if (!x.pairMajor || 256 % x.nrhs) errorQuda("minimal-residual update: 12-component fields with 4 or 8 right-hand sides (got %d x %d)", x.ncomp, x.nrhs);
   const long n4 = (long)x.elems() / 2;
   const unsigned grid = (unsigned)std::min<long>((n4 + 255) / 256, 8192);
+  acct("mr_update_kernel", (double)x.elems() * 8.0 * (fresh ? 4 : 5), "level 0");
   hipLaunchKernelGGL(mr_update_kernel, dim3(grid), dim3(256), 0, computeStream(), (float4 *)x.v, (float4 *)r.v, (const float4 *)rin.v, (const float4 *)Ar.v, d_sums, (float)omega, x.nrhs, n4, fresh ? 1 : 0);
   HIP_CHECK(hipGetLastError());
 }

@@ -1498,6 +1498,10 @@ void applyFineBlockParity(float2 *out, const float2 *in_same, const float2 *in_o
       return;
     }
   }
+  if (g_acctOn) {   // links once per site (+ the dense site matrices), per right-hand side: 8 neighbour panels at ideal re-use = 1 read, own panel, output
+    char tag[64]; snprintf(tag, sizeof(tag), "level 0, %d rhs%s%s", nrhs, s0 != 0.0 ? " xpay" : "", dots ? " + sums" : "");
+    acct("fine_block_kernel", (double)g.Vh * (8.0 * (U.reconstruct == QUDA_RECONSTRUCT_12 ? 48 : 72) + (tmat ? 576.0 : 0.0) + nrhs * 96.0 * (s0 != 0.0 ? 3 : 2)), tag);
+  }
 #define FB_LAUNCH(N) \
   if (!tmat) hipLaunchKernelGGL((fine_block_kernel<N, 0>), dim3(nb), dim3(threads), 0, computeStream(), arg); \
   else if (tmode == 1) hipLaunchKernelGGL((fine_block_kernel<N, 1>), dim3(nb), dim3(threads), 0, computeStream(), arg); \
