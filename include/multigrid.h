@@ -101,6 +101,11 @@ class MG : public Solver {
   // the multi-right-hand-side MFMA coarse operator (block_solver.cpp).  false: this hierarchy does not qualify, the caller applies K per source.
   // active[i] = 0: source i is left alone.  blockRelease frees the per-source state.
   bool cycleBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorField *> &b, const std::vector<char> &active);
+  // out_i = Mhat x_i for the solutions x_i of the LAST cycleBlock on single-parity fields, while they are still on the block fields of the fine
+  // smoother (two multi-right-hand-side stencil launches per group instead of two stencils per source): the outer solver's `A p_k`.  pc: the
+  // even-odd preconditioned operator of the outer solver — it must be the smoother's operator (type, kappa, mu, preconditioning) on fp32 links
+  // the block stencil reads.  false: not available, the caller applies its operator source by source.
+  bool blockApplyLast(std::vector<ColorSpinorField *> &out, const Dirac &pc, const std::vector<char> &active);
   void blockRelease();   // hierarchy contents changed (half-precision mirrors switched on): rebuild or abandon at the next cycle
   DiracMatrix &residualMatrix() const { return mgp.matResidual; }
 };

@@ -280,7 +280,9 @@ struct FineGroup {
 class BlockFineSmoother {
  public:
   const GaugeField *U = nullptr;
-  double kappa = 0, a = 0, binv = 1, omega = 1;
+  double kappa = 0, a = 0, binv = 1, omega = 1, mu = 0;
+  QudaDiracType type = QUDA_INVALID_DIRAC;
+  QudaMatPCType matpcType = QUDA_MATPC_INVALID;
   int par = 0;                         // parity of the preconditioned system
   int nuPre = 0, nuPost = 0;
   bool globalSums = false;             // the MR sums cross ranks
@@ -298,15 +300,16 @@ class BlockFineSmoother {
   static float2 *ghostOf(BlockField &f) { return f.nGhost ? f.v + f.elems() : nullptr; }
   // out = in - kappa^2 A^-1 D_pq A^-1 D_qp in     (reference DiracTwistedMassPC::M / DiracTwistedCloverPC::M, symmetric preconditioning);
   // dots: (out, in) and |out|^2 per right-hand side into g.d_sums
-  void matpc(FineGroup &g, BlockField &out, BlockField &in, bool dots) {
+  void matpc(FineGroup &g, BlockField &out, BlockField &in, bool dots, const GaugeField *links = nullptr) {
     const FineBlockDots d = {nullptr, 3};
     const int p = par, q = 1 - par;
+    const GaugeField &W = links ? *links : *U;
     if (tmat[0]) {
-      applyFineBlockParity(g.T->v, nullptr, in.v, in.nrhs, *U, q, 0.0, 0.0, 1.0, 0.0, tmat[q], 1, ghostOf(in));
-      applyFineBlockParity(out.v, in.v, g.T->v, in.nrhs, *U, p, 1.0, 0.0, -kappa * kappa, 0.0, tmat[p], 1, ghostOf(*g.T), dots ? &d : nullptr);
+      applyFineBlockParity(g.T->v, nullptr, in.v, in.nrhs, W, q, 0.0, 0.0, 1.0, 0.0, tmat[q], 1, ghostOf(in));
+      applyFineBlockParity(out.v, in.v, g.T->v, in.nrhs, W, p, 1.0, 0.0, -kappa * kappa, 0.0, tmat[p], 1, ghostOf(*g.T), dots ? &d : nullptr);
     } else {
-      applyFineBlockParity(g.T->v, nullptr, in.v, in.nrhs, *U, q, 0.0, 0.0, binv, -a, nullptr, 0, ghostOf(in));
-      applyFineBlockParity(out.v, in.v, g.T->v, in.nrhs, *U, p, 1.0, 0.0, -kappa * kappa * binv, -a, nullptr, 0, ghostOf(*g.T), dots ? &d : nullptr);
+      applyFineBlockParity(g.T->v, nullptr, in.v, in.nrhs, W, q, 0.0, 0.0, binv, -a, nullptr, 0, ghostOf(in));
+      applyFineBlockParity(out.v, in.v, g.T->v, in.nrhs, W, p, 1.0, 0.0, -kappa * kappa * binv, -a, nullptr, 0, ghostOf(*g.T), dots ? &d : nullptr);
     }
     if (!dots) return;
     if (!globalSums) { fineBlockDotsFinishDev(g.d_sums, in.nrhs, 3); return; }
@@ -355,7 +358,7 @@ static BlockFineSmoother *blockFineCreate(const Dirac &dirac, const SolverParam 
   if (tmc && !(dirac.Clover() && dirac.Clover()->precision == QUDA_SINGLE_PRECISION)) return nullptr;
   BlockFineSmoother *f = new BlockFineSmoother;
   f->U = U;
-  f->kappa = dirac.Kappa();
+  f->kappa = dirac.Kappa(); f->mu = dirac.Mu(); f->type = ty; f->matpcType = mt;
   f->a = ty == QUDA_WILSONPC_DIRAC ? 0.0 : 2.0 * dirac.Kappa() * (double)flavor * dirac.Mu();
   f->binv = 1.0 / (1.0 + f->a * f->a);
   f->omega = pre.omega;
@@ -394,6 +397,7 @@ struct MGBlockState {
   std::vector<ColorSpinorField *> r, rc, xc, btilde;
   BlockCoarseCycle *coarse = nullptr;
   BlockFineSmoother *fine = nullptr;   // nullptr: the per-source smoothers above
+  bool solutionOnBlocks = false;       // the last cycle left its solutions in fine->groups[].X (blockApplyLast)
   ~MGBlockState() {
     delete fine;
     for (Solver *s : pre) delete s;
@@ -459,6 +463,7 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
     if (active[i] && (b[i]->Precision() != QUDA_SINGLE_PRECISION || x[i]->Precision() != QUDA_SINGLE_PRECISION || (int)b[i]->twistFlavor != (int)mgp.fineFlavor)) blockSmooth = false;
   g_msStats[0]++;
   if (blockSmooth) g_msStats[1]++;
+  st.solutionOnBlocks = blockSmooth;
   if (blockSmooth) {
     BlockFineSmoother &F = *st.fine;
     for (FineGroup &g : F.groups) {
@@ -581,6 +586,27 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
   blas::setGlobalReduction(true);
 }
 
+bool MG::blockApplyLast(std::vector<ColorSpinorField *> &out, const Dirac &pc, const std::vector<char> &active) {
+  if (!blockState || !blockState->fine || !blockState->solutionOnBlocks) return false;
+  BlockFineSmoother &F = *blockState->fine;
+  static int off = -1;
+  if (off < 0) { const char *e = getenv("QUDA_AMD_MULTISRC_BLOCK_OUTER"); off = (e && !atoi(e)) ? 1 : 0; }
+  if (off) return false;
+  const GaugeField *W = pc.Gauge();
+  if (pc.getDiracType() != F.type || pc.getMatPCType() != F.matpcType || pc.Kappa() != F.kappa || pc.Mu() != F.mu || !W || !fineBlockSupported(*W, 8) || !fineBlockSupported(*W, 4)) return false;
+  if (F.tmat[0] && !(pc.Clover() && pc.Clover()->precision == QUDA_SINGLE_PRECISION)) return false;
+  if ((int)out.size() != blockState->nsrc) return false;
+  for (size_t i = 0; i < out.size(); i++)
+    if (active[i] && (out[i]->Precision() != QUDA_SINGLE_PRECISION || out[i]->SiteSubset() != QUDA_PARITY_SITE_SUBSET)) return false;
+  for (FineGroup &g : F.groups) {
+    ColorSpinorField *dst[8];
+    for (int j = 0; j < g.n; j++) dst[j] = active[g.first + j] ? out[g.first + j] : nullptr;
+    F.matpc(g, *g.AR, *g.X, false, W);
+    blockUnpackParity(dst, g.n, *g.AR);
+  }
+  return true;
+}
+
 // x_i = K b_i for all sources (full fields: Schur prepare, parity cycle, reconstruct, as MG::operator(); parity fields: the parity cycle)
 bool MG::cycleBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorField *> &b, const std::vector<char> &active) {
   const int nsrc = (int)x.size();
@@ -602,6 +628,7 @@ bool MG::cycleBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorF
   }
   for (int i = 0; i < nsrc; i++) if (!active[i]) { in[i] = st.btilde[i]; out[i] = st.btilde[i]; }
   cycleParityBlock(out, in, active, !matpc);
+  st.solutionOnBlocks = false;   // the outer solver's direction is the reconstructed full field
   for (int i = 0; i < nsrc; i++) if (active[i]) dirac.reconstruct(*x[i], *b[i], QUDA_MAT_SOLUTION);
   return true;
 }
@@ -619,7 +646,7 @@ static ColorSpinorField *likeF(const ColorSpinorField &x, QudaPrecision prec, bo
 
 struct BlockGcrResult { int iter = 0; std::vector<double> r2, b2; double secs = 0; bool blockCycle = false; };
 
-static BlockGcrResult blockGCR(std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorField *> &b, DiracMatrix &mat, DiracMatrix &matSloppy, MG *K, SolverParam &param) {
+static BlockGcrResult blockGCR(std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorField *> &b, DiracMatrix &mat, DiracMatrix &matSloppy, MG *K, SolverParam &param, const Dirac *sloppyPC) {
   const int ns = (int)x.size(), nK = param.Nkrylov;
   BlockGcrResult res;
   res.r2.assign(ns, 0.0); res.b2.assign(ns, 0.0);
@@ -665,11 +692,18 @@ static BlockGcrResult blockGCR(std::vector<ColorSpinorField *> &x, std::vector<C
     for (int i = 0; i < ns; i++) { pk[i] = p[i][k]; rk[i] = rS[i]; }
     bool done = false;
     if (K) { done = K->cycleBlock(pk, rk, open); res.blockCycle = res.blockCycle || done; }
+    // A p_k for all sources while p_k is still on the smoother's block fields (even-odd outer solve on the smoother's operator)
+    bool applied = false;
+    if (done && sloppyPC) {
+      std::vector<ColorSpinorField *> apk(ns);
+      for (int i = 0; i < ns; i++) apk[i] = Ap[i][k];
+      applied = K->blockApplyLast(apk, *sloppyPC, open);
+    }
     for (int i = 0; i < ns; i++) {
       if (!open[i]) continue;
       if (!done) { if (K) (*K)(*p[i][k], *rS[i]); else blas::copy(*p[i][k], *rS[i]); }
       blas::setGlobalReduction(param.global_reduction);
-      matSloppy(*Ap[i][k], *p[i][k]);
+      if (!applied) matSloppy(*Ap[i][k], *p[i][k]);
       // orthogonalisation against the source's own directions: the blocked two-sweep form where it applies (solver.cpp), else the chain
       bool blocked = false;
       if (blas::multiSupported(*Ap[i][k], k)) {
@@ -799,7 +833,7 @@ void invertMultiSrcQuda(void **_hp_x, void **_hp_b, QudaInvertParam *param) {
     } else if (param->inv_type_precondition != QUDA_INVALID_INVERTER) {
       errorQuda("invertMultiSrcQuda: preconditioner %d not supported (none or QUDA_MG_INVERTER)", param->inv_type_precondition);
     }
-    const BlockGcrResult res = blockGCR(out, in, m, mSloppy, K, sp);
+    const BlockGcrResult res = blockGCR(out, in, m, mSloppy, K, sp, pc_solve ? dSloppy : nullptr);
     g_msStats[3]++;
     param->iter = res.iter;
     param->secs = res.secs;
