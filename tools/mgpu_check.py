@@ -226,6 +226,26 @@ def main():
             if rank == 0:
                 print("OK lattice %s grid %s: MG-GCR (pc smoother %s) %d iterations (plain GCR %d), verify %.1e %.1e %.1e, global |r|/|b| = %.2e"
                       % (X, grid, pc, ipm.iter, it_plain, dev[0], dev[1], dev[2], relm), flush=True)
+            if pc:
+                # three sources through ONE lockstep solve (invertMultiSrcQuda): block smoother with its MR sums across the ranks, ghost zones of
+                # the block fields through the transport, four-source / per-source transfers, block fields on the coarse level
+                rngm = np.random.default_rng(9)
+                srcs = [mg.scatter_field(rngm.random(spinor.size), X, grid, dist.coords, 24) for _ in range(3)]
+                ipm.solve_type = qa.QUDA_DIRECT_PC_SOLVE
+                s0 = qa.multi_src_stats()
+                sols = qa.invert_multi_src(srcs, ipm)
+                s1 = qa.multi_src_stats()
+                it_multi = ipm.iter
+                ipm.solve_type = qa.QUDA_DIRECT_SOLVE
+                worst = 0.0
+                for xs_loc, bs_loc in zip(sols, srcs):
+                    rs = bs_loc - qa.mat(xs_loc, ipm)
+                    n2 = np.array([np.dot(rs, rs), np.dot(bs_loc, bs_loc)])
+                    qa.lib().qudaAmdCommAllreduce(n2.ctypes.data_as(C.POINTER(C.c_double)), 2)
+                    worst = max(worst, float(np.sqrt(n2[0] / n2[1])))
+                assert worst < 5e-10 and s1["block_cycles"] > s0["block_cycles"], ("multi-source mg-gcr", X, grid, worst, s0, s1)
+                if rank == 0:
+                    print("OK lattice %s grid %s: 3 sources in lockstep, %d iterations, worst global |r|/|b| = %.2e, %s" % (X, grid, it_multi, worst, s1), flush=True)
             ipm.inv_type_precondition = qa.QUDA_INVALID_ENUM
             h.free()
         oracle.set_threads(1)
