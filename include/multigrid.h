@@ -139,4 +139,11 @@ struct multigrid_solver {
 // reference (its MG is fp32 throughout): opt-in, QUDA_AMD_MG_HALF=1 or qudaAmdMultigridSetHalfStorage.
 void multigridSetHalfStorage(multigrid_solver &mgs, bool on);
 
+
+// Several sources through ONE lockstep (optionally multigrid-preconditioned) GCR — block_solver.cpp, the solver behind invertMultiSrcQuda and the
+// propagator loop of the QKXTM drivers.  x_i = A^-1 b_i (x is zeroed: no initial guess), K may be nullptr, sloppyPC: the even-odd preconditioned
+// sloppy operator when A is one (lets A p_k come from the smoother's block fields), else nullptr.
+struct MultiSrcSolve { int iter = 0; double secs = 0; std::vector<double> r2, b2; };
+MultiSrcSolve solveMultiSrcGCR(std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorField *> &b, DiracMatrix &mat, DiracMatrix &matSloppy, MG *K, SolverParam &param, const Dirac *sloppyPC);
+
 }  // namespace quda

@@ -777,17 +777,25 @@ static BlockGcrResult blockGCR(std::vector<ColorSpinorField *> &x, std::vector<C
   return res;
 }
 
+MultiSrcSolve solveMultiSrcGCR(std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorField *> &b, DiracMatrix &mat, DiracMatrix &matSloppy, MG *K, SolverParam &param, const Dirac *sloppyPC) {
+  const BlockGcrResult r = blockGCR(x, b, mat, matSloppy, K, param, sloppyPC);
+  g_msStats[3]++;
+  MultiSrcSolve out;
+  out.iter = r.iter; out.secs = r.secs; out.r2 = r.r2; out.b2 = r.b2;
+  return out;
+}
+
 }  // namespace quda
 
 using namespace quda;
 
 extern "C" {
 
+void qudaAmdMultiSrcStats(long long out[4]) { for (int i = 0; i < 4; i++) out[i] = g_msStats[i]; }
+
 // reference include/quda.h:647 (lib/interface_quda.cpp:2546: "currently that code is just a copy of invertQuda and cannot work"): param->num_src
 // sources _hp_b[i] -> solutions _hp_x[i], one operator, one preconditioner.  GCR (optionally MG-preconditioned) direct solves; iter / secs
 // are those of the lockstep solve, true_res the worst source's.
-void qudaAmdMultiSrcStats(long long out[4]) { for (int i = 0; i < 4; i++) out[i] = g_msStats[i]; }
-
 void invertMultiSrcQuda(void **_hp_x, void **_hp_b, QudaInvertParam *param) {
   if (!gaugePrecise) errorQuda("Gauge field not allocated");
   if (param->tune == QUDA_TUNE_YES || param->tune == QUDA_TUNE_NO) setTuning(param->tune);

@@ -224,105 +224,6 @@ template <int NR> struct RawBlock<short, NR> {
 // bytes of one planar block of NR reals x stride sites
 template <typename T> __host__ __device__ constexpr size_t storeSize() { return sizeof(T); }
 
-// ---- SU(3) link: 18 reals row-major (row*6 + col*2 + re/im); R = 18 stored fully, R = 12 rows 0,1 stored,
-// row 2 = conj(row0 x row1) * sign (sign carries a folded anti-periodic boundary, reference
-// tests/test_util.cpp:283-296 / lib/read_gauge.h) ----
-// R = 8 (reference Reconstruct<8>, include/gauge_field_order.h:516-585; lib/read_gauge.h RECONSTRUCT_8 macros): stored are
-//   [arg U00, arg U20, U01.re, U01.im, U02.re, U02.im, U10.re, U10.im]   (16-bit: the two phases in units of pi)
-// and the matrix M = u0 V, V in SU(3), u0 = +-1 the folded anti-periodic boundary sign, comes back from the unit length of row 0 and
-// column 0 and the SU(2) rotation of the lower-right block.  The same for the pre-daggered backward links of this library's layout
-// (U^dagger is as much an SU(3) matrix as U).  37 % of the link bytes of R = 18 for ~110 flops, two sincos, two sqrt and one reciprocal.
-__device__ __forceinline__ void qa_sincos(float x, float *s, float *c) { *s = __sinf(x); *c = __cosf(x); }   // v_sin_f32 / v_cos_f32 (|x| <= pi: ~1e-6)
-__device__ __forceinline__ void qa_sincos(double x, double *s, double *c) { sincos(x, s, c); }
-template <typename real> __device__ __forceinline__ void su3_reconstruct8(real *U, const real *in, real u0, real phaseUnit) {
-  const real a2r = in[2], a2i = in[3], a3r = in[4], a3i = in[5], b1r = in[6], b1i = in[7];
-  const real row_sum = a2r * a2r + a2i * a2i + a3r * a3r + a3i * a3i;
-  const real d0 = (real)1 - row_sum;
-  const real m0 = sqrt(d0 >= (real)0 ? d0 : (real)0);
-  real s0, c0, s1, c1;
-  qa_sincos(in[0] * phaseUnit, &s0, &c0);
-  qa_sincos(in[1] * phaseUnit, &s1, &c1);
-  const real a1r = m0 * c0, a1i = m0 * s0;
-  const real d1 = (real)1 - (m0 * m0 + b1r * b1r + b1i * b1i);
-  const real m1 = sqrt(d1 >= (real)0 ? d1 : (real)0);
-  const real c1r = m1 * c1, c1i = m1 * s1;
-  const real rinv = u0 / row_sum;                 // 1 / (u0 row_sum), u0 = +-1
-  // A = conj(a1) b1 ; A2 = conj(a1) c1, both times u0
-  const real Ar = u0 * (a1r * b1r + a1i * b1i), Ai = u0 * (a1r * b1i - a1i * b1r);
-  const real Br = u0 * (a1r * c1r + a1i * c1i), Bi = u0 * (a1r * c1i - a1i * c1r);
-  // conj(c1) conj(a3) etc.: conj(x) conj(y) = conj(x y)
-  const real c1a3r = c1r * a3r - c1i * a3i, c1a3i = -(c1r * a3i + c1i * a3r);
-  const real c1a2r = c1r * a2r - c1i * a2i, c1a2i = -(c1r * a2i + c1i * a2r);
-  const real b1a3r = b1r * a3r - b1i * a3i, b1a3i = -(b1r * a3i + b1i * a3r);
-  const real b1a2r = b1r * a2r - b1i * a2i, b1a2i = -(b1r * a2i + b1i * a2r);
-  U[0] = a1r; U[1] = a1i; U[2] = a2r; U[3] = a2i; U[4] = a3r; U[5] = a3i;
-  U[6] = b1r; U[7] = b1i;
-  U[8] = -(c1a3r + (Ar * a2r - Ai * a2i)) * rinv;  U[9] = -(c1a3i + (Ar * a2i + Ai * a2r)) * rinv;    // U11
-  U[10] = (c1a2r - (Ar * a3r - Ai * a3i)) * rinv;  U[11] = (c1a2i - (Ar * a3i + Ai * a3r)) * rinv;    // U12
-  U[12] = c1r; U[13] = c1i;
-  U[14] = (b1a3r - (Br * a2r - Bi * a2i)) * rinv;  U[15] = (b1a3i - (Br * a2i + Bi * a2r)) * rinv;    // U21
-  U[16] = -(b1a2r + (Br * a3r - Bi * a3i)) * rinv; U[17] = -(b1a2i + (Br * a3i + Bi * a3r)) * rinv;   // U22
-}
-// the inverse: the 8 stored reals of M = u0 V (reference Reconstruct<8>::Pack)
-template <typename real> __device__ __forceinline__ void su3_pack8(real *out, const real *U, real phaseUnitInv) {
-  out[0] = atan2(U[1], U[0]) * phaseUnitInv;
-  out[1] = atan2(U[13], U[12]) * phaseUnitInv;
-#pragma unroll
-  for (int i = 2; i < 8; i++) out[i] = U[i];
-}
-template <typename T> struct PhaseUnit { static constexpr double value = 1.0; };
-template <> struct PhaseUnit<short> { static constexpr double value = 3.14159265358979323846; };   // 16-bit storage holds phase / pi in [-1, 1]
-
-template <typename T, int R> struct Link {
-  using real = typename Store<T>::real;
-  using Raw = RawBlock<T, R>;
-  // request / finish pair for the fenced stencil pipeline (RawBlock): finish converts and, for R = 12, rebuilds the third row
-  template <int AUX = 0> static __device__ __forceinline__ void request(Raw &raw, const void *blk, int stride, int x) { raw.template load<AUX>(blk, stride, x, nullptr, 0); }
-  static __device__ __forceinline__ void finish(real *U, const Raw &raw, real sign) {
-    if constexpr (R == 8) {
-      real in[8];
-      raw.unpack(in);
-      su3_reconstruct8(U, in, sign, (real)PhaseUnit<T>::value);
-    } else {
-      raw.unpack(U);
-      if (R == 12) third_row(U, sign);
-    }
-  }
-  static __device__ __forceinline__ void third_row(real *U, real sign) {
-    // c = conj(a x b)
-#define QA_CROSS(i, j, k)                                                                               \
-  U[12 + 2 * i] = sign * ((U[2 * j] * U[6 + 2 * k] - U[2 * j + 1] * U[6 + 2 * k + 1]) -                \
-                          (U[2 * k] * U[6 + 2 * j] - U[2 * k + 1] * U[6 + 2 * j + 1]));                \
-  U[12 + 2 * i + 1] = -sign * ((U[2 * j] * U[6 + 2 * k + 1] + U[2 * j + 1] * U[6 + 2 * k]) -           \
-                               (U[2 * k] * U[6 + 2 * j + 1] + U[2 * k + 1] * U[6 + 2 * j]));
-    QA_CROSS(0, 1, 2)
-    QA_CROSS(1, 2, 0)
-    QA_CROSS(2, 0, 1)
-#undef QA_CROSS
-  }
-  template <int AUX = 0> static __device__ __forceinline__ void load(real *U, const void *blk, int stride, int x, real sign) {
-    if constexpr (R == 8) {
-      real in[8];
-      Planar<T, 8>::template load<AUX>(in, blk, stride, x, nullptr, 0);
-      su3_reconstruct8(U, in, sign, (real)PhaseUnit<T>::value);
-      return;
-    }
-    Planar<T, R>::template load<AUX>(U, blk, stride, x, nullptr, 0);
-    if (R == 12) {
-      // c = conj(a x b)
-#define QA_CROSS(i, j, k)                                                                               \
-  U[12 + 2 * i] = sign * ((U[2 * j] * U[6 + 2 * k] - U[2 * j + 1] * U[6 + 2 * k + 1]) -                \
-                          (U[2 * k] * U[6 + 2 * j] - U[2 * k + 1] * U[6 + 2 * j + 1]));                \
-  U[12 + 2 * i + 1] = -sign * ((U[2 * j] * U[6 + 2 * k + 1] + U[2 * j + 1] * U[6 + 2 * k]) -           \
-                               (U[2 * k] * U[6 + 2 * j + 1] + U[2 * k + 1] * U[6 + 2 * j]));
-      QA_CROSS(0, 1, 2)
-      QA_CROSS(1, 2, 0)
-      QA_CROSS(2, 0, 1)
-#undef QA_CROSS
-    }
-  }
-};
-
 // ---- packed fp32 complex arithmetic: a complex number is an aligned register pair (re, im); a complex multiply-add is TWO
 // v_pk_fma_f32 — op_sel / op_sel_hi choose which half of each source feeds the low / high result lane, neg_lo / neg_hi the sign —
 // instead of four scalar multiply-adds.  The compiler's SLP vectoriser builds the same instructions but pays for every pair with
@@ -380,7 +281,148 @@ template <bool HI> __device__ __forceinline__ pkf2 rscale(pkf2 D, pkf2 x) {
 }
 __device__ __forceinline__ pkf2 ld(const float *a, int i) { return (pkf2){a[i], a[i + 1]}; }
 __device__ __forceinline__ void st(float *a, int i, pkf2 v) { a[i] = v.x; a[i + 1] = v.y; }
+// conj(u) h
+__device__ __forceinline__ pkf2 cmulc(pkf2 u, pkf2 h) {
+  pkf2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(u), "v"(h));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "+v"(r) : "v"(u), "v"(h));
+  return r;
+}
+// acc - u h
+__device__ __forceinline__ pkf2 cmsub(pkf2 acc, pkf2 u, pkf2 h) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(acc) : "v"(u), "v"(h));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "+v"(acc) : "v"(u), "v"(h));
+  return acc;
+}
+// element by element: a b + c, a b - c, a b
+__device__ __forceinline__ pkf2 efma(pkf2 a, pkf2 b, pkf2 c) { pkf2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ pkf2 efms(pkf2 a, pkf2 b, pkf2 c) { pkf2 r; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ pkf2 emul(pkf2 a, pkf2 b) { pkf2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 }  // namespace pk
+
+// ---- SU(3) link: 18 reals row-major (row*6 + col*2 + re/im); R = 18 stored fully, R = 12 rows 0,1 stored,
+// row 2 = conj(row0 x row1) * sign (sign carries a folded anti-periodic boundary, reference
+// tests/test_util.cpp:283-296 / lib/read_gauge.h) ----
+// R = 8 (reference Reconstruct<8>, include/gauge_field_order.h:516-585; lib/read_gauge.h RECONSTRUCT_8 macros): stored are
+//   [arg U00, arg U20, U01.re, U01.im, U02.re, U02.im, U10.re, U10.im]   (16-bit: the two phases in units of pi)
+// and the matrix M = u0 V, V in SU(3), u0 = +-1 the folded anti-periodic boundary sign, comes back from the unit length of row 0 and
+// column 0 and the SU(2) rotation of the lower-right block.  The same for the pre-daggered backward links of this library's layout
+// (U^dagger is as much an SU(3) matrix as U).  37 % of the link bytes of R = 18 for ~110 flops, two sincos, two sqrt and one reciprocal.
+__device__ __forceinline__ void qa_sincos(float x, float *s, float *c) { *s = __sinf(x); *c = __cosf(x); }   // v_sin_f32 / v_cos_f32 (|x| <= pi: ~1e-6)
+__device__ __forceinline__ void qa_sincos(double x, double *s, double *c) { sincos(x, s, c); }
+template <typename real> __device__ __forceinline__ void su3_reconstruct8(real *U, const real *in, real u0, real phaseUnit) {
+  const real a2r = in[2], a2i = in[3], a3r = in[4], a3i = in[5], b1r = in[6], b1i = in[7];
+  const real row_sum = a2r * a2r + a2i * a2i + a3r * a3r + a3i * a3i;
+  const real d0 = (real)1 - row_sum;
+  const real m0 = sqrt(d0 >= (real)0 ? d0 : (real)0);
+  real s0, c0, s1, c1;
+  qa_sincos(in[0] * phaseUnit, &s0, &c0);
+  qa_sincos(in[1] * phaseUnit, &s1, &c1);
+  const real a1r = m0 * c0, a1i = m0 * s0;
+  const real d1 = (real)1 - (m0 * m0 + b1r * b1r + b1i * b1i);
+  const real m1 = sqrt(d1 >= (real)0 ? d1 : (real)0);
+  const real c1r = m1 * c1, c1i = m1 * s1;
+  const real rinv = u0 / row_sum;                 // 1 / (u0 row_sum), u0 = +-1
+  // A = conj(a1) b1 ; A2 = conj(a1) c1, both times u0
+  const real Ar = u0 * (a1r * b1r + a1i * b1i), Ai = u0 * (a1r * b1i - a1i * b1r);
+  const real Br = u0 * (a1r * c1r + a1i * c1i), Bi = u0 * (a1r * c1i - a1i * c1r);
+  // conj(c1) conj(a3) etc.: conj(x) conj(y) = conj(x y)
+  const real c1a3r = c1r * a3r - c1i * a3i, c1a3i = -(c1r * a3i + c1i * a3r);
+  const real c1a2r = c1r * a2r - c1i * a2i, c1a2i = -(c1r * a2i + c1i * a2r);
+  const real b1a3r = b1r * a3r - b1i * a3i, b1a3i = -(b1r * a3i + b1i * a3r);
+  const real b1a2r = b1r * a2r - b1i * a2i, b1a2i = -(b1r * a2i + b1i * a2r);
+  U[0] = a1r; U[1] = a1i; U[2] = a2r; U[3] = a2i; U[4] = a3r; U[5] = a3i;
+  U[6] = b1r; U[7] = b1i;
+  U[8] = -(c1a3r + (Ar * a2r - Ai * a2i)) * rinv;  U[9] = -(c1a3i + (Ar * a2i + Ai * a2r)) * rinv;    // U11
+  U[10] = (c1a2r - (Ar * a3r - Ai * a3i)) * rinv;  U[11] = (c1a2i - (Ar * a3i + Ai * a3r)) * rinv;    // U12
+  U[12] = c1r; U[13] = c1i;
+  U[14] = (b1a3r - (Br * a2r - Bi * a2i)) * rinv;  U[15] = (b1a3i - (Br * a2i + Bi * a2r)) * rinv;    // U21
+  U[16] = -(b1a2r + (Br * a3r - Bi * a3i)) * rinv; U[17] = -(b1a2i + (Br * a3i + Bi * a3r)) * rinv;   // U22
+}
+// fp32 (and the 16-bit kernels, which compute in fp32): the same in packed complex arithmetic — 28 v_pk instructions + 24 scalar ones per link
+// instead of 124 (the generic form above compiled to 342 multiplies, 369 multiply-adds and IEEE square roots / divisions with their fix-ups for the 8 links
+// of a site: more than the rest of the stencil).  v_sqrt_f32 / v_rcp_f32 / v_sin_f32 / v_cos_f32 are 1 ulp / 1e-6: inside the 2e-5 of the fp32 goldens.
+__device__ __forceinline__ void su3_reconstruct8(float *U, const float *in, float u0, float phaseUnit) {
+  const pkf2 a2 = {in[2], in[3]}, a3 = {in[4], in[5]}, b1 = {in[6], in[7]};
+  const float rs = a2.x * a2.x + a2.y * a2.y + a3.x * a3.x + a3.y * a3.y;
+  const float d0 = fmaxf(1.f - rs, 0.f);
+  const float m0 = __builtin_amdgcn_sqrtf(d0);
+  const float k = phaseUnit * 0.15915494309189535f;   // v_sin_f32 / v_cos_f32 take revolutions
+  const float t0 = in[0] * k, t1 = in[1] * k;
+  const pkf2 a1 = {m0 * __builtin_amdgcn_cosf(t0), m0 * __builtin_amdgcn_sinf(t0)};
+  const float d1 = fmaxf(1.f - d0 - b1.x * b1.x - b1.y * b1.y, 0.f);
+  const float m1 = __builtin_amdgcn_sqrtf(d1);
+  const pkf2 c1 = {m1 * __builtin_amdgcn_cosf(t1), m1 * __builtin_amdgcn_sinf(t1)};
+  const float ri = __builtin_amdgcn_rcpf(rs);
+  const pkf2 S = {u0, -u0}, RI = {ri, ri}, NRI = {-ri, -ri};
+  const pkf2 A = pk::cmulc(a1, b1), B = pk::cmulc(a1, c1);   // conj(a1) b1, conj(a1) c1
+  // u0 conj(x y) = S o (x y);  U11 = -(u0 conj(c1 a3) + A a2) / rs, U12 = (u0 conj(c1 a2) - A a3) / rs, U21 = (u0 conj(b1 a3) - B a2) / rs, U22 = -(u0 conj(b1 a2) + B a3) / rs
+  const pkf2 u11 = pk::emul(NRI, pk::efma(S, pk::cmul(c1, a3), pk::cmul(A, a2)));
+  const pkf2 u12 = pk::emul(RI, pk::efms(S, pk::cmul(c1, a2), pk::cmul(A, a3)));
+  const pkf2 u21 = pk::emul(RI, pk::efms(S, pk::cmul(b1, a3), pk::cmul(B, a2)));
+  const pkf2 u22 = pk::emul(NRI, pk::efma(S, pk::cmul(b1, a2), pk::cmul(B, a3)));
+  pk::st(U, 0, a1); pk::st(U, 2, a2); pk::st(U, 4, a3);
+  pk::st(U, 6, b1); pk::st(U, 8, u11); pk::st(U, 10, u12);
+  pk::st(U, 12, c1); pk::st(U, 14, u21); pk::st(U, 16, u22);
+}
+// the inverse: the 8 stored reals of M = u0 V (reference Reconstruct<8>::Pack)
+template <typename real> __device__ __forceinline__ void su3_pack8(real *out, const real *U, real phaseUnitInv) {
+  out[0] = atan2(U[1], U[0]) * phaseUnitInv;
+  out[1] = atan2(U[13], U[12]) * phaseUnitInv;
+#pragma unroll
+  for (int i = 2; i < 8; i++) out[i] = U[i];
+}
+template <typename T> struct PhaseUnit { static constexpr double value = 1.0; };
+template <> struct PhaseUnit<short> { static constexpr double value = 3.14159265358979323846; };   // 16-bit storage holds phase / pi in [-1, 1]
+
+template <typename T, int R> struct Link {
+  using real = typename Store<T>::real;
+  using Raw = RawBlock<T, R>;
+  // request / finish pair for the fenced stencil pipeline (RawBlock): finish converts and, for R = 12, rebuilds the third row
+  template <int AUX = 0> static __device__ __forceinline__ void request(Raw &raw, const void *blk, int stride, int x) { raw.template load<AUX>(blk, stride, x, nullptr, 0); }
+  static __device__ __forceinline__ void finish(real *U, const Raw &raw, real sign) {
+    if constexpr (R == 8) {
+      real in[8];
+      raw.unpack(in);
+      su3_reconstruct8(U, in, sign, (real)PhaseUnit<T>::value);
+    } else {
+      raw.unpack(U);
+      if (R == 12) third_row(U, sign);
+    }
+  }
+  static __device__ __forceinline__ void third_row(real *U, real sign) {
+    // c = conj(a x b)
+    if constexpr (sizeof(real) == 4) {
+      // fp32: five packed instructions per element (a_j b_k, - a_k b_j, conjugate and sign in one multiply) instead of eleven scalar ones
+      const pkf2 S = {sign, -sign};
+      const pkf2 a0 = pk::ld(U, 0), a1 = pk::ld(U, 2), a2 = pk::ld(U, 4), b0 = pk::ld(U, 6), b1 = pk::ld(U, 8), b2 = pk::ld(U, 10);
+      pk::st(U, 12, pk::emul(S, pk::cmsub(pk::cmul(a1, b2), a2, b1)));
+      pk::st(U, 14, pk::emul(S, pk::cmsub(pk::cmul(a2, b0), a0, b2)));
+      pk::st(U, 16, pk::emul(S, pk::cmsub(pk::cmul(a0, b1), a1, b0)));
+      return;
+    }
+#define QA_CROSS(i, j, k)                                                                               \
+  U[12 + 2 * i] = sign * ((U[2 * j] * U[6 + 2 * k] - U[2 * j + 1] * U[6 + 2 * k + 1]) -                \
+                          (U[2 * k] * U[6 + 2 * j] - U[2 * k + 1] * U[6 + 2 * j + 1]));                \
+  U[12 + 2 * i + 1] = -sign * ((U[2 * j] * U[6 + 2 * k + 1] + U[2 * j + 1] * U[6 + 2 * k]) -           \
+                               (U[2 * k] * U[6 + 2 * j + 1] + U[2 * k + 1] * U[6 + 2 * j]));
+    QA_CROSS(0, 1, 2)
+    QA_CROSS(1, 2, 0)
+    QA_CROSS(2, 0, 1)
+#undef QA_CROSS
+  }
+  template <int AUX = 0> static __device__ __forceinline__ void load(real *U, const void *blk, int stride, int x, real sign) {
+    if constexpr (R == 8) {
+      real in[8];
+      Planar<T, 8>::template load<AUX>(in, blk, stride, x, nullptr, 0);
+      su3_reconstruct8(U, in, sign, (real)PhaseUnit<T>::value);
+      return;
+    }
+    Planar<T, R>::template load<AUX>(U, blk, stride, x, nullptr, 0);
+    if (R == 12) third_row(U, sign);
+  }
+};
+
 
 // out(3 complex) = U(3x3) * in(3 complex); fp32: 18 packed instructions instead of 36 scalar ones
 __device__ __forceinline__ void su3_mv(float *o, const float *U, const float *v) {

@@ -24,6 +24,7 @@
 #include "device_io.h"
 #include "dslash.h"
 #include "interface_internal.h"
+#include "multigrid.h"
 #include "p2p.h"
 #include "quda_amd_ext.h"
 #include "solver.h"
@@ -249,7 +250,58 @@ void calcMGPropagatorsEach(void **gauge_APE, QudaInvertParam *param, const QudaA
   double secs = 0, gflops = 0;
   int iters = 0;
   const bool rescale = param->mass_normalization == QUDA_MASS_NORMALIZATION || param->mass_normalization == QUDA_ASYMMETRIC_MASS_NORMALIZATION;
-  for (int isc = 0; isc < 12; isc++) {
+  // The twelve spin-colour sources of a flavour through ONE lockstep solve (block_solver.cpp; DESIGN 3 "Several sources in lockstep") when the
+  // solver is multigrid-preconditioned GCR without an initial guess and the fields fit: the hierarchy's cycle runs once per iteration for all of
+  // them.  QUDA_AMD_QKXTM_LOCKSTEP=0 keeps the reference's order of 24 separate solves.
+  bool lockstep = param->inv_type == QUDA_GCR_INVERTER && param->inv_type_precondition == QUDA_MG_INVERTER && param->preconditionerUP && param->preconditionerDN &&
+                  param->use_init_guess != QUDA_USE_INIT_GUESS_YES;
+  {
+    static int env = -1;
+    if (env < 0) { const char *e = getenv("QUDA_AMD_QKXTM_LOCKSTEP"); env = e ? atoi(e) : 1; }
+    if (!env) lockstep = false;
+    if (lockstep) {
+      size_t freeB = 0, totalB = 0;
+      HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
+      const double full = (double)g.V * 24 * (int)param->cuda_prec, parS = 0.5 * (double)g.V * 24 * (int)param->cuda_prec_sloppy;
+      const double need = 12.0 * (2.0 * full + 1.0 * full + (2.0 + 2.0 * param->gcrNkrylov) * parS);
+      if (need > 0.6 * (double)freeB) lockstep = false;
+    }
+  }
+  if (lockstep) {
+    std::vector<ColorSpinorField *> bs(12), xs(12), ins(12), outs(12);
+    for (int isc = 0; isc < 12; isc++) { bs[isc] = new ColorSpinorField(cp); xs[isc] = new ColorSpinorField(cp); }
+    for (int fl = 0; fl < 2; fl++) {
+      const QudaTwistFlavorType flavor = fl == 0 ? QUDA_TWIST_PLUS : QUDA_TWIST_MINUS;   // up, then down (:6401, :6470)
+      param->twist_flavor = flavor;
+      param->preconditioner = fl == 0 ? param->preconditionerUP : param->preconditionerDN;
+      for (int isc = 0; isc < 12; isc++) {
+        hipLaunchKernelGGL(spread_slot_kernel, dim3((g.Vh + 255) / 256, 2), dim3(256), 0, computeStream(), (double *)source.V(), (const double *)phi.V(), source.Stride(),
+                           parityDoubles(source), g.Vh, isc / 3, isc % 3);
+        HIP_CHECK(hipGetLastError());
+        bs[isc]->changeTwist(flavor); xs[isc]->changeTwist(flavor);
+        *bs[isc] = source;
+        blas::zero(*xs[isc]);
+        dirac.prepare(ins[isc], outs[isc], *xs[isc], *bs[isc], param->solution_type);
+        ins[isc]->changeTwist(flavor); outs[isc]->changeTwist(flavor);
+      }
+      param->secs = 0; param->gflops = 0; param->iter = 0;
+      SolverParam sp(*param);
+      MG *K = static_cast<multigrid_solver *>(param->preconditioner)->mg;
+      const MultiSrcSolve res = solveMultiSrcGCR(outs, ins, m, mSloppy, K, sp, dSloppy);
+      secs += res.secs; iters += 12 * res.iter;
+      double worst = 0;
+      for (int isc = 0; isc < 12; isc++) worst = std::max(worst, sqrt(res.r2[isc] / res.b2[isc]));
+      param->true_res = worst;
+      for (int isc = 0; isc < 12; isc++) {
+        dirac.reconstruct(*xs[isc], *bs[isc], param->solution_type);
+        result = *xs[isc];
+        deviceToLex(h_one.data(), result, g, true, rescale ? 2.0 * param->kappa : 1.0);
+        each(ctx, isc, fl == 0 ? +1 : -1, h_one.data(), vec);
+      }
+    }
+    for (int isc = 0; isc < 12; isc++) { delete bs[isc]; delete xs[isc]; }
+  }
+  for (int isc = 0; isc < 12 && !lockstep; isc++) {
     hipLaunchKernelGGL(spread_slot_kernel, dim3((g.Vh + 255) / 256, 2), dim3(256), 0, computeStream(), (double *)source.V(), (const double *)phi.V(), source.Stride(),
                        parityDoubles(source), g.Vh, isc / 3, isc % 3);
     HIP_CHECK(hipGetLastError());

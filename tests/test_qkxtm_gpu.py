@@ -142,10 +142,14 @@ def test_propagators_with_up_and_down_hierarchies(qa, oracle):
         ip.inv_type_precondition = qa.QUDA_MG_INVERTER
         ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
         ip.preconditionerUP, ip.preconditionerDN = hier[+1][0].h, hier[-1][0].h
+        s0 = qa.multi_src_stats()
         worst = _check_propagators(qa, oracle, gauge, g_lex, X, kappa, mu, ip, (3, 0, 7, 9), 6, 1.0, False)
-        print("24 MG-GCR solves: %d outer iterations in total, %.3f s in the solvers, worst true residual %.2e" % (ip.iter, ip.secs, worst))
+        s1 = qa.multi_src_stats()
+        print("24 MG-GCR solves: %d outer iterations in total, %.3f s in the solvers, worst true residual %.2e, %s" % (ip.iter, ip.secs, worst, s1))
         assert worst < 5e-10, worst
         assert ip.iter < 24 * 30, ip.iter
+        # the twelve sources of a flavour went through ONE lockstep solve each, smoothed on block fields (csrc/block_solver.cpp)
+        assert s1["solves"] - s0["solves"] == 2 and s1["block_smoothed"] > s0["block_smoothed"], (s0, s1)
     finally:
         for h, _, _ in hier.values():
             h.free()
