@@ -451,11 +451,60 @@ static void loopSolves(QudaInvertParam *param, const qudaQKXTM_loopInfo &loopInf
     toSink(kind, index, (int)param->twist_flavor, h_src.data(), h_sol.data(), vec);
   };
 
+  // Groups of stochastic sources through ONE lockstep solve (block_solver.cpp) when the solver is multigrid-preconditioned GCR without an initial
+  // guess: the hierarchy's cycle runs once per iteration for the whole group.  The sources of a group are drawn exactly as one by one (the
+  // generator is keyed by the source number); QUDA_AMD_QKXTM_LOCKSTEP=0 keeps the reference's one-by-one order.
+  int group = 1;
+  if (param->inv_type == QUDA_GCR_INVERTER && param->inv_type_precondition == QUDA_MG_INVERTER && param->preconditioner && param->use_init_guess != QUDA_USE_INIT_GUESS_YES) {
+    static int env = -1;
+    if (env < 0) { const char *e = getenv("QUDA_AMD_QKXTM_LOCKSTEP"); env = e ? atoi(e) : 1; }
+    if (env) {
+      size_t freeB = 0, totalB = 0;
+      HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
+      const double full = (double)g.V * 24 * (int)param->cuda_prec, parS = 0.5 * (double)g.V * 24 * (int)param->cuda_prec_sloppy;
+      const double perSource = 3.0 * full + (2.0 + 2.0 * param->gcrNkrylov) * parS;
+      group = 12;
+      while (group > 1 && group * perSource > 0.6 * (double)freeB) group /= 2;
+    }
+  }
+  auto solveGroup = [&](bool lowPrecision, const char *kind, int first, int n) {
+    std::vector<std::vector<double>> h_srcs(n, std::vector<double>(vec));
+    std::vector<ColorSpinorField *> bs(n), xs(n), ins(n), outs(n);
+    for (int j = 0; j < n; j++) {
+      stochasticSource(h_srcs[j].data(), (size_t)g.V * 12, loopInfo.seed, first + j, info.source_type);
+      lexToDevice(stage, h_srcs[j].data(), g, true);
+      bs[j] = new ColorSpinorField(cp); xs[j] = new ColorSpinorField(cp);
+      *bs[j] = stage;
+      blas::zero(*xs[j]);
+      dirac.prepare(ins[j], outs[j], *xs[j], *bs[j], param->solution_type);
+      ins[j]->changeTwist(param->twist_flavor); outs[j]->changeTwist(param->twist_flavor);
+    }
+    const double tol0 = param->tol;
+    const int maxiter0 = param->maxiter;
+    if (lowPrecision) { if (TSM_maxiter == 0) param->tol = TSM_tol; else param->maxiter = (int)TSM_maxiter; }
+    param->secs = 0; param->gflops = 0; param->iter = 0;
+    SolverParam sp(*param);
+    MG *K = static_cast<multigrid_solver *>(param->preconditioner)->mg;
+    const MultiSrcSolve res = solveMultiSrcGCR(outs, ins, m, mSloppy, K, sp, dSloppy);
+    param->tol = tol0; param->maxiter = maxiter0;
+    secs += res.secs; iters += n * res.iter;
+    for (int j = 0; j < n; j++) {
+      dirac.reconstruct(*xs[j], *bs[j], param->solution_type);
+      stage = *xs[j];
+      deviceToLex(h_sol.data(), stage, g, true, rescale ? 2.0 * param->kappa : 1.0);
+      toSink(kind, first + j, (int)param->twist_flavor, h_srcs[j].data(), h_sol.data(), vec);
+      delete bs[j]; delete xs[j];
+    }
+  };
+
   // production sources: low-precision solves under the truncated solver method, full solves otherwise (:9000-9050)
   const int Nrun = useTSM ? loopInfo.TSM_NLP : loopInfo.Nstoch;
-  for (int is = 0; is < Nrun; is++) {
+  for (int is = 0; is < Nrun;) {
+    const int n = std::min(group, Nrun - is);
+    if (n >= 2) { solveGroup(useTSM, useTSM ? "loop_LP" : "loop_stoch", is, n); is += n; continue; }
     stochasticSource(h_src.data(), (size_t)g.V * 12, loopInfo.seed, is, info.source_type);
     solve(useTSM, useTSM ? "loop_LP" : "loop_stoch", is);
+    is++;
   }
   // bias correction of the truncated solver method: TSM_NHP fresh sources solved to both precisions (:9170-9230)
   if (useTSM)
