@@ -529,7 +529,7 @@ def main():
         from synth import smooth_gauge_cayley
         Xc5 = (48, 48, 48, 96)
         gc5 = smooth_gauge_cayley(Xc5, 0.35, workers=min(16, os.cpu_count() or 8))
-        extra["mg_gcr_c5_one_gpu"] = run_mg(qa, Xc5, blocks=((4, 4, 4, 4), (2, 2, 2, 4), (2, 2, 2, 2)), gauge=gc5, setup_repeats=2, multi_src=8)
+        extra["mg_gcr_c5_one_gpu"] = run_mg(qa, Xc5, blocks=((4, 4, 4, 4), (2, 2, 2, 4), (2, 2, 2, 2)), gauge=gc5, setup_repeats=2, multi_src=12)
         # ... with the sloppy and preconditioner links stored as 12 reals (reconstruct_sloppy = reconstruct_precondition = 12, the usual production choice;
         # the precise links stay at 18): every fp32 stencil of the cycle moves 576 instead of 768 B per site
         r12 = run_mg(qa, Xc5, blocks=((4, 4, 4, 4), (2, 2, 2, 4), (2, 2, 2, 2)), gauge=gc5, extras=False, coarse_bench=False, recon_sloppy=qa.QUDA_RECONSTRUCT_12)
