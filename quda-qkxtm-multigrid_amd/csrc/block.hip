@@ -840,21 +840,32 @@ __global__ void __launch_bounds__(256) mr_update_kernel(float4 *x, float4 *r, co
     const double n = sums[2 * nrhs + i];
     al[0] = al[1] = n > 0.0 ? make_float2((float)(omega * sums[i] / n), (float)(omega * sums[nrhs + i] / n)) : make_float2(0.f, 0.f);
   }
-  for (long q = blockIdx.x * 256l + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
-    const float4 rv = rin[q], av = Ar[q];
-    const float2 p0 = cmul(al[0], make_float2(rv.x, rv.y)), p1 = cmul(al[1], make_float2(rv.z, rv.w));
-    const float2 q0 = cmul(al[0], make_float2(av.x, av.y)), q1 = cmul(al[1], make_float2(av.z, av.w));
-    float4 xv = fresh ? make_float4(0.f, 0.f, 0.f, 0.f) : x[q];
-    xv.x += p0.x; xv.y += p0.y; xv.z += p1.x; xv.w += p1.y;
-    x[q] = xv;
-    r[q] = make_float4(rv.x - q0.x, rv.y - q0.y, rv.z - q1.x, rv.w - q1.y);
+  // four 16-byte words per field and thread in flight (the loads of a trip are issued before its first store: blas.hip's streaming kernels, same reason)
+  constexpr int UN = 4;
+  const long stride = (long)gridDim.x * 256;
+  for (long q0i = blockIdx.x * 256l + threadIdx.x; q0i < n4; q0i += UN * stride) {
+    float4 rv[UN], av[UN], xv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const long q = q0i + u * stride;
+      if (q < n4) { rv[u] = rin[q]; av[u] = Ar[q]; xv[u] = fresh ? make_float4(0.f, 0.f, 0.f, 0.f) : x[q]; }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const long q = q0i + u * stride;
+      if (q >= n4) continue;
+      const float2 p0 = cmul(al[0], make_float2(rv[u].x, rv[u].y)), p1 = cmul(al[1], make_float2(rv[u].z, rv[u].w));
+      const float2 m0 = cmul(al[0], make_float2(av[u].x, av[u].y)), m1 = cmul(al[1], make_float2(av[u].z, av[u].w));
+      x[q] = make_float4(xv[u].x + p0.x, xv[u].y + p0.y, xv[u].z + p1.x, xv[u].w + p1.y);
+      r[q] = make_float4(rv[u].x - m0.x, rv[u].y - m0.y, rv[u].z - m1.x, rv[u].w - m1.y);
+    }
   }
 }
 void mrUpdateDev(BlockField &x, BlockField &r, const BlockField &rin, const BlockField &Ar, const double *d_sums, double omega, bool fresh) {
   check(x, r); check(x, rin); check(x, Ar);
   if (!x.pairMajor || 256 % x.nrhs) errorQuda("minimal-residual update: 12-component fields with 4 or 8 right-hand sides (got %d x %d)", x.ncomp, x.nrhs);
   const long n4 = (long)x.elems() / 2;
-  const unsigned grid = (unsigned)std::min<long>((n4 + 255) / 256, 8192);
+  const unsigned grid = (unsigned)std::min<long>((n4 + 4 * 256 - 1) / (4 * 256), 4096);
   acct("mr_update_kernel", (double)x.elems() * 8.0 * (fresh ? 4 : 5), "level 0");
   hipLaunchKernelGGL(mr_update_kernel, dim3(grid), dim3(256), 0, computeStream(), (float4 *)x.v, (float4 *)r.v, (const float4 *)rin.v, (const float4 *)Ar.v, d_sums, (float)omega, x.nrhs, n4, fresh ? 1 : 0);
   HIP_CHECK(hipGetLastError());

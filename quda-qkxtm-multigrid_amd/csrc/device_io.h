@@ -288,6 +288,12 @@ __device__ __forceinline__ pkf2 cmulc(pkf2 u, pkf2 h) {
   asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "+v"(r) : "v"(u), "v"(h));
   return r;
 }
+// acc + conj(u) h
+__device__ __forceinline__ pkf2 cmacc(pkf2 acc, pkf2 u, pkf2 h) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(u), "v"(h));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "+v"(acc) : "v"(u), "v"(h));
+  return acc;
+}
 // acc - u h
 __device__ __forceinline__ pkf2 cmsub(pkf2 acc, pkf2 u, pkf2 h) {
   asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(acc) : "v"(u), "v"(h));

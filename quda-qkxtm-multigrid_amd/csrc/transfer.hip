@@ -351,15 +351,15 @@ __global__ void __launch_bounds__(256) restrict_stream4_kernel(Src4 a, const voi
         float w[16];
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          pkf2 accA = {0.f, 0.f}, accB = {0.f, 0.f};   // conj(V) r for the two vectors of the pair: two packed multiply-adds each (the 4 x 6 x 8 scalar ones per step held the kernel at 0.53-0.59)
 #pragma unroll
           for (int kk = 0; kk < KH; kk++) {
             const float4 v = v_unpack(ph == 0 ? w0[kk] : (ph == 1 ? w1[kk] : w2[kk]));
-            const float2 rr = r[s][chi * KH + kk];
-            acc.x += v.x * rr.x + v.y * rr.y; acc.y += v.x * rr.y - v.y * rr.x;   // conj(V) r
-            acc.z += v.z * rr.x + v.w * rr.y; acc.w += v.z * rr.y - v.w * rr.x;
+            const pkf2 rr = {r[s][chi * KH + kk].x, r[s][chi * KH + kk].y};
+            accA = pk::cmacc(accA, (pkf2){v.x, v.y}, rr);
+            accB = pk::cmacc(accB, (pkf2){v.z, v.w}, rr);
           }
-          w[4 * s] = acc.x; w[4 * s + 1] = acc.y; w[4 * s + 2] = acc.z; w[4 * s + 3] = acc.w;
+          w[4 * s] = accA.x; w[4 * s + 1] = accA.y; w[4 * s + 2] = accB.x; w[4 * s + 3] = accB.y;
         }
         __builtin_amdgcn_sched_barrier(0);
         if (ph == 0) vload(w0, vp + 3); else if (ph == 1) vload(w1, vp + 3); else vload(w2, vp + 3);   // the buffer just used: three steps ahead
@@ -413,11 +413,11 @@ __global__ void __launch_bounds__(256) prolong4_kernel(Src4 a, const void *V, co
   const int f = block_to_fine[(size_t)A * blockVol + b];
   const int parity = f >= a.f[0].Vh, x = f - parity * a.f[0].Vh;
   if (!a.f[0].v[parity]) return;   // this parity is absent from single-parity output fields
-  float2 acc[4][K];
+  pkf2 acc[4][K];
 #pragma unroll
   for (int s = 0; s < 4; s++)
 #pragma unroll
-    for (int k = 0; k < K; k++) acc[s][k] = make_float2(0.f, 0.f);
+    for (int k = 0; k < K; k++) acc[s][k] = (pkf2){0.f, 0.f};
 #pragma unroll
   for (int chi = 0; chi < 2; chi++) {
     raw_t w0[KH], w1[KH], w2[KH];
@@ -433,19 +433,19 @@ __global__ void __launch_bounds__(256) prolong4_kernel(Src4 a, const void *V, co
       const int ph = vp % 3;
 #pragma unroll
       for (int s = 0; s < 4; s++) {
-        const float2 c0 = xc_s[s][chi * NVEC + 2 * vp], c1 = xc_s[s][chi * NVEC + 2 * vp + 1];
+        const float2 d0 = xc_s[s][chi * NVEC + 2 * vp], d1 = xc_s[s][chi * NVEC + 2 * vp + 1];
+        const pkf2 c0 = {d0.x, d0.y}, c1 = {d1.x, d1.y};
 #pragma unroll
         for (int kk = 0; kk < KH; kk++) {
           const float4 w = v_unpack(ph == 0 ? w0[kk] : (ph == 1 ? w1[kk] : w2[kk]));
-          acc[s][chi * KH + kk].x += w.x * c0.x - w.y * c0.y + w.z * c1.x - w.w * c1.y;
-          acc[s][chi * KH + kk].y += w.x * c0.y + w.y * c0.x + w.z * c1.y + w.w * c1.x;
+          acc[s][chi * KH + kk] = pk::cmac(pk::cmac(acc[s][chi * KH + kk], (pkf2){w.x, w.y}, c0), (pkf2){w.z, w.w}, c1);   // V c: four packed multiply-adds
         }
       }
       // pin the sums here (as prolong_kernel): without it the multiply-adds sink below the last fence and every load stays live
 #pragma unroll
       for (int s = 0; s < 4; s++)
 #pragma unroll
-        for (int kk = 0; kk < KH; kk++) asm volatile("" : "+v"(acc[s][chi * KH + kk].x), "+v"(acc[s][chi * KH + kk].y));
+        for (int kk = 0; kk < KH; kk++) asm volatile("" : "+v"(acc[s][chi * KH + kk]));
       __builtin_amdgcn_sched_barrier(0);
       if (ph == 0) vload(w0, vp + 3); else if (ph == 1) vload(w1, vp + 3); else vload(w2, vp + 3);
       __builtin_amdgcn_sched_barrier(0);
@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(256) prolong4_kernel(Src4 a, const void *V, co
       for (int k = 0; k < K; k += 2) *reinterpret_cast<float4 *>(base + fidx<NV>(a.f[s].stride, x, k)) = make_float4(acc[s][k].x, acc[s][k].y, acc[s][k + 1].x, acc[s][k + 1].y);
     } else {
 #pragma unroll
-      for (int k = 0; k < K; k++) *reinterpret_cast<float2 *>(base + fidx<NV>(a.f[s].stride, x, k)) = acc[s][k];
+      for (int k = 0; k < K; k++) *reinterpret_cast<float2 *>(base + fidx<NV>(a.f[s].stride, x, k)) = make_float2(acc[s][k].x, acc[s][k].y);
     }
   }
 }
