@@ -429,8 +429,10 @@ bool MG::blockPrepare(int nsrc) {
   if (nb > kMaxBlockRhs) return false;
   MGBlockState *st = new MGBlockState;
   st->nsrc = nsrc; st->nb = nb;
-  st->coarse = blockCoarseCreate(*coarse, nb);
-  if (!st->coarse) { delete st; return false; }
+  // nullptr (a K-cycle below the first coarse level, an operator the MFMA kernel does not take): the coarse solves run source by source through
+  // the hierarchy's own coarse solver, the fine level keeps its block smoother and four-source transfers
+  const bool vBelow = mgp.cycle_type == QUDA_MG_CYCLE_VCYCLE || mgp.level == mgp.Nlevel - 2;   // else the coarse solver is a GCR around the next level's cycle
+  st->coarse = vBelow ? blockCoarseCreate(*coarse, nb) : nullptr;
   for (int i = 0; i < nsrc; i++) {
     st->prePar.push_back(new SolverParam(*param_presmooth));
     st->postPar.push_back(new SolverParam(*param_postsmooth));
@@ -540,10 +542,18 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
     else blas::zero(*st.rc[i]);
     i++;
   }
-  // everything below the fine level for all sources at once, on the matrix cores
-  blockPack(*st.coarse->L[0].b, st.rc);
-  st.coarse->cycle();
-  blockUnpack(st.xc, *st.coarse->L[0].x);
+  if (st.coarse) {
+    // everything below the fine level for all sources at once, on the matrix cores
+    blockPack(*st.coarse->L[0].b, st.rc);
+    st.coarse->cycle();
+    blockUnpack(st.xc, *st.coarse->L[0].x);
+  } else {
+    for (int i = 0; i < nsrc; i++) {
+      if (!active[i]) continue;
+      blas::zero(*st.xc[i]);
+      (*coarse_solver)(*st.xc[i], *st.rc[i]);
+    }
+  }
   for (int i = 0; i < nsrc;) {
     if (quadGroup(i)) {
       ColorSpinorField *f4[4];

@@ -58,13 +58,14 @@ def test_multi_source_mg_gcr_matches_single_source_solves(qa, oracle, X, levels,
         qa.lib().qudaAmdSetPartitionMask(0)
 
 
-@pytest.mark.parametrize("action,matpc,nu_pre,nsrc,mask", [("tm", "oo", 0, 9, 14), ("tmc", "ee", 2, 12, 0), ("tm", "ee", 2, 4, 15), ("tm", "eeasym", 2, 3, 0)],
-                         ids=["odd-odd-no-presmoothing-9-sources-yzt", "twisted-clover-12-sources", "4-sources-xyzt", "asymmetric-falls-back"])
-def test_fine_level_block_smoother(qa, oracle, action, matpc, nu_pre, nsrc, mask):
+@pytest.mark.parametrize("action,matpc,nu_pre,nsrc,mask,cycle", [("tm", "oo", 0, 9, 14, "V"), ("tmc", "ee", 2, 12, 0, "V"), ("tm", "ee", 2, 4, 15, "V"), ("tm", "eeasym", 2, 3, 0, "V"),
+                                                                  ("tm", "ee", 2, 6, 0, "K")],
+                         ids=["odd-odd-no-presmoothing-9-sources-yzt", "twisted-clover-12-sources", "4-sources-xyzt", "asymmetric-falls-back", "k-cycle-coarse-solves-per-source"])
+def test_fine_level_block_smoother(qa, oracle, action, matpc, nu_pre, nsrc, mask, cycle):
     """the fine-level smoothing of all sources on block fields (groups of 8 / 4 through the multi-right-hand-side stencil, MR sums in its epilogue,
     coefficient on the device): same outer iteration count and the same solutions as the single-source solves — odd-odd preconditioning, no
     pre-smoothing, twisted clover (dense site matrices), padded groups, partitioned dimensions; the asymmetric preconditioning is outside it
-    and must run source by source"""
+    and must run source by source; below a K-cycle the coarse solves run source by source while the fine level keeps its block smoother"""
     X, kappa, mu = (16, 8, 8, 16), 0.124, 0.005
     qa.lib().qudaAmdSetPartitionMask(mask)
     try:
@@ -77,7 +78,7 @@ def test_fine_level_block_smoother(qa, oracle, action, matpc, nu_pre, nsrc, mask
             qa.load_clover(None, None, ip)
         ip.matpc_type = qa.MATPC[matpc]
         mp = qa.multigrid_param(ip, n_level=3, geo_block=[(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)], n_vec=8, nu_pre=nu_pre, setup_maxiter=300, setup_tol=1e-5, smoother_pc=True,
-                                cycle=qa.QUDA_MG_CYCLE_VCYCLE)
+                                cycle=qa.QUDA_MG_CYCLE_VCYCLE if cycle == "V" else qa.QUDA_MG_CYCLE_RECURSIVE)
         mg = qa.Multigrid(mp)
         try:
             rng = np.random.default_rng(47)

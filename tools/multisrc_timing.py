@@ -21,6 +21,7 @@ Lt = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 nsrc = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 outer = sys.argv[4] if len(sys.argv) > 4 else "pc"
 acct = sys.argv[5] if len(sys.argv) > 5 else "/tmp/multisrc_acct.json"
+cycle = os.environ.get("QA_MULTISRC_CYCLE", "V")   # K: the reference harness' default K-cycle (coarse solves source by source, block smoother on the fine level)
 X = (Ls, Ls, Ls, Lt)
 kappa, mu = 0.124, 0.005
 qa.init(0)
@@ -29,7 +30,7 @@ qa.load_gauge(gauge, qa.gauge_param(X, cuda_prec=8, prec_sloppy=4, prec_precondi
 ip = qa.invert_param(qa.QUDA_TWISTED_MASS_DSLASH, kappa, mu, +1, "ee", 0, cuda_prec=8, prec_sloppy=4, prec_precondition=4, solution_type=qa.QUDA_MAT_SOLUTION)
 ip.solve_type, ip.inv_type, ip.gcrNkrylov, ip.tol, ip.maxiter = qa.QUDA_DIRECT_SOLVE, qa.QUDA_GCR_INVERTER, 20, 1e-10, 5000
 blocks = [(4, 4, 4, 4), (2, 2, 2, 4) if X == (48, 48, 48, 96) else (2, 2, 2, 2), (2, 2, 2, 2)]
-mp = qa.multigrid_param(ip, n_level=3, geo_block=blocks, n_vec=24, setup_maxiter=500, setup_tol=5e-6, smoother_pc=True, cycle=qa.QUDA_MG_CYCLE_VCYCLE)
+mp = qa.multigrid_param(ip, n_level=3, geo_block=blocks, n_vec=24, setup_maxiter=500, setup_tol=5e-6, smoother_pc=True, cycle=qa.QUDA_MG_CYCLE_VCYCLE if cycle == "V" else qa.QUDA_MG_CYCLE_RECURSIVE)
 mg = qa.Multigrid(mp)
 ip.inv_type_precondition, ip.preconditioner = qa.QUDA_MG_INVERTER, mg.h
 ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
@@ -66,7 +67,7 @@ if markers:
     qa.lib().qudaAmdAccountDump(acct.encode()); qa.lib().qudaAmdProfileMarker(2); qa.lib().qudaAmdDeviceSynchronize()
 ip.solve_type = qa.QUDA_DIRECT_SOLVE
 worst = max(float(np.linalg.norm(b - qa.mat(x, ip)) / np.linalg.norm(b)) for x, b in zip(xs, bs))
-print("SOLVE " + json.dumps(dict(lattice="x".join(map(str, X)), sources=nsrc, outer=outer, sequential=dict(solver_secs=round(seq_solver, 4), wall_secs=round(seq_wall, 4), iters=iters, repeats=[round(a, 4) for a, _ in seq]),
+print("SOLVE " + json.dumps(dict(lattice="x".join(map(str, X)), sources=nsrc, outer=outer, cycle=cycle, sequential=dict(solver_secs=round(seq_solver, 4), wall_secs=round(seq_wall, 4), iters=iters, repeats=[round(a, 4) for a, _ in seq]),
                                lockstep=dict(solver_secs=round(blk_solver, 4), wall_secs=round(blk_wall, 4), iters=blk_iter, worst_true_res=worst, repeats=[round(a, 4) for a, _ in reps]), speedup_solver=round(seq_solver / blk_solver, 3),
                                solver_secs=blk_solver, acct=os.path.basename(acct))))
 mg.free()
