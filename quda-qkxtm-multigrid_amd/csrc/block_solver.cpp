@@ -46,6 +46,13 @@ struct BlockLevel {
   double omega = 1.0;
   BlockField *b = nullptr, *x = nullptr, *bt = nullptr, *r = nullptr, *Ar = nullptr, *t = nullptr, *w1 = nullptr, *w2 = nullptr;
   std::vector<ColorSpinorField *> fine, coarse;   // per right-hand side staging fields of the transfer to the next level
+  // K-cycle (QUDA_MG_CYCLE_RECURSIVE on the level above): this level's system is solved by a flexible GCR around its own cycle (reference
+  // lib/multigrid.cpp:230-260: coarse solver = GCR(10), at most 11 iterations, to the smoother tolerance of this level) — source kb, work fields
+  bool kSolve = false;
+  int kKrylov = 10, kMaxiter = 11;
+  double kTol = 0.25;
+  BlockField *kb = nullptr, *ky = nullptr, *kr = nullptr;
+  std::vector<BlockField *> KP, KAP;
 };
 
 class BlockCoarseCycle {
@@ -57,11 +64,14 @@ class BlockCoarseCycle {
   double tol = 0.25;
   std::vector<BlockField *> P, AP;
   BlockField *y = nullptr;
-  long applies = 0, gcrIters = 0;
+  std::vector<MG *> parents;   // MG object of every level of the sub-hierarchy (creation only)
+  long applies = 0, gcrIters = 0, kIters = 0;
 
   ~BlockCoarseCycle() {
     for (BlockLevel &l : L) {
-      for (BlockField *f : {l.b, l.x, l.bt, l.r, l.Ar, l.t, l.w1, l.w2}) delete f;
+      for (BlockField *f : {l.b, l.x, l.bt, l.r, l.Ar, l.t, l.w1, l.w2, l.kb, l.ky, l.kr}) delete f;
+      for (BlockField *f : l.KP) delete f;
+      for (BlockField *f : l.KAP) delete f;
       for (ColorSpinorField *f : l.fine) delete f;
       for (ColorSpinorField *f : l.coarse) delete f;
     }
@@ -138,41 +148,43 @@ class BlockCoarseCycle {
       blockblas::caxpy(mal.data(), *l.Ar, *l.r);   // r -= alpha Ar
     }
   }
-  // restarted GCR(nKrylov) on Mhat x_p = bt to |r| <= tol |bt| per right-hand side, in lockstep (reference lib/inv_gcr_quda.cpp:235-516)
-  void gcr(BlockLevel &l) {
+  // restarted flexible GCR(nK) per right-hand side in lockstep (reference lib/inv_gcr_quda.cpp:235-516): y = A^-1 b to |r| <= tol |b|, p_k = K r
+  // (prec == nullptr: p_k = r).  r is work space; op / prec are (out, in)
+  template <typename Op, typename Prec>
+  int gcrLockstep(BlockField &b, BlockField &yv, BlockField &r, std::vector<BlockField *> &Pv, std::vector<BlockField *> &APv, int nK, int maxit, double tl, Op op, Prec prec) {
     std::vector<double> b2(nb), r2(nb), stop(nb), nrm(nb);
     std::vector<Complex> dot(nb), c(nb);
-    blockblas::norm2(b2.data(), *l.bt);
-    blockblas::copy(*l.r, *l.bt);
-    blockblas::zero(*y);
+    blockblas::norm2(b2.data(), b);
+    blockblas::copy(r, b);
+    blockblas::zero(yv);
     bool any = false;
-    for (int i = 0; i < nb; i++) { stop[i] = tol * tol * b2[i]; r2[i] = b2[i]; any = any || b2[i] > 0.0; }
+    for (int i = 0; i < nb; i++) { stop[i] = tl * tl * b2[i]; r2[i] = b2[i]; any = any || b2[i] > 0.0; }
     // coefficients per right-hand side
-    std::vector<std::vector<Complex>> alpha(nKrylov, std::vector<Complex>(nb));
-    std::vector<std::vector<double>> gamma(nKrylov, std::vector<double>(nb));
-    std::vector<std::vector<std::vector<Complex>>> beta(nKrylov, std::vector<std::vector<Complex>>(nKrylov, std::vector<Complex>(nb)));
+    std::vector<std::vector<Complex>> alpha(nK, std::vector<Complex>(nb));
+    std::vector<std::vector<double>> gamma(nK, std::vector<double>(nb));
+    std::vector<std::vector<std::vector<Complex>>> beta(nK, std::vector<std::vector<Complex>>(nK, std::vector<Complex>(nb)));
     auto open = [&]() { for (int i = 0; i < nb; i++) if (r2[i] > stop[i]) return true; return false; };
     int k = 0, total = 0;
-    while (any && open() && total < maxiter) {
-      blockblas::copy(*P[k], *l.r);
-      matpc(l, *AP[k], *P[k]);
+    while (any && open() && total < maxit) {
+      prec(*Pv[k], r);
+      op(*APv[k], *Pv[k]);
       for (int j = 0; j < k; j++) {
-        blockblas::cDot(dot.data(), *AP[j], *AP[k]);
+        blockblas::cDot(dot.data(), *APv[j], *APv[k]);
         for (int i = 0; i < nb; i++) { beta[j][k][i] = dot[i]; c[i] = -dot[i]; }
-        blockblas::caxpy(c.data(), *AP[j], *AP[k]);
+        blockblas::caxpy(c.data(), *APv[j], *APv[k]);
       }
-      blockblas::cDotNormA(dot.data(), nrm.data(), *AP[k], *l.r);
+      blockblas::cDotNormA(dot.data(), nrm.data(), *APv[k], r);
       for (int i = 0; i < nb; i++) {
         gamma[k][i] = sqrt(nrm[i]);
         alpha[k][i] = gamma[k][i] > 0.0 ? dot[i] / gamma[k][i] : Complex(0.0);
         c[i] = gamma[k][i] > 0.0 ? Complex(1.0 / gamma[k][i] - 1.0) : Complex(0.0);   // AP_k *= 1 / gamma  (y += c x with x = y)
       }
-      blockblas::caxpy(c.data(), *AP[k], *AP[k]);
+      blockblas::caxpy(c.data(), *APv[k], *APv[k]);
       for (int i = 0; i < nb; i++) c[i] = -alpha[k][i];
-      blockblas::caxpy(c.data(), *AP[k], *l.r);
-      blockblas::norm2(r2.data(), *l.r);
+      blockblas::caxpy(c.data(), *APv[k], r);
+      blockblas::norm2(r2.data(), r);
       k++; total++;
-      if (k == nKrylov || total == maxiter || !open()) {
+      if (k == nK || total == maxit || !open()) {
         // solution update by back substitution per right-hand side (reference :125-157), then the true residual
         std::vector<std::vector<Complex>> delta(k, std::vector<Complex>(nb));
         for (int i = 0; i < nb; i++)
@@ -181,17 +193,34 @@ class BlockCoarseCycle {
             for (int j = a + 1; j < k; j++) d -= beta[a][j][i] * delta[j][i];
             delta[a][i] = gamma[a][i] > 0.0 ? d / gamma[a][i] : Complex(0.0);
           }
-        for (int a = 0; a < k; a++) blockblas::caxpy(delta[a].data(), *P[a], *y);
-        matpc(l, *l.r, *y);
-        xmy(*l.bt, *l.r);
-        blockblas::norm2(r2.data(), *l.r);
+        for (int a = 0; a < k; a++) blockblas::caxpy(delta[a].data(), *Pv[a], yv);
+        if (total < maxit) {   // true residual of the restart (it decides whether the iteration goes on)
+          op(r, yv);
+          xmy(b, r);
+          blockblas::norm2(r2.data(), r);
+        }
         k = 0;
       }
     }
-    gcrIters += total;
+    return total;
+  }
+  // coarsest grid: GCR(nKrylov) on Mhat x_p = bt
+  void gcr(BlockLevel &l) {
+    gcrIters += gcrLockstep(*l.bt, *y, *l.r, P, AP, nKrylov, maxiter, tol, [&](BlockField &out, BlockField &in) { matpc(l, out, in); },
+                            [&](BlockField &out, BlockField &in) { blockblas::copy(out, in); });
     // x_p = y (other parity of x is rebuilt by reconstruct)
     copyParity(*l.x, *y, l.p);
   }
+  // K-cycle: level lev's full system M x = kb by GCR around its own cycle; the solution lands in l.x like a cycle's
+  void kgcr(int lev) {
+    BlockLevel &l = L[lev];
+    kIters += gcrLockstep(*l.kb, *l.ky, *l.kr, l.KP, l.KAP, l.kKrylov, l.kMaxiter, l.kTol, [&](BlockField &out, BlockField &in) { apply(out, in, *l.Y); },
+                          [&](BlockField &out, BlockField &in) { blockblas::copy(*l.b, in); cycle(lev); blockblas::copy(out, *l.x); });
+    blockblas::copy(*l.x, *l.ky);
+  }
+  // the solve of level lev as the level above wants it: its cycle, or (K-cycle above) the GCR around it; source in source(lev)
+  BlockField &source(int lev) { return L[lev].kSolve ? *L[lev].kb : *L[lev].b; }
+  void solve(int lev) { if (L[lev].kSolve) kgcr(lev); else cycle(lev); }
 
   // x = cycle(b) on level 0 of the sub-hierarchy; fields of L[0].b / L[0].x are filled / read by the caller
   void cycle(int lev = 0) {
@@ -211,8 +240,8 @@ class BlockCoarseCycle {
     BlockLevel &c = L[lev + 1];
     blockUnpack(l.fine, *l.r);
     for (int i = 0; i < nb; i++) l.T->R(*l.coarse[i], *l.fine[i]);
-    blockPack(*c.b, l.coarse);
-    cycle(lev + 1);
+    blockPack(source(lev + 1), l.coarse);
+    solve(lev + 1);
     blockUnpack(l.coarse, *c.x);
     for (int i = 0; i < nb; i++) l.T->P(*l.fine[i], *l.coarse[i]);
     blockPack(*l.w1, l.fine);
@@ -223,7 +252,7 @@ class BlockCoarseCycle {
   }
 };
 
-static BlockCoarseCycle *blockCoarseCreate(MG &top, int nb) {
+static BlockCoarseCycle *blockCoarseCreate(MG &top, int nb, const MGParam *parent) {
   const MGParam &tp = top.params();
   if (tp.level < 1) return nullptr;
   BlockCoarseCycle *bc = new BlockCoarseCycle;
@@ -238,14 +267,27 @@ static BlockCoarseCycle *blockCoarseCreate(MG &top, int nb) {
     const DiracCoarse *dc = dynamic_cast<const DiracCoarse *>(p.matResidual.Expose());
     const DiracCoarsePC *ds = dynamic_cast<const DiracCoarsePC *>(p.matSmooth.Expose());
     if (!dc || !ds || !m->smootherIsPC() || !blockCoarseSupported(dc->Links(), nb)) { delete bc; return nullptr; }
-    if (!coarsest && !(p.cycle_type == QUDA_MG_CYCLE_VCYCLE || p.level == p.Nlevel - 2)) { delete bc; return nullptr; }
     BlockLevel &L = bc->L[l];
+    {
+      // the level above runs a K-cycle and this level is not the coarsest: GCR around this level's cycle (parameters of MG's coarse solver, multigrid.cpp)
+      const MGParam *pp = l == 0 ? parent : &bc->parents[l - 1]->params();
+      L.kSolve = !coarsest && pp && pp->cycle_type != QUDA_MG_CYCLE_VCYCLE;
+      L.kTol = p.mg_global.smoother_tol[p.level];
+    }
+    bc->parents.push_back(m);
     L.Y = &dc->Links(); L.H = &ds->HatLinks();
     const QudaMatPCType pc = ds->getMatPCType();
     L.p = (pc == QUDA_MATPC_ODD_ODD) ? 1 : 0;
     L.nuPre = p.nu_pre; L.nuPost = p.nu_post; L.omega = p.omega;
     const int nGhost = blockGhost(L.Y->Xc, false).nGhost;
     for (BlockField **f : {&L.b, &L.x, &L.bt, &L.r, &L.Ar, &L.t, &L.w1, &L.w2}) { *f = new BlockField(L.Y->nSites, L.Y->n, nb, nGhost); blockblas::zero(**f); }
+    if (L.kSolve) {
+      for (BlockField **f : {&L.kb, &L.ky, &L.kr}) { *f = new BlockField(L.Y->nSites, L.Y->n, nb, nGhost); blockblas::zero(**f); }
+      for (int k = 0; k < L.kKrylov; k++) {
+        L.KP.push_back(new BlockField(L.Y->nSites, L.Y->n, nb, nGhost)); L.KAP.push_back(new BlockField(L.Y->nSites, L.Y->n, nb, nGhost));
+        blockblas::zero(*L.KP.back()); blockblas::zero(*L.KAP.back());
+      }
+    }
     if (!coarsest) {
       L.T = m->getTransfer();
       if (!L.T) { delete bc; return nullptr; }
@@ -431,8 +473,7 @@ bool MG::blockPrepare(int nsrc) {
   st->nsrc = nsrc; st->nb = nb;
   // nullptr (a K-cycle below the first coarse level, an operator the MFMA kernel does not take): the coarse solves run source by source through
   // the hierarchy's own coarse solver, the fine level keeps its block smoother and four-source transfers
-  const bool vBelow = mgp.cycle_type == QUDA_MG_CYCLE_VCYCLE || mgp.level == mgp.Nlevel - 2;   // else the coarse solver is a GCR around the next level's cycle
-  st->coarse = vBelow ? blockCoarseCreate(*coarse, nb) : nullptr;
+  st->coarse = blockCoarseCreate(*coarse, nb, &mgp);
   for (int i = 0; i < nsrc; i++) {
     st->prePar.push_back(new SolverParam(*param_presmooth));
     st->postPar.push_back(new SolverParam(*param_postsmooth));
@@ -544,8 +585,8 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
   }
   if (st.coarse) {
     // everything below the fine level for all sources at once, on the matrix cores
-    blockPack(*st.coarse->L[0].b, st.rc);
-    st.coarse->cycle();
+    blockPack(st.coarse->source(0), st.rc);
+    st.coarse->solve(0);
     blockUnpack(st.xc, *st.coarse->L[0].x);
   } else {
     for (int i = 0; i < nsrc; i++) {

@@ -60,12 +60,12 @@ def test_multi_source_mg_gcr_matches_single_source_solves(qa, oracle, X, levels,
 
 @pytest.mark.parametrize("action,matpc,nu_pre,nsrc,mask,cycle", [("tm", "oo", 0, 9, 14, "V"), ("tmc", "ee", 2, 12, 0, "V"), ("tm", "ee", 2, 4, 15, "V"), ("tm", "eeasym", 2, 3, 0, "V"),
                                                                   ("tm", "ee", 2, 6, 0, "K")],
-                         ids=["odd-odd-no-presmoothing-9-sources-yzt", "twisted-clover-12-sources", "4-sources-xyzt", "asymmetric-falls-back", "k-cycle-coarse-solves-per-source"])
+                         ids=["odd-odd-no-presmoothing-9-sources-yzt", "twisted-clover-12-sources", "4-sources-xyzt", "asymmetric-falls-back", "k-cycle"])
 def test_fine_level_block_smoother(qa, oracle, action, matpc, nu_pre, nsrc, mask, cycle):
     """the fine-level smoothing of all sources on block fields (groups of 8 / 4 through the multi-right-hand-side stencil, MR sums in its epilogue,
     coefficient on the device): same outer iteration count and the same solutions as the single-source solves — odd-odd preconditioning, no
     pre-smoothing, twisted clover (dense site matrices), padded groups, partitioned dimensions; the asymmetric preconditioning is outside it
-    and must run source by source; below a K-cycle the coarse solves run source by source while the fine level keeps its block smoother"""
+    and must run source by source; below a K-cycle the first coarse level is solved by a lockstep GCR around its block cycle, as the single-source coarse solver does per source"""
     X, kappa, mu = (16, 8, 8, 16), 0.124, 0.005
     qa.lib().qudaAmdSetPartitionMask(mask)
     try:
