@@ -103,7 +103,7 @@ void bicgstabDots(Complex *ts, double *tt, Complex *r0s, Complex *r0t, const Blo
 // x_i += a_i p_i + w_i s_i ; r_i = s_i - w_i t_i (in place of s) ; p_i = r_i + b_i (p_i - w_i v_i) ; r2_i = |r_i|^2   (one pass: 5 reads, 3 writes)
 void bicgstabFused(double *r2, const Complex *a, const Complex *w, const Complex *b, BlockField &p, BlockField &r, BlockField &x, const BlockField &t, const BlockField &v);
 // minimal-residual step, coefficient from device sums [Re (Ar, r) | Im (Ar, r) | |Ar|^2][nrhs]: x = [x +] alpha rin, r = rin - alpha Ar, alpha = omega (Ar, r) / |Ar|^2
-void mrUpdateDev(BlockField &x, BlockField &r, const BlockField &rin, const BlockField &Ar, const double *d_sums, double omega, bool fresh);
+void mrUpdateDev(BlockField &x, BlockField &r, const BlockField &rin, const BlockField &Ar, const double *d_sums, double omega, bool fresh, bool needResidual = true);   // needResidual = false: the last step of a post-smoother, only x is updated
 void negate(BlockField &x);                                                           // x = -x
 }  // namespace blockblas
 

@@ -832,7 +832,7 @@ void bicgstabFused(double *r2, const Complex *al, const Complex *om, const Compl
 }
 // one minimal-residual step with the coefficient taken from DEVICE sums (fineBlockDotsFinishDev, mode 3: Re / Im (Ar, r), |Ar|^2 per right-hand
 // side): alpha_i = omega (Ar_i, r_i) / |Ar_i|^2 (0 for a column of zeros);  x = [x +] alpha rin ;  r = rin - alpha Ar — no host round trip
-__global__ void __launch_bounds__(256) mr_update_kernel(float4 *x, float4 *r, const float4 *rin, const float4 *Ar, const double *sums, float omega, int nrhs, long n4, int fresh) {
+__global__ void __launch_bounds__(256) mr_update_kernel(float4 *x, float4 *r, const float4 *rin, const float4 *Ar, const double *sums, float omega, int nrhs, long n4, int fresh, int needR) {
   // 12-component fields are pair-major (block.h): both halves of a 16-byte word belong to right-hand side (word index % nrhs)
   const int i = threadIdx.x % nrhs;
   float2 al[2];
@@ -848,7 +848,7 @@ __global__ void __launch_bounds__(256) mr_update_kernel(float4 *x, float4 *r, co
 #pragma unroll
     for (int u = 0; u < UN; u++) {
       const long q = q0i + u * stride;
-      if (q < n4) { rv[u] = rin[q]; av[u] = Ar[q]; xv[u] = fresh ? make_float4(0.f, 0.f, 0.f, 0.f) : x[q]; }
+      if (q < n4) { rv[u] = rin[q]; av[u] = needR ? Ar[q] : make_float4(0.f, 0.f, 0.f, 0.f); xv[u] = fresh ? make_float4(0.f, 0.f, 0.f, 0.f) : x[q]; }
     }
 #pragma unroll
     for (int u = 0; u < UN; u++) {
@@ -857,17 +857,17 @@ __global__ void __launch_bounds__(256) mr_update_kernel(float4 *x, float4 *r, co
       const float2 p0 = cmul(al[0], make_float2(rv[u].x, rv[u].y)), p1 = cmul(al[1], make_float2(rv[u].z, rv[u].w));
       const float2 m0 = cmul(al[0], make_float2(av[u].x, av[u].y)), m1 = cmul(al[1], make_float2(av[u].z, av[u].w));
       x[q] = make_float4(xv[u].x + p0.x, xv[u].y + p0.y, xv[u].z + p1.x, xv[u].w + p1.y);
-      r[q] = make_float4(rv[u].x - m0.x, rv[u].y - m0.y, rv[u].z - m1.x, rv[u].w - m1.y);
+      if (needR) r[q] = make_float4(rv[u].x - m0.x, rv[u].y - m0.y, rv[u].z - m1.x, rv[u].w - m1.y);
     }
   }
 }
-void mrUpdateDev(BlockField &x, BlockField &r, const BlockField &rin, const BlockField &Ar, const double *d_sums, double omega, bool fresh) {
+void mrUpdateDev(BlockField &x, BlockField &r, const BlockField &rin, const BlockField &Ar, const double *d_sums, double omega, bool fresh, bool needResidual) {
   check(x, r); check(x, rin); check(x, Ar);
   if (!x.pairMajor || 256 % x.nrhs) errorQuda("minimal-residual update: 12-component fields with 4 or 8 right-hand sides (got %d x %d)", x.ncomp, x.nrhs);
   const long n4 = (long)x.elems() / 2;
   const unsigned grid = (unsigned)std::min<long>((n4 + 4 * 256 - 1) / (4 * 256), 4096);
-  acct("mr_update_kernel", (double)x.elems() * 8.0 * (fresh ? 4 : 5), "level 0");
-  hipLaunchKernelGGL(mr_update_kernel, dim3(grid), dim3(256), 0, computeStream(), (float4 *)x.v, (float4 *)r.v, (const float4 *)rin.v, (const float4 *)Ar.v, d_sums, (float)omega, x.nrhs, n4, fresh ? 1 : 0);
+  acct("mr_update_kernel", (double)x.elems() * 8.0 * ((fresh ? 4 : 5) - (needResidual ? 0 : 2)), needResidual ? "level 0" : "level 0, last step (x only)");
+  hipLaunchKernelGGL(mr_update_kernel, dim3(grid), dim3(256), 0, computeStream(), (float4 *)x.v, (float4 *)r.v, (const float4 *)rin.v, (const float4 *)Ar.v, d_sums, (float)omega, x.nrhs, n4, fresh ? 1 : 0, needResidual ? 1 : 0);
   HIP_CHECK(hipGetLastError());
 }
 void negate(BlockField &x) {

@@ -362,11 +362,11 @@ class BlockFineSmoother {
     HIP_CHECK(hipStreamSynchronize(computeStream()));
   }
   // nu MR steps on (X, R); fresh: X is not defined yet and the residual is `first` (the source itself), not R
-  void mr(FineGroup &g, int nu, BlockField *first) {
+  void mr(FineGroup &g, int nu, BlockField *first, bool needResidual) {
     for (int k = 0; k < nu; k++) {
       BlockField &rin = (k == 0 && first) ? *first : *g.R;
       matpc(g, *g.AR, rin, true);
-      blockblas::mrUpdateDev(*g.X, *g.R, rin, *g.AR, g.d_sums, omega, k == 0 && first);
+      blockblas::mrUpdateDev(*g.X, *g.R, rin, *g.AR, g.d_sums, omega, k == 0 && first, needResidual || k + 1 < nu);
     }
   }
   // R = B - M X
@@ -524,7 +524,7 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
       }
       blockPackParity(*g.B, src, g.n);
       if (F.nuPre > 0) {
-        F.mr(g, F.nuPre, g.B);
+        F.mr(g, F.nuPre, g.B, true);
         blockUnpackParity(dst, g.n, *g.R);
       }
       for (int j = 0; j < g.n; j++) {
@@ -627,7 +627,7 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
       blockPackParity(*g.X, corr, g.n, F.nuPre > 0);   // X (+)= P e
       if (F.nuPost > 0) {
         F.residual(g);
-        F.mr(g, F.nuPost, nullptr);
+        F.mr(g, F.nuPost, nullptr, false);
       }
       blockUnpackParity(dst, g.n, *g.X);
     }
