@@ -670,12 +670,11 @@ bool MG::cycleBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorF
   for (int i = 0; i < nsrc; i++) {
     if (!active[i]) continue;
     st.r[i]->twistFlavor = x[i]->twistFlavor = b[i]->twistFlavor;
-    blas::copy(*st.r[i], *b[i]);
+    // (no copies: prepare() reads b and leaves the prepared source in the parity of x that reconstruct() fills last — MG::cycleUnfused)
     ColorSpinorField *pin = nullptr, *pout = nullptr;
-    dirac.prepare(pin, pout, *x[i], *st.r[i], QUDA_MAT_SOLUTION);
-    st.btilde[i]->twistFlavor = b[i]->twistFlavor;
-    blas::copy(*st.btilde[i], *pin);
-    in[i] = st.btilde[i]; out[i] = pout;
+    dirac.prepare(pin, pout, *x[i], *b[i], QUDA_MAT_SOLUTION);
+    pin->twistFlavor = b[i]->twistFlavor;
+    in[i] = pin; out[i] = pout;
   }
   for (int i = 0; i < nsrc; i++) if (!active[i]) { in[i] = st.btilde[i]; out[i] = st.btilde[i]; }
   cycleParityBlock(out, in, active, !matpc);
