@@ -568,7 +568,7 @@ void MG::cycleParity(ColorSpinorField &x, ColorSpinorField &b, bool fullResidual
     StageTimer t(mgp.level, 2);
     transfer->setSiteSubset(QUDA_PARITY_SITE_SUBSET, odd ? QUDA_ODD_PARITY : QUDA_EVEN_PARITY);
     transfer->R(*r_coarse, *rin);
-    blas::zero(*x_coarse);
+    if (ownCoarseSolver) blas::zero(*x_coarse);   // a V-cycle below (coarse_solver IS the next level's cycle) defines x in full from a zero guess of its own
   }
   { StageTimer t(mgp.level, 3); (*coarse_solver)(*x_coarse, *r_coarse); }
   {
@@ -667,7 +667,7 @@ void MG::cycleUnfused(ColorSpinorField &x, ColorSpinorField &b) {
     {
       StageTimer t(mgp.level, 2);
       transfer->R(*r_coarse, *r);
-      blas::zero(*x_coarse);
+      if (ownCoarseSolver) blas::zero(*x_coarse);
     }
     {
       StageTimer t(mgp.level, 3);
