@@ -77,7 +77,8 @@ void blockExchangeGhostRaw(const float2 *field, float2 *ghostZone, int ncomp, in
 // blockCoarseSupported() says whether a given operator / batch qualifies.  On a grid-decomposed lattice `in` must carry the ghost zone
 // of blockGhost(G.Xc, false) (it is filled here); `in` is therefore not const.
 bool blockCoarseSupported(const CoarseGauge &G, int nrhs);
-void applyCoarseBlock(BlockField &out, BlockField &in, const CoarseGauge &G);
+// parity >= 0: only the output sites of that parity are computed (and written) — half the link traffic where the caller wants one parity anyway
+void applyCoarseBlock(BlockField &out, BlockField &in, const CoarseGauge &G, int parity = -1);
 
 // [site][9] table of the panel indices of a site's 8 neighbours (order of the link matrices: 2 mu forward, 2 mu + 1 backward) and of
 // the site itself: parity * Vh + x_cb, or — across a partitioned face — the ghost panel nSites + offset + face index; device memory,

@@ -281,6 +281,7 @@ struct BlockCoarseArg {
   int Vh;
   unsigned inBytes;
   int spw;   // consecutive sites per work-group
+  int siteBegin, siteEnd;   // output sites [siteBegin, siteEnd): the whole lattice, or one parity half of it (the even-odd operators need no more)
   const int *nbr;   // [site][9]: index (parity * Vh + x_cb) of the 8 neighbours and of the site itself (neighbour_table)
 };
 
@@ -392,7 +393,7 @@ template <int N, int NRHS> __global__ void __launch_bounds__(256, (BlockCoarseTr
   using Tr = BlockCoarseTraits<N, NRHS>;
   constexpr int RT = Tr::RT, NT = Tr::NT, JP = Tr::JP, SG = Tr::SG, NG = Tr::NG, GI = Tr::GI, GD = Tr::GD;
   extern __shared__ float lds[];   // [4 waves][RT][NT][4][64] partial tiles
-  const int Vh = arg.Vh, nSites = 2 * arg.Vh;
+  const int Vh = arg.Vh, nSites = arg.siteEnd;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: everything derived from it stays in SGPRs
   const int lane = threadIdx.x & 63, row16 = lane & 15, kq = lane >> 4, ncol = lane & 15, odd = ncol & 1;
   constexpr unsigned siteBytes = 9u * JP * N * 16u;
@@ -410,7 +411,7 @@ template <int N, int NRHS> __global__ void __launch_bounds__(256, (BlockCoarseTr
   // lattice, so the panels a site shares with its y and z neighbours are met again in the same L2
   const int nwg = (int)gridDim.x;
   const int chunk = (nwg & 7) == 0 ? ((int)blockIdx.x & 7) * (nwg >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
-  const int A0 = chunk * arg.spw;
+  const int A0 = arg.siteBegin + chunk * arg.spw;
   if (A0 >= nSites) return;
 
   // ONE first-in-first-out ring of requests per wave, GD groups deep: for every group its B fragments (8-byte loads from the input
@@ -548,7 +549,7 @@ bool blockCoarseSupported(const CoarseGauge &G, int nrhs) {
   return !off;
 }
 
-void applyCoarseBlock(BlockField &out, BlockField &in, const CoarseGauge &G) {
+void applyCoarseBlock(BlockField &out, BlockField &in, const CoarseGauge &G, int parity) {
   if (!blockCoarseSupported(G, in.nrhs)) errorQuda("block coarse operator: n = %d, nrhs = %d not supported", G.n, in.nrhs);
   if (in.ncomp != G.n || out.ncomp != G.n || in.nSites != G.nSites || out.nSites != G.nSites || in.nrhs != out.nrhs) errorQuda("block fields do not match the coarse operator");
   if (in.v == out.v) errorQuda("in and out must not alias");
@@ -565,16 +566,19 @@ void applyCoarseBlock(BlockField &out, BlockField &in, const CoarseGauge &G) {
     static int spwEnv = -1;
     if (spwEnv < 0) { const char *e = getenv("QUDA_AMD_BLOCK_COARSE_SPW"); spwEnv = e ? atoi(e) : 0; }
     int spw = spwEnv > 0 ? spwEnv : 4;   // measured at 12^3 x 24, n = 48: 4 sites 1066 / 1407 / 1834 us (8 / 16 / 24 right-hand sides), 8 sites 1084 / 1429 / 1864, 32 sites 1226 / 1520 / 1888
-    while (spw > 1 && G.nSites / spw < 4 * 768) spw /= 2;
+    arg.siteBegin = parity < 0 ? 0 : parity * arg.Vh;
+    arg.siteEnd = parity < 0 ? G.nSites : (parity + 1) * arg.Vh;
+    while (spw > 1 && (arg.siteEnd - arg.siteBegin) / spw < 4 * 768) spw /= 2;
     arg.spw = spw;
   }
+  const int nOut = arg.siteEnd - arg.siteBegin;
   for (int d = 0; d < 4; d++) arg.Xc[d] = G.Xc[d];
   arg.nbr = coarseNeighbourTable(G.Xc);
   if (g_acctOn) {   // the 9 link matrices of a site once, input and output panels once
-    char tag[64]; snprintf(tag, sizeof(tag), "coarse %dx%dx%dx%d n %d, %d rhs", G.Xc[0], G.Xc[1], G.Xc[2], G.Xc[3], G.n, in.nrhs);
-    acct("coarse_block_kernel", (double)G.nSites * (9.0 * G.n * G.n * 8 + 2.0 * G.n * in.nrhs * 8), tag);
+    char tag[80]; snprintf(tag, sizeof(tag), "coarse %dx%dx%dx%d n %d, %d rhs%s", G.Xc[0], G.Xc[1], G.Xc[2], G.Xc[3], G.n, in.nrhs, parity < 0 ? "" : ", one parity");
+    acct("coarse_block_kernel", (double)nOut * (9.0 * G.n * G.n * 8 + 2.0 * G.n * in.nrhs * 8), tag);
   }
-#define QA_CASE(NN, RR) if (G.n == NN && in.nrhs == RR) { launchCoarseBlock<NN, RR>(arg, G.nSites); return; }
+#define QA_CASE(NN, RR) if (G.n == NN && in.nrhs == RR) { launchCoarseBlock<NN, RR>(arg, nOut); return; }
   QA_CASE(48, 24) QA_CASE(48, 8) QA_CASE(48, 16) QA_CASE(48, 32)
   QA_CASE(16, 8) QA_CASE(16, 16) QA_CASE(16, 24) QA_CASE(16, 32)
   QA_CASE(32, 8) QA_CASE(32, 16) QA_CASE(32, 24) QA_CASE(32, 32)

@@ -88,7 +88,7 @@ class BlockCoarseCycle {
     const size_t half = (size_t)src.Vh * src.ncomp * src.nrhs;
     HIP_CHECK(hipMemcpyAsync(dst.v + (size_t)par * half, src.v + (size_t)par * half, half * sizeof(float2), hipMemcpyDeviceToDevice, computeStream()));
   }
-  void apply(BlockField &out, BlockField &in, const CoarseGauge &G) { applyCoarseBlock(out, in, G); applies++; }
+  void apply(BlockField &out, BlockField &in, const CoarseGauge &G, int parity = -1) { applyCoarseBlock(out, in, G, parity); applies++; }
   // y = x - y
   void xmy(const BlockField &x, BlockField &yv) {
     blockblas::negate(yv);
@@ -97,10 +97,10 @@ class BlockCoarseCycle {
   }
 
   // out_p = in_p - Yhat_pq Yhat_qp in_p   (in: other parity zero; out: other parity zero)   reference DiracCoarsePC::M, lib/dirac_coarse.cpp:332-350
+  // (the two hops are computed on the output parity only: l.t is written on parity q alone, its other half stays zero from its creation)
   void matpc(BlockLevel &l, BlockField &out, BlockField &in) {
-    apply(*l.t, in, *l.H);
-    zeroParity(*l.t, l.p);
-    apply(out, *l.t, *l.H);
+    apply(*l.t, in, *l.H, 1 - l.p);
+    apply(out, *l.t, *l.H, l.p);
     zeroParity(out, 1 - l.p);
     xmy(in, out);
   }
@@ -109,22 +109,22 @@ class BlockCoarseCycle {
     const int p = l.p, q = 1 - p;
     blockblas::copy(*l.w1, *l.b);
     zeroParity(*l.w1, p);
-    apply(*l.w2, *l.w1, *l.H);          // parity q: Xinv b_q
+    apply(*l.w2, *l.w1, *l.H, q);       // parity q: Xinv b_q
     zeroParity(*l.w2, p);
-    apply(*l.w1, *l.w2, *l.Y);          // parity p: D_pq (Xinv b_q)
+    apply(*l.w1, *l.w2, *l.Y, p);       // parity p: D_pq (Xinv b_q)
     xmy(*l.b, *l.w1);                   // b - ...
     zeroParity(*l.w1, q);
-    apply(*l.bt, *l.w1, *l.H);          // parity p: Xinv ( . )
+    apply(*l.bt, *l.w1, *l.H, p);       // parity p: Xinv ( . )
     zeroParity(*l.bt, q);
   }
   // x_q = Xinv (b_q - D_qp x_p)   (reference DiracCoarsePC::reconstruct, :352-372); x_q is overwritten
   void reconstruct(BlockLevel &l) {
     const int p = l.p, q = 1 - p;
     zeroParity(*l.x, q);
-    apply(*l.w1, *l.x, *l.Y);           // parity q: D_qp x_p
+    apply(*l.w1, *l.x, *l.Y, q);        // parity q: D_qp x_p
     xmy(*l.b, *l.w1);
     zeroParity(*l.w1, p);
-    apply(*l.w2, *l.w1, *l.H);          // parity q: Xinv ( . )
+    apply(*l.w2, *l.w1, *l.H, q);       // parity q: Xinv ( . )
     copyParity(*l.x, *l.w2, q);
   }
   // MR on the preconditioned system, per right-hand side alpha (reference lib/inv_mr_quda.cpp:40-200)
