@@ -701,6 +701,9 @@ template <int OP, int NSUM> __global__ void __launch_bounds__(kBS) block_blas_ke
       arg.zo[q] = z; arg.yo[q] = r;
       arg.xo[q] = make_float4(r.x + d0.x, r.y + d0.y, r.z + d1.x, r.w + d1.y);
       s[0][0] += (double)r.x * r.x + (double)r.y * r.y; s[0][1] += (double)r.z * r.z + (double)r.w * r.w;
+    } else if (OP == 9) {   // y = x - y
+      const float4 x = arg.x[q], y = arg.y[q];
+      arg.yo[q] = make_float4(x.x - y.x, x.y - y.y, x.z - y.z, x.w - y.w);
     } else {
       const float4 x = arg.yo[q];
       arg.yo[q] = make_float4(-x.x, -x.y, -x.z, -x.w);
@@ -873,6 +876,13 @@ void mrUpdateDev(BlockField &x, BlockField &r, const BlockField &rin, const Bloc
   acct("mr_update_kernel", (double)x.elems() * 8.0 * ((fresh ? 4 : 5) - (needResidual ? 0 : 2)), needResidual ? "level 0" : "level 0, last step (x only)");
   hipLaunchKernelGGL(mr_update_kernel, dim3(grid), dim3(256), 0, computeStream(), (float4 *)x.v, (float4 *)r.v, (const float4 *)rin.v, (const float4 *)Ar.v, d_sums, (float)omega, x.nrhs, n4, fresh ? 1 : 0, needResidual ? 1 : 0);
   HIP_CHECK(hipGetLastError());
+}
+void xmy(const BlockField &x, BlockField &y) {   // y = x - y
+  check(x, y);
+  BArg a = {};
+  a.x = (const float4 *)x.v; a.y = (const float4 *)y.v; a.yo = (float4 *)y.v;
+  setCoef(a.c.a, nullptr, 0); setCoef(a.c.b, nullptr, 0);
+  run<9, 0>(a, x);
 }
 void negate(BlockField &x) {
   BArg a = {};

@@ -90,11 +90,7 @@ class BlockCoarseCycle {
   }
   void apply(BlockField &out, BlockField &in, const CoarseGauge &G, int parity = -1) { applyCoarseBlock(out, in, G, parity); applies++; }
   // y = x - y
-  void xmy(const BlockField &x, BlockField &yv) {
-    blockblas::negate(yv);
-    std::vector<Complex> one(nb, Complex(1.0, 0.0));
-    blockblas::caxpy(one.data(), x, yv);
-  }
+  void xmy(const BlockField &x, BlockField &yv) { blockblas::xmy(x, yv); }
 
   // out_p = in_p - Yhat_pq Yhat_qp in_p   (in: other parity zero; out: other parity zero)   reference DiracCoarsePC::M, lib/dirac_coarse.cpp:332-350
   // (the two hops are computed on the output parity only: l.t is written on parity q alone, its other half stays zero from its creation)
