@@ -24,7 +24,8 @@ from test_mg_gpu import _setup, _true_residual  # noqa: E402
 
 @pytest.mark.parametrize("outer_pc", [False, True], ids=["full-system", "even-odd-outer"])
 @pytest.mark.parametrize("X,levels,blocks,nvec,nsrc,mask", [((16, 8, 8, 16), 3, [(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)], 8, 5, 0), ((16, 16, 16, 16), 3, [(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)], 24, 12, 0),
-                                                    ((16, 8, 8, 16), 2, (4, 4, 4, 4), 8, 3, 9)], ids=["5-sources-n16", "12-sources-n48", "3-sources-partitioned-xt"])
+                                                    ((16, 8, 8, 16), 2, (4, 4, 4, 4), 8, 3, 9), ((8, 8, 8, 16), 2, (4, 4, 4, 4), 8, 1, 0)],
+                         ids=["5-sources-n16", "12-sources-n48", "3-sources-partitioned-xt", "a-single-source"])
 def test_multi_source_mg_gcr_matches_single_source_solves(qa, oracle, X, levels, blocks, nvec, nsrc, mask, outer_pc):
     kappa, mu = 0.124, 0.005
     qa.lib().qudaAmdSetPartitionMask(mask)
@@ -108,6 +109,39 @@ def test_fine_level_block_smoother(qa, oracle, action, matpc, nu_pre, nsrc, mask
     finally:
         qa.lib().qudaAmdSetPartitionMask(0)
         qa.lib().freeCloverQuda()
+
+
+def test_sources_of_different_kind_in_one_lockstep_solve(qa, oracle):
+    """random sources next to sources whose solution is a constant spinor (almost in the coarse space) and a scaled, perturbed copy of one: every
+    column is solved to its own relative tolerance and the smooth solution comes back to 1e-8.  (A source that converged earlier would stop
+    being updated — its column turns to zeros in the block cycle; with this preconditioner all of them need the same 10 iterations, which the
+    test reports.)"""
+    X, kappa, mu = (16, 8, 8, 16), 0.124, 0.005
+    gauge, ip = _setup(qa, X, kappa, mu)
+    mp = qa.multigrid_param(ip, n_level=3, geo_block=[(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)], n_vec=8, setup_maxiter=300, setup_tol=1e-5, smoother_pc=True, cycle=qa.QUDA_MG_CYCLE_VCYCLE)
+    mg = qa.Multigrid(mp)
+    try:
+        V = int(np.prod(X))
+        rng = np.random.default_rng(53)
+        smooth = np.tile(rng.random(24), V)
+        ip.inv_type_precondition = qa.QUDA_INVALID_ENUM
+        b_smooth = qa.mat(smooth, ip)
+        bs = [rng.random(V * 24), b_smooth, rng.random(V * 24), 3.0 * b_smooth + 1e-3 * rng.random(V * 24), rng.random(V * 24)]
+        ip.inv_type_precondition, ip.preconditioner = qa.QUDA_MG_INVERTER, mg.h
+        ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
+        ip.solve_type = qa.QUDA_DIRECT_PC_SOLVE
+        iters = []
+        for b in bs:
+            qa.invert(b, ip)
+            iters.append(ip.iter)
+        xs = qa.invert_multi_src(bs, ip)
+        assert abs(ip.iter - max(iters)) <= 1, (ip.iter, iters)
+        for i in range(len(bs)):
+            assert _true_residual(oracle, gauge, X, kappa, mu, xs[i], bs[i]) < 1e-10, (i, iters)
+        assert np.linalg.norm(xs[1] - smooth) < 1e-8 * np.linalg.norm(smooth)
+        print("sources of different difficulty: single-source iterations %s, lockstep %d" % (iters, ip.iter))
+    finally:
+        mg.free()
 
 
 def test_multi_source_plain_gcr(qa, oracle):
