@@ -144,6 +144,38 @@ def test_sources_of_different_kind_in_one_lockstep_solve(qa, oracle):
         mg.free()
 
 
+@pytest.mark.parametrize("cycle", ["V", "K"])
+def test_a_source_that_converges_early_is_left_alone(qa, oracle, monkeypatch, cycle):
+    """source 2 of 6 is given a tolerance 1e5 times looser (a test hook of the lockstep solver): it is finished after about half of the iterations,
+    its column of every block field turns to zeros from then on (smoother groups, restrictor quads, coarse block cycle, lockstep coarsest GCR), and the
+    other five still come out at 1e-10 in the usual number of iterations"""
+    X, kappa, mu = (16, 8, 8, 16), 0.124, 0.005
+    gauge, ip = _setup(qa, X, kappa, mu)
+    mp = qa.multigrid_param(ip, n_level=3, geo_block=[(4, 4, 4, 4), (2, 2, 2, 2), (2, 2, 2, 2)], n_vec=8, setup_maxiter=300, setup_tol=1e-5, smoother_pc=True,
+                            cycle=qa.QUDA_MG_CYCLE_VCYCLE if cycle == "V" else qa.QUDA_MG_CYCLE_RECURSIVE)
+    mg = qa.Multigrid(mp)
+    try:
+        V = int(np.prod(X))
+        rng = np.random.default_rng(59)
+        bs = [rng.random(V * 24) for _ in range(6)]
+        ip.inv_type_precondition, ip.preconditioner = qa.QUDA_MG_INVERTER, mg.h
+        ip.tol_precondition, ip.maxiter_precondition, ip.precondition_cycle, ip.omega = 1e-1, 1, 1, 1.0
+        ip.solve_type = qa.QUDA_DIRECT_PC_SOLVE
+        ip.reliable_delta = 1e-6      # residual checks (and with them the decision that a source is finished) at every restart only otherwise
+        qa.invert(bs[0], ip)
+        it_single = ip.iter
+        monkeypatch.setenv("QUDA_AMD_MULTISRC_TEST_LOOSE", "2:1e5")
+        xs = qa.invert_multi_src(bs, ip)
+        monkeypatch.delenv("QUDA_AMD_MULTISRC_TEST_LOOSE")
+        assert abs(ip.iter - it_single) <= 1, (ip.iter, it_single)
+        res = [_true_residual(oracle, gauge, X, kappa, mu, xs[i], bs[i]) for i in range(6)]
+        print("early source (%s-cycle): residuals %s, %d iterations" % (cycle, ["%.1e" % r for r in res], ip.iter))
+        assert all(r < 1e-10 for i, r in enumerate(res) if i != 2), res
+        assert 1e-10 < res[2] < 1e-4, res      # stopped early, at its own tolerance
+    finally:
+        mg.free()
+
+
 def test_multi_source_plain_gcr(qa, oracle):
     """without a preconditioner the lockstep solver is nsrc independent GCR(20) solves sharing their Krylov index"""
     X, kappa, mu = (8, 8, 8, 8), 0.124, 0.005
