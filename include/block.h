@@ -105,6 +105,9 @@ void bicgstabDots(Complex *ts, double *tt, Complex *r0s, Complex *r0t, const Blo
 void bicgstabFused(double *r2, const Complex *a, const Complex *w, const Complex *b, BlockField &p, BlockField &r, BlockField &x, const BlockField &t, const BlockField &v);
 // minimal-residual step, coefficient from device sums [Re (Ar, r) | Im (Ar, r) | |Ar|^2][nrhs]: x = [x +] alpha rin, r = rin - alpha Ar, alpha = omega (Ar, r) / |Ar|^2
 void mrUpdateDev(BlockField &x, BlockField &r, const BlockField &rin, const BlockField &Ar, const double *d_sums, double omega, bool fresh, bool needResidual = true);   // needResidual = false: the last step of a post-smoother, only x is updated
+// two minimal-residual steps in one sweep from w1 = A r, w2 = A w1 and the epilogue sums of the two launches (block.hip mr2_update_kernel)
+void mr2UpdateDev(BlockField &x, BlockField &r, const BlockField &rin, const BlockField &w1, const BlockField &w2, const double *d_s3, const double *d_s7, double omega, bool fresh,
+                  bool needResidual = true);
 void xmy(const BlockField &x, BlockField &y);                                         // y = x - y
 void negate(BlockField &x);                                                           // x = -x
 }  // namespace blockblas

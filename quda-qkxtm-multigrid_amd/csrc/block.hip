@@ -868,6 +868,66 @@ __global__ void __launch_bounds__(256) mr_update_kernel(float4 *x, float4 *r, co
     }
   }
 }
+// TWO minimal-residual steps as one sweep.  With w1 = A r and w2 = A w1 (two operator applications, no update between them) the second step's
+// residual and its image are r1 = r - a0 w1, A r1 = w1 - a0 w2, so both coefficients follow from sums the stencil epilogues leave behind:
+//   s3 (mode 3 of the launch that made w1):  (w1, r), |w1|^2        s7 (mode 2 of the launch that made w2, a = r):  (w2, w1), |w2|^2, (r, w1), (r, w2)
+//   a0 = omega (w1, r) / |w1|^2
+//   (A r1, r1) = (w1, r) - a0 |w1|^2 - conj(a0) (w2, r) + |a0|^2 (w2, w1)        |A r1|^2 = |w1|^2 - 2 Re(conj(a0) (w2, w1)) + |a0|^2 |w2|^2
+//   a1 = omega (A r1, r1) / |A r1|^2
+//   x [+]= (a0 + a1) r - a0 a1 w1        r <- r - (a0 + a1) w1 + a0 a1 w2
+// — 6 field passes (4 without the residual) instead of the 10 of two single steps, the same iterates up to rounding.
+__global__ void __launch_bounds__(256) mr2_update_kernel(float4 *x, float4 *r, const float4 *rin, const float4 *w1, const float4 *w2, const double *s3, const double *s7, double omega, int nrhs,
+                                                        long n4, int fresh, int needR) {
+  const int i = threadIdx.x % nrhs;
+  float2 cs, cp;   // a0 + a1, a0 a1
+  {
+    const double cr = s3[i], ci = s3[nrhs + i], n1 = s3[2 * nrhs + i];
+    const double dr = s7[i], di = s7[nrhs + i], n2 = s7[2 * nrhs + i], er = s7[5 * nrhs + i], ei = s7[6 * nrhs + i];   // d = (w2, w1), e = (r, w2): (w2, r) = conj(e)
+    double a0r = 0, a0i = 0, a1r = 0, a1i = 0;
+    if (n1 > 0.0) { a0r = omega * cr / n1; a0i = omega * ci / n1; }
+    const double a02 = a0r * a0r + a0i * a0i;
+    // conj(a0) conj(e) = conj(a0 e)
+    const double ae_r = a0r * er - a0i * ei, ae_i = a0r * ei + a0i * er;
+    const double nr = cr - a0r * n1 - ae_r + a02 * dr, ni = ci - a0i * n1 + ae_i + a02 * di;
+    const double den = n1 - 2.0 * (a0r * dr + a0i * di) + a02 * n2;   // Re(conj(a0) d) = a0r dr + a0i di
+    if (den > 0.0) { a1r = omega * nr / den; a1i = omega * ni / den; }
+    cs = make_float2((float)(a0r + a1r), (float)(a0i + a1i));
+    cp = make_float2((float)(a0r * a1r - a0i * a1i), (float)(a0r * a1i + a0i * a1r));
+  }
+  constexpr int UN = 2;
+  const long stride = (long)gridDim.x * 256;
+  for (long q0i = blockIdx.x * 256l + threadIdx.x; q0i < n4; q0i += UN * stride) {
+    float4 rv[UN], av[UN], bv[UN], xv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const long q = q0i + u * stride;
+      if (q < n4) { rv[u] = rin[q]; av[u] = w1[q]; bv[u] = needR ? w2[q] : make_float4(0.f, 0.f, 0.f, 0.f); xv[u] = fresh ? make_float4(0.f, 0.f, 0.f, 0.f) : x[q]; }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const long q = q0i + u * stride;
+      if (q >= n4) continue;
+      const float2 sr0 = cmul(cs, make_float2(rv[u].x, rv[u].y)), sr1 = cmul(cs, make_float2(rv[u].z, rv[u].w));
+      const float2 pa0 = cmul(cp, make_float2(av[u].x, av[u].y)), pa1 = cmul(cp, make_float2(av[u].z, av[u].w));
+      x[q] = make_float4(xv[u].x + sr0.x - pa0.x, xv[u].y + sr0.y - pa0.y, xv[u].z + sr1.x - pa1.x, xv[u].w + sr1.y - pa1.y);
+      if (needR) {
+        const float2 sa0 = cmul(cs, make_float2(av[u].x, av[u].y)), sa1 = cmul(cs, make_float2(av[u].z, av[u].w));
+        const float2 pb0 = cmul(cp, make_float2(bv[u].x, bv[u].y)), pb1 = cmul(cp, make_float2(bv[u].z, bv[u].w));
+        r[q] = make_float4(rv[u].x - sa0.x + pb0.x, rv[u].y - sa0.y + pb0.y, rv[u].z - sa1.x + pb1.x, rv[u].w - sa1.y + pb1.y);
+      }
+    }
+  }
+}
+void mr2UpdateDev(BlockField &x, BlockField &r, const BlockField &rin, const BlockField &w1, const BlockField &w2, const double *d_s3, const double *d_s7, double omega, bool fresh, bool needResidual) {
+  check(x, r); check(x, rin); check(x, w1); check(x, w2);
+  if (!x.pairMajor || 256 % x.nrhs) errorQuda("minimal-residual update: 12-component fields with 4 or 8 right-hand sides (got %d x %d)", x.ncomp, x.nrhs);
+  const long n4 = (long)x.elems() / 2;
+  const unsigned grid = (unsigned)std::min<long>((n4 + 2 * 256 - 1) / (2 * 256), 8192);
+  acct("mr_update_kernel", (double)x.elems() * 8.0 * ((fresh ? 3 : 4) + (needResidual ? 2 : 0)), needResidual ? "level 0, two steps" : "level 0, two steps (x only)");
+  hipLaunchKernelGGL(mr2_update_kernel, dim3(grid), dim3(256), 0, computeStream(), (float4 *)x.v, (float4 *)r.v, (const float4 *)rin.v, (const float4 *)w1.v, (const float4 *)w2.v, d_s3, d_s7, omega,
+                     x.nrhs, n4, fresh ? 1 : 0, needResidual ? 1 : 0);
+  HIP_CHECK(hipGetLastError());
+}
 void mrUpdateDev(BlockField &x, BlockField &r, const BlockField &rin, const BlockField &Ar, const double *d_sums, double omega, bool fresh, bool needResidual) {
   check(x, r); check(x, rin); check(x, Ar);
   if (!x.pairMajor || 256 % x.nrhs) errorQuda("minimal-residual update: 12-component fields with 4 or 8 right-hand sides (got %d x %d)", x.ncomp, x.nrhs);

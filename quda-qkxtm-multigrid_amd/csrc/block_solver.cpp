@@ -313,8 +313,8 @@ static BlockCoarseCycle *blockCoarseCreate(MG &top, int nb, const MGParam *paren
 // solver.cpp with device-side scalars (fp32 fields, fp64 sums, rank-local), reference lib/inv_mr_quda.cpp:40-200.
 struct FineGroup {
   int first = 0, n = 0, nrhs = 0;   // sources [first, first + n) are the first n columns of blocks with nrhs columns
-  BlockField *B = nullptr, *X = nullptr, *R = nullptr, *AR = nullptr, *T = nullptr;
-  double *d_sums = nullptr;
+  BlockField *B = nullptr, *X = nullptr, *R = nullptr, *AR = nullptr, *T = nullptr, *W2 = nullptr;
+  double *d_sums = nullptr, *d_sums7 = nullptr;
 };
 class BlockFineSmoother {
  public:
@@ -325,22 +325,25 @@ class BlockFineSmoother {
   int par = 0;                         // parity of the preconditioned system
   int nuPre = 0, nuPost = 0;
   bool globalSums = false;             // the MR sums cross ranks
+  bool twoStep = true;                 // QUDA_AMD_MULTISRC_MR_PAIRS=0: one update per step
   float *tmat[2] = {nullptr, nullptr};   // twisted clover: dense (A + i a g5)^-1 per parity
   size_t tmatBytes = 0;
   std::vector<FineGroup> groups;
 
   ~BlockFineSmoother() {
     for (FineGroup &g : groups) {
-      for (BlockField *f : {g.B, g.X, g.R, g.AR, g.T}) delete f;
+      for (BlockField *f : {g.B, g.X, g.R, g.AR, g.T, g.W2}) delete f;
       if (g.d_sums) poolDeviceFree(g.d_sums, 0);
+      if (g.d_sums7) poolDeviceFree(g.d_sums7, 0);
     }
     for (int p = 0; p < 2; p++) if (tmat[p]) poolDeviceFree(tmat[p], tmatBytes);
   }
   static float2 *ghostOf(BlockField &f) { return f.nGhost ? f.v + f.elems() : nullptr; }
   // out = in - kappa^2 A^-1 D_pq A^-1 D_qp in     (reference DiracTwistedMassPC::M / DiracTwistedCloverPC::M, symmetric preconditioning);
   // dots: (out, in) and |out|^2 per right-hand side into g.d_sums
-  void matpc(FineGroup &g, BlockField &out, BlockField &in, bool dots, const GaugeField *links = nullptr) {
-    const FineBlockDots d = {nullptr, 3};
+  // dots: 0 none; 3: (out, in), |out|^2 -> g.d_sums; 2: the seven sums with a = `dotA` -> g.d_sums7 (rank-local device sums; sums across ranks go the mode-3 way only)
+  void matpc(FineGroup &g, BlockField &out, BlockField &in, int dots, const GaugeField *links = nullptr, const BlockField *dotA = nullptr) {
+    const FineBlockDots d = {dots == 2 ? dotA->v : nullptr, dots == 2 ? 2 : 3};
     const int p = par, q = 1 - par;
     const GaugeField &W = links ? *links : *U;
     if (tmat[0]) {
@@ -351,6 +354,7 @@ class BlockFineSmoother {
       applyFineBlockParity(out.v, in.v, g.T->v, in.nrhs, W, p, 1.0, 0.0, -kappa * kappa * binv, -a, nullptr, 0, ghostOf(*g.T), dots ? &d : nullptr);
     }
     if (!dots) return;
+    if (dots == 2) { fineBlockDotsFinishDev(g.d_sums7, in.nrhs, 2); return; }
     if (!globalSums) { fineBlockDotsFinishDev(g.d_sums, in.nrhs, 3); return; }
     // sums over all ranks (smoother with global_reduction on a grid-decomposed lattice): through the host, one round trip per step and group
     double sums[3 * 8];
@@ -360,15 +364,24 @@ class BlockFineSmoother {
   }
   // nu MR steps on (X, R); fresh: X is not defined yet and the residual is `first` (the source itself), not R
   void mr(FineGroup &g, int nu, BlockField *first, bool needResidual) {
-    for (int k = 0; k < nu; k++) {
+    int k = 0;
+    // pairs of steps as one update (blockblas::mr2UpdateDev: w1 = A r, w2 = A w1, both coefficients from the epilogue sums) while two or more are left
+    while (twoStep && !globalSums && k + 1 < nu) {
       BlockField &rin = (k == 0 && first) ? *first : *g.R;
-      matpc(g, *g.AR, rin, true);
+      matpc(g, *g.AR, rin, 3);
+      matpc(g, *g.W2, *g.AR, 2, nullptr, &rin);
+      blockblas::mr2UpdateDev(*g.X, *g.R, rin, *g.AR, *g.W2, g.d_sums, g.d_sums7, omega, k == 0 && first, needResidual || k + 2 < nu);
+      k += 2;
+    }
+    for (; k < nu; k++) {
+      BlockField &rin = (k == 0 && first) ? *first : *g.R;
+      matpc(g, *g.AR, rin, 3);
       blockblas::mrUpdateDev(*g.X, *g.R, rin, *g.AR, g.d_sums, omega, k == 0 && first, needResidual || k + 1 < nu);
     }
   }
   // R = B - M X
   void residual(FineGroup &g) {
-    matpc(g, *g.AR, *g.X, false);
+    matpc(g, *g.AR, *g.X, 0);
     std::vector<Complex> zero(g.nrhs, Complex(0.0, 0.0)), mone(g.nrhs, Complex(-1.0, 0.0));
     blockblas::cxpaypbz(*g.B, zero.data(), *g.B, mone.data(), *g.AR);   // AR = B - AR
     std::swap(g.R, g.AR);
@@ -404,6 +417,7 @@ static BlockFineSmoother *blockFineCreate(const Dirac &dirac, const SolverParam 
   f->par = mt == QUDA_MATPC_ODD_ODD ? 1 : 0;
   f->nuPre = pre.maxiter; f->nuPost = post.maxiter;
   f->globalSums = pre.global_reduction && commReductionsNeeded();
+  { const char *e = getenv("QUDA_AMD_MULTISRC_MR_PAIRS"); f->twoStep = !(e && !atoi(e)); }
   const int Vh = U->geom.Vh;
   if (tmc) {
     f->tmatBytes = (size_t)Vh * 144 * sizeof(float);
@@ -418,8 +432,9 @@ static BlockFineSmoother *blockFineCreate(const Dirac &dirac, const SolverParam 
     const int left = nsrc - first;
     g.first = first; g.n = left >= 8 ? 8 : left; g.nrhs = g.n > 4 ? 8 : 4;
     g.B = new BlockField(Vh, 12, g.nrhs, nGhost); g.X = new BlockField(Vh, 12, g.nrhs, nGhost); g.R = new BlockField(Vh, 12, g.nrhs, nGhost);
-    g.AR = new BlockField(Vh, 12, g.nrhs, nGhost); g.T = new BlockField(Vh, 12, g.nrhs, nGhost);
+    g.AR = new BlockField(Vh, 12, g.nrhs, nGhost); g.T = new BlockField(Vh, 12, g.nrhs, nGhost); g.W2 = new BlockField(Vh, 12, g.nrhs, nGhost);
     g.d_sums = (double *)poolDeviceMalloc(3 * 8 * sizeof(double));
+    g.d_sums7 = (double *)poolDeviceMalloc(7 * 8 * sizeof(double));
     f->groups.push_back(g);
     first += g.n;
   }
@@ -649,7 +664,7 @@ bool MG::blockApplyLast(std::vector<ColorSpinorField *> &out, const Dirac &pc, c
   for (FineGroup &g : F.groups) {
     ColorSpinorField *dst[8];
     for (int j = 0; j < g.n; j++) dst[j] = active[g.first + j] ? out[g.first + j] : nullptr;
-    F.matpc(g, *g.AR, *g.X, false, W);
+    F.matpc(g, *g.AR, *g.X, 0, W);
     blockUnpackParity(dst, g.n, *g.AR);
   }
   return true;
