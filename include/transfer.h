@@ -48,6 +48,9 @@ class Transfer {
   bool canQuad() const;
   void R4(ColorSpinorField *const coarse[4], const ColorSpinorField *const fine[4]) const;
   void P4(ColorSpinorField *const fine[4], const ColorSpinorField *const coarse[4]) const;
+  // the same with the four fine vectors in columns col0 .. col0 + 3 of a pair-major block field (block.h) of the subset parity: `panel` = its data, nrhs its columns
+  void R4Block(ColorSpinorField *const coarse[4], const float2 *panel, int nrhs, int col0) const;
+  void P4Block(float2 *panel, int nrhs, int col0, bool accumulate, const ColorSpinorField *const coarse[4]) const;
   // both halves of the Galerkin split in one pass over V: `leaving` = R over the fine sites whose dir-neighbour lies outside
   // their aggregate, `staying` = R over the others (equal to R(.., dir, 1) and R(.., dir, 0))
   void RSplit(ColorSpinorField &leaving, ColorSpinorField &staying, const ColorSpinorField &fine, int dir) const;

@@ -473,6 +473,13 @@ static bool blockQuadTransfer() {
   return on != 0;
 }
 
+// QUDA_AMD_MULTISRC_DIRECT=0: the quads go through fields (unpack, R4 / P4, pack) instead of their block columns
+static bool blockDirectTransfer() {
+  static int on = -1;
+  if (on < 0) { const char *e = getenv("QUDA_AMD_MULTISRC_DIRECT"); on = (e && !atoi(e)) ? 0 : 1; }
+  return on != 0;
+}
+
 void MG::blockRelease() { delete blockState; blockState = nullptr; }
 
 bool MG::blockPrepare(int nsrc) {
@@ -519,11 +526,31 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
   g_msStats[0]++;
   if (blockSmooth) g_msStats[1]++;
   st.solutionOnBlocks = blockSmooth;
+  // quads of active sources for the four-source transfers; with the block smoother a quad sits inside one smoother group and (unless the local term has
+  // to be applied to the residual first) is restricted from / prolongated onto its block columns directly
+  const bool quad = transfer->canQuad() && blockQuadTransfer();
+  const bool blockDirect = blockSmooth && quad && !(fullResidual && symmetric) && blockDirectTransfer();
+  std::vector<char> quadAt(nsrc + 4, 0), inQuad(nsrc + 4, 0);
+  auto groupOf = [&](int i, int &col0) -> FineGroup * {
+    for (FineGroup &g : st.fine->groups) if (i >= g.first && i + 3 < g.first + g.n) { col0 = i - g.first; return &g; }
+    return nullptr;
+  };
+  auto planQuads = [&](bool fieldsKnown) {
+    for (int i = 0; quad && i + 4 <= nsrc;) {
+      bool ok = true;
+      int col0;
+      for (int s = 0; s < 4; s++) ok = ok && active[i + s] && (!fieldsKnown || rin[i + s]->Precision() == QUDA_SINGLE_PRECISION);
+      if (ok && blockSmooth && !groupOf(i, col0)) ok = false;
+      if (ok) { quadAt[i] = 1; for (int s = 0; s < 4; s++) inQuad[i + s] = 1; i += 4; } else i++;
+    }
+  };
+  if (blockSmooth) planQuads(false);
   if (blockSmooth) {
     BlockFineSmoother &F = *st.fine;
     for (FineGroup &g : F.groups) {
       const ColorSpinorField *src[8];
       ColorSpinorField *dst[8];
+      bool anyField = false;
       for (int j = 0; j < g.n; j++) {
         const int i = g.first + j;
         src[j] = active[i] ? b[i] : nullptr;
@@ -532,16 +559,16 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
         x[i]->twistFlavor = b[i]->twistFlavor;
         ColorSpinorField &rp = odd ? st.r[i]->Odd() : st.r[i]->Even();
         st.r[i]->twistFlavor = rp.twistFlavor = b[i]->twistFlavor;
-        dst[j] = &rp;
+        if (!(blockDirect && inQuad[i])) { dst[j] = &rp; anyField = true; }
       }
       blockPackParity(*g.B, src, g.n);
       if (F.nuPre > 0) {
         F.mr(g, F.nuPre, g.B, true);
-        blockUnpackParity(dst, g.n, *g.R);
+        if (anyField) blockUnpackParity(dst, g.n, *g.R);
       }
       for (int j = 0; j < g.n; j++) {
         const int i = g.first + j;
-        if (!active[i]) continue;
+        if (!active[i] || (blockDirect && inQuad[i])) continue;
         if (F.nuPre > 0) {
           if (fullResidual && symmetric) dirac.localTermParity(*dst[j], *dst[j], odd ? 1 : 0);
           rin[i] = dst[j];
@@ -576,17 +603,18 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
   }
   transfer->setSiteSubset(QUDA_PARITY_SITE_SUBSET, odd ? QUDA_ODD_PARITY : QUDA_EVEN_PARITY);
   // V (2304 B per fine site) is the traffic of the restrictor and the prolongator: groups of four active sources share one pass over it
-  const bool quad = transfer->canQuad() && blockQuadTransfer();
-  auto quadGroup = [&](int i) {
-    if (!quad || i + 4 > nsrc) return false;
-    for (int s = 0; s < 4; s++) if (!active[i + s] || rin[i + s]->Precision() != QUDA_SINGLE_PRECISION) return false;
-    return true;
-  };
+  if (!blockSmooth) planQuads(true);
   for (int i = 0; i < st.nb;) {
-    if (quadGroup(i)) {
+    if (i < nsrc && quadAt[i]) {
       ColorSpinorField *c4[4] = {st.rc[i], st.rc[i + 1], st.rc[i + 2], st.rc[i + 3]};
-      const ColorSpinorField *f4[4] = {rin[i], rin[i + 1], rin[i + 2], rin[i + 3]};
-      transfer->R4(c4, f4);
+      if (blockDirect) {
+        int col0;
+        FineGroup *g = groupOf(i, col0);
+        transfer->R4Block(c4, (st.fine->nuPre > 0 ? g->R : g->B)->v, g->nrhs, col0);
+      } else {
+        const ColorSpinorField *f4[4] = {rin[i], rin[i + 1], rin[i + 2], rin[i + 3]};
+        transfer->R4(c4, f4);
+      }
       g_msStats[2]++;
       i += 4;
       continue;
@@ -607,14 +635,17 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
       (*coarse_solver)(*st.xc[i], *st.rc[i]);
     }
   }
+  // prolongation: sources outside the quads (and all of them without the block smoother) through fields ...
   for (int i = 0; i < nsrc;) {
-    if (quadGroup(i)) {
-      ColorSpinorField *f4[4];
-      const ColorSpinorField *c4[4] = {st.xc[i], st.xc[i + 1], st.xc[i + 2], st.xc[i + 3]};
-      for (int s = 0; s < 4; s++) f4[s] = odd ? &st.r[i + s]->Odd() : &st.r[i + s]->Even();
-      transfer->P4(f4, c4);
-      g_msStats[2]++;
-      if (!blockSmooth) for (int s = 0; s < 4; s++) blas::xpy(*f4[s], *x[i + s]);
+    if (quadAt[i]) {
+      if (!blockDirect) {
+        ColorSpinorField *f4[4];
+        const ColorSpinorField *c4[4] = {st.xc[i], st.xc[i + 1], st.xc[i + 2], st.xc[i + 3]};
+        for (int s = 0; s < 4; s++) f4[s] = odd ? &st.r[i + s]->Odd() : &st.r[i + s]->Even();
+        transfer->P4(f4, c4);
+        g_msStats[2]++;
+        if (!blockSmooth) for (int s = 0; s < 4; s++) blas::xpy(*f4[s], *x[i + s]);
+      }
       i += 4;
       continue;
     }
@@ -625,25 +656,38 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
     }
     i++;
   }
-  transfer->setSiteSubset(QUDA_FULL_SITE_SUBSET, QUDA_INVALID_PARITY);
   if (blockSmooth) {
     BlockFineSmoother &F = *st.fine;
     for (FineGroup &g : F.groups) {
       const ColorSpinorField *corr[8];
       ColorSpinorField *dst[8];
+      bool viaFields = false;
       for (int j = 0; j < g.n; j++) {
         const int i = g.first + j;
-        corr[j] = active[i] ? (odd ? &st.r[i]->Odd() : &st.r[i]->Even()) : nullptr;
+        const bool direct = blockDirect && inQuad[i];
+        corr[j] = active[i] && !direct ? (odd ? &st.r[i]->Odd() : &st.r[i]->Even()) : nullptr;
         dst[j] = active[i] ? x[i] : nullptr;
+        viaFields = viaFields || (active[i] && !direct);
       }
-      blockPackParity(*g.X, corr, g.n, F.nuPre > 0);   // X (+)= P e
+      // X (+)= P e: corrections that went through fields are packed onto X (columns without one get zeros, or stay as they are when X already
+      // holds the pre-smoothed solution); ... the quads are prolongated straight onto their columns
+      if (viaFields || F.nuPre == 0) blockPackParity(*g.X, corr, g.n, F.nuPre > 0);   // (after pre-smoothing the idle and padding columns of X are zero already)
+      for (int j = 0; j + 3 < g.n; j++) {
+        const int i = g.first + j;
+        if (!blockDirect || !quadAt[i]) continue;
+        const ColorSpinorField *c4[4] = {st.xc[i], st.xc[i + 1], st.xc[i + 2], st.xc[i + 3]};
+        transfer->P4Block(g.X->v, g.nrhs, j, true, c4);
+        g_msStats[2]++;
+      }
       if (F.nuPost > 0) {
         F.residual(g);
         F.mr(g, F.nuPost, nullptr, false);
       }
       blockUnpackParity(dst, g.n, *g.X);
     }
+    transfer->setSiteSubset(QUDA_FULL_SITE_SUBSET, QUDA_INVALID_PARITY);
   } else {
+    transfer->setSiteSubset(QUDA_FULL_SITE_SUBSET, QUDA_INVALID_PARITY);
     for (int i = 0; i < nsrc; i++) if (active[i]) (*st.post[i])(*x[i], *b[i]);
   }
   blas::setGlobalReduction(true);

@@ -310,8 +310,12 @@ __global__ void __launch_bounds__(256) restrict_stream_kernel(CoarseVec out, Fin
 // of a step meeting the site's components of four sources; the reduce-scatter butterfly that summed four STEPS of one source there sums one step
 // of four SOURCES here (16 values -> lanes 0..15). ----
 struct Src4 { FineVec f[4]; CoarseVec c[4]; };
-template <int NCF, int NVEC, int NV>
-__global__ void __launch_bounds__(256) restrict_stream4_kernel(Src4 a, const void *V, const int *block_to_fine, int blockVol, MaskArg mask, AggMap amap) {
+// BLK: the four fine vectors are columns col0 .. col0 + 3 of a pair-major block field of ONE parity (block.h; the multi-source smoother keeps its
+// residuals and solutions there): word (x 6 + k) nrhs + column holds components 2k, 2k + 1 — no unpacking into fields in front of the restrictor, no
+// packing behind the prolongator
+struct Blk4 { float4 *panel; int nrhs, col0, parity, Vh, accumulate; };
+template <int NCF, int NVEC, int NV, bool BLK = false>
+__global__ void __launch_bounds__(256) restrict_stream4_kernel(Src4 a, const void *V, const int *block_to_fine, int blockVol, MaskArg mask, AggMap amap, Blk4 blk) {
   constexpr int K = 4 * NCF, KH = K / 2, NVP = NVEC / 2, NST = 2 * NVP;
   typedef typename VRaw<false>::type raw_t;
   __shared__ float4 part[4][NST][4];   // [wave][chirality * NVP + vector pair][source]
@@ -324,11 +328,26 @@ __global__ void __launch_bounds__(256) restrict_stream4_kernel(Src4 a, const voi
   bool have = false;
   if (b < blockVol && mask_keep(mask, b)) {
     const int f = block_to_fine[(size_t)A * blockVol + b];
-    const int parity = f >= a.f[0].Vh, x = f - parity * a.f[0].Vh;
-    if (a.f[0].v[parity]) {
-      have = true;
+    if constexpr (BLK) {
+      const int parity = f >= blk.Vh, x = f - parity * blk.Vh;
+      if (parity == blk.parity) {
+        have = true;
+        const float4 *p = blk.panel + (size_t)x * 6 * blk.nrhs + blk.col0;
 #pragma unroll
-      for (int s = 0; s < 4; s++) load_fine_site<NV, K>(r[s], a.f[s].v[parity], a.f[s].stride, x);
+        for (int kk = 0; kk < K / 2; kk++)
+#pragma unroll
+          for (int s = 0; s < 4; s++) {
+            const float4 w = p[kk * blk.nrhs + s];
+            r[s][2 * kk] = make_float2(w.x, w.y); r[s][2 * kk + 1] = make_float2(w.z, w.w);
+          }
+      }
+    } else {
+      const int parity = f >= a.f[0].Vh, x = f - parity * a.f[0].Vh;
+      if (a.f[0].v[parity]) {
+        have = true;
+#pragma unroll
+        for (int s = 0; s < 4; s++) load_fine_site<NV, K>(r[s], a.f[s].v[parity], a.f[s].stride, x);
+      }
     }
   }
   if (__builtin_amdgcn_ballot_w64(have) == 0) {   // wave-uniform
@@ -395,8 +414,8 @@ __global__ void __launch_bounds__(256) restrict_stream4_kernel(Src4 a, const voi
     ob[((size_t)(c0 + 1) * o.stride + xc) * 2] = t.z; ob[((size_t)(c0 + 1) * o.stride + xc) * 2 + 1] = t.w;
   }
 }
-template <int NCF, int NVEC, int NV>
-__global__ void __launch_bounds__(256) prolong4_kernel(Src4 a, const void *V, const int *block_to_fine, int blockVol, AggMap amap) {
+template <int NCF, int NVEC, int NV, bool BLK = false>
+__global__ void __launch_bounds__(256) prolong4_kernel(Src4 a, const void *V, const int *block_to_fine, int blockVol, AggMap amap, Blk4 blk) {
   constexpr int K = 4 * NCF, KH = K / 2, NVP = NVEC / 2;
   typedef typename VRaw<false>::type raw_t;
   __shared__ float2 xc_s[4][2 * NVEC];
@@ -411,8 +430,9 @@ __global__ void __launch_bounds__(256) prolong4_kernel(Src4 a, const void *V, co
   __syncthreads();
   if (b >= blockVol) return;
   const int f = block_to_fine[(size_t)A * blockVol + b];
-  const int parity = f >= a.f[0].Vh, x = f - parity * a.f[0].Vh;
-  if (!a.f[0].v[parity]) return;   // this parity is absent from single-parity output fields
+  const int fVh = BLK ? blk.Vh : a.f[0].Vh;
+  const int parity = f >= fVh, x = f - parity * fVh;
+  if (BLK ? parity != blk.parity : !a.f[0].v[parity]) return;   // this parity is absent from single-parity output fields
   pkf2 acc[4][K];
 #pragma unroll
   for (int s = 0; s < 4; s++)
@@ -450,6 +470,18 @@ __global__ void __launch_bounds__(256) prolong4_kernel(Src4 a, const void *V, co
       if (ph == 0) vload(w0, vp + 3); else if (ph == 1) vload(w1, vp + 3); else vload(w2, vp + 3);
       __builtin_amdgcn_sched_barrier(0);
     }
+  }
+  if constexpr (BLK) {
+    float4 *p = blk.panel + (size_t)x * 6 * blk.nrhs + blk.col0;
+#pragma unroll
+    for (int kk = 0; kk < K / 2; kk++)
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        float4 o = make_float4(acc[s][2 * kk].x, acc[s][2 * kk].y, acc[s][2 * kk + 1].x, acc[s][2 * kk + 1].y);
+        if (blk.accumulate) { const float4 w = p[kk * blk.nrhs + s]; o.x += w.x; o.y += w.y; o.z += w.z; o.w += w.w; }
+        p[kk * blk.nrhs + s] = o;
+      }
+    return;
   }
 #pragma unroll
   for (int s = 0; s < 4; s++) {
@@ -1561,9 +1593,9 @@ void Transfer::R4(ColorSpinorField *const coarse[4], const ColorSpinorField *con
     acct("restrict_stream4_kernel", frac * fineVol * ((double)fineSpin * fineColor * Nvec * 8 + 4.0 * fineSpin * fineColor * 8.0) + 4.0 * nAgg * 2 * Nvec * 8, "level 0 -> coarse, 4 sources");
   }
   switch (Nvec) {
-    case 8: hipLaunchKernelGGL((restrict_stream4_kernel<3, 8, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, m, aggMapOf(*this)); break;
-    case 24: hipLaunchKernelGGL((restrict_stream4_kernel<3, 24, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, m, aggMapOf(*this)); break;
-    default: hipLaunchKernelGGL((restrict_stream4_kernel<3, 32, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, m, aggMapOf(*this)); break;
+    case 8: hipLaunchKernelGGL((restrict_stream4_kernel<3, 8, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, m, aggMapOf(*this), Blk4{}); break;
+    case 24: hipLaunchKernelGGL((restrict_stream4_kernel<3, 24, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, m, aggMapOf(*this), Blk4{}); break;
+    default: hipLaunchKernelGGL((restrict_stream4_kernel<3, 32, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, m, aggMapOf(*this), Blk4{}); break;
   }
   HIP_CHECK(hipGetLastError());
   flops_ += 4 * 8ull * fineSpin * fineColor * Nvec * fineVol;
@@ -1586,12 +1618,50 @@ void Transfer::P4(ColorSpinorField *const fine[4], const ColorSpinorField *const
     acct("prolong4_kernel", frac * fineVol * ((double)fineSpin * fineColor * Nvec * 8 + 4.0 * fineSpin * fineColor * 8.0) + 4.0 * nAgg * 2 * Nvec * 8, "coarse -> level 0, 4 sources");
   }
   switch (Nvec) {
-    case 8: hipLaunchKernelGGL((prolong4_kernel<3, 8, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, amap); break;
-    case 24: hipLaunchKernelGGL((prolong4_kernel<3, 24, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, amap); break;
-    default: hipLaunchKernelGGL((prolong4_kernel<3, 32, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, amap); break;
+    case 8: hipLaunchKernelGGL((prolong4_kernel<3, 8, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, amap, Blk4{}); break;
+    case 24: hipLaunchKernelGGL((prolong4_kernel<3, 24, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, amap, Blk4{}); break;
+    default: hipLaunchKernelGGL((prolong4_kernel<3, 32, 4>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, amap, Blk4{}); break;
   }
   HIP_CHECK(hipGetLastError());
   flops_ += 4 * 8ull * fineSpin * fineColor * Nvec * fineVol;
+}
+
+// ... with the fine vectors in four columns of a pair-major block field of one parity (block.h): the multi-source smoother's residuals in, its solutions out
+void Transfer::R4Block(ColorSpinorField *const coarse[4], const float2 *panel, int nrhs, int col0) const {
+  if (!canQuad() || site_subset != QUDA_PARITY_SITE_SUBSET) errorQuda("four-source restrictor on block fields: fine level, single-parity transfers");
+  Src4 a;
+  memset(&a, 0, sizeof(a));
+  for (int s = 0; s < 4; s++) a.c[s] = coarseVec(*coarse[s]);
+  const Blk4 blk = {reinterpret_cast<float4 *>(const_cast<float2 *>(panel)), nrhs, col0, subset_parity == QUDA_ODD_PARITY ? 1 : 0, (int)(fineVol / 2), 0};
+  MaskArg m;
+  m.dir = -1; m.boundary = 0; m.pm = parityMajor ? 1 : 0;
+  for (int d = 0; d < 4; d++) { m.bs[d] = geo_bs[d]; m.single[d] = Xc[d] == 1; }
+  const int threads = (blockVol + 63) / 64 * 64;
+  acct("restrict_stream4_kernel", 0.5 * fineVol * ((double)fineSpin * fineColor * Nvec * 8 + 4.0 * fineSpin * fineColor * 8.0) + 4.0 * nAgg * 2 * Nvec * 8, "level 0 (block columns) -> coarse, 4 sources");
+  switch (Nvec) {
+    case 8: hipLaunchKernelGGL((restrict_stream4_kernel<3, 8, 4, true>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, m, aggMapOf(*this), blk); break;
+    case 24: hipLaunchKernelGGL((restrict_stream4_kernel<3, 24, 4, true>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, m, aggMapOf(*this), blk); break;
+    default: hipLaunchKernelGGL((restrict_stream4_kernel<3, 32, 4, true>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, m, aggMapOf(*this), blk); break;
+  }
+  HIP_CHECK(hipGetLastError());
+  flops_ += 4 * 8ull * fineSpin * fineColor * Nvec * fineVol / 2;
+}
+void Transfer::P4Block(float2 *panel, int nrhs, int col0, bool accumulate, const ColorSpinorField *const coarse[4]) const {
+  if (!canQuad() || site_subset != QUDA_PARITY_SITE_SUBSET) errorQuda("four-source prolongator on block fields: fine level, single-parity transfers");
+  Src4 a;
+  memset(&a, 0, sizeof(a));
+  for (int s = 0; s < 4; s++) a.c[s] = coarseVec(*coarse[s]);
+  const Blk4 blk = {reinterpret_cast<float4 *>(panel), nrhs, col0, subset_parity == QUDA_ODD_PARITY ? 1 : 0, (int)(fineVol / 2), accumulate ? 1 : 0};
+  const int threads = (blockVol + 63) / 64 * 64;
+  const AggMap amap = aggMapOf(*this);
+  acct("prolong4_kernel", 0.5 * fineVol * ((double)fineSpin * fineColor * Nvec * 8 + (accumulate ? 8.0 : 4.0) * fineSpin * fineColor * 8.0) + 4.0 * nAgg * 2 * Nvec * 8, "coarse -> level 0 (block columns), 4 sources");
+  switch (Nvec) {
+    case 8: hipLaunchKernelGGL((prolong4_kernel<3, 8, 4, true>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, amap, blk); break;
+    case 24: hipLaunchKernelGGL((prolong4_kernel<3, 24, 4, true>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, amap, blk); break;
+    default: hipLaunchKernelGGL((prolong4_kernel<3, 32, 4, true>), dim3(nAgg), dim3(threads), 0, computeStream(), a, (const void *)V, block_to_fine, blockVol, amap, blk); break;
+  }
+  HIP_CHECK(hipGetLastError());
+  flops_ += 4 * 8ull * fineSpin * fineColor * Nvec * fineVol / 2;
 }
 
 void Transfer::column(ColorSpinorField &fine, int j) const {
