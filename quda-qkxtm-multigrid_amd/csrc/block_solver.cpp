@@ -452,6 +452,8 @@ struct MGBlockState {
   BlockCoarseCycle *coarse = nullptr;
   BlockFineSmoother *fine = nullptr;   // nullptr: the per-source smoothers above
   bool solutionOnBlocks = false;       // the last cycle left its solutions in fine->groups[].X (blockApplyLast)
+  bool wantImage = false;              // the caller will ask for A x of the cycle's solutions: the post-smoother keeps its last residual
+  bool residualOnBlocks = false;       // ... and did: fine->groups[].R = b - A x
   ~MGBlockState() {
     delete fine;
     for (Solver *s : pre) delete s;
@@ -526,6 +528,7 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
   g_msStats[0]++;
   if (blockSmooth) g_msStats[1]++;
   st.solutionOnBlocks = blockSmooth;
+  st.residualOnBlocks = blockSmooth && st.wantImage && st.fine->nuPost > 0;
   // quads of active sources for the four-source transfers; with the block smoother a quad sits inside one smoother group and (unless the local term has
   // to be applied to the residual first) is restricted from / prolongated onto its block columns directly
   const bool quad = transfer->canQuad() && blockQuadTransfer();
@@ -681,7 +684,7 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
       }
       if (F.nuPost > 0) {
         F.residual(g);
-        F.mr(g, F.nuPost, nullptr, false);
+        F.mr(g, F.nuPost, nullptr, st.wantImage);
       }
       blockUnpackParity(dst, g.n, *g.X);
     }
@@ -692,6 +695,8 @@ void MG::cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorS
   }
   blas::setGlobalReduction(true);
 }
+
+void MG::blockWantImage(int nsrc, bool on) { if (blockPrepare(nsrc)) blockState->wantImage = on; }
 
 bool MG::blockApplyLast(std::vector<ColorSpinorField *> &out, const Dirac &pc, const std::vector<char> &active) {
   if (!blockState || !blockState->fine || !blockState->solutionOnBlocks) return false;
@@ -705,11 +710,20 @@ bool MG::blockApplyLast(std::vector<ColorSpinorField *> &out, const Dirac &pc, c
   if ((int)out.size() != blockState->nsrc) return false;
   for (size_t i = 0; i < out.size(); i++)
     if (active[i] && (out[i]->Precision() != QUDA_SINGLE_PRECISION || out[i]->SiteSubset() != QUDA_PARITY_SITE_SUBSET)) return false;
+  // the post-smoother's last residual r = b - A x is at hand (MR keeps it with the solution): A x = b - r, one sweep instead of two stencil launches
+  // (the same operator in exact arithmetic; in fp32 the recursion of two MR steps from an explicitly computed residual is as good as the product)
+  static int viaResidual = -1;
+  if (viaResidual < 0) { const char *e = getenv("QUDA_AMD_MULTISRC_IMAGE_FROM_RESIDUAL"); viaResidual = e ? atoi(e) : 1; }
   for (FineGroup &g : F.groups) {
     ColorSpinorField *dst[8];
     for (int j = 0; j < g.n; j++) dst[j] = active[g.first + j] ? out[g.first + j] : nullptr;
-    F.matpc(g, *g.AR, *g.X, 0, W);
-    blockUnpackParity(dst, g.n, *g.AR);
+    if (blockState->residualOnBlocks && viaResidual) {   // (sloppy and preconditioner links hold the same matrices, to the rounding of their storage)
+      blockblas::xmy(*g.B, *g.R);    // R <- b - r
+      blockUnpackParity(dst, g.n, *g.R);
+    } else {
+      F.matpc(g, *g.AR, *g.X, 0, W);
+      blockUnpackParity(dst, g.n, *g.AR);
+    }
   }
   return true;
 }
@@ -804,7 +818,11 @@ static BlockGcrResult blockGCR(std::vector<ColorSpinorField *> &x, std::vector<C
     grow(k);
     for (int i = 0; i < ns; i++) { pk[i] = p[i][k]; rk[i] = rS[i]; }
     bool done = false;
-    if (K) { done = K->cycleBlock(pk, rk, open); res.blockCycle = res.blockCycle || done; }
+    if (K) {
+      if (sloppyPC) K->blockWantImage(ns, true);
+      done = K->cycleBlock(pk, rk, open);
+      res.blockCycle = res.blockCycle || done;
+    }
     // A p_k for all sources while p_k is still on the smoother's block fields (even-odd outer solve on the smoother's operator)
     bool applied = false;
     if (done && sloppyPC) {
