@@ -185,10 +185,12 @@ class DiracMatrix {
   unsigned long long flops() const { return dirac->Flops(); }
   bool isPC() const { return dirac->isPC(); }
   const Dirac *Expose() const { return dirac; }
+  virtual bool isM() const { return false; }   // the operator itself (not M^dag M, ...)
 };
 class DiracM : public DiracMatrix {
  public:
   using DiracMatrix::DiracMatrix;
+  bool isM() const override { return true; }
   void operator()(ColorSpinorField &out, const ColorSpinorField &in) const override { dirac->M(out, in); }
 };
 class DiracMdagM : public DiracMatrix {

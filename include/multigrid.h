@@ -62,6 +62,7 @@ class MG : public Solver {
   bool fusedTried = false, fusedVerified = false;
   void cycleUnfused(ColorSpinorField &out, ColorSpinorField &in);
   MGBlockState *blockState = nullptr;
+  int lastParityCycle = -1;   // parity of the even-odd system the last operator() call post-smoothed with MR (imageOfLast), -1: none
   bool blockPrepare(int nsrc);
   void cycleParityBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorField *> &b, const std::vector<char> &active, bool fullResidual);
  public:
@@ -105,6 +106,7 @@ class MG : public Solver {
   // smoother (two multi-right-hand-side stencil launches per group instead of two stencils per source): the outer solver's `A p_k`.  pc: the
   // even-odd preconditioned operator of the outer solver — it must be the smoother's operator (type, kappa, mu, preconditioning) on fp32 links
   // the block stencil reads.  false: not available, the caller applies its operator source by source.
+  bool imageOfLast(ColorSpinorField &Ax, const ColorSpinorField &b, const DiracMatrix &A) override;
   void blockWantImage(int nsrc, bool on);   // the next cycleBlock (of nsrc sources) keeps what blockApplyLast needs to answer from the post-smoother's residual
   bool blockApplyLast(std::vector<ColorSpinorField *> &out, const Dirac &pc, const std::vector<char> &active);
   void blockRelease();   // hierarchy contents changed (half-precision mirrors switched on): rebuild or abandon at the next cycle

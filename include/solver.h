@@ -52,6 +52,9 @@ class Solver {
   virtual unsigned long long flops() const { return 0; }
   // b - A x of the system the last call worked on, in the solver's work precision, if the solver keeps it (MR); else nullptr
   virtual const ColorSpinorField *lastResidual() const { return nullptr; }
+  // used as a preconditioner x = K b: A x for the x of the LAST call, if the solver can give it without applying A (a multigrid cycle that ends in
+  // an MR smoother on A's own even-odd system holds b - A x: multigrid.cpp); false: not available, the caller applies A
+  virtual bool imageOfLast(ColorSpinorField &, const ColorSpinorField &, const DiracMatrix &) { return false; }
   static Solver *create(SolverParam &param, DiracMatrix &mat, DiracMatrix &matSloppy, DiracMatrix &matPrecon);  // reference lib/solver.cpp:13
   static double stopping(double tol, double b2, QudaResidualType type);
   bool convergence(double r2, double hq2, double r2_tol, double hq_tol) const;

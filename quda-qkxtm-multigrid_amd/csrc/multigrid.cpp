@@ -578,10 +578,51 @@ void MG::cycleParity(ColorSpinorField &x, ColorSpinorField &b, bool fullResidual
     blas::xpy(rp, x);
   }
   { StageTimer t(mgp.level, 5); (*postsmoother)(x, b); }
+  if (mgp.nu_post > 0) lastParityCycle = odd ? 1 : 0;
   blas::setGlobalReduction(true);
 }
 
+// A x for the x = K b of the last call, from the post-smoother's residual r~ = b~ - Mhat x_p of the even-odd system it worked on (MR keeps it):
+//   A = Mhat (even-odd outer solve on the smoother's operator):   A x = b - r~
+//   A = M (full system; x reconstructed from x_p):  (M x)_q = b_q exactly, (M x)_p = b_p - A_pp r~ (symmetric preconditioning) resp. b_p - r~ (asymmetric)
+// — the relation MG::cycleParity uses the other way round to restrict the full residual behind an even-odd smoother.  One or two sweeps instead of
+// an application of A: 2 of the 12 stencil launches of an outer GCR iteration.
+bool MG::imageOfLast(ColorSpinorField &Ax, const ColorSpinorField &b, const DiracMatrix &A) {
+  static int on = -1;
+  if (on < 0) { const char *e = getenv("QUDA_AMD_MG_IMAGE_FROM_RESIDUAL"); on = e ? atoi(e) : 1; }
+  if (!on || mgp.level != 0 || lastParityCycle < 0 || !A.isM() || !pcSmooth) return false;
+  const Dirac *Ad = A.Expose(), *S = mgp.matSmooth.Expose();
+  const ColorSpinorField *res = postsmoother->lastResidual();
+  if (!Ad || !S || !res || res->Precision() != Ax.Precision() || b.Precision() != Ax.Precision() || Ax.V() == b.V()) return false;
+  if (Ad->Kappa() != S->Kappa() || Ad->Mu() != S->Mu()) return false;
+  const QudaDiracType st = S->getDiracType(), at = Ad->getDiracType();
+  const QudaMatPCType mt = S->getMatPCType();
+  const bool symmetric = mt == QUDA_MATPC_EVEN_EVEN || mt == QUDA_MATPC_ODD_ODD;
+  const int par = lastParityCycle;
+  if (b.SiteSubset() == QUDA_PARITY_SITE_SUBSET) {
+    if (at != st || Ad->getMatPCType() != mt || res->VolumeCB() != b.VolumeCB()) return false;
+    blas::cxpaypbz(b, Complex(-1.0, 0.0), *res, Complex(0.0, 0.0), Ax);   // Ax = b - r~ in one sweep
+    return true;
+  }
+  const bool pair = (st == QUDA_WILSONPC_DIRAC && at == QUDA_WILSON_DIRAC) || (st == QUDA_TWISTED_MASSPC_DIRAC && at == QUDA_TWISTED_MASS_DIRAC) ||
+                    (st == QUDA_TWISTED_CLOVERPC_DIRAC && at == QUDA_TWISTED_CLOVER_DIRAC);
+  if (!pair || res->VolumeCB() != b.VolumeCB()) return false;
+  blas::copy(Ax, b);
+  ColorSpinorField &target = par ? Ax.Odd() : Ax.Even();
+  if (symmetric) {
+    ColorSpinorField &scratch = par ? r->Odd() : r->Even();
+    if (scratch.Precision() != res->Precision()) return false;
+    scratch.twistFlavor = b.twistFlavor;
+    S->localTermParity(scratch, *res, par);
+    blas::mxpy(scratch, target);
+  } else {
+    blas::mxpy(*res, target);
+  }
+  return true;
+}
+
 void MG::operator()(ColorSpinorField &x, ColorSpinorField &b) {
+  lastParityCycle = -1;
   if (b.SiteSubset() != QUDA_FULL_SITE_SUBSET) { cycleParity(x, b, false); return; }
   if (mgp.level >= 1 && coarseCycleEnabled() && !mgProfiling()) {
     // the whole cycle from this level down in one launch (coarse_cycle.h); the first use is checked against the kernel-per-operation path

@@ -452,7 +452,8 @@ void GCR::operator()(ColorSpinorField &x, ColorSpinorField &b) {
       } else {
         blas::copy(*p[k], rSloppy);
       }
-      matSloppy(*Ap[k], *p[k]);
+      // a multigrid cycle that ends in an MR smoother on this operator's even-odd system knows A p_k already (MG::imageOfLast)
+      if (!(K && param.precondition_cycle == 1 && precMatch && K->imageOfLast(*Ap[k], rSloppy, matSloppy))) matSloppy(*Ap[k], *p[k]);
     }
     // Blocked orthogonalisation (reference :53-84, :103-121 pipelined forms): all k inner products (Ap_i, Ap_k), (Ap_k, r) and |Ap_k|^2
     // in ONE sweep, then the k updates, the normalisation and the residual update in ONE sweep — 2 k + 6 field passes instead of the
