@@ -601,7 +601,8 @@ bool MG::imageOfLast(ColorSpinorField &Ax, const ColorSpinorField &b, const Dira
   const int par = lastParityCycle;
   if (b.SiteSubset() == QUDA_PARITY_SITE_SUBSET) {
     if (at != st || Ad->getMatPCType() != mt || res->VolumeCB() != b.VolumeCB()) return false;
-    blas::cxpaypbz(b, Complex(-1.0, 0.0), *res, Complex(0.0, 0.0), Ax);   // Ax = b - r~ in one sweep
+    blas::copy(Ax, b);      // (Ax may hold anything, NaNs of recycled memory included: no z = x - y + 0 z form)
+    blas::mxpy(*res, Ax);
     return true;
   }
   const bool pair = (st == QUDA_WILSONPC_DIRAC && at == QUDA_WILSON_DIRAC) || (st == QUDA_TWISTED_MASSPC_DIRAC && at == QUDA_TWISTED_MASS_DIRAC) ||
