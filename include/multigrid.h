@@ -107,6 +107,7 @@ class MG : public Solver {
   // even-odd preconditioned operator of the outer solver — it must be the smoother's operator (type, kappa, mu, preconditioning) on fp32 links
   // the block stencil reads.  false: not available, the caller applies its operator source by source.
   bool imageOfLast(ColorSpinorField &Ax, const ColorSpinorField &b, const DiracMatrix &A) override;
+  bool blockImageFull(std::vector<ColorSpinorField *> &out, std::vector<ColorSpinorField *> &b, const Dirac &full, const std::vector<char> &active);
   void blockWantImage(int nsrc, bool on);   // the next cycleBlock (of nsrc sources) keeps what blockApplyLast needs to answer from the post-smoother's residual
   bool blockApplyLast(std::vector<ColorSpinorField *> &out, const Dirac &pc, const std::vector<char> &active);
   void blockRelease();   // hierarchy contents changed (half-precision mirrors switched on): rebuild or abandon at the next cycle

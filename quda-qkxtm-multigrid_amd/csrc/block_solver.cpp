@@ -728,6 +728,42 @@ bool MG::blockApplyLast(std::vector<ColorSpinorField *> &out, const Dirac &pc, c
   return true;
 }
 
+// Full-system outer solve: M x_i for the reconstructed solutions of the last cycleBlock, from the post-smoother's residuals on the block fields —
+// (M x)_q = b_q, (M x)_p = b_p - A_pp r~ (symmetric preconditioning; see MG::imageOfLast): unpack r~ into scratch fields, local term, subtract.
+bool MG::blockImageFull(std::vector<ColorSpinorField *> &out, std::vector<ColorSpinorField *> &b, const Dirac &full, const std::vector<char> &active) {
+  if (!blockState || !blockState->fine || !blockState->residualOnBlocks) return false;
+  static int viaResidual = -1;
+  if (viaResidual < 0) { const char *e = getenv("QUDA_AMD_MULTISRC_IMAGE_FROM_RESIDUAL"); viaResidual = e ? atoi(e) : 1; }
+  if (!viaResidual) return false;
+  BlockFineSmoother &F = *blockState->fine;
+  MGBlockState &st = *blockState;
+  const Dirac &S = *mgp.matSmooth.Expose();
+  const QudaDiracType at = full.getDiracType();
+  const bool pair = (F.type == QUDA_WILSONPC_DIRAC && at == QUDA_WILSON_DIRAC) || (F.type == QUDA_TWISTED_MASSPC_DIRAC && at == QUDA_TWISTED_MASS_DIRAC) ||
+                    (F.type == QUDA_TWISTED_CLOVERPC_DIRAC && at == QUDA_TWISTED_CLOVER_DIRAC);
+  if (!pair || full.Kappa() != F.kappa || full.Mu() != F.mu || (int)out.size() != st.nsrc) return false;
+  for (size_t i = 0; i < out.size(); i++)
+    if (active[i] && (out[i]->Precision() != QUDA_SINGLE_PRECISION || out[i]->SiteSubset() != QUDA_FULL_SITE_SUBSET || b[i]->Precision() != QUDA_SINGLE_PRECISION)) return false;
+  const int par = F.par;
+  for (FineGroup &g : F.groups) {
+    ColorSpinorField *dst[8];
+    for (int j = 0; j < g.n; j++) {
+      const int i = g.first + j;
+      dst[j] = active[i] ? (par ? &st.r[i]->Odd() : &st.r[i]->Even()) : nullptr;
+      if (dst[j]) dst[j]->twistFlavor = b[i]->twistFlavor;
+    }
+    blockUnpackParity(dst, g.n, *g.R);
+    for (int j = 0; j < g.n; j++) {
+      const int i = g.first + j;
+      if (!active[i]) continue;
+      S.localTermParity(*dst[j], *dst[j], par);     // symmetric preconditioning only (the block smoother's condition)
+      blas::copy(*out[i], *b[i]);
+      blas::mxpy(*dst[j], par ? out[i]->Odd() : out[i]->Even());
+    }
+  }
+  return true;
+}
+
 // x_i = K b_i for all sources (full fields: Schur prepare, parity cycle, reconstruct, as MG::operator(); parity fields: the parity cycle)
 bool MG::cycleBlock(std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorField *> &b, const std::vector<char> &active) {
   const int nsrc = (int)x.size();
@@ -766,7 +802,8 @@ static ColorSpinorField *likeF(const ColorSpinorField &x, QudaPrecision prec, bo
 
 struct BlockGcrResult { int iter = 0; std::vector<double> r2, b2; double secs = 0; bool blockCycle = false; };
 
-static BlockGcrResult blockGCR(std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorField *> &b, DiracMatrix &mat, DiracMatrix &matSloppy, MG *K, SolverParam &param, const Dirac *sloppyPC) {
+static BlockGcrResult blockGCR(std::vector<ColorSpinorField *> &x, std::vector<ColorSpinorField *> &b, DiracMatrix &mat, DiracMatrix &matSloppy, MG *K, SolverParam &param, const Dirac *sloppyPC,
+                               const Dirac *sloppyFull = nullptr) {
   const int ns = (int)x.size(), nK = param.Nkrylov;
   BlockGcrResult res;
   res.r2.assign(ns, 0.0); res.b2.assign(ns, 0.0);
@@ -819,7 +856,7 @@ static BlockGcrResult blockGCR(std::vector<ColorSpinorField *> &x, std::vector<C
     for (int i = 0; i < ns; i++) { pk[i] = p[i][k]; rk[i] = rS[i]; }
     bool done = false;
     if (K) {
-      if (sloppyPC) K->blockWantImage(ns, true);
+      if (sloppyPC || sloppyFull) K->blockWantImage(ns, true);
       done = K->cycleBlock(pk, rk, open);
       res.blockCycle = res.blockCycle || done;
     }
@@ -829,6 +866,10 @@ static BlockGcrResult blockGCR(std::vector<ColorSpinorField *> &x, std::vector<C
       std::vector<ColorSpinorField *> apk(ns);
       for (int i = 0; i < ns; i++) apk[i] = Ap[i][k];
       applied = K->blockApplyLast(apk, *sloppyPC, open);
+    } else if (done && sloppyFull) {
+      std::vector<ColorSpinorField *> apk(ns);
+      for (int i = 0; i < ns; i++) apk[i] = Ap[i][k];
+      applied = K->blockImageFull(apk, rk, *sloppyFull, open);
     }
     for (int i = 0; i < ns; i++) {
       if (!open[i]) continue;
@@ -972,7 +1013,7 @@ void invertMultiSrcQuda(void **_hp_x, void **_hp_b, QudaInvertParam *param) {
     } else if (param->inv_type_precondition != QUDA_INVALID_INVERTER) {
       errorQuda("invertMultiSrcQuda: preconditioner %d not supported (none or QUDA_MG_INVERTER)", param->inv_type_precondition);
     }
-    const BlockGcrResult res = blockGCR(out, in, m, mSloppy, K, sp, pc_solve ? dSloppy : nullptr);
+    const BlockGcrResult res = blockGCR(out, in, m, mSloppy, K, sp, pc_solve ? dSloppy : nullptr, pc_solve ? nullptr : dSloppy);
     g_msStats[3]++;
     param->iter = res.iter;
     param->secs = res.secs;
