@@ -53,6 +53,7 @@ class DiracCoarse : public Dirac {
   void Dslash(ColorSpinorField &out, const ColorSpinorField &in, const QudaParity parity) const override;
   void DslashXpay(ColorSpinorField &out, const ColorSpinorField &in, const QudaParity parity, const ColorSpinorField &x, const double &k) const override;
   void Clover(ColorSpinorField &out, const ColorSpinorField &in, const QudaParity parity) const;
+  void localTermParity(ColorSpinorField &out, const ColorSpinorField &in, int parity) const override { Clover(out, in, parity ? QUDA_ODD_PARITY : QUDA_EVEN_PARITY); }
   void M(ColorSpinorField &out, const ColorSpinorField &in) const override;
   void MdagM(ColorSpinorField &out, const ColorSpinorField &in) const override;
   void prepare(ColorSpinorField *&src, ColorSpinorField *&sol, ColorSpinorField &x, ColorSpinorField &b, const QudaSolutionType) const override;
