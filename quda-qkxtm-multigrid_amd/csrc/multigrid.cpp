@@ -696,11 +696,7 @@ void MG::cycleUnfused(ColorSpinorField &x, ColorSpinorField &b) {
     dirac.prepare(in, out, x, *r, QUDA_MAT_SOLUTION);
     if (pcSmooth) { b_tilde->twistFlavor = b.twistFlavor; blas::copy(*b_tilde, *in); }  // keep the prepared source for the post-smoother
     g_mgCalls[mgp.level]++;
-    {
-      StageTimer t(mgp.level, 0);
-      (*presmoother)(*out, *in);
-      dirac.reconstruct(x, b, QUDA_MAT_SOLUTION);
-    }
+    { StageTimer t(mgp.level, 0); (*presmoother)(*out, *in); }
     {
       StageTimer t(mgp.level, 1);
       // behind an even-odd smoother the full residual of the reconstructed x lives on the solved parity: r_p = A_pp r~ (r~ = the residual MR ended with),
@@ -712,9 +708,12 @@ void MG::cycleUnfused(ColorSpinorField &x, ColorSpinorField &b) {
       const ColorSpinorField *res = (reuse && pcSmooth && mgp.nu_pre > 0 && (mt == QUDA_MATPC_EVEN_EVEN || mt == QUDA_MATPC_ODD_ODD)) ? presmoother->lastResidual() : nullptr;
       if (res && res->Precision() == r->Precision() && res->VolumeCB() == r->VolumeCB()) {
         const int par = mt == QUDA_MATPC_ODD_ODD ? 1 : 0;
+        // (no reconstruction of the other parity of x here: only the operator residual below needs it; the post-smoother works on the solved parity and
+        // the reconstruction at the end rebuilds the other one from it)
         dirac.localTermParity(par ? r->Odd() : r->Even(), *res, par);
         blas::zero(par ? r->Even() : r->Odd());
       } else {
+        dirac.reconstruct(x, b, QUDA_MAT_SOLUTION);
         mgp.matResidual(*r, x);
         blas::axpby(1.0, b, -1.0, *r);  // r = b - A x   (full residual: coarse_grid_solution_type = MAT)
       }
