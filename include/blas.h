@@ -43,6 +43,7 @@ double axpyNorm(const double &a, const ColorSpinorField &x, ColorSpinorField &y)
 
 void caxpy(const Complex &a, const ColorSpinorField &x, ColorSpinorField &y);         // y = a x + y
 void caxpby(const Complex &a, const ColorSpinorField &x, const Complex &b, ColorSpinorField &y);
+void xmyz(const ColorSpinorField &x, const ColorSpinorField &y, ColorSpinorField &z);   // z = x - y (z write-only; y may be z)
 void cxpaypbz(const ColorSpinorField &x, const Complex &a, const ColorSpinorField &y, const Complex &b, ColorSpinorField &z);  // z = x + a y + b z
 double caxpyNorm(const Complex &a, const ColorSpinorField &x, ColorSpinorField &y);
 void caxpyXmaz(const Complex &a, ColorSpinorField &x, ColorSpinorField &y, const ColorSpinorField &z);   // y += a x ; x -= a z

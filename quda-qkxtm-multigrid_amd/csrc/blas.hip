@@ -295,6 +295,12 @@ template <int NRM> struct CaxpbyF { double ar, ai, br, bi; QA_FLAGS(1, 1, 0, 0, 
       if (NRM) r[0] += (double)y[i] * (double)y[i] + (double)y[i + 1] * (double)y[i + 1];
     }
   } };
+// z = x - y   (z is not read: it may hold anything)
+struct XmyzF { QA_FLAGS(1, 1, 0, 0, 0, 0, 1, 0, 0)
+  template <typename real, int M> __device__ void operator()(real *x, real *y, real *z, real *, double *) const {
+#pragma unroll
+    for (int i = 0; i < M; i++) z[i] = x[i] - y[i];
+  } };
 // z = x + a y + b z
 struct CxpaypbzF { double ar, ai, br, bi; QA_FLAGS(1, 1, 1, 0, 0, 0, 1, 0, 0)
   template <typename real, int M> __device__ void operator()(real *x, real *y, real *z, real *, double *) const {
@@ -880,6 +886,7 @@ double caxpyNorm(const Complex &a, const ColorSpinorField &x, ColorSpinorField &
   CaxpbyF<1> f; f.ar = a.real(); f.ai = a.imag(); f.br = 1.0; f.bi = 0.0; double r[1];
   launch(f, x, &y, nullptr, nullptr, r); return r[0];
 }
+void xmyz(const ColorSpinorField &x, const ColorSpinorField &y, ColorSpinorField &z) { launch(XmyzF(), x, &y, &z, nullptr, nullptr); }
 void cxpaypbz(const ColorSpinorField &x, const Complex &a, const ColorSpinorField &y, const Complex &b, ColorSpinorField &z) {
   CxpaypbzF f; f.ar = a.real(); f.ai = a.imag(); f.br = b.real(); f.bi = b.imag();
   launch(f, x, &y, &z, nullptr, nullptr);

@@ -87,6 +87,7 @@ struct CcArg {
   u32x4_t *redPeer[kMaxRanks]; // the same window on every rank
   int *errWord;
   unsigned long long waitTicks;
+  int resFromSmoother;   // the full residual a level restricts comes from its pre-smoother's residual (cc_residual_local), not from the operator
 };
 
 struct CcShared {
@@ -699,6 +700,24 @@ template <int N> __device__ __forceinline__ void cc_residual(const CcArg &a, con
   }
 }
 
+// The same residual without the operator: behind the even-odd pre-smoother (x_q reconstructed or not) the full residual is rf_p = X_pp r~ with r~ the
+// residual MR ended with (L.r), rf_q = 0 — MG::imageOfLast / MG::cycleUnfused.  One local matrix per solved site, no halo, and the reconstruct phase
+// in front of cc_residual is not needed either.  No barrier at the end.
+template <int N> __device__ __forceinline__ void cc_residual_local(const CcArg &a, const CcLevel &L, CcShared &s, CcCtx &c) {
+  const int p = L.solvePar, q = 1 - p;
+  for (int t = blockIdx.x; t < L.Vh; t += gridDim.x) {
+    LinkRegs<N, 8, 9> lk;
+    cc_links_issue(lk, L.links, (size_t)p * L.Vh + t, L.ntLinks);
+    if (threadIdx.x < N) s.xin[8][threadIdx.x] = ldc(a, L.r + (size_t)threadIdx.x * L.Vh + t);
+    __syncthreads();
+    cc_links_finish(s, lk, L.links, (size_t)p * L.Vh + t, L.ntLinks);
+    if (threadIdx.x < N) {
+      stc(a, L.rf.p[p] + (size_t)threadIdx.x * L.rf.stride + t, s.yout[threadIdx.x]);
+      stc(a, L.rf.p[q] + (size_t)threadIdx.x * L.rf.stride + t, make_float2(0.f, 0.f));
+    }
+  }
+}
+
 // next.b = R rf: V^dagger summed over each aggregate, per chirality (reference lib/restrictor.cu:51-125; the lane-group scheme of
 // transfer.hip restrict_small_kernel).  N = components of this level, NC = 2 Nvec of the next.  No barrier at the end.
 template <int N> __device__ __forceinline__ void cc_restrict(const CcArg &a, const CcLevel &L, const CcLevel &C) {
@@ -1022,9 +1041,13 @@ template <int N> __global__ void __launch_bounds__(kThreads) coarse_cycle_kernel
     cc_prepare<N>(a, L, s, c, false);
     cc_barrier(a, s, c);
     cc_mr<N>(a, L, s, c, L.nuPre, false);
-    cc_reconstruct<N>(a, L, s, c);
-    cc_barrier(a, s, c);
-    cc_residual<N>(a, L, s, c);
+    if (a.resFromSmoother && L.nuPre > 0) {
+      cc_residual_local<N>(a, L, s, c);
+    } else {
+      cc_reconstruct<N>(a, L, s, c);
+      cc_barrier(a, s, c);
+      cc_residual<N>(a, L, s, c);
+    }
     cc_barrier(a, s, c);
     cc_restrict<N>(a, L, a.L[l + 1]);
     cc_barrier(a, s, c);
@@ -1215,6 +1238,7 @@ CoarseCycle *coarseCycleCreate(MG &top) {
   a.state = cc->sync; a.bar = cc->sync + 16; a.partial = cc->partial;
   a.world = g.size; a.rank = g.rank;
   a.errWord = p2pErrorWord(); a.waitTicks = p2pTimeoutTicks();
+  { const char *e = getenv("QUDA_AMD_MG_SMOOTHER_RESIDUAL"); a.resFromSmoother = e ? atoi(e) : 1; }   // the same switch as MG::cycleUnfused
   float2 *w = cc->work;
   for (int l = 0; l < nl; l++) {
     CcLevel &L = a.L[l];

@@ -601,23 +601,21 @@ bool MG::imageOfLast(ColorSpinorField &Ax, const ColorSpinorField &b, const Dira
   const int par = lastParityCycle;
   if (b.SiteSubset() == QUDA_PARITY_SITE_SUBSET) {
     if (at != st || Ad->getMatPCType() != mt || res->VolumeCB() != b.VolumeCB()) return false;
-    blas::copy(Ax, b);      // (Ax may hold anything, NaNs of recycled memory included: no z = x - y + 0 z form)
-    blas::mxpy(*res, Ax);
+    blas::xmyz(b, *res, Ax);   // (Ax is only written: it may hold anything, NaNs of recycled memory included)
     return true;
   }
   const bool pair = (st == QUDA_WILSONPC_DIRAC && at == QUDA_WILSON_DIRAC) || (st == QUDA_TWISTED_MASSPC_DIRAC && at == QUDA_TWISTED_MASS_DIRAC) ||
                     (st == QUDA_TWISTED_CLOVERPC_DIRAC && at == QUDA_TWISTED_CLOVER_DIRAC);
   if (!pair || res->VolumeCB() != b.VolumeCB()) return false;
-  blas::copy(Ax, b);
   ColorSpinorField &target = par ? Ax.Odd() : Ax.Even();
+  const ColorSpinorField &bp = par ? b.Odd() : b.Even();
+  blas::copy(par ? Ax.Even() : Ax.Odd(), par ? b.Even() : b.Odd());
   if (symmetric) {
-    ColorSpinorField &scratch = par ? r->Odd() : r->Even();
-    if (scratch.Precision() != res->Precision()) return false;
-    scratch.twistFlavor = b.twistFlavor;
-    S->localTermParity(scratch, *res, par);
-    blas::mxpy(scratch, target);
+    target.twistFlavor = b.twistFlavor;
+    S->localTermParity(target, *res, par);
+    blas::xmyz(bp, target, target);
   } else {
-    blas::mxpy(*res, target);
+    blas::xmyz(bp, *res, target);
   }
   return true;
 }
