@@ -230,12 +230,21 @@ class BlockCoarseCycle {
     }
     prepare(l);
     mr(l, l.nuPre, false);
-    reconstruct(l);
-    apply(*l.r, *l.x, *l.Y);            // r = b - M x on every site
-    xmy(*l.b, *l.r);
+    BlockField *full = l.r;
+    if (l.nuPre > 0) {
+      // the full residual behind the even-odd pre-smoother is X_pp r~ on the solved parity and zero on the other (MG::imageOfLast): the operator on
+      // MR's residual (zero on the other parity), output parity p only — one half application instead of reconstruct + full operator (four halves)
+      apply(*l.w1, *l.r, *l.Y, l.p);
+      zeroParity(*l.w1, 1 - l.p);
+      full = l.w1;
+    } else {
+      reconstruct(l);
+      apply(*l.r, *l.x, *l.Y);            // r = b - M x on every site
+      xmy(*l.b, *l.r);
+    }
     // restrict / prolongate per right-hand side with the single-vector kernels of the level (aggregates of the coarse levels are tiny)
     BlockLevel &c = L[lev + 1];
-    blockUnpack(l.fine, *l.r);
+    blockUnpack(l.fine, *full);
     for (int i = 0; i < nb; i++) l.T->R(*l.coarse[i], *l.fine[i]);
     blockPack(source(lev + 1), l.coarse);
     solve(lev + 1);
