@@ -1127,10 +1127,21 @@ template <int NRHS, int CL = 0, int XY = 0> __global__ void __launch_bounds__(25
   // loads run at 0.54-0.70 of the 16-byte rate on gfx950, and the kernel is bound by its L2 -> L1 requests).  History: with the rhs-fastest
   // order the lane pair (i, i ^ 1) shared its loads and transposed 2 x 2 by DPP — 620 of the kernel's ~1950 vector instructions.
   float4 pA[6], pB[6];
+#ifndef QA_FB_PANEL_POLICY
+#define QA_FB_PANEL_POLICY 0   // 0 plain loads, 1 non-temporal (L1 bypassed), 2 sc1 raw buffer loads: measured, see DESIGN 3
+#endif
   auto load_panel = [&](float4 *raw, const float2 *base, int site) {
     const float4 *p = reinterpret_cast<const float4 *>(base) + (long)site * 6 * NRHS + i;
 #pragma unroll
-    for (int k = 0; k < 6; k++) raw[k] = p[k * NRHS];
+    for (int k = 0; k < 6; k++) {
+      if (QA_FB_PANEL_POLICY == 1) {
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p + k * NRHS));
+        raw[k] = make_float4(v.x, v.y, v.z, v.w);
+      } else {
+        raw[k] = p[k * NRHS];
+      }
+    }
   };
   auto unpack_panel = [&](float *psi, const float4 *raw) {
 #pragma unroll
