@@ -590,7 +590,7 @@ void MG::cycleParity(ColorSpinorField &x, ColorSpinorField &b, bool fullResidual
 bool MG::imageOfLast(ColorSpinorField &Ax, const ColorSpinorField &b, const DiracMatrix &A) {
   static int on = -1;
   if (on < 0) { const char *e = getenv("QUDA_AMD_MG_IMAGE_FROM_RESIDUAL"); on = e ? atoi(e) : 1; }
-  if (!on || mgp.level != 0 || lastParityCycle < 0 || !A.isM() || !pcSmooth) return false;
+  if (!on || lastParityCycle < 0 || !A.isM() || !pcSmooth) return false;
   const Dirac *Ad = A.Expose(), *S = mgp.matSmooth.Expose();
   const ColorSpinorField *res = postsmoother->lastResidual();
   if (!Ad || !S || !res || res->Precision() != Ax.Precision() || b.Precision() != Ax.Precision() || Ax.V() == b.V()) return false;
@@ -604,9 +604,10 @@ bool MG::imageOfLast(ColorSpinorField &Ax, const ColorSpinorField &b, const Dira
     blas::xmyz(b, *res, Ax);   // (Ax is only written: it may hold anything, NaNs of recycled memory included)
     return true;
   }
+  // (coarse levels: the K-cycle's GCR around this level's cycle asks for M_c x — the same relation with the coarse local term X_pp)
   const bool pair = (st == QUDA_WILSONPC_DIRAC && at == QUDA_WILSON_DIRAC) || (st == QUDA_TWISTED_MASSPC_DIRAC && at == QUDA_TWISTED_MASS_DIRAC) ||
-                    (st == QUDA_TWISTED_CLOVERPC_DIRAC && at == QUDA_TWISTED_CLOVER_DIRAC);
-  if (!pair || res->VolumeCB() != b.VolumeCB()) return false;
+                    (st == QUDA_TWISTED_CLOVERPC_DIRAC && at == QUDA_TWISTED_CLOVER_DIRAC) || (st == QUDA_COARSEPC_DIRAC && at == QUDA_COARSE_DIRAC);
+  if (!pair || res->VolumeCB() != b.VolumeCB() || res->Ncolor() != b.Ncolor()) return false;
   ColorSpinorField &target = par ? Ax.Odd() : Ax.Even();
   const ColorSpinorField &bp = par ? b.Odd() : b.Even();
   blas::copy(par ? Ax.Even() : Ax.Odd(), par ? b.Even() : b.Odd());
@@ -635,6 +636,7 @@ void MG::operator()(ColorSpinorField &x, ColorSpinorField &b) {
       if (half) setCoarseHalfStorage(true);
       ColorSpinorField ref(x);
       double fail = coarseCycleApply(fused, x, b) ? 0.0 : 1.0;
+      lastParityCycle = -1;   // x is the fused kernel's now: the smoother residual of the reference cycle above does not belong to it
       HIP_CHECK(hipStreamSynchronize(computeStream()));
       if (p2pTakeError()) fail = 1.0;
       if (fail == 0.0) {
@@ -741,6 +743,7 @@ void MG::cycleUnfused(ColorSpinorField &x, ColorSpinorField &b) {
     }
     (*postsmoother)(*out, *in);
     dirac.reconstruct(x, b, QUDA_MAT_SOLUTION);
+    if (pcSmooth && mgp.nu_post > 0) lastParityCycle = dirac.getMatPCType() == QUDA_MATPC_ODD_ODD || dirac.getMatPCType() == QUDA_MATPC_ODD_ODD_ASYMMETRIC ? 1 : 0;
   } else {
     // coarsest-grid solve
     g_mgCalls[mgp.level]++;
