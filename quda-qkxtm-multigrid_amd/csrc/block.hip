@@ -594,7 +594,7 @@ void applyCoarseBlock(BlockField &out, BlockField &in, const CoarseGauge &G, int
 namespace blockblas {
 
 constexpr int kBS = 192;
-constexpr int kMaxBlocks = 1024;
+constexpr int kMaxBlocks = 4096;   // 1024 left two thirds of the CUs' wave slots empty on the 12^3 x 24 level (260 us per 255 MB sweep)
 constexpr int kMaxSums = 8;        // real sums per right-hand side of one kernel
 static double *d_part = nullptr;   // [block][sum][rhs]
 static double *h_res = nullptr;    // pinned
