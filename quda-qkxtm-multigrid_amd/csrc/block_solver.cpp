@@ -59,6 +59,7 @@ struct BlockLevel {
 class BlockCoarseCycle {
  public:
   int nl = 0, nb = 0;   // levels, right-hand sides of the block (a multiple of 8)
+  int nReal = 0;        // columns that carry a source (the rest pad the block: their staging fields are zero from their creation and stay so)
   std::vector<BlockLevel> L;
   // coarsest-grid GCR
   int nKrylov = 20, maxiter = 1000;
@@ -245,11 +246,11 @@ class BlockCoarseCycle {
     // restrict / prolongate per right-hand side with the single-vector kernels of the level (aggregates of the coarse levels are tiny)
     BlockLevel &c = L[lev + 1];
     blockUnpack(l.fine, *full);
-    for (int i = 0; i < nb; i++) l.T->R(*l.coarse[i], *l.fine[i]);
+    for (int i = 0; i < nReal; i++) l.T->R(*l.coarse[i], *l.fine[i]);
     blockPack(source(lev + 1), l.coarse);
     solve(lev + 1);
     blockUnpack(l.coarse, *c.x);
-    for (int i = 0; i < nb; i++) l.T->P(*l.fine[i], *l.coarse[i]);
+    for (int i = 0; i < nReal; i++) l.T->P(*l.fine[i], *l.coarse[i]);
     blockPack(*l.w1, l.fine);
     std::vector<Complex> one(nb, Complex(1.0, 0.0));
     blockblas::caxpy(one.data(), *l.w1, *l.x);
@@ -504,6 +505,7 @@ bool MG::blockPrepare(int nsrc) {
   // nullptr (a K-cycle below the first coarse level, an operator the MFMA kernel does not take): the coarse solves run source by source through
   // the hierarchy's own coarse solver, the fine level keeps its block smoother and four-source transfers
   st->coarse = blockCoarseCreate(*coarse, nb, &mgp);
+  if (st->coarse) st->coarse->nReal = nsrc;
   for (int i = 0; i < nsrc; i++) {
     st->prePar.push_back(new SolverParam(*param_presmooth));
     st->postPar.push_back(new SolverParam(*param_postsmooth));
